@@ -1,0 +1,346 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores: forward and data-gradient.
+//
+// Replaces tf.nn.conv2d / tf.nn.atrous_conv2d (+bias_add, relu, dropout) -- deeplab.py:58-59,65-66,71,
+// 92-96,100,104 -- and the Conv2DBackpropInput half of the autodiff of deeplab.py:192.
+//
+//   out[m][n] = sum_k A[m][k] * Bw[k][n]       m = (b,oh,ow) pixel, k = (tap, c), n = output channel
+//
+// A is never materialised: each workgroup gathers its [BM x BK] slice of the im2col matrix straight
+// from the NHWC activation (16-byte loads along the channel axis, zero fill outside the image;
+// dilation is just a different tap offset) and transposes it into a k-major LDS tile, so that the
+// MFMA operand reads (one fp32 per lane: lane&31 = row, lane>>5 = k parity) are conflict-free
+// ds_read_b32.  Bw is the HWIO filter as it lies in memory for the forward pass; for the data
+// gradient the same kernel reads the filter "transposed" (k = (tap, co), n = ci, contiguous along k)
+// and mirrors the tap offsets, so no transposed copy of the weights is ever written.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 -- exact fp32 multiply-add chains, accumulation in k order.
+// Tiling: 256 threads = 4 wavefronts, each owning a 64x64 accumulator block (2x2 MFMA tiles, 64
+// accumulator VGPRs); global->register prefetch of tile k+1 overlaps the MFMAs of tile k; two LDS
+// buffers, one barrier per K step; two workgroups per CU.  blockIdx is remapped so that the eight
+// workgroups that share an XCD (and its L2) work on neighbouring tiles (8 M-tiles x all N-tiles).
+// Epilogue (bias / ReLU / dropout, or the ReLU-gradient gate for dgrad) is fused.
+#include "common.h"
+
+namespace {
+
+using namespace emadapt;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct IgemmArgs {
+    const float *x;     // activation to gather from: [B,H,W,Cx]
+    const float *w;     // filter, HWIO
+    float *y;           // [M][N]
+    const float *bias;  // [N] or null
+    const float *gate;  // [M][N] or null (dgrad: stored activation; out = gate>0 ? out*scale : 0)
+    const unsigned char *mask;  // [M][N] keep mask or null
+    int H, W, Cx, N, KW, dil, sign, pad_h, pad_w;
+    int M, K, ntaps;
+    int epi;            // EMADAPT_EPI_*
+    float scale;        // gate scale
+    float keep;         // dropout keep probability (1 = off)
+    unsigned long long seed;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// keep decision of the built-in dropout generator: uniform 24-bit draw per (seed, element).
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float keep) {
+    const unsigned u = (unsigned)(mix64(seed ^ (idx * 0xD1342543DE82EF95ull)) >> 40);
+    return (float)u * (1.0f / 16777216.0f) < keep;
+}
+
+template <int BM, int BN, int BK, bool BT>
+__global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
+    constexpr int WM = 64, WN = 64;                // per-wave accumulator block
+    constexpr int WAVES_N = BN / WN;               // waves along N
+    static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AS = BM + 1;                     // LDS pitch of the k-major A tile (odd: conflict-free transposing stores)
+    constexpr int BS = BT ? BN + 1 : BN;
+    constexpr int KQ = BK / 4;                     // float4 quads along k
+    constexpr int A_RSTEP = 256 / KQ;              // rows covered by one pass of the 256 threads
+    constexpr int A_N = BM / A_RSTEP;              // A float4 loads per thread
+    constexpr int QN = BN / 4;
+    constexpr int B_KSTEP = 256 / QN;
+    constexpr int B_N = BT ? (BN / A_RSTEP) : (BK / B_KSTEP);
+    static_assert(A_N >= 1 && B_N >= 1, "tile too small for 256 threads");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;                        // [2][BK][AS]
+    float *Bs = lds + 2 * BK * AS;          // [2][BK][BS]   (2*BK*AS*4 bytes is a multiple of 16)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // ---- XCD-aware tile order: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous run of
+    //      tiles, ordered as groups of 8 M-tiles x all N-tiles (operands of neighbours hit in its L2).
+    int tile_m, tile_n;
+    {
+        const int nblk = a.tiles_m * a.tiles_n;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 8;
+        const int per_group = GM * a.tiles_n;
+        const int g = t / per_group;
+        const int first_m = g * GM;
+        const int gsz = (a.tiles_m - first_m < GM) ? (a.tiles_m - first_m) : GM;
+        const int in_g = t - g * per_group;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread gather state for the A rows it loads ----
+    const int a_kq = tid % KQ;
+    const int a_r0 = tid / KQ;
+    int a_pix[A_N];  // linear pixel index of the row (b*H+oh)*W+ow, or -1
+    int a_oh[A_N], a_ow[A_N];
+#pragma unroll
+    for (int j = 0; j < A_N; j++) {
+        const int m = m0 + a_r0 + j * A_RSTEP;
+        if (m < a.M) {
+            const int ow = m % a.W;
+            const int t2 = m / a.W;
+            a_pix[j] = m;
+            a_oh[j] = t2 % a.H;
+            a_ow[j] = ow;
+        } else {
+            a_pix[j] = -1;
+            a_oh[j] = -(1 << 20);
+            a_ow[j] = -(1 << 20);
+        }
+    }
+    // k tracker of this thread's quad: k = kt*BK + a_kq*4 -> (tap = kh*KW + kw, c)
+    int k_c = a_kq * 4, k_kh = 0, k_kw = 0, k_tap = 0;
+    while (k_c >= a.Cx) { k_c -= a.Cx; k_tap++; if (++k_kw == a.KW) { k_kw = 0; k_kh++; } }
+
+    // B loader coordinates
+    const int b_nq = tid % QN, b_kr = tid / QN;       // !BT: float4 along n
+    const int b_nr = tid / KQ;                        //  BT: float4 along k (same k quad as A)
+
+    float4 ra[A_N], rb[B_N];
+
+    auto load_tiles = [&](int kt) {
+        const bool kvalid = k_tap < a.ntaps;
+        const int dh = a.sign * (k_kh * a.dil - a.pad_h);
+        const int dw = a.sign * (k_kw * a.dil - a.pad_w);
+#pragma unroll
+        for (int j = 0; j < A_N; j++) {
+            const int ih = a_oh[j] + dh, iw = a_ow[j] + dw;
+            const bool ok = kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            ra[j] = ok ? ldg4(a.x + ((long long)(a_pix[j] + dh * a.W + dw) * a.Cx + k_c))
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if constexpr (!BT) {
+#pragma unroll
+            for (int j = 0; j < B_N; j++) {
+                const int k = kt * BK + b_kr + j * B_KSTEP;
+                const int n = n0 + b_nq * 4;
+                rb[j] = (k < a.K && n < a.N) ? ldg4(a.w + ((long long)k * a.N + n)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < B_N; j++) {
+                const int n = n0 + b_nr + j * A_RSTEP;
+                rb[j] = (kvalid && n < a.N) ? ldg4(a.w + (((long long)k_tap * a.N + n) * a.Cx + k_c))
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        // advance the k tracker to the next K step
+        k_c += BK;
+        while (k_c >= a.Cx) { k_c -= a.Cx; k_tap++; if (++k_kw == a.KW) { k_kw = 0; k_kh++; } }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float *as = As + buf * BK * AS;
+        float *bs = Bs + buf * BK * BS;
+#pragma unroll
+        for (int j = 0; j < A_N; j++) {
+            const int r = a_r0 + j * A_RSTEP;
+            as[(a_kq * 4 + 0) * AS + r] = ra[j].x;
+            as[(a_kq * 4 + 1) * AS + r] = ra[j].y;
+            as[(a_kq * 4 + 2) * AS + r] = ra[j].z;
+            as[(a_kq * 4 + 3) * AS + r] = ra[j].w;
+        }
+        if constexpr (!BT) {
+#pragma unroll
+            for (int j = 0; j < B_N; j++)
+                *reinterpret_cast<float4 *>(&bs[(b_kr + j * B_KSTEP) * BS + b_nq * 4]) = rb[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < B_N; j++) {
+                const int n = b_nr + j * A_RSTEP;
+                bs[(a_kq * 4 + 0) * BS + n] = rb[j].x;
+                bs[(a_kq * 4 + 1) * BS + n] = rb[j].y;
+                bs[(a_kq * 4 + 2) * BS + n] = rb[j].z;
+                bs[(a_kq * 4 + 3) * BS + n] = rb[j].w;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nk = (a.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tiles(kt + 1);
+        const float *as = As + cur * BK * AS + wm * WM + l31;
+        const float *bs = Bs + cur * BK * BS + wn * WN + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) av[i] = as[(kk * 2 + lh) * AS + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; j++) bv[j] = bs[(kk * 2 + lh) * BS + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue; C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const float inv_keep = 1.0f / a.keep;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= a.N) continue;
+            const float bcol = (a.epi != EMADAPT_EPI_NONE && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= a.M) continue;
+                const long long o = (long long)row * a.N + col;
+                float v = acc[i][j][r] + bcol;
+                if (a.epi == EMADAPT_EPI_BIAS_RELU) {
+                    v = v > 0.f ? v : 0.f;
+                    if (a.keep < 1.0f) {
+                        const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
+                        v = kp ? v * inv_keep : 0.f;
+                    }
+                }
+                if (a.gate) v = a.gate[o] > 0.f ? v * a.scale : 0.f;
+                a.y[o] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, bool BT>
+int launch_igemm(IgemmArgs &a, hipStream_t stream) {
+    constexpr int AS = BM + 1, BS = BT ? BN + 1 : BN;
+    constexpr size_t lds = sizeof(float) * 2 * BK * (AS + BS);
+    static_assert((2 * BK * AS * 4) % 16 == 0, "B tile must stay 16-byte aligned");
+    static bool attr_set = false;
+    if (!attr_set) {
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<BM, BN, BK, BT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    a.tiles_m = (int)ceil_div(a.M, BM);
+    a.tiles_n = (int)ceil_div(a.N, BN);
+    const long long nblk = (long long)a.tiles_m * a.tiles_n;
+    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, BT>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    return launch_status();
+}
+
+template <bool BT>
+int dispatch_igemm(IgemmArgs &a, hipStream_t stream) {
+    if (a.N <= 64) return launch_igemm<256, 64, 16, BT>(a, stream);
+    return launch_igemm<128, 128, 32, BT>(a, stream);
+}
+
+int check_desc(const emadapt_conv_desc *d) {
+    if (!d) return EMADAPT_ERR_INVALID;
+    if (d->B < 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->dil <= 0)
+        return EMADAPT_ERR_INVALID;
+    if (d->Cin % 4 != 0 || d->Cout % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;
+    if ((long long)d->B * d->H * d->W >= (1LL << 30)) return EMADAPT_ERR_UNSUPPORTED;
+    if ((long long)d->B * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) >= (1LL << 40)) return EMADAPT_ERR_UNSUPPORTED;
+    return EMADAPT_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+namespace emadapt {
+// SAME padding of a stride-1 (dilated) convolution: TF pads (dilated_k - 1)/2 before, the rest after
+// (nn_ops._with_space_to_batch_base_paddings): 3x3 rate r -> r; 4x4 rate 4 -> 6 (taps -6,-2,+2,+6).
+int conv_pad_before(int k, int dil) { return ((k - 1) * dil) / 2; }
+}  // namespace emadapt
+
+extern "C" {
+
+int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
+                     int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y) return EMADAPT_ERR_INVALID;
+    if (epilogue < EMADAPT_EPI_NONE || epilogue > EMADAPT_EPI_BIAS_RELU) return EMADAPT_ERR_INVALID;
+    if (epilogue != EMADAPT_EPI_NONE && !bias) return EMADAPT_ERR_INVALID;
+    if (!(keep_prob > 0.f) || keep_prob > 1.f) return EMADAPT_ERR_INVALID;
+    if (keep_prob < 1.f && epilogue != EMADAPT_EPI_BIAS_RELU) return EMADAPT_ERR_INVALID;
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return EMADAPT_ERR_INVALID;
+    if (d->B == 0) return EMADAPT_OK;
+    IgemmArgs a;
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
+    a.H = d->H; a.W = d->W; a.Cx = d->Cin; a.N = d->Cout; a.KW = d->KW; a.dil = d->dil; a.sign = 1;
+    a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
+    a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cin;
+    a.epi = epilogue; a.scale = 1.f; a.keep = keep_prob; a.seed = drop_seed;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    return dispatch_igemm<false>(a, stream);
+}
+
+int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float *w, float *dx, const float *gate,
+                       float gate_scale, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dy || !w || !dx) return EMADAPT_ERR_INVALID;
+    if (!aligned16(dy) || !aligned16(w) || !aligned16(dx)) return EMADAPT_ERR_INVALID;
+    if (d->B == 0) return EMADAPT_OK;
+    IgemmArgs a;
+    a.x = dy; a.w = w; a.y = dx; a.bias = nullptr; a.gate = gate; a.mask = nullptr;
+    a.H = d->H; a.W = d->W; a.Cx = d->Cout; a.N = d->Cin; a.KW = d->KW; a.dil = d->dil; a.sign = -1;
+    a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
+    a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cout;
+    a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; a.keep = 1.f; a.seed = 0;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    return dispatch_igemm<true>(a, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,270 @@
+// Filter gradient of the (dilated) convolutions on the gfx950 matrix cores.
+//
+// Replaces the Conv2DBackpropFilter half of the autodiff of deeplab.py:192:
+//
+//   dw[k][n] = sum_m A[m][k] * dy[m][n]        k = (tap, ci), n = co, m = (b,oh,ow) pixel
+//
+// i.e. a GEMM whose reduction runs over the pixels.  Both operands are read in their natural memory
+// layout -- the im2col slice A[m][k..k+127] is contiguous along the channel axis and dy[m][n..] is a
+// row of the NHWC gradient -- and both land in LDS as [pixel][k or n] tiles with plain 16-byte stores;
+// the MFMA operand reads (lane&31 along k/n, lane>>5 = pixel parity) are conflict-free ds_read_b32.
+// Every thread's k quad (tap, ci) is fixed for the whole kernel, only the pixel advances.
+//
+// Layers whose [K x N] filter has few 128x128 tiles (conv1_x .. conv5_x) would leave most of the 256
+// CUs idle, so the pixel range is split across workgroups ("split-M"); each split writes an fp32
+// partial slab and a second kernel adds the slabs in a fixed order -- deterministic, no atomics.
+#include "common.h"
+
+namespace emadapt {
+int launch_slab_sum(const float *slab, int nslab, long long n, float *out, hipStream_t stream);
+int conv_pad_before(int k, int dil);
+}  // namespace emadapt
+
+namespace {
+
+using namespace emadapt;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float *x;   // [B,H,W,Cin]
+    const float *dy;  // [M][N]
+    float *out;       // dw or slab base: [splits][K][N]
+    int H, W, Cin, N, KW, dil, pad_h, pad_w;
+    int M, K, ntaps;
+    int tiles_k, tiles_n, splits;
+    int rows_per_split;  // multiple of BMR
+};
+
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+constexpr int BMR = 32;  // pixels per reduction step
+
+template <int BKO, int BN>
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(WgradArgs a) {
+    // 4 waves: 2 along k (64 rows each) x 2 along n
+    constexpr int WK = BKO / 2, WN = BN / 2;
+    constexpr int TK = WK / 32, TN = WN / 32;
+    static_assert(BKO == 128, "k tile is 128");
+    constexpr int XQ = BKO / 4;            // 32 float4 quads along k
+    constexpr int X_RSTEP = 256 / XQ;      // 8 pixel rows per pass
+    constexpr int X_N = BMR / X_RSTEP;     // 4 loads per thread
+    constexpr int YQ = BN / 4;
+    constexpr int Y_RSTEP = 256 / YQ;
+    constexpr int Y_N = BMR / Y_RSTEP;
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Xs = lds;                    // [2][BMR][BKO]
+    float *Ys = lds + 2 * BMR * BKO;    // [2][BMR][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+
+    int bid = blockIdx.x;
+    const int split = bid % a.splits;
+    bid /= a.splits;
+    const int tile_n = bid % a.tiles_n;
+    const int tile_k = bid / a.tiles_n;
+    const int k0 = tile_k * BKO, n0 = tile_n * BN;
+    const int m_begin = split * a.rows_per_split;
+    int m_end = m_begin + a.rows_per_split;
+    if (m_end > a.M) m_end = a.M;
+
+    // fixed k quad of this thread
+    const int x_kq = tid % XQ, x_r0 = tid / XQ;
+    const int k = k0 + x_kq * 4;
+    const bool kvalid = k < a.K;
+    const int tap = kvalid ? k / a.Cin : 0;
+    const int c = kvalid ? k % a.Cin : 0;
+    const int dh = (tap / a.KW) * a.dil - a.pad_h;
+    const int dw = (tap % a.KW) * a.dil - a.pad_w;
+    const long long x_off = ((long long)dh * a.W + dw) * a.Cin + c;
+
+    // pixel trackers for the X rows this thread loads: m = m_begin + x_r0 + j*X_RSTEP (+ BMR per step)
+    int x_oh[X_N], x_ow[X_N];
+#pragma unroll
+    for (int j = 0; j < X_N; j++) {
+        const int m = m_begin + x_r0 + j * X_RSTEP;
+        x_ow[j] = m % a.W;
+        x_oh[j] = (m / a.W) % a.H;
+    }
+    const int y_nq = tid % YQ, y_r0 = tid / YQ;
+    const int y_n = n0 + y_nq * 4;
+    const bool nvalid = y_n < a.N;
+
+    float4 rx[X_N], ry[Y_N];
+
+    auto load_tiles = [&](int mb) {  // mb = first pixel of the step
+#pragma unroll
+        for (int j = 0; j < X_N; j++) {
+            const int m = mb + x_r0 + j * X_RSTEP;
+            const int ih = x_oh[j] + dh, iw = x_ow[j] + dw;
+            const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            rx[j] = ok ? ldg4(a.x + ((long long)m * a.Cin + x_off)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // advance this row's pixel by BMR for the next step
+            x_ow[j] += BMR;
+            while (x_ow[j] >= a.W) {
+                x_ow[j] -= a.W;
+                if (++x_oh[j] == a.H) x_oh[j] = 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < Y_N; j++) {
+            const int m = mb + y_r0 + j * Y_RSTEP;
+            ry[j] = (nvalid && m < m_end) ? ldg4(a.dy + ((long long)m * a.N + y_n)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float *xs = Xs + buf * BMR * BKO;
+        float *ys = Ys + buf * BMR * BN;
+#pragma unroll
+        for (int j = 0; j < X_N; j++)
+            *reinterpret_cast<float4 *>(&xs[(x_r0 + j * X_RSTEP) * BKO + x_kq * 4]) = rx[j];
+#pragma unroll
+        for (int j = 0; j < Y_N; j++)
+            *reinterpret_cast<float4 *>(&ys[(y_r0 + j * Y_RSTEP) * BN + y_nq * 4]) = ry[j];
+    };
+
+    f32x16 acc[TK][TN];
+#pragma unroll
+    for (int i = 0; i < TK; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BMR - 1) / BMR : 0;
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (nsteps > 0) {
+        load_tiles(m_begin);
+        store_tiles(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; s++) {
+            const int cur = s & 1;
+            const bool more = s + 1 < nsteps;
+            if (more) load_tiles(m_begin + (s + 1) * BMR);
+            const float *xs = Xs + cur * BMR * BKO + wk * WK + l31;
+            const float *ys = Ys + cur * BMR * BN + wn * WN + l31;
+#pragma unroll
+            for (int kk = 0; kk < BMR / 2; kk++) {
+                float av[TK], bv[TN];
+#pragma unroll
+                for (int i = 0; i < TK; i++) av[i] = xs[(kk * 2 + lh) * BKO + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bv[j] = ys[(kk * 2 + lh) * BN + j * 32];
+#pragma unroll
+                for (int i = 0; i < TK; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_tiles(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    float *out = a.out + (long long)split * a.K * a.N;
+#pragma unroll
+    for (int i = 0; i < TK; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= a.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = k0 + wk * WK + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < a.K) out[(long long)row * a.N + col] = acc[i][j][r];
+            }
+        }
+}
+
+struct Plan {
+    int bn, tiles_k, tiles_n, splits, rows_per_split;
+};
+
+Plan make_plan(const emadapt_conv_desc *d) {
+    Plan p;
+    const long long M = (long long)d->B * d->H * d->W;
+    const int K = d->KH * d->KW * d->Cin;
+    p.bn = d->Cout <= 64 ? 64 : 128;
+    p.tiles_k = (int)ceil_div(K, 128);
+    p.tiles_n = (int)ceil_div(d->Cout, p.bn);
+    const long long tiles = (long long)p.tiles_k * p.tiles_n;
+    long long splits = ceil_div(1024, tiles);           // aim for >= ~1024 workgroups (256 CUs x 2 x 2 waves of work)
+    const long long max_by_rows = ceil_div(M, 512);     // at least 512 pixels per split
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
+    if (splits > 2048) splits = 2048;
+    long long rps = ceil_div(M, splits);
+    rps = ceil_div(rps, BMR) * BMR;
+    p.rows_per_split = (int)rps;
+    p.splits = (int)ceil_div(M, rps);
+    return p;
+}
+
+int check_desc(const emadapt_conv_desc *d) {
+    if (!d) return EMADAPT_ERR_INVALID;
+    if (d->B < 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->dil <= 0)
+        return EMADAPT_ERR_INVALID;
+    if (d->Cin % 4 != 0 || d->Cout % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;
+    if ((long long)d->B * d->H * d->W >= (1LL << 30)) return EMADAPT_ERR_UNSUPPORTED;
+    return EMADAPT_OK;
+}
+
+template <int BN>
+int launch_wgrad(const WgradArgs &a, hipStream_t stream) {
+    constexpr size_t lds = sizeof(float) * 2 * BMR * (128 + BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<128, BN>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
+    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((wgrad_kernel<128, BN>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t emadapt_conv_wgrad_workspace_bytes(const emadapt_conv_desc *d) {
+    if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
+    const Plan p = make_plan(d);
+    if (p.splits <= 1) return 0;
+    return (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+}
+
+int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, void *workspace,
+                       size_t workspace_bytes, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !dy || !dw) return EMADAPT_ERR_INVALID;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dw) |
+         reinterpret_cast<uintptr_t>(workspace)) & 15)
+        return EMADAPT_ERR_INVALID;
+    hipStream_t stream = as_stream(stream_);
+    const long long KN = (long long)d->KH * d->KW * d->Cin * d->Cout;
+    if (d->B == 0) {
+        EMADAPT_HIP_TRY(hipMemsetAsync(dw, 0, KN * sizeof(float), stream));
+        return EMADAPT_OK;
+    }
+    const Plan p = make_plan(d);
+    if (p.splits > 1 && (!workspace || workspace_bytes < emadapt_conv_wgrad_workspace_bytes(d)))
+        return EMADAPT_ERR_WORKSPACE;
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.out = p.splits > 1 ? static_cast<float *>(workspace) : dw;
+    a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.N = d->Cout; a.KW = d->KW; a.dil = d->dil;
+    a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
+    a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cin;
+    a.tiles_k = p.tiles_k; a.tiles_n = p.tiles_n; a.splits = p.splits; a.rows_per_split = p.rows_per_split;
+    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    rc = (p.bn == 64) ? launch_wgrad<64>(a, stream) : launch_wgrad<128>(a, stream);
+    if (rc) return rc;
+    if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
+    return rc;
+}
+
+}  // extern "C"

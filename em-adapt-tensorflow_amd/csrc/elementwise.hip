@@ -1,0 +1,460 @@
+// HBM-bound kernels of the EM-Adapt step for gfx950: max-pool fwd/bwd, softmax cross-entropy
+// fwd+bwd, bias gradient, L2 loss, gradient accumulation + momentum update, channel padding.
+//
+// All tensors are NHWC fp32 with C % 4 == 0, so every thread moves 16 bytes per access
+// (global_load/store_dwordx4) and a wavefront covers 1 KiB of contiguous channels/pixels.
+// Reductions are two-stage with a fixed summation order (no float atomics): results are
+// bitwise reproducible run to run.
+#include <float.h>
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+using namespace emadapt;
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// ------------------------------------------------------------------------------------------
+// tf.nn.max_pool 3x3, SAME (deeplab.py:77,82)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float *__restrict__ x, int B, int H, int W, int C4,
+                                                        int stride, int OH, int OW, int pt, int pl,
+                                                        float *__restrict__ y, unsigned char *__restrict__ idx) {
+    const long long n = (long long)B * OH * OW * C4;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(t % C4);
+        long long r = t / C4;
+        const int ow = (int)(r % OW);
+        r /= OW;
+        const int oh = (int)(r % OH);
+        const int b = (int)(r / OH);
+        float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+        int bi0 = -1, bi1 = -1, bi2 = -1, bi3 = -1;
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const int h = oh * stride - pt + kh;
+            if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; kw++) {
+                const int w = ow * stride - pl + kw;
+                if ((unsigned)w >= (unsigned)W) continue;
+                const float4 v = ld4(x + (((long long)b * H + h) * W + w) * C4 * 4 + c4 * 4);
+                const int tap = kh * 3 + kw;
+                if (bi0 < 0 || v.x > best.x) { best.x = v.x; bi0 = tap; }
+                if (bi1 < 0 || v.y > best.y) { best.y = v.y; bi1 = tap; }
+                if (bi2 < 0 || v.z > best.z) { best.z = v.z; bi2 = tap; }
+                if (bi3 < 0 || v.w > best.w) { best.w = v.w; bi3 = tap; }
+            }
+        }
+        st4(y + t * 4, best);
+        if (idx) *reinterpret_cast<uchar4 *>(idx + t * 4) = make_uchar4(bi0, bi1, bi2, bi3);
+    }
+}
+
+// MaxPoolGrad (+ ReluGrad of the producing layer): gather form, one thread per input pixel x 4 channels.
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float *__restrict__ dy,
+                                                        const unsigned char *__restrict__ idx,
+                                                        const float *__restrict__ gate, int B, int H, int W, int C4,
+                                                        int stride, int OH, int OW, int pt, int pl,
+                                                        float *__restrict__ dx) {
+    const long long n = (long long)B * H * W * C4;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(t % C4);
+        long long r = t / C4;
+        const int w = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const int th = h + pt - kh;
+            if (th < 0 || th % stride != 0) continue;
+            const int oh = th / stride;
+            if (oh >= OH) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; kw++) {
+                const int tw = w + pl - kw;
+                if (tw < 0 || tw % stride != 0) continue;
+                const int ow = tw / stride;
+                if (ow >= OW) continue;
+                const long long o = ((((long long)b * OH + oh) * OW + ow) * C4 + c4) * 4;
+                const uchar4 id = *reinterpret_cast<const uchar4 *>(idx + o);
+                const float4 g = ld4(dy + o);
+                const int tap = kh * 3 + kw;
+                if (id.x == tap) acc.x += g.x;
+                if (id.y == tap) acc.y += g.y;
+                if (id.z == tap) acc.z += g.z;
+                if (id.w == tap) acc.w += g.w;
+            }
+        }
+        if (gate) {
+            const float4 a = ld4(gate + t * 4);
+            acc.x = a.x > 0.f ? acc.x : 0.f;
+            acc.y = a.y > 0.f ? acc.y : 0.f;
+            acc.z = a.z > 0.f ? acc.z : 0.f;
+            acc.w = a.w > 0.f ? acc.w : 0.f;
+        }
+        st4(dx + t * 4, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic deterministic reductions
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;
+}
+
+// out[0] = scale * sum(partials[0..n)) in index order chunks (single block).
+__global__ void __launch_bounds__(256) final_sum_kernel(const float *__restrict__ partials, int n, float scale,
+                                                      float *__restrict__ out) {
+    __shared__ float sh[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    v = block_sum_256(v, sh);
+    if (threadIdx.x == 0) out[0] = v * scale;
+}
+
+// BiasAddGrad stage 1: partial[chunk][n] = sum over the chunk's rows of dy[m][n].
+// block = 64 column-quads x 4 row lanes.
+__global__ void __launch_bounds__(256) bias_grad_partial_kernel(const float *__restrict__ dy, long long M, int N4,
+                                                              long long rows_per_chunk, float *__restrict__ partial) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + tx;
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk;
+    if (r1 > M) r1 = M;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < N4) {
+        for (long long r = r0 + ty; r < r1; r += 4) {
+            const float4 v = ld4(dy + (r * N4 + q) * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    __shared__ float4 sh[4][64];
+    sh[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && q < N4) {
+        float4 s = sh[0][tx];
+#pragma unroll
+        for (int j = 1; j < 4; j++) {
+            s.x += sh[j][tx].x; s.y += sh[j][tx].y; s.z += sh[j][tx].z; s.w += sh[j][tx].w;
+        }
+        st4(partial + ((long long)blockIdx.y * N4 + q) * 4, s);
+    }
+}
+
+// stage 2 (also used by the conv filter-gradient): out[i] = sum_s slab[s][i], s ascending.
+__global__ void __launch_bounds__(256) slab_sum_kernel(const float *__restrict__ slab, int nslab, long long n4,
+                                                     float *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        float4 s = ld4(slab + i * 4);
+        for (int k = 1; k < nslab; k++) {
+            const float4 v = ld4(slab + ((long long)k * n4 + i) * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        st4(out + i * 4, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// sparse softmax cross-entropy + gradient (deeplab.py:182); one thread per pixel row
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_ce_kernel(const float *__restrict__ logits, long long ldl,
+                                                       const long long *__restrict__ labels, long long M, int C,
+                                                       float grad_scale, float *__restrict__ dlogits,
+                                                       float *__restrict__ partial) {
+    __shared__ float sh[4];
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float loss = 0.f;
+    if (r < M) {
+        const float *p = logits + r * ldl;
+        float mx = p[0];
+        for (int c = 1; c < C; c++) mx = fmaxf(mx, p[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; c++) s += expf(p[c] - mx);
+        const long long lab = labels[r];
+        const float lse = logf(s);
+        if (lab >= 0 && lab < C) loss = lse - (p[lab] - mx);
+        if (dlogits) {
+            float *d = dlogits + r * ldl;
+            const float inv = 1.0f / s;
+            for (int c = 0; c < C; c++) {
+                const float sm = expf(p[c] - mx) * inv;
+                d[c] = (sm - (c == lab ? 1.f : 0.f)) * grad_scale;
+            }
+            for (int c = C; c < ldl; c++) d[c] = 0.f;
+        }
+    }
+    loss = block_sum_256(loss, sh);
+    if (threadIdx.x == 0 && partial) partial[blockIdx.x] = loss;
+}
+
+__global__ void __launch_bounds__(256) l2_partial_kernel(const float *__restrict__ x, long long n,
+                                                       float *__restrict__ partial) {
+    __shared__ float sh[4];
+    float v = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        v += x[i] * x[i];
+    v = block_sum_256(v, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// optimiser (deeplab.py:202-205)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sgd_accumulate_kernel(float *__restrict__ accum, const float *__restrict__ g,
+                                                           const float *__restrict__ w, long long n,
+                                                           long long n_decay, float wd, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (i < n_decay) gi = gi + wd * w[i];
+        accum[i] = accum[i] + gi * scale;
+    }
+}
+
+__global__ void __launch_bounds__(256) sgd_accumulate_kernel_v4(float *__restrict__ accum,
+                                                              const float *__restrict__ g,
+                                                              const float *__restrict__ w, long long n4,
+                                                              long long n_decay4, float wd, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        float4 gi = ld4(g + i * 4);
+        if (i < n_decay4) {
+            const float4 wi = ld4(w + i * 4);
+            gi.x = gi.x + wd * wi.x; gi.y = gi.y + wd * wi.y; gi.z = gi.z + wd * wi.z; gi.w = gi.w + wd * wi.w;
+        }
+        float4 a = ld4(accum + i * 4);
+        a.x = a.x + gi.x * scale; a.y = a.y + gi.y * scale; a.z = a.z + gi.z * scale; a.w = a.w + gi.w * scale;
+        st4(accum + i * 4, a);
+    }
+}
+
+__global__ void __launch_bounds__(256) sgd_momentum_kernel(float *__restrict__ w, float *__restrict__ v,
+                                                         float *__restrict__ accum, long long n, float lr, float mu,
+                                                         float ascale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float vi = mu * v[i] + accum[i] * ascale;
+        v[i] = vi;
+        w[i] = w[i] - lr * vi;
+        accum[i] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) sgd_momentum_kernel_v4(float *__restrict__ w, float *__restrict__ v,
+                                                            float *__restrict__ accum, long long n4, float lr,
+                                                            float mu, float ascale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = ld4(accum + i * 4);
+        float4 vi = ld4(v + i * 4);
+        float4 wi = ld4(w + i * 4);
+        vi.x = mu * vi.x + a.x * ascale; vi.y = mu * vi.y + a.y * ascale;
+        vi.z = mu * vi.z + a.z * ascale; vi.w = mu * vi.w + a.w * ascale;
+        wi.x = wi.x - lr * vi.x; wi.y = wi.y - lr * vi.y; wi.z = wi.z - lr * vi.z; wi.w = wi.w - lr * vi.w;
+        st4(v + i * 4, vi);
+        st4(w + i * 4, wi);
+        st4(accum + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
+__global__ void __launch_bounds__(256) copy_pad_kernel(const float *__restrict__ src, long long rows, int Cs,
+                                                     float *__restrict__ dst, int Cd) {
+    const long long n = rows * Cd;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / Cd;
+        const int c = (int)(i % Cd);
+        dst[i] = c < Cs ? src[r * Cs + c] : 0.f;
+    }
+}
+
+inline int grid_for(long long n, int block = 256, int cap = 2048) {
+    long long g = ceil_div(n, block);
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+void same_pad(int in, int stride, int *out, int *pad_before) {
+    *out = (in + stride - 1) / stride;
+    int total = (*out - 1) * stride + 3 - in;
+    if (total < 0) total = 0;
+    *pad_before = total / 2;
+}
+
+constexpr int kSumPartials = 1024;  // stage-1 blocks of the scalar reductions
+
+}  // namespace
+
+namespace emadapt {
+// used by conv_wgrad.hip
+int launch_slab_sum(const float *slab, int nslab, long long n, float *out, hipStream_t stream) {
+    if (n % 4 != 0) return EMADAPT_ERR_INVALID;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, slab, nslab, n / 4, out);
+    return launch_status();
+}
+}  // namespace emadapt
+
+extern "C" {
+
+int emadapt_maxpool_fwd(const float *x, int B, int H, int W, int C, int stride, float *y, uint8_t *idx,
+                        void *stream_) {
+    if (!x || !y || B < 0 || H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
+    if (C % 4 != 0 || (stride != 1 && stride != 2)) return EMADAPT_ERR_UNSUPPORTED;
+    if (!aligned16(x) || !aligned16(y)) return EMADAPT_ERR_INVALID;
+    if (B == 0) return EMADAPT_OK;
+    int OH, OW, pt, pl;
+    same_pad(H, stride, &OH, &pt);
+    same_pad(W, stride, &OW, &pl);
+    const long long n = (long long)B * OH * OW * (C / 4);
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)B * H * W * C * 4.0 + (double)n * 20.0, stream);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W, C / 4,
+                       stride, OH, OW, pt, pl, y, idx);
+    return launch_status();
+}
+
+int emadapt_maxpool_bwd(const float *dy, const uint8_t *idx, const float *gate, int B, int H, int W, int C,
+                        int stride, float *dx, void *stream_) {
+    if (!dy || !idx || !dx || B < 0 || H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
+    if (C % 4 != 0 || (stride != 1 && stride != 2)) return EMADAPT_ERR_UNSUPPORTED;
+    if (B == 0) return EMADAPT_OK;
+    int OH, OW, pt, pl;
+    same_pad(H, stride, &OH, &pt);
+    same_pad(W, stride, &OW, &pl);
+    const long long n = (long long)B * H * W * (C / 4);
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 16.0 * (gate ? 2.0 : 1.0) + (double)B * OH * OW * C * 5.0, stream);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, dy, idx, gate, B, H,
+                       W, C / 4, stride, OH, OW, pt, pl, dx);
+    return launch_status();
+}
+
+size_t emadapt_bias_grad_workspace_bytes(int64_t M, int N) {
+    (void)M;
+    return (size_t)256 * (size_t)(N > 0 ? N : 0) * sizeof(float) + 256;
+}
+
+int emadapt_bias_grad(const float *dy, int64_t M, int N, float *db, void *workspace, size_t workspace_bytes,
+                      void *stream_) {
+    if (!dy || !db || M <= 0 || N <= 0) return EMADAPT_ERR_INVALID;
+    if (N % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < emadapt_bias_grad_workspace_bytes(M, N)) return EMADAPT_ERR_WORKSPACE;
+    const int N4 = N / 4;
+    const int gx = (int)ceil_div(N4, 64);
+    long long chunks = 1024 / gx;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 256) chunks = 256;
+    long long rows_per_chunk = ceil_div(M, chunks);
+    if (rows_per_chunk < 16) rows_per_chunk = 16;
+    chunks = ceil_div(M, rows_per_chunk);
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)M * N * 4.0, stream);
+    float *partial = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(gx, (unsigned)chunks), dim3(256), 0, stream, dy, (long long)M,
+                       N4, rows_per_chunk, partial);
+    int rc = launch_status();
+    if (rc) return rc;
+    return launch_slab_sum(partial, (int)chunks, N, db, stream);
+}
+
+size_t emadapt_softmax_ce_workspace_bytes(int64_t M) { return (size_t)(ceil_div(M > 0 ? M : 1, 256)) * 4 + 256; }
+
+int emadapt_softmax_ce(const float *logits, int64_t ldl, const int64_t *labels, int64_t M, int C, float grad_scale,
+                       float *dlogits, float *loss_sum, void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!logits || !labels || M <= 0 || C <= 0 || ldl < C) return EMADAPT_ERR_INVALID;
+    if (loss_sum && (!workspace || workspace_bytes < emadapt_softmax_ce_workspace_bytes(M)))
+        return EMADAPT_ERR_WORKSPACE;
+    const int grid = (int)ceil_div(M, 256);
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)M * (ldl * 8.0 + 8.0), stream);
+    float *partial = loss_sum ? static_cast<float *>(workspace) : nullptr;
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(grid), dim3(256), 0, stream, logits, (long long)ldl,
+                       reinterpret_cast<const long long *>(labels), (long long)M, C, grad_scale, dlogits, partial);
+    int rc = launch_status();
+    if (rc || !loss_sum) return rc;
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, stream, partial, grid, 1.0f, loss_sum);
+    return launch_status();
+}
+
+size_t emadapt_l2_loss_workspace_bytes(int64_t n) {
+    (void)n;
+    return kSumPartials * sizeof(float);
+}
+
+int emadapt_l2_loss(const float *x, int64_t n, float *out, void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!x || !out || n < 0) return EMADAPT_ERR_INVALID;
+    if (!workspace || workspace_bytes < emadapt_l2_loss_workspace_bytes(n)) return EMADAPT_ERR_WORKSPACE;
+    hipStream_t stream = as_stream(stream_);
+    const int grid = grid_for(n, 256, kSumPartials);
+    float *partial = static_cast<float *>(workspace);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 4.0, stream);
+    hipLaunchKernelGGL(l2_partial_kernel, dim3(grid), dim3(256), 0, stream, x, (long long)n, partial);
+    int rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, stream, partial, grid, 0.5f, out);
+    return launch_status();
+}
+
+int emadapt_sgd_accumulate(float *accum, const float *g, const float *w, int64_t n, int64_t n_decay,
+                           float weight_decay, float scale, void *stream_) {
+    if (!accum || !g || n < 0 || n_decay < 0 || n_decay > n) return EMADAPT_ERR_INVALID;
+    if (n_decay > 0 && !w) return EMADAPT_ERR_INVALID;
+    if (n == 0) return EMADAPT_OK;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 12.0 + (double)n_decay * 4.0, stream);
+    if (n % 4 == 0 && n_decay % 4 == 0 && aligned16(accum) && aligned16(g) && (!w || aligned16(w))) {
+        hipLaunchKernelGGL(sgd_accumulate_kernel_v4, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, accum, g,
+                           w, (long long)(n / 4), (long long)(n_decay / 4), weight_decay, scale);
+    } else {
+        hipLaunchKernelGGL(sgd_accumulate_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, accum, g, w,
+                           (long long)n, (long long)n_decay, weight_decay, scale);
+    }
+    return launch_status();
+}
+
+int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, float momentum, float accum_scale,
+                         void *stream_) {
+    if (!w || !v || !accum || n < 0) return EMADAPT_ERR_INVALID;
+    if (n == 0) return EMADAPT_OK;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 24.0, stream);
+    if (n % 4 == 0 && aligned16(w) && aligned16(v) && aligned16(accum)) {
+        hipLaunchKernelGGL(sgd_momentum_kernel_v4, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, w, v, accum,
+                           (long long)(n / 4), lr, momentum, accum_scale);
+    } else {
+        hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, w, v, accum,
+                           (long long)n, lr, momentum, accum_scale);
+    }
+    return launch_status();
+}
+
+int emadapt_copy_pad_channels(const float *src, int64_t rows, int Csrc, float *dst, int Cdst, void *stream_) {
+    if (!src || !dst || rows < 0 || Csrc <= 0 || Cdst <= 0) return EMADAPT_ERR_INVALID;
+    if (rows == 0) return EMADAPT_OK;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)rows * (Csrc + Cdst) * 4.0, stream);
+    hipLaunchKernelGGL(copy_pad_kernel, dim3(grid_for(rows * Cdst, 256, 8192)), dim3(256), 0, stream, src,
+                       (long long)rows, Csrc, dst, Cdst);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,619 @@
+// E-step (weak-label assignment) for gfx950.
+//
+// Replaces the reference's estep.py:33-84 (estep_py) + tf.argmax (deeplab.py:123) and the native
+// entry estep/weaklabel.cpp:7-124.  One 256-thread workgroup per image:
+//
+//   * every thread owns the pixels  i = tid + 256*e  (e < EPT): their running per-pixel maximum
+//     stays in registers, the channels of the classes present in the image stay in LDS
+//     ([slot][pixel], conflict-free for the pixel-strided access), so one (iteration, class) step
+//     never touches HBM;
+//   * the k-th smallest of (max - channel) -- np.partition in the reference -- is found exactly by a
+//     bitwise binary search on the raw IEEE bits (order-preserving for the non-negative differences):
+//     31 rounds of "count keys < candidate" done with wavefront ballots + s_bcnt1 (scalar pipe, no
+//     cross-lane shuffles) and one LDS word per wave per round; no sorting, no atomics;
+//   * arithmetic is fp32 add / sub / compare only, in the reference's order, and the two np.mean()
+//     calls follow NumPy's pairwise summation tree, so label maps AND float maps are bit-identical;
+//   * the class visiting order (random.shuffle in the reference) is an input.
+//
+// Traffic: logits are read from HBM once (the second pass of the suppress step hits L1/L2), the
+// int64 label map is written once; the float map is written only when the caller asks for it.
+#include <float.h>
+#include <math.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+using namespace emadapt;
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxC = 256;       // classes
+constexpr int kMaxLeaves = 192;  // leaves of NumPy's pairwise-sum tree for HW <= 8192
+constexpr int kMaxEPT = 32;      // pixels per thread -> HW <= 8192
+constexpr size_t kLdsBudget = 160 * 1024;
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// Batch-global maximum of the logits (np.amax(feature_map), estep.py:50) as an order-preserving key.
+__global__ void __launch_bounds__(256) estep_gmax_kernel(const float *__restrict__ logits, long long rows,
+                                                       int C, long long ldl, unsigned *out) {
+    float m = -INFINITY;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows;
+         r += (long long)gridDim.x * blockDim.x) {
+        const float *p = logits + r * ldl;
+        for (int c = 0; c < C; c++) m = fmaxf(m, p[c]);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        atomicMax(out, f2key(m));
+    }
+}
+
+struct EstepArgs {
+    const float *logits;
+    long long ldl;
+    const void *label;
+    int label_kind;
+    long long label_len;
+    const int *perms;
+    int HW, C, suppress, num_iter;
+    float margin;
+    int k_bg, k_fg;
+    const unsigned *gmax_key;
+    float *map_out;
+    long long *labels_out;
+    int p_res;  // present-channel slots resident in LDS
+    int hwp;    // HW rounded up to a multiple of 4 (LDS row pitch)
+};
+
+// One leaf (n <= 128) of NumPy's float32 pairwise summation.
+__device__ float np_leaf_sum(const float *a, int n) {
+    if (n < 8) {
+        float r = 0.f;
+        for (int i = 0; i < n; i++) r = r + a[i];
+        return r;
+    }
+    float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    const int lim = n - (n % 8);
+    for (; i < lim; i += 8) {
+        r0 = r0 + a[i + 0];
+        r1 = r1 + a[i + 1];
+        r2 = r2 + a[i + 2];
+        r3 = r3 + a[i + 3];
+        r4 = r4 + a[i + 4];
+        r5 = r5 + a[i + 5];
+        r6 = r6 + a[i + 6];
+        r7 = r7 + a[i + 7];
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res = res + a[i];
+    return res;
+}
+
+struct Lds {
+    float *mx;        // [hwp]
+    float *chan;      // [p_res][hwp]
+    int *slot;        // [kMaxC]  class -> slot (or -1)
+    int *red;         // [2][kWaves]
+    float *leafsum;   // [kMaxLeaves]
+    int *leaf_off;    // [kMaxLeaves]
+    int *leaf_n;      // [kMaxLeaves]
+    int *stk;         // [3][16]
+    unsigned char *prog;  // [2*kMaxLeaves]  0 = push next leaf, 1 = add
+    int *misc;        // [0]=P [1]=nleaf [2]=nprog
+    float *scal;      // [0]=shift
+};
+
+__device__ __forceinline__ Lds carve(char *base, int hwp, int p_res) {
+    Lds l;
+    l.mx = reinterpret_cast<float *>(base);
+    l.chan = l.mx + hwp;
+    l.slot = reinterpret_cast<int *>(l.chan + (size_t)p_res * hwp);
+    l.red = l.slot + kMaxC;
+    l.leafsum = reinterpret_cast<float *>(l.red + 2 * kWaves);
+    l.leaf_off = reinterpret_cast<int *>(l.leafsum + kMaxLeaves);
+    l.leaf_n = l.leaf_off + kMaxLeaves;
+    l.stk = l.leaf_n + kMaxLeaves;
+    l.misc = l.stk + 48;
+    l.scal = reinterpret_cast<float *>(l.misc + 4);
+    l.prog = reinterpret_cast<unsigned char *>(l.scal + 4);
+    return l;
+}
+
+size_t lds_bytes(int hwp, int p_res) {
+    return sizeof(float) * ((size_t)hwp + (size_t)p_res * hwp) + sizeof(int) * (kMaxC + 2 * kWaves) +
+           sizeof(float) * kMaxLeaves + sizeof(int) * (2 * kMaxLeaves + 48 + 4) + sizeof(float) * 4 +
+           2 * kMaxLeaves;
+}
+
+// np.mean over l.mx[0..HW): leaves in parallel, then the combine program on thread 0.
+// Every thread must call; the result is valid on thread 0 only.
+__device__ float np_mean_lds(const Lds &l, int HW, int tid) {
+    const int nleaf = l.misc[1];
+    if (tid < nleaf) l.leafsum[tid] = np_leaf_sum(l.mx + l.leaf_off[tid], l.leaf_n[tid]);
+    __syncthreads();
+    float res = 0.f;
+    if (tid == 0) {
+        float st[16];
+        int sp = 0, next = 0;
+        const int nprog = l.misc[2];
+        for (int p = 0; p < nprog; p++) {
+            if (l.prog[p] == 0) {
+                st[sp++] = l.leafsum[next++];
+            } else {
+                float b = st[--sp];
+                float a = st[--sp];
+                st[sp++] = a + b;
+            }
+        }
+        res = __fdiv_rn(st[0], (float)HW);
+    }
+    return res;
+}
+
+template <int EPT>
+__global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Lds l = carve(smem, a.hwp, a.p_res);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int HW = a.HW, C = a.C, hwp = a.hwp, p_res = a.p_res;
+
+    // ---- image-level label set (estep.py:35-44) ----
+    for (int c = tid; c < kMaxC; c += kThreads) l.slot[c] = 0;
+    __syncthreads();
+    if (a.label_kind == EMADAPT_LABEL_MULTIHOT) {
+        const unsigned char *mh = static_cast<const unsigned char *>(a.label) + (size_t)b * C;
+        for (int c = tid; c < C; c += kThreads)
+            if (mh[c]) l.slot[c] = 1;
+    } else if (a.label_kind == EMADAPT_LABEL_F32) {
+        const float *lab = static_cast<const float *>(a.label) + (size_t)b * a.label_len;
+        for (long long i = tid; i < a.label_len; i += kThreads) {
+            int v = (int)(unsigned char)(int)lab[i];  // label.astype(np.uint8)
+            if (v < C) l.slot[v] = 1;
+        }
+    } else {
+        const int *lab = static_cast<const int *>(a.label) + (size_t)b * a.label_len;
+        for (long long i = tid; i < a.label_len; i += kThreads) {
+            int v = (int)(unsigned char)lab[i];
+            if (v < C) l.slot[v] = 1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int P = 0;
+        for (int c = 0; c < C; c++) l.slot[c] = l.slot[c] ? P++ : -1;
+        l.misc[0] = P;
+        // NumPy pairwise-sum tree for n = HW: leaves + post-order combine program.
+        int nleaf = 0, nprog = 0, sp = 0;
+        int *s_off = l.stk, *s_n = l.stk + 16, *s_st = l.stk + 32;
+        s_off[0] = 0; s_n[0] = HW; s_st[0] = 0; sp = 1;
+        while (sp > 0) {
+            const int off = s_off[sp - 1], n = s_n[sp - 1], st = s_st[sp - 1];
+            if (n <= 128) {
+                l.leaf_off[nleaf] = off; l.leaf_n[nleaf] = n; nleaf++;
+                l.prog[nprog++] = 0;
+                sp--;
+            } else {
+                int n2 = n / 2;
+                n2 -= n2 % 8;
+                if (st == 0) {
+                    s_st[sp - 1] = 1;
+                    s_off[sp] = off; s_n[sp] = n2; s_st[sp] = 0; sp++;
+                } else if (st == 1) {
+                    s_st[sp - 1] = 2;
+                    s_off[sp] = off + n2; s_n[sp] = n - n2; s_st[sp] = 0; sp++;
+                } else {
+                    l.prog[nprog++] = 1;
+                    sp--;
+                }
+            }
+        }
+        l.misc[1] = nleaf;
+        l.misc[2] = nprog;
+    }
+    __syncthreads();
+
+    const float gmax = a.suppress ? key2f(*a.gmax_key) : 0.f;
+    const bool suppress = a.suppress != 0;
+    float mx[EPT];
+
+    // ---- suppress absent classes (estep.py:46-55), per-pixel max, present channels -> LDS ----
+#pragma unroll 1
+    for (int e = 0; e < EPT; e++) {
+        const int i = tid + e * kThreads;
+        if (i < HW) {
+            const size_t row = (size_t)b * HW + i;
+            const float *p = a.logits + row * a.ldl;
+            float m = FLT_MAX;
+            if (suppress) {
+                for (int c = 0; c < C; c++) {
+                    const float v = p[c];
+                    const float t = (l.slot[c] >= 0) ? v : v + gmax;
+                    m = (t < m) ? t : m;
+                }
+            }
+            const float repl = m - a.margin;
+            float mxv = 0.f;
+            for (int c = 0; c < C; c++) {
+                float v = p[c];
+                const int s = l.slot[c];
+                if (suppress && s < 0 && v > m) v = repl;
+                mxv = (c == 0 || v > mxv) ? v : mxv;
+                if (s >= 0 && s < p_res) l.chan[(size_t)s * hwp + i] = v;
+                else if (a.map_out) a.map_out[row * C + c] = v;
+            }
+            l.mx[i] = mxv;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {  // running max of the thread's own pixels -> registers
+        const int i = tid + e * kThreads;
+        mx[e] = (i < HW) ? l.mx[i] : 0.f;
+    }
+    __syncthreads();
+    const float mean0 = np_mean_lds(l, HW, tid);  // estep.py:56 (thread 0 holds it)
+
+    // ---- num_iter sweeps over the classes in the given order (estep.py:62-79) ----
+    int par = 0;
+    for (int it = 0; it < a.num_iter; it++) {
+        for (int q = 0; q < C; q++) {
+            const int j = (q == 0) ? 0 : a.perms[(size_t)it * (C - 1) + (q - 1)];
+            if ((unsigned)j >= (unsigned)C) continue;
+            const int s = l.slot[j];
+            if (s < 0) continue;
+            const int k = (j == 0) ? a.k_bg : a.k_fg;
+            const bool in_lds = s < p_res;
+            float *gch = a.map_out + (size_t)b * HW * C + j;  // non-resident channel lives in map_out
+
+            unsigned key[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int i = tid + e * kThreads;
+                key[e] = 0xFFFFFFFFu;
+                if (i < HW) {
+                    const float ch = in_lds ? l.chan[(size_t)s * hwp + i] : gch[(size_t)i * C];
+                    key[e] = __float_as_uint(mx[e] - ch);  // >= +0: raw bits are order-preserving
+                }
+            }
+            // k-th smallest key (0-indexed): largest r with #(key < r) <= k.
+            unsigned res = 0;
+            for (int bit = 30; bit >= 0; bit--) {
+                const unsigned cand = res | (1u << bit);
+                int cnt = 0;
+#pragma unroll
+                for (int e = 0; e < EPT; e++) cnt += __popcll(__ballot(key[e] < cand));
+                if (lane == 0) l.red[par * kWaves + wave] = cnt;
+                __syncthreads();
+                const int tot = l.red[par * kWaves + 0] + l.red[par * kWaves + 1] +
+                                l.red[par * kWaves + 2] + l.red[par * kWaves + 3];
+                par ^= 1;
+                if (tot <= k) res = cand;
+            }
+            const float t = __uint_as_float(res);
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int i = tid + e * kThreads;
+                if (i < HW) {
+                    float *pc = in_lds ? &l.chan[(size_t)s * hwp + i] : &gch[(size_t)i * C];
+                    const float v = *pc + t;
+                    *pc = v;
+                    mx[e] = (v > mx[e]) ? v : mx[e];
+                }
+            }
+        }
+    }
+
+    // ---- re-centre (estep.py:80-82) and argmax (deeplab.py:123) ----
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int i = tid + e * kThreads;
+        if (i < HW) l.mx[i] = mx[e];
+    }
+    __syncthreads();
+    const float mean1 = np_mean_lds(l, HW, tid);
+    if (tid == 0) l.scal[0] = mean0 - mean1;
+    __syncthreads();
+    const float shift = l.scal[0];
+
+#pragma unroll 1
+    for (int e = 0; e < EPT; e++) {
+        const int i = tid + e * kThreads;
+        if (i < HW) {
+            const size_t row = (size_t)b * HW + i;
+            const float *p = a.logits + row * a.ldl;
+            float m = FLT_MAX;
+            if (suppress && !a.map_out) {
+                for (int c = 0; c < C; c++) {
+                    const float v = p[c];
+                    const float t = (l.slot[c] >= 0) ? v : v + gmax;
+                    m = (t < m) ? t : m;
+                }
+            }
+            const float repl = m - a.margin;
+            int best = 0;
+            float bv = 0.f;
+            for (int c = 0; c < C; c++) {
+                const int s = l.slot[c];
+                float v;
+                if (s >= 0 && s < p_res) v = l.chan[(size_t)s * hwp + i];
+                else if (a.map_out) v = a.map_out[row * C + c];
+                else {
+                    v = p[c];
+                    if (suppress && s < 0 && v > m) v = repl;
+                }
+                v = v + shift;
+                if (a.map_out) a.map_out[row * C + c] = v;
+                if (c == 0 || v > bv) { bv = v; best = c; }
+            }
+            a.labels_out[row] = best;
+        }
+    }
+}
+
+template <int EPT>
+int launch_estep(const EstepArgs &a, int B, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&estep_kernel<EPT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(estep_kernel<EPT>, dim3(B), dim3(kThreads), lds, stream, a);
+    return launch_status();
+}
+
+int choose_p_res(int hwp, int C) {
+    const size_t fixed = lds_bytes(hwp, 0);
+    if (fixed >= kLdsBudget) return -1;
+    size_t p = (kLdsBudget - fixed) / (sizeof(float) * (size_t)hwp);
+    if (p > (size_t)C) p = C;
+    return (int)p;
+}
+
+__global__ void resize_nearest_kernel(const float *__restrict__ in, int B, int H, int W, float *__restrict__ out,
+                                      int oh, int ow, float hs, float ws) {
+    const long long n = (long long)B * oh * ow;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % ow);
+        const int y = (int)((idx / ow) % oh);
+        const int b = (int)(idx / ((long long)ow * oh));
+        int sy = (int)floorf((float)y * hs);
+        int sx = (int)floorf((float)x * ws);
+        sy = sy < H - 1 ? sy : H - 1;
+        sx = sx < W - 1 ? sx : W - 1;
+        out[idx] = in[((long long)b * H + sy) * W + sx];
+    }
+}
+
+std::mutex g_seed_mu;
+uint64_t g_seed_state = 0x9E3779B97F4A7C15ull;
+
+uint64_t splitmix64(uint64_t &s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t emadapt_estep_workspace_bytes(int B, int H, int W, int C) {
+    (void)B; (void)H; (void)W; (void)C;
+    return 256;  // batch-max key (+ padding)
+}
+
+int emadapt_estep_needs_map(int H, int W, int C) {
+    if (H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
+    const long long HW = (long long)H * W;
+    if (HW > (long long)kThreads * kMaxEPT || C > kMaxC) return EMADAPT_ERR_UNSUPPORTED;
+    const int p_res = choose_p_res((int)((HW + 3) / 4 * 4), C);
+    if (p_res < 0) return EMADAPT_ERR_UNSUPPORTED;
+    return p_res < C ? 1 : 0;
+}
+
+int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label_kind, int64_t label_len,
+                  const int32_t *perms, int B, int H, int W, int C, int suppress_others, int num_iter,
+                  float margin_others, int k_bg, int k_fg, float *map_out, int64_t *labels_out,
+                  void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = as_stream(stream_);
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || num_iter < 0) return EMADAPT_ERR_INVALID;
+    if (B == 0) return EMADAPT_OK;
+    if (!logits || !label || !labels_out || ldl < C) return EMADAPT_ERR_INVALID;
+    if (num_iter > 0 && C > 1 && !perms) return EMADAPT_ERR_INVALID;
+    if (label_kind < 0 || label_kind > 2) return EMADAPT_ERR_INVALID;
+    if (label_kind != EMADAPT_LABEL_MULTIHOT && label_len < 0) return EMADAPT_ERR_INVALID;
+    const long long HW = (long long)H * W;
+    if (HW > (long long)kThreads * kMaxEPT || C > kMaxC) return EMADAPT_ERR_UNSUPPORTED;
+    if (num_iter > 0 && (k_bg < 0 || k_bg >= HW || k_fg < 0 || k_fg >= HW)) return EMADAPT_ERR_INVALID;
+    if (!workspace || workspace_bytes < emadapt_estep_workspace_bytes(B, H, W, C)) return EMADAPT_ERR_WORKSPACE;
+
+    const int hwp = (int)((HW + 3) / 4 * 4);
+    const int p_res = choose_p_res(hwp, C);
+    if (p_res < 0) return EMADAPT_ERR_UNSUPPORTED;
+    if (p_res < C && !map_out) return EMADAPT_ERR_WORKSPACE;  // more classes may be present than fit in LDS
+
+    unsigned *gkey = static_cast<unsigned *>(workspace);
+    const double bytes = (double)B * HW * (C * 4.0 + 8.0) + (map_out ? (double)B * HW * C * 4.0 : 0.0);
+    ProfScope prof(EMADAPT_K_ESTEP, 0.0, bytes, stream);
+    if (suppress_others) {
+        EMADAPT_HIP_TRY(hipMemsetAsync(gkey, 0, 16, stream));
+        const long long rows = (long long)B * HW;
+        int grid = (int)ceil_div(rows, 256);
+        if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(estep_gmax_kernel, dim3(grid), dim3(256), 0, stream, logits, rows, C, (long long)ldl, gkey);
+        int rc = launch_status();
+        if (rc) return rc;
+    }
+    EstepArgs a;
+    a.logits = logits; a.ldl = ldl; a.label = label; a.label_kind = label_kind; a.label_len = label_len;
+    a.perms = perms; a.HW = (int)HW; a.C = C; a.suppress = suppress_others ? 1 : 0; a.num_iter = num_iter;
+    a.margin = margin_others; a.k_bg = k_bg; a.k_fg = k_fg; a.gmax_key = gkey; a.map_out = map_out;
+    a.labels_out = reinterpret_cast<long long *>(labels_out); a.p_res = p_res; a.hwp = hwp;
+    const size_t lds = align_up(lds_bytes(hwp, p_res), 16);
+    const int ept = (int)ceil_div(HW, kThreads);
+    if (ept <= 1) return launch_estep<1>(a, B, lds, stream);
+    if (ept <= 7) return launch_estep<7>(a, B, lds, stream);   // 41x41 = 1681 (321x321 input)
+    if (ept <= 17) return launch_estep<17>(a, B, lds, stream); // 65x65 = 4225 (513x513 input)
+    return launch_estep<32>(a, B, lds, stream);
+}
+
+int emadapt_resize_nearest(const float *in, int B, int H, int W, float *out, int oh, int ow, void *stream_) {
+    if (!in || !out || B < 0 || H <= 0 || W <= 0 || oh <= 0 || ow <= 0) return EMADAPT_ERR_INVALID;
+    if (B == 0) return EMADAPT_OK;
+    const long long n = (long long)B * oh * ow;
+    int grid = (int)ceil_div(n, 256);
+    if (grid > 2048) grid = 2048;
+    const float hs = (float)H / (float)oh, ws = (float)W / (float)ow;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 8.0, stream);
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid), dim3(256), 0, stream, in, B, H, W, out, oh, ow, hs, ws);
+    return launch_status();
+}
+
+int emadapt_estep_host(float *map, int B, int H, int W, int C, const void *label, int label_kind,
+                       int64_t label_len, const int32_t *perms, int suppress_others, int num_iter,
+                       float margin_others, int k_bg, int k_fg, int64_t *labels_out) {
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
+    if (B == 0) return EMADAPT_OK;
+    if (!map || !label) return EMADAPT_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return EMADAPT_ERR_NODEVICE;
+    const size_t HW = (size_t)H * W;
+    const size_t n_map = (size_t)B * HW * C;
+    const size_t lab_elems = (label_kind == EMADAPT_LABEL_MULTIHOT) ? (size_t)B * C : (size_t)B * label_len;
+    const size_t lab_bytes = lab_elems * (label_kind == EMADAPT_LABEL_MULTIHOT ? 1 : 4);
+    const size_t perm_elems = (size_t)(num_iter > 0 ? num_iter : 0) * (size_t)(C > 1 ? C - 1 : 0);
+    const size_t ws_bytes = emadapt_estep_workspace_bytes(B, H, W, C);
+
+    float *d_in = nullptr, *d_map = nullptr;
+    void *d_lab = nullptr, *d_ws = nullptr;
+    int32_t *d_perm = nullptr;
+    int64_t *d_out = nullptr;
+    int rc = EMADAPT_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_in); (void)hipFree(d_map); (void)hipFree(d_lab);
+        (void)hipFree(d_ws); (void)hipFree(d_perm); (void)hipFree(d_out);
+    };
+#define TRY_OR_CLEAN(expr)                          \
+    do {                                            \
+        hipError_t _e = (expr);                     \
+        if (_e != hipSuccess) {                     \
+            cleanup();                              \
+            return ::emadapt::hip_fail(_e);         \
+        }                                           \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc(&d_in, n_map * 4));
+    TRY_OR_CLEAN(hipMalloc(&d_map, n_map * 4));
+    TRY_OR_CLEAN(hipMalloc(&d_lab, lab_bytes ? lab_bytes : 4));
+    TRY_OR_CLEAN(hipMalloc(&d_ws, ws_bytes));
+    TRY_OR_CLEAN(hipMalloc(&d_perm, perm_elems ? perm_elems * 4 : 4));
+    TRY_OR_CLEAN(hipMalloc(&d_out, (size_t)B * HW * 8));
+    TRY_OR_CLEAN(hipMemcpy(d_in, map, n_map * 4, hipMemcpyHostToDevice));
+    if (lab_bytes) TRY_OR_CLEAN(hipMemcpy(d_lab, label, lab_bytes, hipMemcpyHostToDevice));
+    if (perm_elems) {
+        if (!perms) { cleanup(); return EMADAPT_ERR_INVALID; }
+        TRY_OR_CLEAN(hipMemcpy(d_perm, perms, perm_elems * 4, hipMemcpyHostToDevice));
+    }
+    rc = emadapt_estep(d_in, C, d_lab, label_kind, label_len, d_perm, B, H, W, C, suppress_others, num_iter,
+                       margin_others, k_bg, k_fg, d_map, d_out, d_ws, ws_bytes, nullptr);
+    if (rc == EMADAPT_OK) {
+        TRY_OR_CLEAN(hipDeviceSynchronize());
+        TRY_OR_CLEAN(hipMemcpy(map, d_map, n_map * 4, hipMemcpyDeviceToHost));
+        if (labels_out) TRY_OR_CLEAN(hipMemcpy(labels_out, d_out, (size_t)B * HW * 8, hipMemcpyDeviceToHost));
+    }
+#undef TRY_OR_CLEAN
+    cleanup();
+    return rc;
+}
+
+void emadapt_estep_seed(uint64_t seed) {
+    std::lock_guard<std::mutex> lk(g_seed_mu);
+    g_seed_state = seed ^ 0x9E3779B97F4A7C15ull;
+}
+
+float *e_step_perm(float *map, const int *shape, const int *stride, const int *label, const int *perms,
+                   const bool suppress_others, const int num_iter, const float margin_others, float bg, float fg) {
+    if (!map || !shape || !stride || !label) return nullptr;
+    const int B = shape[0], H = shape[1], W = shape[2], C = shape[3];
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0) return nullptr;
+    const size_t HW = (size_t)H * W;
+    // thresholds as the native reference computes them (weaklabel.cpp:88): float * int, truncated
+    const int k_bg = (int)(bg * (float)(int)HW);
+    const int k_fg = (int)(fg * (float)(int)HW);
+    // gather to a contiguous [B,H,W,C] staging copy honouring the byte strides (estep.py:30)
+    const bool contiguous = stride[3] == 4 && stride[2] == 4 * C && stride[1] == 4 * C * W &&
+                            stride[0] == (long long)4 * C * W * H;
+    std::vector<float> staging;
+    float *buf = map;
+    if (!contiguous) {
+        staging.resize((size_t)B * HW * C);
+        const char *base = reinterpret_cast<const char *>(map);
+        for (int b = 0; b < B; b++)
+            for (int h = 0; h < H; h++)
+                for (int w = 0; w < W; w++)
+                    for (int c = 0; c < C; c++)
+                        staging[(((size_t)b * H + h) * W + w) * C + c] = *reinterpret_cast<const float *>(
+                            base + (ptrdiff_t)b * stride[0] + (ptrdiff_t)h * stride[1] + (ptrdiff_t)w * stride[2] +
+                            (ptrdiff_t)c * stride[3]);
+        buf = staging.data();
+    }
+    int rc = emadapt_estep_host(buf, B, H, W, C, label, EMADAPT_LABEL_I32, (int64_t)HW, perms, suppress_others,
+                                num_iter, margin_others, k_bg, k_fg, nullptr);
+    if (rc != EMADAPT_OK) return nullptr;
+    if (!contiguous) {
+        char *base = reinterpret_cast<char *>(map);
+        for (int b = 0; b < B; b++)
+            for (int h = 0; h < H; h++)
+                for (int w = 0; w < W; w++)
+                    for (int c = 0; c < C; c++)
+                        *reinterpret_cast<float *>(base + (ptrdiff_t)b * stride[0] + (ptrdiff_t)h * stride[1] +
+                                                   (ptrdiff_t)w * stride[2] + (ptrdiff_t)c * stride[3]) =
+                            staging[(((size_t)b * H + h) * W + w) * C + c];
+    }
+    return map;
+}
+
+float *e_step(float *map, const int *shape, const int *stride, const int *label, const bool suppress_others,
+              const int num_iter, const float margin_others, float bg, float fg) {
+    if (!shape) return nullptr;
+    const int C = shape[3];
+    std::vector<int> perms;
+    if (num_iter > 0 && C > 1) {
+        perms.resize((size_t)num_iter * (C - 1));
+        std::lock_guard<std::mutex> lk(g_seed_mu);
+        for (int it = 0; it < num_iter; it++) {
+            int *p = perms.data() + (size_t)it * (C - 1);
+            for (int c = 0; c < C - 1; c++) p[c] = c + 1;
+            for (int i = C - 2; i > 0; i--) {  // Fisher-Yates
+                const int j = (int)(splitmix64(g_seed_state) % (uint64_t)(i + 1));
+                const int t = p[i]; p[i] = p[j]; p[j] = t;
+            }
+        }
+    }
+    return e_step_perm(map, shape, stride, label, perms.empty() ? nullptr : perms.data(), suppress_others, num_iter,
+                       margin_others, bg, fg);
+}
+
+}  // extern "C"

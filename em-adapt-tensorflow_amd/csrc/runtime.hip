@@ -1,0 +1,112 @@
+// Library-level entry points: version, error strings, event-based per-kernel timing.
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace emadapt {
+
+thread_local int g_last_hip_error = 0;
+
+namespace {
+struct ProfRec {
+    int kind;
+    double flops, bytes;
+    hipEvent_t start, stop;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec *> g_prof_recs;
+std::vector<ProfRec *> g_prof_free;
+}  // namespace
+
+ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t stream)
+    : kind_(kind), stream_(stream), rec_(nullptr) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec *r;
+    if (!g_prof_free.empty()) {
+        r = g_prof_free.back();
+        g_prof_free.pop_back();
+    } else {
+        r = new ProfRec();
+        if (hipEventCreate(&r->start) != hipSuccess || hipEventCreate(&r->stop) != hipSuccess) {
+            delete r;
+            return;
+        }
+    }
+    r->kind = kind;
+    r->flops = flops;
+    r->bytes = bytes;
+    (void)hipEventRecord(r->start, stream);
+    rec_ = r;
+}
+
+ProfScope::~ProfScope() {
+    if (!rec_) return;
+    ProfRec *r = static_cast<ProfRec *>(rec_);
+    (void)hipEventRecord(r->stop, stream_);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_recs.push_back(r);
+}
+
+}  // namespace emadapt
+
+using namespace emadapt;
+
+extern "C" {
+
+int emadapt_version(void) { return 100; /* 0.1.0 */ }
+
+const char *emadapt_strerror(int code) {
+    switch (code) {
+        case EMADAPT_OK: return "ok";
+        case EMADAPT_ERR_INVALID: return "invalid argument";
+        case EMADAPT_ERR_UNSUPPORTED: return "unsupported shape";
+        case EMADAPT_ERR_HIP: return "HIP runtime error";
+        case EMADAPT_ERR_WORKSPACE: return "workspace missing or too small";
+        case EMADAPT_ERR_NODEVICE: return "no gfx950 device";
+        default: return "unknown error";
+    }
+}
+
+int emadapt_last_hip_error(void) { return g_last_hip_error; }
+
+int emadapt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void emadapt_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+
+void emadapt_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (ProfRec *r : g_prof_recs) g_prof_free.push_back(r);
+    g_prof_recs.clear();
+}
+
+int emadapt_prof_collect(int64_t launches[EMADAPT_K_COUNT], double ms[EMADAPT_K_COUNT],
+                         double flops[EMADAPT_K_COUNT], double bytes[EMADAPT_K_COUNT]) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int k = 0; k < EMADAPT_K_COUNT; k++) {
+        launches[k] = 0;
+        ms[k] = flops[k] = bytes[k] = 0.0;
+    }
+    for (ProfRec *r : g_prof_recs) {
+        EMADAPT_HIP_TRY(hipEventSynchronize(r->stop));
+        float t = 0.f;
+        EMADAPT_HIP_TRY(hipEventElapsedTime(&t, r->start, r->stop));
+        int k = (r->kind >= 0 && r->kind < EMADAPT_K_COUNT) ? r->kind : EMADAPT_K_OTHER;
+        launches[k] += 1;
+        ms[k] += t;
+        flops[k] += r->flops;
+        bytes[k] += r->bytes;
+    }
+    return EMADAPT_OK;
+}
+
+}  // extern "C"

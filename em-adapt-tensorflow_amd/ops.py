@@ -1,0 +1,249 @@
+"""Thin torch-tensor wrappers over the C ABI (include/emadapt.h).
+
+torch provides device memory and the current HIP stream; every computation happens inside
+libemadapt_hip.so.  All tensors are fp32, NHWC, contiguous; filters are HWIO like the reference's
+``tf.get_variable`` shapes (deeplab.py:131-149).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, EPI_BIAS, EPI_BIAS_RELU, EPI_NONE, LABEL_F32, LABEL_I32, LABEL_MULTIHOT  # noqa: F401
+
+
+def _stream(t=None):
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _check(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (there is no CPU path)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+class Workspace:
+    """Grow-only scratch buffer per device (partial slabs of the deterministic reductions)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 256)
+        key = str(device)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+_WS = Workspace()
+
+
+def conv_desc(B, H, W, Cin, Cout, KH, KW, dil):
+    return ConvDesc(int(B), int(H), int(W), int(Cin), int(Cout), int(KH), int(KW), int(dil))
+
+
+def _desc_from(x, w, dil):
+    B, H, W, Cin = x.shape
+    KH, KW, Ci, Cout = w.shape
+    if Ci != Cin:
+        raise ValueError("filter Cin %d != activation channels %d" % (Ci, Cin))
+    return conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+
+
+def conv_fwd(x, w, bias=None, dil=1, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None):
+    """conv2d/atrous_conv2d SAME stride 1 + bias (+ReLU (+dropout)); deeplab.py:58-59,65-66,71,92-96,100,104."""
+    _check(x, name="x"); _check(w, name="w"); _check(bias, name="bias")
+    _check(drop_mask, torch.uint8, "drop_mask")
+    d = _desc_from(x, w, dil)
+    y = out if out is not None else torch.empty((d.B, d.H, d.W, d.Cout), dtype=torch.float32, device=x.device)
+    _check(y, name="out")
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    _lib.call("emadapt_conv_fwd", ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), epi, float(keep_prob),
+              _p(drop_mask), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+    return y
+
+
+def conv_dgrad(dy, w, dil=1, gate=None, gate_scale=1.0, out=None):
+    """Gradient w.r.t. the conv input, optionally gated by the stored activation that fed the conv."""
+    _check(dy, name="dy"); _check(w, name="w"); _check(gate, name="gate")
+    B, H, W, Cout = dy.shape
+    KH, KW, Cin, Co = w.shape
+    if Co != Cout:
+        raise ValueError("filter Cout %d != dy channels %d" % (Co, Cout))
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
+    _check(dx, name="out")
+    _lib.call("emadapt_conv_dgrad", ctypes.byref(d), _p(dy), _p(w), _p(dx), _p(gate), float(gate_scale), _stream())
+    return dx
+
+
+def conv_wgrad(x, dy, KH, KW, dil=1, out=None):
+    """Gradient w.r.t. the HWIO filter (deterministic split-M reduction)."""
+    _check(x, name="x"); _check(dy, name="dy")
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    dw = out if out is not None else torch.empty((KH, KW, Cin, Cout), dtype=torch.float32, device=x.device)
+    _check(dw, name="out")
+    nbytes = _lib.load().emadapt_conv_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, x.device)
+    _lib.call("emadapt_conv_wgrad", ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream())
+    return dw
+
+
+def bias_grad(dy, out=None):
+    _check(dy, name="dy")
+    N = dy.shape[-1]
+    M = dy.numel() // N
+    db = out if out is not None else torch.empty((N,), dtype=torch.float32, device=dy.device)
+    nbytes = _lib.load().emadapt_bias_grad_workspace_bytes(M, N)
+    ws = _WS.get(nbytes, dy.device)
+    _lib.call("emadapt_bias_grad", _p(dy), M, N, _p(db), _p(ws), ws.numel(), _stream())
+    return db
+
+
+def pool_out_size(n, stride):
+    return (n + stride - 1) // stride
+
+
+def maxpool_fwd(x, stride, out=None, idx=None):
+    """3x3 max-pool, SAME (deeplab.py:77,82). Returns (y, idx) with idx the winning tap (uint8)."""
+    _check(x, name="x")
+    B, H, W, C = x.shape
+    OH, OW = pool_out_size(H, stride), pool_out_size(W, stride)
+    y = out if out is not None else torch.empty((B, OH, OW, C), dtype=torch.float32, device=x.device)
+    if idx is None:
+        idx = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=x.device)
+    _lib.call("emadapt_maxpool_fwd", _p(x), B, H, W, C, int(stride), _p(y), _p(idx), _stream())
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_shape, stride, gate=None, out=None):
+    _check(dy, name="dy"); _check(idx, torch.uint8, "idx"); _check(gate, name="gate")
+    B, H, W, C = in_shape
+    dx = out if out is not None else torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    _lib.call("emadapt_maxpool_bwd", _p(dy), _p(idx), _p(gate), B, H, W, C, int(stride), _p(dx), _stream())
+    return dx
+
+
+def copy_pad_channels(src, Cdst, out=None):
+    _check(src, name="src")
+    Cs = src.shape[-1]
+    rows = src.numel() // Cs
+    dst = out if out is not None else torch.empty(tuple(src.shape[:-1]) + (Cdst,), dtype=torch.float32,
+                                                  device=src.device)
+    _lib.call("emadapt_copy_pad_channels", _p(src), rows, Cs, _p(dst), int(Cdst), _stream())
+    return dst
+
+
+def resize_nearest(label, oh, ow, out=None):
+    """tf.image.resize_nearest_neighbor + squeeze (deeplab.py:110). label: f32 [B,H,W] or [B,H,W,1]."""
+    _check(label, name="label")
+    if label.dim() == 4:
+        label = label.reshape(label.shape[:3])
+    B, H, W = label.shape
+    y = out if out is not None else torch.empty((B, oh, ow), dtype=torch.float32, device=label.device)
+    _lib.call("emadapt_resize_nearest", _p(label), B, H, W, _p(y), int(oh), int(ow), _stream())
+    return y
+
+
+def estep_device(logits, label, perms, num_classes, suppress_others=True, num_iter=5, margin_others=1e-5,
+                 bg_p=0.5, fg_p=0.25, label_kind=LABEL_F32, want_map=False, labels_out=None, map_out=None):
+    """Device E-step (deeplab.py:109-124 without the host round trip).
+
+    logits: f32 [B,H,W,ldl] with ldl >= num_classes (padded class dimension allowed);
+    label : f32/i32 pixel labels [B, ...] or uint8 multi-hot [B,C]; perms: int32 [num_iter, C-1] (device).
+    Returns (labels int64 [B,H,W], float_map or None).
+    """
+    _check(logits, name="logits")
+    B, H, W, ldl = logits.shape
+    C = int(num_classes)
+    dt = {LABEL_F32: torch.float32, LABEL_I32: torch.int32, LABEL_MULTIHOT: torch.uint8}[label_kind]
+    _check(label, dt, "label")
+    _check(perms, torch.int32, "perms")
+    lib = _lib.load()
+    label_len = 0 if label_kind == LABEL_MULTIHOT else (label.numel() // B if B else 0)
+    if labels_out is None:
+        labels_out = torch.empty((B, H, W), dtype=torch.int64, device=logits.device)
+    hw = H * W
+    k_bg, k_fg = int(hw * bg_p), int(hw * fg_p)  # estep.py:58-59
+    # the float map doubles as the home of present channels that do not fit in LDS
+    if map_out is None and (want_map or lib.emadapt_estep_needs_map(H, W, C)):
+        map_out = torch.empty((B, H, W, C), dtype=torch.float32, device=logits.device)
+    nbytes = lib.emadapt_estep_workspace_bytes(B, H, W, C)
+    ws = _WS.get(nbytes + 256, logits.device)
+    _lib.call("emadapt_estep", _p(logits), ldl, _p(label), label_kind, label_len, _p(perms), B, H, W, C,
+              int(bool(suppress_others)), int(num_iter), float(margin_others), k_bg, k_fg, _p(map_out),
+              _p(labels_out), _p(ws), ws.numel(), _stream())
+    return labels_out, map_out
+
+
+def softmax_ce(logits, labels, num_classes, grad_scale=None, want_grad=True, want_loss=True, dlogits=None):
+    """sparse softmax cross-entropy (sum over pixels) and its gradient (deeplab.py:182).
+
+    logits f32 [..., ldl]; labels int64 [...]. Returns (loss_sum f32[1] or None, dlogits or None)."""
+    _check(logits, name="logits"); _check(labels, torch.int64, "labels")
+    ldl = logits.shape[-1]
+    M = logits.numel() // ldl
+    if grad_scale is None:
+        grad_scale = 1.0 / M
+    if want_grad and dlogits is None:
+        dlogits = torch.empty_like(logits)
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device) if want_loss else None
+    nbytes = _lib.load().emadapt_softmax_ce_workspace_bytes(M)
+    ws = _WS.get(nbytes, logits.device)
+    _lib.call("emadapt_softmax_ce", _p(logits), ldl, _p(labels), M, int(num_classes), float(grad_scale),
+              _p(dlogits) if want_grad else None, _p(loss), _p(ws), ws.numel(), _stream())
+    return loss, (dlogits if want_grad else None)
+
+
+def l2_loss(x):
+    _check(x, name="x")
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    ws = _WS.get(_lib.load().emadapt_l2_loss_workspace_bytes(x.numel()), x.device)
+    _lib.call("emadapt_l2_loss", _p(x), x.numel(), _p(out), _p(ws), ws.numel(), _stream())
+    return out
+
+
+def sgd_accumulate(accum, g, w, n_decay, weight_decay, scale):
+    _check(accum, name="accum"); _check(g, name="g"); _check(w, name="w")
+    _lib.call("emadapt_sgd_accumulate", _p(accum), _p(g), _p(w), accum.numel(), int(n_decay), float(weight_decay),
+              float(scale), _stream())
+
+
+def sgd_momentum(w, v, accum, lr, momentum, accum_scale=1.0):
+    _check(w, name="w"); _check(v, name="v"); _check(accum, name="accum")
+    _lib.call("emadapt_sgd_momentum", _p(w), _p(v), _p(accum), w.numel(), float(lr), float(momentum),
+              float(accum_scale), _stream())
+
+
+def prof_enable(on=True):
+    _lib.load().emadapt_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    _lib.load().emadapt_prof_reset()
+
+
+def prof_collect():
+    """{kernel class: dict(launches, ms, flops, bytes)} accumulated since the last reset."""
+    n = len(_lib.K_NAMES)
+    launches = (ctypes.c_int64 * n)()
+    ms = (ctypes.c_double * n)()
+    flops = (ctypes.c_double * n)()
+    nbytes = (ctypes.c_double * n)()
+    _lib.call("emadapt_prof_collect", launches, ms, flops, nbytes)
+    return {name: dict(launches=int(launches[i]), ms=float(ms[i]), flops=float(flops[i]), bytes=float(nbytes[i]))
+            for i, name in enumerate(_lib.K_NAMES)}

@@ -1,0 +1,213 @@
+/* emadapt.h -- C ABI of libemadapt_hip.so: the MI355X (gfx950) implementation of the
+ * EM-Adapt training hot path of xtudbxk/em-adapt-tensorflow.
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes (no torch / framework
+ * types) and -- except e_step / e_step_perm / emadapt_estep_host, which take HOST buffers
+ * like the reference's own native entry -- DEVICE pointers plus a HIP stream handle passed
+ * as void* (NULL = the default stream).  All device entries are asynchronous on that
+ * stream, allocate nothing and never synchronise, so a caller may capture them in a hipGraph.
+ * They return EMADAPT_OK (0) or a negative EMADAPT_ERR_* code; emadapt_strerror() names it.
+ *
+ * Each declaration cites the reference interface (file:line in xtudbxk/em-adapt-tensorflow)
+ * that it replaces.  Tensors are NHWC fp32, filters HWIO fp32, exactly as in the reference.
+ */
+#ifndef EMADAPT_H_
+#define EMADAPT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMADAPT_OK 0
+#define EMADAPT_ERR_INVALID (-1)     /* bad argument (null pointer, bad size, k out of range ...) */
+#define EMADAPT_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for             */
+#define EMADAPT_ERR_HIP (-3)         /* a HIP runtime call failed (see emadapt_last_hip_error)   */
+#define EMADAPT_ERR_WORKSPACE (-4)   /* workspace too small                                      */
+#define EMADAPT_ERR_NODEVICE (-5)    /* no usable gfx950 device                                  */
+
+int emadapt_version(void);                 /* 10000*major + 100*minor + patch */
+const char *emadapt_strerror(int code);
+int emadapt_last_hip_error(void);          /* hipError_t of the last failing HIP call on this thread */
+int emadapt_device_count(void);            /* does not initialise a context */
+
+/* ------------------------------------------------------------------------------------------
+ * E-step (weak-label assignment)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Drop-in for the reference's native entry
+ *   extern "C" float *e_step(float*,const int*,const int*,const int*,bool,int,float,float,float)
+ *   -- estep/weaklabel.cpp:6-7, bound by estep.py:14-15 and called at estep.py:30.
+ * Same signature, same ownership (caller owns everything, `map` is updated in place and
+ * returned), HOST pointers.  shape = int32[4] {B,H,W,C}; stride = int32[4] in BYTES (numpy
+ * strides_as(c_int)); label = int32 [B,H,W] contiguous.
+ * Semantics are those of estep.py:33-84 (estep_py, the path deeplab.py:114 uses), which
+ * the reference's C++ only approximates: batch-safe, label set from
+ * every pixel, running max initialised correctly, one class order per iteration shared by
+ * the batch.  The class order comes from an internal generator (emadapt_estep_seed); use
+ * e_step_perm for an explicit order.  Returns NULL on error (the reference never does). */
+float *e_step(float *map, const int *shape, const int *stride, const int *label,
+              const bool suppress_others, const int num_iter, const float margin_others,
+              float bg, float fg);
+
+/* e_step with the visiting order as an input: perms = int32 [num_iter, C-1], each row a
+ * permutation of 1..C-1 (class 0 is always visited first, estep.py:64-66). */
+float *e_step_perm(float *map, const int *shape, const int *stride, const int *label,
+                   const int *perms, const bool suppress_others, const int num_iter,
+                   const float margin_others, float bg, float fg);
+
+/* Seed of the generator e_step draws its class orders from (replaces the reference's
+ * unseeded rand()/random_shuffle, weaklabel.cpp:83). */
+void emadapt_estep_seed(uint64_t seed);
+
+/* Label-kind selector for the entries below. */
+#define EMADAPT_LABEL_F32 0      /* float pixel labels [B, label_len]; cast to uint8 like estep.py:35 */
+#define EMADAPT_LABEL_I32 1      /* int32 pixel labels [B, label_len]                               */
+#define EMADAPT_LABEL_MULTIHOT 2 /* uint8 image-level multi-hot [B, C] ("synthetic image-level labels") */
+
+/* Host-buffer E-step with explicit thresholds: what the Python operator estep()
+ * (estep.py:18-27) binds.  map: float32 [B,H,W,C] contiguous, updated in place (float map
+ * of estep.py:82); labels_out: optional int64 [B,H,W] = argmax over C, first max
+ * (deeplab.py:123).  k_bg = int(H*W*bg_p), k_fg = int(H*W*fg_p) (estep.py:58-59). */
+int emadapt_estep_host(float *map, int B, int H, int W, int C, const void *label, int label_kind,
+                       int64_t label_len, const int32_t *perms, int suppress_others, int num_iter,
+                       float margin_others, int k_bg, int k_fg, int64_t *labels_out);
+
+/* Bytes of device workspace emadapt_estep needs. */
+size_t emadapt_estep_workspace_bytes(int B, int H, int W, int C);
+
+/* 1 when emadapt_estep needs a non-NULL map_out for this geometry (H*W*C too large for every class
+ * that may be present to stay in LDS), 0 when map_out may be NULL, <0 for an unsupported geometry. */
+int emadapt_estep_needs_map(int H, int W, int C);
+
+/* Device E-step: replaces deeplab.py:109-124 (py_func(estep) + argmax) with no host round trip.
+ *   logits     f32 [B*H*W rows][ldl], first C entries of each row used (not modified)
+ *   label      per label_kind; label_len = elements per image for the pixel kinds
+ *   perms      int32 [num_iter, C-1] on the device
+ *   map_out    f32 [B,H,W,C] float map of estep.py:82, or NULL when only labels are wanted
+ *              (required when more classes are present in an image than fit in LDS: the
+ *              call then fails with EMADAPT_ERR_WORKSPACE if it is NULL)
+ *   labels_out int64 [B,H,W]
+ * One workgroup per image; present channels and the running max live in LDS. */
+int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label_kind,
+                  int64_t label_len, const int32_t *perms, int B, int H, int W, int C,
+                  int suppress_others, int num_iter, float margin_others, int k_bg, int k_fg,
+                  float *map_out, int64_t *labels_out, void *workspace, size_t workspace_bytes,
+                  void *stream);
+
+/* tf.image.resize_nearest_neighbor(label,[oh,ow]) + squeeze, align_corners=False -- deeplab.py:110.
+ * in: f32 [B,H,W] (the trailing singleton channel of the placeholder dropped), out: f32 [B,oh,ow]. */
+int emadapt_resize_nearest(const float *in, int B, int H, int W, float *out, int oh, int ow, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution stack (DeepLab VGG-16 with dilation): implicit-GEMM on MFMA
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct emadapt_conv_desc {
+    int B, H, W;   /* input = output spatial size: every conv is stride 1, SAME (deeplab.py:58,65,92,95) */
+    int Cin, Cout; /* both multiples of 4 (callers pad 3->4 input channels and C->round4 classes)          */
+    int KH, KW;    /* 3x3, 4x4 (fc6) or 1x1                                                                */
+    int dil;       /* atrous rate: 1, 2 (conv5_x, deeplab.py:65), 4 (fc6, deeplab.py:92), 12 (LargeFOV)    */
+} emadapt_conv_desc;
+
+#define EMADAPT_EPI_NONE 0       /* y = conv                                   */
+#define EMADAPT_EPI_BIAS 1       /* y = conv + b              (fc8)            */
+#define EMADAPT_EPI_BIAS_RELU 2  /* y = max(conv + b, 0)      (conv*, fc6/7)   */
+
+/* Forward: tf.nn.conv2d / tf.nn.atrous_conv2d + tf.nn.bias_add (+ tf.nn.relu (+ tf.nn.dropout))
+ * -- deeplab.py:58-59,65-66,71,92-96,100,104.   x f32 [B,H,W,Cin]; w f32 HWIO [KH,KW,Cin,Cout];
+ * bias f32 [Cout]; y f32 [B,H,W,Cout].  Dropout (only with EPI_BIAS_RELU): keep_prob < 1 scales kept
+ * values by 1/keep_prob (tf.nn.dropout); the keep mask is drop_mask (uint8 [B,H,W,Cout], 1 = keep)
+ * when non-NULL, else a counter-based hash of (drop_seed, element index). */
+int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w, const float *bias,
+                     float *y, int epilogue, float keep_prob, const uint8_t *drop_mask,
+                     uint64_t drop_seed, void *stream);
+
+/* Data gradient (Conv2DBackpropInput of the autodiff in deeplab.py:192):
+ *   dx[b,h,w,ci] = sum_{taps,co} dy[b,h-off,w-off,co] * w[tap,ci,co]
+ * fused with the gradient of what precedes the conv: when `gate` is non-NULL (f32 [B,H,W,Cin], the
+ * stored post-ReLU(/dropout) activation that fed this conv) dx = gate>0 ? dx*gate_scale : 0
+ * (ReluGrad, and dropout's 1/keep_prob when the gate is a dropped activation). */
+int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float *w, float *dx,
+                       const float *gate, float gate_scale, void *stream);
+
+/* Filter gradient (Conv2DBackpropFilter): dw[tap,ci,co] = sum_{b,h,w} x[b,h+off,w+off,ci]*dy[b,h,w,co].
+ * Deterministic: the pixel dimension is split over workgroups into fp32 partial slabs in `workspace`
+ * that a second kernel sums in a fixed order (no atomics).  dw f32 HWIO. */
+size_t emadapt_conv_wgrad_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* BiasAddGrad: db[n] = sum_m dy[m,n]; dy f32 [M,N].  Deterministic two-stage reduction. */
+size_t emadapt_bias_grad_workspace_bytes(int64_t M, int N);
+int emadapt_bias_grad(const float *dy, int64_t M, int N, float *db, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/* tf.nn.max_pool ksize 3x3, stride 2 or 1, SAME (deeplab.py:77,82); padding never wins.
+ * x f32 [B,H,W,C] -> y f32 [B,OH,OW,C], OH = ceil(H/stride); idx uint8 [B,OH,OW,C] = winning tap
+ * (0..8, first maximum in window scan order) kept for the backward pass. */
+int emadapt_maxpool_fwd(const float *x, int B, int H, int W, int C, int stride, float *y, uint8_t *idx,
+                        void *stream);
+/* MaxPoolGrad fused with the ReluGrad of the layer below: dx[p] = sum over windows whose winner is p
+ * of dy, then dx = gate>0 ? dx : 0 when gate (f32 [B,H,W,C], = the pool input) is non-NULL. */
+int emadapt_maxpool_bwd(const float *dy, const uint8_t *idx, const float *gate, int B, int H, int W,
+                        int C, int stride, float *dx, void *stream);
+
+/* Zero-pad / strip the channel dimension: dst[m, 0:Cdst] = src[m, 0:min(Csrc,Cdst)], rest 0. */
+int emadapt_copy_pad_channels(const float *src, int64_t rows, int Csrc, float *dst, int Cdst, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss and optimiser
+ * ---------------------------------------------------------------------------------------- */
+
+/* tf.nn.sparse_softmax_cross_entropy_with_logits + tf.reduce_mean (deeplab.py:182) and its gradient.
+ *   logits f32 [M][ldl] (first C used), labels int64 [M]
+ *   dlogits f32 [M][ldl] = (softmax - onehot) * grad_scale in the first C columns, 0 in the padding
+ *           columns (may be NULL); grad_scale = 1/M for the mean
+ *   loss_sum f32[1] = sum_m CE_m  (deterministic two-stage reduction; may be NULL) */
+size_t emadapt_softmax_ce_workspace_bytes(int64_t M);
+int emadapt_softmax_ce(const float *logits, int64_t ldl, const int64_t *labels, int64_t M, int C,
+                       float grad_scale, float *dlogits, float *loss_sum, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
+/* tf.nn.l2_loss: out[0] = sum(x^2)/2 (deeplab.py:184; logging only). */
+size_t emadapt_l2_loss_workspace_bytes(int64_t n);
+int emadapt_l2_loss(const float *x, int64_t n, float *out, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* Gradient accumulation, deeplab.py:202 with the weight-decay term of deeplab.py:184-185 folded in:
+ *   accum[i] += (g[i] + (i < n_decay ? weight_decay * w[i] : 0)) * scale      (scale = 1/accum_num)
+ * The first n_decay elements of the segment are filter weights, the rest biases. */
+int emadapt_sgd_accumulate(float *accum, const float *g, const float *w, int64_t n, int64_t n_decay,
+                           float weight_decay, float scale, void *stream);
+/* tf.train.MomentumOptimizer.apply_gradients on the accumulators + the clean op
+ * (deeplab.py:203-205): v = momentum*v + accum*accum_scale; w -= lr*v; accum = 0. */
+int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, float momentum,
+                         float accum_scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement support (bench.py): per-kernel HIP-event timing on the launch stream.
+ * ---------------------------------------------------------------------------------------- */
+#define EMADAPT_K_IGEMM_FWD 0   /* conv forward implicit GEMM           */
+#define EMADAPT_K_IGEMM_DGRAD 1 /* conv data-gradient implicit GEMM     */
+#define EMADAPT_K_IGEMM_WGRAD 2 /* conv filter-gradient implicit GEMM   */
+#define EMADAPT_K_ESTEP 3       /* E-step scan                          */
+#define EMADAPT_K_OTHER 4       /* pools, loss, optimiser, reductions   */
+#define EMADAPT_K_COUNT 5
+
+void emadapt_prof_enable(int on); /* 1: bracket every launch with hipEventRecord; 0: off (default) */
+void emadapt_prof_reset(void);
+/* Synchronises the recorded events and returns, per kernel class: launches, total ms, total
+ * algorithmic FLOPs (conv classes) and algorithmic bytes (the others). */
+int emadapt_prof_collect(int64_t launches[EMADAPT_K_COUNT], double ms[EMADAPT_K_COUNT],
+                         double flops[EMADAPT_K_COUNT], double bytes[EMADAPT_K_COUNT]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMADAPT_H_ */

@@ -1,0 +1,211 @@
+"""GPU parity of every HIP kernel of the conv / pool / loss / optimiser path against the CPU oracle
+(oracle/deeplab_oracle.py: PyTorch-CPU ops with the TF semantics of deeplab.py spelled out, fp64 here so
+that the check measures the kernel's own error).  All calls go through the C ABI.
+
+Tolerances: conv kernels accumulate in fp32 (v_mfma_f32_32x32x2_f32 = exact fp32 FMA chain), so the
+relative error vs fp64 is ~1e-6; the bar below is 2e-5 relative to the tensor's max magnitude, far inside
+north_star's 1e-3.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import em_adapt_tensorflow_amd.ops as ops
+    from oracle import deeplab_oracle as do
+    return ops, do, torch
+
+
+def _rel(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def _t(torch, a, dtype=None):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype or torch.float32, device="cuda:0")
+
+
+# (B, H, W, Cin, Cout, k, dil): covers 1x1 / 3x3 / 4x4, dilation 1/2/4/12, multi-tile M and N, N<=64 and
+# N>64 tile configs, K tails (K % 32 != 0), Cin=4 (padded RGB), Cout=24 (padded 21 classes), M tails.
+CONV_SHAPES = [
+    (1, 7, 9, 4, 8, 3, 1),
+    (2, 13, 11, 8, 16, 3, 1),
+    (2, 12, 12, 16, 64, 3, 2),
+    (1, 19, 17, 16, 136, 3, 1),
+    (2, 11, 11, 32, 160, 4, 4),
+    (1, 25, 25, 24, 40, 3, 12),
+    (3, 9, 9, 160, 24, 1, 1),
+    (1, 33, 31, 4, 64, 3, 1),
+    (2, 23, 23, 64, 256, 3, 2),
+    (1, 41, 41, 24, 288, 1, 1),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv_fwd_dgrad_wgrad(env, shape):
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    rng = np.random.default_rng(hash(shape) % (1 << 31))
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    w = rng.normal(0, 0.2, (k, k, Cin, Cout)).astype(np.float32)
+    b = rng.normal(0, 0.5, (Cout,)).astype(np.float32)
+    dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
+
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    y_lin = do.conv_same(xt, wt, bt, dil)
+    y_lin.backward(torch.tensor(dy, dtype=torch.float64))
+
+    xg, wg, bg, dyg = _t(torch, x), _t(torch, w), _t(torch, b), _t(torch, dy)
+    # forward: plain, +bias, +bias+relu
+    assert _rel(ops.conv_fwd(xg, wg, None, dil).cpu(), (y_lin - bt).detach()) < 2e-5
+    assert _rel(ops.conv_fwd(xg, wg, bg, dil, relu=False).cpu(), y_lin.detach()) < 2e-5
+    assert _rel(ops.conv_fwd(xg, wg, bg, dil, relu=True).cpu(), torch.relu(y_lin).detach()) < 2e-5
+    # data gradient, plain and gated by a stored activation (ReluGrad / dropout scale)
+    assert _rel(ops.conv_dgrad(dyg, wg, dil).cpu(), xt.grad) < 2e-5
+    gate = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    want = np.where(gate > 0, xt.grad.numpy() * 2.0, 0.0)
+    assert _rel(ops.conv_dgrad(dyg, wg, dil, gate=_t(torch, gate), gate_scale=2.0).cpu(), want) < 2e-5
+    # filter and bias gradients
+    assert _rel(ops.conv_wgrad(xg, dyg, k, k, dil).cpu(), wt.grad) < 2e-5
+    assert _rel(ops.bias_grad(dyg).cpu(), bt.grad) < 2e-5
+
+
+def test_conv_wgrad_split_m_is_deterministic_and_right(env):
+    """Large pixel count, small filter: the split-M path (partial slabs + ordered sum)."""
+    ops, do, torch = env
+    rng = np.random.default_rng(5)
+    B, H, W, Cin, Cout, k = 2, 97, 95, 8, 64, 3
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
+    wt = torch.zeros((k, k, Cin, Cout), dtype=torch.float64, requires_grad=True)
+    y = do.conv_same(torch.tensor(x, dtype=torch.float64), wt, torch.zeros(Cout, dtype=torch.float64), 1)
+    y.backward(torch.tensor(dy, dtype=torch.float64))
+    xg, dyg = _t(torch, x), _t(torch, dy)
+    a = ops.conv_wgrad(xg, dyg, k, k, 1).cpu().numpy()
+    b = ops.conv_wgrad(xg, dyg, k, k, 1).cpu().numpy()
+    assert np.array_equal(a, b), "filter gradient must be bitwise reproducible"
+    assert _rel(a, wt.grad) < 2e-5
+
+
+def test_dropout_epilogue(env):
+    ops, do, torch = env
+    rng = np.random.default_rng(3)
+    B, H, W, Cin, Cout = 2, 9, 9, 16, 72
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    w = rng.normal(0, 0.3, (1, 1, Cin, Cout)).astype(np.float32)
+    b = rng.normal(0, 0.1, (Cout,)).astype(np.float32)
+    xg, wg, bg = _t(torch, x), _t(torch, w), _t(torch, b)
+    base = ops.conv_fwd(xg, wg, bg, 1, relu=True).cpu().numpy()
+    mask = (rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8)
+    got = ops.conv_fwd(xg, wg, bg, 1, relu=True, keep_prob=0.5, drop_mask=_t(torch, mask, torch.uint8)).cpu().numpy()
+    assert np.array_equal(got, np.where(mask > 0, base / np.float32(0.5), 0).astype(np.float32))
+    # built-in generator: kept values are exactly x/keep, the keep rate is ~keep, seeds differ, same seed repeats
+    big = ops.conv_fwd(_t(torch, rng.normal(0, 1, (4, 32, 32, Cin)).astype(np.float32)), wg, bg, 1, relu=False)
+    xb = _t(torch, np.abs(rng.normal(0, 1, (4, 32, 32, Cin))).astype(np.float32) + 0.1)
+    wpos = _t(torch, np.abs(w))
+    ref = ops.conv_fwd(xb, wpos, _t(torch, np.abs(b)), 1, relu=True).cpu().numpy()
+    d1 = ops.conv_fwd(xb, wpos, _t(torch, np.abs(b)), 1, relu=True, keep_prob=0.75, drop_seed=11).cpu().numpy()
+    d1b = ops.conv_fwd(xb, wpos, _t(torch, np.abs(b)), 1, relu=True, keep_prob=0.75, drop_seed=11).cpu().numpy()
+    d2 = ops.conv_fwd(xb, wpos, _t(torch, np.abs(b)), 1, relu=True, keep_prob=0.75, drop_seed=12).cpu().numpy()
+    assert np.array_equal(d1, d1b) and not np.array_equal(d1, d2)
+    kept = d1 != 0
+    assert abs(kept.mean() - 0.75) < 0.01
+    assert np.array_equal(d1[kept], (ref / np.float32(0.75))[kept])
+    del big
+
+
+@pytest.mark.parametrize("shape", [(2, 21, 21, 8, 2), (1, 16, 18, 16, 2), (2, 11, 11, 12, 1), (1, 41, 41, 64, 1),
+                                   (1, 33, 33, 4, 2)])
+def test_maxpool(env, shape):
+    ops, do, torch = env
+    B, H, W, C, stride = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    y = do.maxpool_same(xt, stride)
+    dy = rng.normal(0, 1, tuple(y.shape)).astype(np.float32)
+    y.backward(torch.tensor(dy, dtype=torch.float64))
+    xg = _t(torch, x)
+    yg, idx = ops.maxpool_fwd(xg, stride)
+    assert np.array_equal(yg.cpu().numpy(), y.detach().numpy().astype(np.float32))
+    dx = ops.maxpool_bwd(_t(torch, dy), idx, (B, H, W, C), stride)
+    assert _rel(dx.cpu(), xt.grad) < 1e-6
+    gated = ops.maxpool_bwd(_t(torch, dy), idx, (B, H, W, C), stride, gate=xg)
+    assert _rel(gated.cpu(), np.where(x > 0, xt.grad.numpy(), 0)) < 1e-6
+
+
+def test_maxpool_ties_go_to_first_maximum(env):
+    ops, do, torch = env
+    x = np.zeros((1, 5, 5, 4), np.float32)  # all equal (post-ReLU zeros)
+    yg, idx = ops.maxpool_fwd(_t(torch, x), 1)
+    idx = idx.cpu().numpy()
+    assert idx[0, 2, 2, 0] == 0 and idx[0, 0, 0, 0] == 4  # interior: first tap; corner: first valid tap (1,1)
+
+
+def test_softmax_ce_and_l2(env):
+    ops, do, torch = env
+    rng = np.random.default_rng(9)
+    M, C, ldl = 3000, 21, 24
+    logits = rng.normal(0, 3, (M, ldl)).astype(np.float32)
+    labels = rng.integers(0, C, (M,)).astype(np.int64)
+    lt = torch.tensor(logits[:, :C], dtype=torch.float64, requires_grad=True)
+    loss = torch.nn.functional.cross_entropy(lt, torch.tensor(labels), reduction="sum")
+    (loss / M).backward()
+    ls, dl = ops.softmax_ce(_t(torch, logits), _t(torch, labels, torch.int64), C)
+    assert abs(float(ls.cpu()) - float(loss)) / float(loss) < 1e-5
+    dl = dl.cpu().numpy()
+    assert _rel(dl[:, :C], lt.grad) < 1e-5
+    assert np.all(dl[:, C:] == 0)
+    x = rng.normal(0, 1, (100003,)).astype(np.float32)
+    assert abs(float(ops.l2_loss(_t(torch, x)).cpu()) - float((x.astype(np.float64) ** 2).sum() / 2)) < 1e-2
+
+
+def test_sgd_kernels_and_padding(env):
+    ops, do, torch = env
+    rng = np.random.default_rng(4)
+    for n, nd in [(4096, 4000), (1003, 500)]:
+        w = rng.normal(0, 1, n).astype(np.float32)
+        g = rng.normal(0, 1, n).astype(np.float32)
+        acc = rng.normal(0, 1, n).astype(np.float32)
+        v = rng.normal(0, 1, n).astype(np.float32)
+        wd, scale, lr, mu = np.float32(1e-2), np.float32(0.2), np.float32(1e-3), np.float32(0.9)
+        accg, wg_, vg = _t(torch, acc), _t(torch, w), _t(torch, v)
+        ops.sgd_accumulate(accg, _t(torch, g), wg_, nd, wd, scale)
+        gg = g.copy()
+        gg[:nd] = gg[:nd] + wd * w[:nd]
+        want_acc = acc + gg * scale
+        assert _rel(accg.cpu(), want_acc) < 1e-6
+        ops.sgd_momentum(wg_, vg, accg, lr, mu, 1.0)
+        want_v = mu * v + want_acc
+        assert _rel(vg.cpu(), want_v) < 1e-6
+        assert _rel(wg_.cpu(), w - lr * want_v) < 1e-6
+        assert float(accg.abs().max().cpu()) == 0.0
+    src = rng.normal(0, 1, (5, 7, 3)).astype(np.float32)
+    got = ops.copy_pad_channels(_t(torch, src), 4).cpu().numpy()
+    assert np.array_equal(got[..., :3], src) and np.all(got[..., 3] == 0)
+    back = ops.copy_pad_channels(_t(torch, got), 3).cpu().numpy()
+    assert np.array_equal(back, src)
+
+
+def test_profiler_counts_launches(env):
+    ops, do, torch = env
+    ops.prof_reset()
+    ops.prof_enable(True)
+    x = torch.zeros((1, 8, 8, 8), device="cuda:0")
+    w = torch.zeros((3, 3, 8, 8), device="cuda:0")
+    ops.conv_fwd(x, w, None, 1)
+    ops.conv_dgrad(x, w, 1)
+    torch.cuda.synchronize()
+    r = ops.prof_collect()
+    ops.prof_enable(False)
+    ops.prof_reset()
+    assert r["igemm_fwd"]["launches"] == 1 and r["igemm_dgrad"]["launches"] == 1
+    assert r["igemm_fwd"]["flops"] == 2.0 * 64 * 72 * 8 and r["igemm_fwd"]["ms"] > 0
