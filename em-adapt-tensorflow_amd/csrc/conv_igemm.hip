@@ -228,7 +228,6 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
     }
 
     // ---- fused epilogue; C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const float inv_keep = 1.0f / a.keep;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -246,7 +245,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
                     v = v > 0.f ? v : 0.f;
                     if (a.keep < 1.0f) {
                         const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
-                        v = kp ? v * inv_keep : 0.f;
+                        v = kp ? v / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
                     }
                 }
                 if (a.gate) v = a.gate[o] > 0.f ? v * a.scale : 0.f;
