@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Benchmark of the EM-Adapt training hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one full update of the reference's loop body (deeplab.py:265-270) on one synthetic batch:
+forward through the DeepLab conv stack, on-device E-step, hand-written backward, gradient accumulate
+(accum_num = 1), gradient all-reduce across ranks (N > 1) and the Momentum update.  Per GPU the workload is
+BASELINE.json configs[1]: 321x321x3 inputs, batch 16, 21 classes, fp32, the network as written in the
+reference (fc6 4x4 rate 4 -> 4096; `--preset largefov` selects the 3x3 rate-12 variant).  Inputs, labels,
+dropout and the E-step visiting orders are resident in HBM before the timed region starts.
+
+For N > 1 the driver launches this file with torch.distributed.run, one rank per GPU (RCCL); every rank
+keeps batch 16 (weak scaling) and the value is the whole-job images/s with the time taken as the MAX over
+ranks between two barriers.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant kernel class (conv implicit-GEMM fwd / dgrad / wgrad) timed live with HIP events
+                  on the launch stream: algorithmic FLOPs / time vs the gfx950 fp32-matrix peak (157.3 TFLOP/s);
+  cpu_baseline -- the CPU oracle (PyTorch-CPU restatement of the same step + NumPy E-step, a stand-in for the
+                  reference's TF-CPU path, which cannot be installed here) timed on this host's cores on a
+                  bounded sample (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=321)
+    ap.add_argument("--classes", type=int, default=21)
+    ap.add_argument("--preset", default="ref", choices=["ref", "largefov"])
+    ap.add_argument("--width", type=int, default=64)
+    ap.add_argument("--keep-prob", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Time the CPU oracle on a bounded sample of the same workload (test infrastructure used as a baseline)."""
+    import numpy as np
+    import torch
+    from oracle import deeplab_oracle as do
+    from oracle import estep_oracle as eo
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = args.cpu_batch
+    oracle = do.DeepLabOracle(category_num=args.classes, preset=args.preset, width=args.width, dtype=torch.float32)
+    params = do.init_params(oracle.specs, seed=2, std=0.01)
+    plist = {k: [w.copy(), b.copy()] for k, (w, b) in params.items()}
+    vel = {k: [np.zeros_like(w), np.zeros_like(b)] for k, (w, b) in params.items()}
+    images, labels = do.synthetic_batch(B, args.size, args.classes, seed=0)
+    rng = np.random.default_rng(1)
+    S = do.output_size(args.size, oracle.specs)
+    perms = eo.draw_perms(5, args.classes, seed=3)
+
+    def one_step():
+        masks = {l: (rng.random((B, S, S, plist[l][1].shape[0])) < args.keep_prob) for l in ("fc6", "fc7")}
+        r = oracle.micro_step({k: (v[0], v[1]) for k, v in plist.items()}, images, labels, perms, weight_decay=1e-5,
+                              keep_prob=args.keep_prob, masks=masks)
+        acc = {k: [g[0], g[1]] for k, g in r["grads"].items()}
+        do.momentum_update(plist, vel, acc, 1e-3, 0.9)
+
+    one_step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        one_step()
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(B * args.cpu_steps / dt, 4),
+        "unit": "images/s",
+        "cores": int(torch.get_num_threads()),
+        "kind": "port",
+        "sample": "%d images/step x %d timed steps (after 1 warm-up) of the same step: %dx%d, %d classes, preset %s, "
+                  "fp32, PyTorch-CPU convs + NumPy E-step oracle; %.1f s" % (B, args.cpu_steps, args.size, args.size,
+                                                                            args.classes, args.preset, dt),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and rank == 0 and distributed:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from em_adapt_tensorflow_amd import ops
+    from em_adapt_tensorflow_amd.data import SyntheticData
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from em_adapt_tensorflow_amd.estep import draw_perms
+    import numpy as np
+    import random
+
+    cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
+           "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device}
+    data = SyntheticData(dict(cfg, seed=rank, unique_batches=2))
+    adapt = ADAPT(dict(cfg, data=data))
+    adapt.build()
+    adapt.pre_train(base_lr=1e-3, weight_decay=1e-5, momentum=0.9, batch_size=args.batch)
+    batches = data.next_batch("train", args.batch)
+    pool = [next(batches) for _ in range(2)]
+    # E-step visiting orders for every step, drawn like the reference does and parked in HBM
+    random.seed(3 + rank)
+    total_steps = args.warmup + args.steps
+    host = np.stack([draw_perms(5, args.classes, rng=random) for _ in range(max(total_steps, 1))])
+    adapt._perm_pool = torch.as_tensor(host).to(device)
+    adapt._perm_pos = 0
+
+    def step(i):
+        x, y = pool[i % len(pool)]
+        adapt.micro_step(x, y, keep_prob=args.keep_prob)
+        adapt.apply_update()
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    if not args.no_prof:
+        ops.prof_reset()
+        ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = None
+    if not args.no_prof:
+        ops.prof_enable(False)
+        prof = ops.prof_collect()
+        ops.prof_reset()
+    if distributed:
+        from em_adapt_tensorflow_amd.dist import all_reduce_max
+        dt = all_reduce_max(dt, device)
+    loss = float(adapt.loss["norm"].cpu())
+    if not np.isfinite(loss):
+        raise SystemExit("non-finite loss in the benchmark step")
+
+    if rank == 0:
+        global_batch = args.batch * world
+        ms = dt / max(args.steps, 1) * 1e3
+        fwd_flops, fb_flops = adapt.flops_per_image()
+        out = {
+            "metric": "images/sec (fwd+E-step+bwd), DeepLab-LargeFOV 321x321 bs16, 1/2/4/8 MI355X",
+            "value": round(global_batch * args.steps / dt, 3),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "fp32",
+            "data": "synthetic",
+            "config": {
+                "workload": "DeepLab VGG-16 (%s preset: fc6 %s) %dx%d, %d classes, batch %d per GPU, fp32, "
+                            "random-init N(0,0.01) weights, synthetic pixel labels, keep_prob %.2f, accum_num 1" % (
+                                args.preset, "4x4 rate 4 -> 4096" if args.preset == "ref" else "3x3 rate 12 -> 1024",
+                                args.size, args.size, args.classes, args.batch, args.keep_prob),
+                "global_batch": global_batch,
+                "parallelism": "dp%d" % world,
+                "gflop_per_image_fwd_bwd": round(fb_flops / 1e9, 1),
+                "params": adapt.parameter_count(),
+            },
+            "final_loss": round(loss, 5),
+        }
+        if prof is not None:
+            conv = {k: prof[k] for k in ("igemm_fwd", "igemm_dgrad", "igemm_wgrad")}
+            dom = max(conv, key=lambda k: conv[k]["ms"])
+            d = conv[dom]
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+            all_flops = sum(v["flops"] for v in conv.values())
+            all_ms = sum(v["ms"] for v in conv.values())
+            out["roofline"] = {
+                "bound": "mfma",
+                "kernel": dom,
+                "achieved": round(tf, 2),
+                "peak": PEAK_FP32_MATRIX_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "traffic": None,
+                "launches": d["launches"],
+                "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+                "flop_per_launch": d["flops"] / max(d["launches"], 1),
+                "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None,
+                "step_tflops": round(fb_flops * args.batch / (ms * 1e-3) / 1e12, 2),
+            }
+            out["kernel_ms_per_step"] = {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in prof.items()}
+            e = prof["estep"]
+            if e["ms"] > 0:
+                out["estep"] = {"ms": round(e["ms"] / max(e["launches"], 1), 4),
+                                "achieved_GBps": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 2), "bound": "hbm",
+                                "peak_GBps": 8000}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

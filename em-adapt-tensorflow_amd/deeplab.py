@@ -1,0 +1,584 @@
+"""``ADAPT``: the EM-Adapt DeepLab trainer with the reference's class surface (deeplab.py:12-285),
+executing on MI355X through libemadapt_hip.so.
+
+What the reference expresses as TF graph nodes is a static plan here:
+
+  create_network / build_block / build_fc   (deeplab.py:35-107)  -> list of fused ops
+        conv + bias + relu (+ dropout) = ONE implicit-GEMM launch with a fused epilogue
+  e_step                                    (deeplab.py:109-124) -> resize_nearest + device E-step kernel
+  getloss                                   (deeplab.py:180-186) -> fused softmax-CE fwd+bwd (+ L2 on demand)
+  optimize / pre_train                      (deeplab.py:188-208, network.py:91-102)
+        -> hand-written backward (dgrad / wgrad / pool-grad kernels), accumulate, Momentum
+  train inner loop                          (deeplab.py:265-270) -> micro_step() / apply_update()
+
+Memory layout (sized for 288 GB HBM: everything stays resident, nothing is recomputed):
+  * all 32 parameter tensors live in ONE flat fp32 buffer, ordered fc8 .. conv1_1 (the order in which
+    backward produces their gradients), with twin flat buffers for gradients, accumulators and momentum;
+    the optimiser is one launch over the flat buffer and data-parallel buckets are contiguous slices;
+  * conv1_1's 3 input channels are zero-padded to 4 and fc8's C classes to a multiple of 4 inside the
+    buffers so every kernel moves 16-byte vectors; ``weights[layer]`` exposes the reference-shaped views;
+  * activations are NHWC fp32, kept for backward (post-ReLU/dropout output of every conv, pool outputs and
+    a uint8 arg-max tap per pool output).
+"""
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .estep import draw_perms
+from .network import Network, round_up
+
+_ALIGN = 64  # floats: every layer segment of the flat buffers starts on a 256-byte boundary
+
+
+class _Op:
+    __slots__ = ("name", "kind", "out_name", "k", "rate", "relu", "drop", "cin", "cout", "cin_p", "cout_p",
+                 "stride", "in_hw", "out_hw", "seg", "w_pad", "b_pad", "gw_pad", "gb_pad", "index")
+
+    def __init__(self, **kw):
+        for s in self.__slots__:
+            setattr(self, s, None)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class ADAPT(Network):
+    def __init__(self, config):
+        Network.__init__(self, config)
+        self.stride = {}
+        self.stride["input"] = 1
+        # different lr for different variable -- kept for surface parity; the reference never applies
+        # them (the loop at deeplab.py:194-200 rebinds a local), so neither do we.
+        self.lr_1_list = []
+        self.lr_2_list = []
+        self.lr_10_list = []
+        self.lr_20_list = []
+        # build-time knobs beyond the reference's config keys
+        self.preset = self.config.get("preset", "ref")          # "ref": fc6 4x4 rate 4 (deeplab.py:92,145); "largefov": 3x3 rate 12
+        self.width = int(self.config.get("width", 64))          # channel multiplier (64 in the reference)
+        fcw = self.config.get("fc_width", None)
+        self.fc_width = int(fcw) if fcw is not None else (4096 if self.preset == "ref" else 1024) * self.width // 64
+        self.seed = int(self.config.get("seed", 2))
+        self.input_channel = int(self.config.get("input_channel", 3))
+        self._plan = []
+        self._shapes = {}
+        self._dry = False
+        self._flat = None
+        self._bufs = None
+        self._step = 0
+        self._micro = 0
+        self._estep_cfg = None
+        self._weight_decay = 0.0
+        self._momentum = 0.9
+        self._gradsync = None
+        self._perm_pool = None
+        self._perm_pos = 0
+        self.init_model = None
+
+    # ------------------------------------------------------------------------------------------
+    # graph construction -- same call sequence as the reference
+    # ------------------------------------------------------------------------------------------
+    def build(self):
+        if "output" not in self.net:
+            # placeholders (deeplab.py:27-29): filled by the feed of each step
+            self.net["input"] = None
+            self.net["label"] = None
+            self.net["drop_probe"] = None
+            self.net["output"] = self.create_network()
+            self.pred()
+            bs = self.config.get("batch_size", None)
+            if bs:
+                self._alloc(int(bs))
+        return self.net["output"]
+
+    def create_network(self):
+        if "init_model_path" in self.config:
+            self.load_init_model()
+        fc = None
+        # pass 1 (dry) collects shapes so the flat buffers can be laid out; pass 2 binds the views
+        for dry in (True, False):
+            self._dry = dry
+            self._plan = []
+            self.stride = {"input": 1}
+            self.weights = {}
+            self.trainable_list = []
+            self.lr_1_list, self.lr_2_list, self.lr_10_list, self.lr_20_list = [], [], [], []
+            if not dry:
+                self._allocate_flat()
+            # build block (deeplab.py:40-45)
+            block = self.build_block("input", ["conv1_1", "relu1_1", "conv1_2", "relu1_2", "pool1"])
+            block = self.build_block(block, ["conv2_1", "relu2_1", "conv2_2", "relu2_2", "pool2"])
+            block = self.build_block(block, ["conv3_1", "relu3_1", "conv3_2", "relu3_2", "conv3_3", "relu3_3", "pool3"])
+            block = self.build_block(block, ["conv4_1", "relu4_1", "conv4_2", "relu4_2", "conv4_3", "relu4_3", "pool4"])
+            block = self.build_block(block, ["conv5_1", "relu5_1", "conv5_2", "relu5_2", "conv5_3", "relu5_3", "pool5"])
+            fc = self.build_fc(block, ["fc6", "relu6", "drop6", "fc7", "relu7", "drop7", "fc8"])
+        self._finish_plan()
+        # classifier: raw logits, no softmax (deeplab.py:48-49)
+        return fc
+
+    def build_block(self, last_layer, layer_lists):
+        for layer in layer_lists:
+            if layer.startswith("conv"):
+                self.stride[layer] = self.stride[last_layer]
+                weights, bias = self.get_weights_and_bias(layer)
+                rate = 2 if layer[4] == "5" else 1  # atrous_conv2d rate 2 for conv5_x (deeplab.py:60-67)
+                self._add_conv(layer, 3, rate)
+                self.net[layer] = None  # pre-activation is not materialised: bias+ReLU are fused into the conv
+                last_layer = layer
+            if layer.startswith("relu"):
+                self.stride[layer] = self.stride[last_layer]
+                self._fuse(layer, relu=True)
+                last_layer = layer
+            if layer.startswith("pool"):
+                if layer[4] not in ["4", "5"]:
+                    self.stride[layer] = 2 * self.stride[last_layer]
+                    self._add_pool(layer, 2)  # ksize 3x3, strides 2, SAME (deeplab.py:74-78)
+                else:
+                    self.stride[layer] = self.stride[last_layer]
+                    self._add_pool(layer, 1)  # ksize 3x3, strides 1, SAME (deeplab.py:79-83)
+                last_layer = layer
+        return last_layer
+
+    def build_fc(self, last_layer, layer_lists):
+        for layer in layer_lists:
+            if layer.startswith("fc"):
+                weights, bias = self.get_weights_and_bias(layer)
+                shape = self._shapes[layer]
+                if last_layer.startswith("pool"):
+                    rate = 4 if self.preset == "ref" else 12  # atrous_conv2d rate 4 on pool5 (deeplab.py:91-92)
+                else:
+                    rate = 1
+                self._add_conv(layer, shape[0], rate)
+                self.net[layer] = None
+                last_layer = layer
+            if layer.startswith("relu"):
+                self._fuse(layer, relu=True)
+                last_layer = layer
+            if layer.startswith("drop"):
+                self._fuse(layer, drop=True)  # tf.nn.dropout(x, drop_probe) (deeplab.py:102-105)
+                last_layer = layer
+        return last_layer
+
+    def e_step(self, last_layer, bg_p, fg_p, num_iter, suppress_others, margin_others):
+        """deeplab.py:109-124: resize_nearest(label) -> estep -> argmax, all on the device at run time."""
+        self._estep_cfg = dict(layer=last_layer, bg_p=bg_p, fg_p=fg_p, num_iter=num_iter,
+                               suppress_others=suppress_others, margin_others=margin_others)
+        self.net["e_step"] = None    # float map: only produced on request (want_map)
+        self.net["e_argmax"] = None  # int64 label map buffer once allocated
+        return "e_argmax"
+
+    def load_init_model(self):
+        """deeplab.py:126-129: a pickled dict {layer: {"w","b"}} stored with np.save."""
+        model_path = self.config["init_model_path"]
+        self.init_model = np.load(model_path, encoding="latin1", allow_pickle=True).item()
+        print("load init model success: %s" % model_path)
+
+    def get_weights_and_bias(self, layer):
+        """Shapes exactly as deeplab.py:131-149 (with 64 -> self.width); returns HWIO weight and bias views."""
+        if layer.startswith("conv"):
+            shape = [3, 3, 0, 0]
+            if layer == "conv1_1":
+                shape[2] = self.input_channel
+            else:
+                shape[2] = self.width * self.stride[layer]
+                if shape[2] > 8 * self.width:
+                    shape[2] = 8 * self.width
+                if layer in ["conv2_1", "conv3_1", "conv4_1"]:
+                    shape[2] = int(shape[2] / 2)
+            shape[3] = self.width * self.stride[layer]
+            if shape[3] > 8 * self.width:
+                shape[3] = 8 * self.width
+        if layer.startswith("fc"):
+            if layer == "fc6":
+                k = 4 if self.preset == "ref" else 3
+                shape = [k, k, 8 * self.width, self.fc_width]
+            if layer == "fc7":
+                shape = [1, 1, self.fc_width, self.fc_width]
+            if layer == "fc8":
+                shape = [1, 1, self.fc_width, self.category_num]
+        self._shapes[layer] = tuple(shape)
+        if self._dry:
+            return None, None
+        seg = self._segments[layer]
+        weights, bias = seg["w"], seg["b"]
+        self._init_layer(layer, weights, bias)
+        self.weights[layer] = (weights, bias)
+        if layer != "fc8":
+            self.lr_1_list.append(weights)
+            self.lr_2_list.append(bias)
+        else:
+            self.lr_10_list.append(weights)
+            self.lr_20_list.append(bias)
+        self.trainable_list.append(weights)
+        self.trainable_list.append(bias)
+        return weights, bias
+
+    def _init_layer(self, layer, weights, bias):
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(self.seed * 1000003 + len(self.trainable_list))
+        if self.init_model is None:
+            # deeplab.py:150-154: random_normal_initializer(stddev=0.01), zero bias
+            weights.copy_(torch.randn(weights.shape, generator=gen, device=self.device) * 0.01)
+            bias.zero_()
+        elif layer == "fc8":
+            # deeplab.py:156-164: xavier_initializer(uniform=True) for the filter AND the bias
+            kh, kw, cin, cout = weights.shape
+            lim = (6.0 / (kh * kw * cin + kh * kw * cout)) ** 0.5
+            weights.copy_((torch.rand(weights.shape, generator=gen, device=self.device) * 2 - 1) * lim)
+            blim = (6.0 / (2 * cout)) ** 0.5
+            bias.copy_((torch.rand(bias.shape, generator=gen, device=self.device) * 2 - 1) * blim)
+        else:
+            weights.copy_(torch.as_tensor(np.asarray(self.init_model[layer]["w"], dtype=np.float32)).to(self.device))
+            bias.copy_(torch.as_tensor(np.asarray(self.init_model[layer]["b"], dtype=np.float32)).to(self.device))
+
+    # ------------------------------------------------------------------------------------------
+    # plan + memory
+    # ------------------------------------------------------------------------------------------
+    def _add_conv(self, layer, k, rate):
+        kh, kw, cin, cout = self._shapes[layer]
+        op = _Op(name=layer, kind="conv", out_name=layer, k=k, rate=rate, relu=False, drop=False, cin=cin, cout=cout,
+                 cin_p=round_up(cin, 4), cout_p=round_up(cout, 4), index=len(self._plan))
+        if not self._dry:
+            seg = self._segments[layer]
+            op.seg, op.w_pad, op.b_pad, op.gw_pad, op.gb_pad = seg, seg["w_pad"], seg["b_pad"], seg["gw_pad"], seg["gb_pad"]
+        self._plan.append(op)
+
+    def _add_pool(self, layer, stride):
+        self._plan.append(_Op(name=layer, kind="pool", out_name=layer, stride=stride, index=len(self._plan)))
+
+    def _fuse(self, layer, relu=False, drop=False):
+        op = self._plan[-1]
+        assert op.kind == "conv", "relu/dropout must follow a conv"
+        if relu:
+            op.relu = True
+        if drop:
+            op.drop = True
+        op.out_name = layer
+        self.net[layer] = None
+
+    def _allocate_flat(self):
+        """One flat buffer each for params / grads / accumulators / momentum, fc8 first (backward order)."""
+        order = list(self._shapes.keys())  # build order from the dry pass
+        self._segments = {}
+        off = 0
+        for layer in reversed(order):
+            kh, kw, cin, cout = self._shapes[layer]
+            cin_p, cout_p = round_up(cin, 4), round_up(cout, 4)
+            nw, nb = kh * kw * cin_p * cout_p, cout_p
+            start = off
+            self._segments[layer] = dict(start=start, nw=nw, nb=nb, shape=(kh, kw, cin, cout), pshape=(kh, kw, cin_p, cout_p))
+            off = round_up(start + nw + nb, _ALIGN)
+            self._segments[layer]["end"] = off
+        total = off
+        dev = self.device
+        self._flat = dict(
+            params=torch.zeros(total, dtype=torch.float32, device=dev),
+            grads=torch.zeros(total, dtype=torch.float32, device=dev),
+            accum=torch.zeros(total, dtype=torch.float32, device=dev),
+            momentum=torch.zeros(total, dtype=torch.float32, device=dev),
+            total=total,
+        )
+        for layer, seg in self._segments.items():
+            s, nw, nb = seg["start"], seg["nw"], seg["nb"]
+            kh, kw, cin, cout = seg["shape"]
+            for prefix, buf in (("", "params"), ("g", "grads")):
+                wp = self._flat[buf][s:s + nw].view(seg["pshape"])
+                bp = self._flat[buf][s + nw:s + nw + nb]
+                seg[prefix + "w_pad"], seg[prefix + "b_pad"] = wp, bp
+                seg[prefix + "w"], seg[prefix + "b"] = wp[:, :, :cin, :cout], bp[:cout]
+
+    def _finish_plan(self):
+        h, w = self.h, self.w
+        for op in self._plan:
+            op.in_hw = (h, w)
+            if op.kind == "pool":
+                h, w = ops.pool_out_size(h, op.stride), ops.pool_out_size(w, op.stride)
+            op.out_hw = (h, w)
+        self.out_hw = (h, w)
+        self.c_pad = round_up(self.category_num, 4)
+
+    def parameter_count(self):
+        return sum(int(np.prod(s["shape"])) + s["shape"][3] for s in self._segments.values())
+
+    def flops_per_image(self):
+        """Algorithmic FLOPs of one fwd+bwd (bwd = 2x fwd), un-padded shapes."""
+        macs = 0
+        for op in self._plan:
+            if op.kind == "conv":
+                macs += op.out_hw[0] * op.out_hw[1] * op.k * op.k * op.cin * op.cout
+        return 2.0 * macs, 6.0 * macs
+
+    def _alloc(self, B):
+        if self._bufs is not None and self._bufs["B"] == B:
+            return self._bufs
+        dev = self.device
+        f32 = torch.float32
+        bufs = {"B": B, "act": {}, "idx": {}}
+        bufs["x4"] = torch.zeros((B, self.h, self.w, round_up(self.input_channel, 4)), dtype=f32, device=dev)
+        maxn = bufs["x4"].numel()
+        c = bufs["x4"].shape[3]
+        for op in self._plan:
+            oh, ow = op.out_hw
+            if op.kind == "conv":
+                c = op.cout_p
+                bufs["act"][op.name] = torch.empty((B, oh, ow, c), dtype=f32, device=dev)
+            else:
+                bufs["act"][op.name] = torch.empty((B, oh, ow, c), dtype=f32, device=dev)
+                bufs["idx"][op.name] = torch.empty((B, oh, ow, c), dtype=torch.uint8, device=dev)
+            maxn = max(maxn, bufs["act"][op.name].numel())
+            self.net[op.out_name] = bufs["act"][op.name]
+        bufs["gA"] = torch.empty(maxn, dtype=f32, device=dev)
+        bufs["gB"] = torch.empty(maxn, dtype=f32, device=dev)
+        S1, S2 = self.out_hw
+        bufs["shrink"] = torch.empty((B, S1, S2), dtype=f32, device=dev)
+        bufs["labels"] = torch.empty((B, S1, S2), dtype=torch.int64, device=dev)
+        bufs["label_full"] = torch.empty((B, self.h, self.w), dtype=f32, device=dev)
+        self.net["e_argmax"] = bufs["labels"]
+        last = self._plan[-1]
+        self.net["output"] = bufs["act"][last.name][..., :self.category_num]
+        self._bufs = bufs
+        return bufs
+
+    # ------------------------------------------------------------------------------------------
+    # execution
+    # ------------------------------------------------------------------------------------------
+    def _to_dev(self, a, dtype=torch.float32):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype, non_blocking=True).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype, non_blocking=True)
+
+    def forward(self, images, keep_prob=1.0, drop_masks=None):
+        """The conv stack (deeplab.py:35-49). images [B,H,W,3]; returns the fc8 logits view [B,S,S,C]."""
+        images = self._to_dev(images)
+        B = images.shape[0]
+        bufs = self._alloc(B)
+        self.net["input"] = images
+        self.net["drop_probe"] = keep_prob
+        if images.shape[3] == bufs["x4"].shape[3]:
+            x = images
+        else:
+            x = ops.copy_pad_channels(images, bufs["x4"].shape[3], out=bufs["x4"])
+        bufs["x_in"] = x
+        for op in self._plan:
+            out = bufs["act"][op.name]
+            if op.kind == "conv":
+                kp = keep_prob if op.drop else 1.0
+                mask = None
+                if op.drop and kp < 1.0 and drop_masks is not None:
+                    mask = self._pad_mask(drop_masks[op.name], op)
+                ops.conv_fwd(x, op.w_pad, op.b_pad, op.rate, relu=op.relu, keep_prob=kp, drop_mask=mask,
+                             drop_seed=(self.seed << 32) + self._micro * 64 + op.index, out=out)
+            else:
+                ops.maxpool_fwd(x, op.stride, out=out, idx=bufs["idx"][op.name])
+            x = out
+        bufs["keep_prob"] = keep_prob
+        return self.net["output"]
+
+    def _pad_mask(self, m, op):
+        m = self._to_dev(m, torch.uint8)
+        if m.shape[-1] != op.cout_p:
+            mp = torch.zeros(tuple(m.shape[:-1]) + (op.cout_p,), dtype=torch.uint8, device=self.device)
+            mp[..., :m.shape[-1]] = m
+            m = mp
+        return m
+
+    def _next_perms(self):
+        cfg = self._estep_cfg
+        n_it, C = cfg["num_iter"], self.category_num
+        if self._perm_pool is None or self._perm_pos >= self._perm_pool.shape[0]:
+            # drawn with the reference's calls on Python's global generator (estep.py:64-66), 64 steps at a time
+            host = np.stack([draw_perms(n_it, C, rng=random) for _ in range(64)])
+            self._perm_pool = torch.as_tensor(host).to(self.device)
+            self._perm_pos = 0
+        p = self._perm_pool[self._perm_pos]
+        self._perm_pos += 1
+        return p
+
+    def run_estep(self, labels, perms=None, want_map=False):
+        """deeplab.py:109-124 on the current logits. labels: pixel labels [B,H,W(,1)] f32, or uint8 multi-hot [B,C]."""
+        cfg = self._estep_cfg
+        bufs = self._bufs
+        logits = bufs["act"][self._plan[-1].name]
+        if perms is None:
+            perms = self._next_perms()
+        else:
+            perms = self._to_dev(perms, torch.int32)
+        if isinstance(labels, torch.Tensor) and labels.dtype == torch.uint8 or (
+                isinstance(labels, np.ndarray) and labels.dtype == np.uint8 and labels.ndim == 2):
+            lab = self._to_dev(labels, torch.uint8)
+            kind = ops.LABEL_MULTIHOT
+        else:
+            full = self._to_dev(labels)
+            self.net["label"] = full
+            lab = ops.resize_nearest(full, self.out_hw[0], self.out_hw[1], out=bufs["shrink"])
+            kind = ops.LABEL_F32
+        labels_out, fmap = ops.estep_device(
+            logits, lab, perms, self.category_num, suppress_others=cfg["suppress_others"], num_iter=cfg["num_iter"],
+            margin_others=cfg["margin_others"], bg_p=cfg["bg_p"], fg_p=cfg["fg_p"], label_kind=kind,
+            want_map=want_map, labels_out=bufs["labels"], map_out=bufs.get("estep_map"))
+        if fmap is not None:
+            bufs["estep_map"] = fmap
+            self.net["e_step"] = fmap
+        return labels_out
+
+    def getloss(self, weight_decay):
+        weaklabel_layer = self.e_step("fc8", bg_p=0.4, fg_p=0.2, num_iter=5, suppress_others=True, margin_others=1e-5)
+        self._weight_decay = float(weight_decay)
+        self.loss["norm"] = None   # device scalars, refreshed by micro_step()/eval_loss()
+        self.loss["l2"] = None
+        self.loss["total"] = None
+        return weaklabel_layer
+
+    def optimize(self, base_lr, momentum):
+        self.net["lr"] = float(base_lr)
+        self._momentum = float(momentum)
+        # the three "ops" of the reference's loop (deeplab.py:202-205), as callables
+        self.net["accum_gradient"] = self._flat["accum"]
+        self.net["accum_gradient_accum"] = self.micro_step
+        self.net["accum_gradient_update"] = self.apply_update
+        self.net["accum_gradient_clean"] = lambda: None  # folded into the update kernel (accum is zeroed there)
+        self.net["train_op"] = self.apply_update
+        self.net["g"] = 1.0
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1:
+            from .dist import GradSync
+            self._gradsync = GradSync(self._flat["accum"], [(s["start"], s["end"]) for s in self._bucket_order()],
+                                      bucket_bytes=int(self.config.get("bucket_mb", 64)) << 20)
+
+    def _bucket_order(self):
+        return [self._segments[op.name] for op in reversed(self._plan) if op.kind == "conv"]
+
+    def _ce(self, want_grad=True):
+        bufs = self._bufs
+        logits = bufs["act"][self._plan[-1].name]
+        M = logits.numel() // logits.shape[-1]
+        dl = bufs["gA"][:logits.numel()].view(logits.shape) if want_grad else None
+        loss_sum, dl = ops.softmax_ce(logits, bufs["labels"], self.category_num, grad_scale=1.0 / M,
+                                      want_grad=want_grad, want_loss=True, dlogits=dl)
+        self.loss["norm"] = loss_sum / M
+        return dl
+
+    def backward(self, dlogits, last_micro=True):
+        """Hand-written autodiff of deeplab.py:192 (fc8 .. conv1_1), accumulating as deeplab.py:202."""
+        bufs = self._bufs
+        B = bufs["B"]
+        keep = bufs.get("keep_prob", 1.0)
+        d = dlogits
+        cur, other = bufs["gA"], bufs["gB"]
+        inv_accum = 1.0 / float(self.accum_num)
+        plan = self._plan
+        for i in range(len(plan) - 1, -1, -1):
+            op = plan[i]
+            prev = plan[i - 1] if i > 0 else None
+            if op.kind == "conv":
+                x_in = bufs["act"][prev.name] if prev is not None else bufs["x_in"]
+                ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
+                ops.bias_grad(d, out=op.gb_pad)
+                seg = op.seg
+                s, n = seg["start"], seg["nw"] + seg["nb"]
+                ops.sgd_accumulate(self._flat["accum"][s:s + n], self._flat["grads"][s:s + n],
+                                   self._flat["params"][s:s + n], seg["nw"], self._weight_decay, inv_accum)
+                if last_micro and self._gradsync is not None:
+                    self._gradsync.segment_ready(seg["start"], seg["end"])
+                if prev is None:
+                    break
+                out = other[:x_in.numel()].view(x_in.shape)
+                if prev.kind == "conv" and prev.relu:
+                    scale = (1.0 / keep) if (prev.drop and keep < 1.0) else 1.0
+                    d = ops.conv_dgrad(d, op.w_pad, op.rate, gate=x_in, gate_scale=scale, out=out)
+                else:
+                    d = ops.conv_dgrad(d, op.w_pad, op.rate, out=out)
+            else:
+                x_in = bufs["act"][prev.name]
+                gate = x_in if (prev.kind == "conv" and prev.relu) else None
+                out = other[:x_in.numel()].view(x_in.shape)
+                d = ops.maxpool_bwd(d, bufs["idx"][op.name], tuple(x_in.shape), op.stride, gate=gate, out=out)
+            cur, other = other, cur
+        del B
+
+    def micro_step(self, images, labels, keep_prob=0.5, perms=None, drop_masks=None):
+        """sess.run(net["accum_gradient_accum"], feed) of deeplab.py:267: fwd + E-step + bwd + accumulate."""
+        self.forward(images, keep_prob, drop_masks)
+        self.run_estep(labels, perms)
+        dl = self._ce(want_grad=True)
+        last = (self._micro % self.accum_num) == self.accum_num - 1
+        self.backward(dl, last_micro=last)
+        self._micro += 1
+        return self.loss["norm"]
+
+    def apply_update(self):
+        """accum_gradient_update + accum_gradient_clean (deeplab.py:203-205,268-270)."""
+        scale = 1.0
+        if self._gradsync is not None:
+            self._gradsync.wait()
+            scale = 1.0 / self._gradsync.world_size
+        f = self._flat
+        ops.sgd_momentum(f["params"], f["momentum"], f["accum"], self.net["lr"], self._momentum, scale)
+        self._step += 1
+
+    def eval_loss(self, images, labels, keep_prob=0.5, perms=None, drop_masks=None):
+        """sess.run(loss["total"], feed) of deeplab.py:274: a forward + E-step + CE + L2, no gradients."""
+        self.forward(images, keep_prob, drop_masks)
+        self.run_estep(labels, perms)
+        self._ce(want_grad=False)
+        l2 = None
+        for op in self._plan:
+            if op.kind == "conv":
+                t = ops.l2_loss(op.w_pad.reshape(-1))  # padding entries are exactly zero
+                l2 = t if l2 is None else l2 + t
+        self.loss["l2"] = l2
+        self.loss["total"] = self.loss["norm"] + self._weight_decay * l2
+        return float(self.loss["total"])
+
+    # ------------------------------------------------------------------------------------------
+    # training loop (deeplab.py:210-285)
+    # ------------------------------------------------------------------------------------------
+    def train(self, base_lr, weight_decay, momentum, batch_size, epoches, max_iterations=None, log=print):
+        assert self.data is not None, "data is None"
+        train_iter = self.data.next_batch(category="train", batch_size=batch_size, epoches=-1)
+        self.config.setdefault("batch_size", batch_size)
+        self.build()
+        self.pre_train(base_lr, weight_decay, momentum, batch_size,
+                       save_layers=["input", "output", "label", "pred", "is_training", "drop_probe"])
+        if self.config.get("model_path", False) is not False:
+            log("start to load model: %s" % self.config.get("model_path"))
+            self.restore_from_model(self.saver["norm"], self.config.get("model_path"), checkpoint=False)
+            log("model loaded ...")
+        start_time = time.time()
+        log("start_time: %f" % start_time)
+        log("config -- lr:%f weight_decay:%f momentum:%f batch_size:%f epoches:%f" % (
+            base_lr, weight_decay, momentum, batch_size, epoches))
+        epoch, i = 0.0, 0
+        iterations_per_epoch_train = max(self.data.get_data_len() // batch_size, 1)
+        saver_dir = self.config.get("saver_path", "saver")
+        while epoch < epoches and (max_iterations is None or i < max_iterations):
+            if i == 0:
+                self.net["lr"] = base_lr
+            for mult, new_lr in ((10, 1e-4), (20, 1e-5), (30, 1e-6)):  # deeplab.py:245-262
+                if i == mult * iterations_per_epoch_train:
+                    log("save model before new_lr:%f" % new_lr)
+                    self.saver["lr"].save(None, os.path.join(saver_dir, "lr-%f" % base_lr), global_step=i)
+                    self.net["lr"] = new_lr
+                    base_lr = new_lr
+            data_x, data_y = next(train_iter)
+            self.net["accum_gradient_accum"](data_x, data_y, 0.5)
+            if i % self.accum_num == self.accum_num - 1:
+                self.net["accum_gradient_update"]()
+                self.net["accum_gradient_clean"]()
+            if i % 500 == 10:
+                loss = self.eval_loss(data_x, data_y, 0.5)
+                log("epoch:%f, iteration:%f, lr:%f, loss:%f" % (epoch, i, self.net["lr"], loss))
+            if i % 6000 == 5999:
+                self.saver["norm"].save(None, os.path.join(saver_dir, "norm"), global_step=i)
+            i += 1
+            epoch = i / iterations_per_epoch_train
+        torch.cuda.synchronize(self.device)
+        if self.config.get("save_final", True):
+            self.saver["norm"].save(None, os.path.join(saver_dir, "norm"), global_step=i)
+        end_time = time.time()
+        log("end_time:%f" % end_time)
+        log("duration time:%f" % (end_time - start_time))
+        return i
