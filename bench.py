@@ -48,8 +48,21 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = cgroup quota / affinity")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args()
+
+
+def host_cores():
+    """CPU cores this process may really use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
 
 
 def cpu_baseline(args):
@@ -59,7 +72,7 @@ def cpu_baseline(args):
     from oracle import deeplab_oracle as do
     from oracle import estep_oracle as eo
 
-    cores = os.cpu_count() or 1
+    cores = args.cpu_threads or host_cores()
     torch.set_num_threads(cores)
     B = args.cpu_batch
     oracle = do.DeepLabOracle(category_num=args.classes, preset=args.preset, width=args.width, dtype=torch.float32)

@@ -84,6 +84,9 @@ def load(build_if_missing=True):
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch ships its own libamdhip64; import it FIRST so that our library binds to the HIP runtime torch
+    # already loaded (one runtime per process: torch's streams and allocations are then valid in our launches).
+    import torch  # noqa: F401
     if build_if_missing and os.environ.get("EMADAPT_NO_BUILD") != "1":
         try:
             if _build.is_stale():

@@ -167,7 +167,7 @@ class ADAPT(Network):
         self._estep_cfg = dict(layer=last_layer, bg_p=bg_p, fg_p=fg_p, num_iter=num_iter,
                                suppress_others=suppress_others, margin_others=margin_others)
         self.net["e_step"] = None    # float map: only produced on request (want_map)
-        self.net["e_argmax"] = None  # int64 label map buffer once allocated
+        self.net["e_argmax"] = self._bufs["labels"] if self._bufs is not None else None  # int64 label map buffer
         return "e_argmax"
 
     def load_init_model(self):
