@@ -1,0 +1,95 @@
+"""CPU tests of the host-side mirror of the reference interface: plan construction, parameter shapes
+(deeplab.py:131-149), flat-buffer layout, FLOP/parameter counts of SURVEY section 8, perms drawing."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+
+def _adapt(**kw):
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    cfg = {"input_size": (321, 321), "category_num": 21, "device": "cpu"}
+    cfg.update(kw)
+    a = ADAPT(cfg)
+    a.build()
+    return a
+
+
+def test_needs_gpu_unless_device_given():
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        ADAPT({"input_size": (321, 321)})
+
+
+def test_reference_shapes_and_counts():
+    a = _adapt(width=64)
+    shapes = {k: tuple(w.shape) for k, (w, b) in a.weights.items()}
+    assert shapes["conv1_1"] == (3, 3, 3, 64) and shapes["conv2_1"] == (3, 3, 64, 128)
+    assert shapes["conv4_1"] == (3, 3, 256, 512) and shapes["conv5_3"] == (3, 3, 512, 512)
+    assert shapes["fc6"] == (4, 4, 512, 4096) and shapes["fc7"] == (1, 1, 4096, 4096) and shapes["fc8"] == (1, 1, 4096, 21)
+    assert a.parameter_count() == 65_140_565                      # 65.14 M
+    fwd, fb = a.flops_per_image()
+    assert abs(fwd / 1e9 - 251.9) < 0.1 and abs(fb / 1e9 - 755.7) < 0.2
+    assert a.out_hw == (41, 41)
+    names = [op.out_name for op in a._plan]
+    assert names[:3] == ["relu1_1", "relu1_2", "pool1"] and names[-3:] == ["drop6", "drop7", "fc8"]
+    rates = {op.name: op.rate for op in a._plan if op.kind == "conv"}
+    assert rates["conv5_2"] == 2 and rates["fc6"] == 4 and rates["conv4_3"] == 1
+    assert [op.stride for op in a._plan if op.kind == "pool"] == [2, 2, 2, 1, 1]
+    assert len(a.trainable_list) == 32 and a.trainable_list[0] is a.weights["conv1_1"][0]
+
+
+def test_largefov_and_513():
+    a = _adapt(preset="largefov", input_size=(513, 513), category_num=41)
+    assert tuple(a.weights["fc6"][0].shape) == (3, 3, 512, 1024)
+    assert a.out_hw == (65, 65)
+    fwd, fb = a.flops_per_image()
+    assert abs(fb / 1e9 - 772.0) < 0.5
+    assert {op.name: op.rate for op in a._plan if op.kind == "conv"}["fc6"] == 12
+
+
+def test_flat_layout_is_backward_ordered_and_padded():
+    a = _adapt(width=8, input_size=(65, 65))
+    segs = a._segments
+    order = sorted(segs, key=lambda k: segs[k]["start"])
+    assert order[0] == "fc8" and order[-1] == "conv1_1"
+    for k, s in segs.items():
+        assert s["start"] % 64 == 0 and s["nw"] % 4 == 0 and s["nb"] % 4 == 0
+    assert segs["conv1_1"]["pshape"] == (3, 3, 4, 8) and segs["fc8"]["pshape"][3] == 24
+    w = a.weights["conv1_1"][0]
+    assert w.data_ptr() == a._flat["params"][segs["conv1_1"]["start"]:].data_ptr()
+    # padding lanes are zero after init; the weights themselves are ~N(0, 0.01^2)
+    wp = segs["conv1_1"]["w_pad"]
+    assert float(wp[:, :, 3, :].abs().max()) == 0.0
+    assert 0.005 < float(a.weights["fc6"][0].std()) < 0.02 and float(a.weights["fc6"][1].abs().max()) == 0.0
+    # views write through to the flat buffer
+    a.weights["fc8"][1].fill_(3.0)
+    s = segs["fc8"]
+    assert float(a._flat["params"][s["start"] + s["nw"]]) == 3.0
+
+
+def test_default_perms_follow_python_random_like_the_reference():
+    from em_adapt_tensorflow_amd.estep import draw_perms
+    random.seed(5)
+    got = draw_perms(5, 21)
+    r = random.Random(5)
+    want = []
+    for _ in range(5):
+        t = list(range(1, 21))
+        r.shuffle(t)
+        want.append(t)
+    assert np.array_equal(got, np.array(want))
+
+
+def test_synthetic_data_shapes():
+    from em_adapt_tensorflow_amd.data import SyntheticData
+    d = SyntheticData({"input_size": (33, 33), "category_num": 21, "device": "cpu", "length": 10})
+    it = d.next_batch("train", 3)
+    x, y = next(it)
+    assert tuple(x.shape) == (3, 33, 33, 3) and tuple(y.shape) == (3, 33, 33, 1)
+    vals = set(np.unique(y.numpy()).tolist())
+    assert 0.0 in vals and vals <= set(float(v) for v in range(21)) | {255.0}
+    assert d.get_data_len() == 10
