@@ -41,9 +41,17 @@ struct IgemmArgs {
     float keep;         // dropout keep probability (1 = off)
     unsigned long long seed;
     int tiles_m, tiles_n;
+    unsigned x_bytes, w_bytes;  // extents for the bounds-checked buffer loads (< 2 GiB each)
+    unsigned magic_cx, magic_kw;  // ceil(2^32/Cx), ceil(2^32/KW): k / Cx and tap / KW by one v_mul_hi_u32
 };
 
-__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// 16-byte buffer load with hardware range checking: an offset at/after the end of the buffer returns 0,
+// which is how out-of-image taps, K/M/N tails are zero-filled without any branch or exec masking.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
     z += 0x9E3779B97F4A7C15ull;
@@ -103,64 +111,69 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-thread gather state for the A rows it loads ----
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
     const int a_kq = tid % KQ;
     const int a_r0 = tid / KQ;
-    int a_pix[A_N];  // linear pixel index of the row (b*H+oh)*W+ow, or -1
+    int a_base[A_N];  // element offset of the row's pixel: ((b*H+oh)*W+ow)*Cx
     int a_oh[A_N], a_ow[A_N];
 #pragma unroll
     for (int j = 0; j < A_N; j++) {
         const int m = m0 + a_r0 + j * A_RSTEP;
         if (m < a.M) {
-            const int ow = m % a.W;
             const int t2 = m / a.W;
-            a_pix[j] = m;
+            a_base[j] = m * a.Cx;
             a_oh[j] = t2 % a.H;
-            a_ow[j] = ow;
+            a_ow[j] = m - t2 * a.W;
         } else {
-            a_pix[j] = -1;
+            a_base[j] = 0;
             a_oh[j] = -(1 << 20);
             a_ow[j] = -(1 << 20);
         }
     }
-    // k tracker of this thread's quad: k = kt*BK + a_kq*4 -> (tap = kh*KW + kw, c)
-    int k_c = a_kq * 4, k_kh = 0, k_kw = 0, k_tap = 0;
-    while (k_c >= a.Cx) { k_c -= a.Cx; k_tap++; if (++k_kw == a.KW) { k_kw = 0; k_kh++; } }
-
     // B loader coordinates
     const int b_nq = tid % QN, b_kr = tid / QN;       // !BT: float4 along n
     const int b_nr = tid / KQ;                        //  BT: float4 along k (same k quad as A)
 
     float4 ra[A_N], rb[B_N];
 
+    // Out-of-range accesses are marked by setting bit 31 of the byte offset: every buffer is < 2 GiB, so the
+    // hardware range check returns zeros for them -- no branch, no exec masking.
+    constexpr unsigned kOOB = 0x80000000u;
     auto load_tiles = [&](int kt) {
-        const bool kvalid = k_tap < a.ntaps;
-        const int dh = a.sign * (k_kh * a.dil - a.pad_h);
-        const int dw = a.sign * (k_kw * a.dil - a.pad_w);
+        // this thread's k quad: k = kt*BK + a_kq*4 -> (tap = kh*KW + kw, channel c), exact for k < 2^20
+        const unsigned k = (unsigned)(kt * BK + a_kq * 4);
+        const unsigned tap = __umulhi(k, a.magic_cx);
+        const int c = (int)(k - tap * (unsigned)a.Cx);
+        const unsigned kh = __umulhi(tap, a.magic_kw);
+        const int kw = (int)(tap - kh * (unsigned)a.KW);
+        const bool kvalid = (int)tap < a.ntaps;
+        const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
+        const int dw = a.sign * (kw * a.dil - a.pad_w);
+        const int tap_off = (dh * a.W + dw) * a.Cx + c;
 #pragma unroll
         for (int j = 0; j < A_N; j++) {
             const int ih = a_oh[j] + dh, iw = a_ow[j] + dw;
             const bool ok = kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            ra[j] = ok ? ldg4(a.x + ((long long)(a_pix[j] + dh * a.W + dw) * a.Cx + k_c))
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = (unsigned)(a_base[j] + tap_off) * 4u;
+            ra[j] = buf_ld4(xr, off | (ok ? 0u : kOOB));
         }
         if constexpr (!BT) {
 #pragma unroll
             for (int j = 0; j < B_N; j++) {
-                const int k = kt * BK + b_kr + j * B_KSTEP;
+                const int kb = kt * BK + b_kr + j * B_KSTEP;
                 const int n = n0 + b_nq * 4;
-                rb[j] = (k < a.K && n < a.N) ? ldg4(a.w + ((long long)k * a.N + n)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const unsigned off = (unsigned)(kb * a.N + n) * 4u;
+                rb[j] = buf_ld4(wr, off | ((kb < a.K && n < a.N) ? 0u : kOOB));
             }
         } else {
 #pragma unroll
             for (int j = 0; j < B_N; j++) {
                 const int n = n0 + b_nr + j * A_RSTEP;
-                rb[j] = (kvalid && n < a.N) ? ldg4(a.w + (((long long)k_tap * a.N + n) * a.Cx + k_c))
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                const unsigned off = (unsigned)(((int)tap * a.N + n) * a.Cx + c) * 4u;
+                rb[j] = buf_ld4(wr, off | ((kvalid && n < a.N) ? 0u : kOOB));
             }
         }
-        // advance the k tracker to the next K step
-        k_c += BK;
-        while (k_c >= a.Cx) { k_c -= a.Cx; k_tap++; if (++k_kw == a.KW) { k_kw = 0; k_kh++; } }
     };
 
     auto store_tiles = [&](int buf) {
@@ -198,32 +211,46 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+    // Pipeline: registers always hold the tile AFTER the one being multiplied.  Each iteration first parks that
+    // tile in the idle LDS buffer, immediately re-issues the global loads for the tile after it (they get a whole
+    // iteration of MFMAs to land, so nothing waits in front of the barrier), then runs the MFMAs of the current tile.
     const int nk = (a.K + BK - 1) / BK;
     load_tiles(0);
     store_tiles(0);
+    if (nk > 1) load_tiles(1);
     __syncthreads();
 
     const int l31 = lane & 31, lh = lane >> 5;
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tiles(kt + 1);
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        if (kt + 2 < nk) load_tiles(kt + 2);
         const float *as = As + cur * BK * AS + wm * WM + l31;
         const float *bs = Bs + cur * BK * BS + wn * WN + l31;
+        // LDS fragment reads run one k-pair ahead of the MFMAs that consume them
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[0][i] = as[lh * AS + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = bs[lh * BS + j * 32];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // fragment 0 (two ds_read2_b32)
 #pragma unroll
         for (int kk = 0; kk < BK / 2; kk++) {
-            float av[TM], bv[TN];
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = as[(kk * 2 + lh) * AS + i * 32];
+                for (int i = 0; i < TM; i++) av[(kk + 1) & 1][i] = as[((kk + 1) * 2 + lh) * AS + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; j++) bv[j] = bs[(kk * 2 + lh) * BS + j * 32];
+                for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = bs[((kk + 1) * 2 + lh) * BS + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
+            // pin the order: fragment kk+1's LDS reads are issued before the MFMAs of fragment kk
+            if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (more) store_tiles(cur ^ 1);
         __syncthreads();
     }
 
@@ -286,11 +313,17 @@ int check_desc(const emadapt_conv_desc *d) {
         return EMADAPT_ERR_INVALID;
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;
     if ((long long)d->B * d->H * d->W >= (1LL << 30)) return EMADAPT_ERR_UNSUPPORTED;
-    if ((long long)d->B * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) >= (1LL << 40)) return EMADAPT_ERR_UNSUPPORTED;
+    // activations and filters are addressed with 32-bit byte offsets (bounds-checked buffer loads)
+    if ((long long)d->B * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) * 4 >= (1LL << 31)) return EMADAPT_ERR_UNSUPPORTED;
+    if ((long long)d->KH * d->KW * d->Cin * d->Cout * 4 >= (1LL << 31)) return EMADAPT_ERR_UNSUPPORTED;
     return EMADAPT_OK;
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ceil(2^32 / d) for d >= 2: __umulhi(n, magic) == n / d exactly for n < 2^20, d <= 4096 (d == 1 -> identity
+// is handled by the 0 encoding below: __umulhi(n, 0xFFFFFFFF) = n - 1 for n >= 1, so d == 1 uses its own path).
+inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 
 }  // namespace
 
@@ -319,6 +352,8 @@ int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w,
     a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
     a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cin;
     a.epi = epilogue; a.scale = 1.f; a.keep = keep_prob; a.seed = drop_seed;
+    a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
+    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
     return dispatch_igemm<false>(a, stream);
@@ -337,6 +372,8 @@ int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float 
     a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
     a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cout;
     a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; a.keep = 1.f; a.seed = 0;
+    a.x_bytes = (unsigned)((long long)a.M * d->Cout * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
+    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
     return dispatch_igemm<true>(a, stream);

@@ -34,9 +34,16 @@ struct WgradArgs {
     int M, K, ntaps;
     int tiles_k, tiles_n, splits;
     int rows_per_split;  // multiple of BMR
+    unsigned x_bytes, y_bytes;      // extents for the bounds-checked buffer loads (< 2 GiB each)
+    unsigned magic_w, magic_h;      // ceil(2^32/W), ceil(2^32/H): pixel -> (oh, ow) by v_mul_hi_u32
 };
 
-__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// 16-byte buffer load with hardware range checking (offsets with bit 31 set are out of range -> zeros).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 constexpr int BMR = 32;  // pixels per reduction step
 
@@ -78,16 +85,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgradArgs a) {
     const int c = kvalid ? k % a.Cin : 0;
     const int dh = (tap / a.KW) * a.dil - a.pad_h;
     const int dw = (tap % a.KW) * a.dil - a.pad_w;
-    const long long x_off = ((long long)dh * a.W + dw) * a.Cin + c;
+    const int x_off = (dh * a.W + dw) * a.Cin + c;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dy), 0, (int)a.y_bytes, 0x00020000);
+    constexpr unsigned kOOB = 0x80000000u;
 
-    // pixel trackers for the X rows this thread loads: m = m_begin + x_r0 + j*X_RSTEP (+ BMR per step)
-    int x_oh[X_N], x_ow[X_N];
-#pragma unroll
-    for (int j = 0; j < X_N; j++) {
-        const int m = m_begin + x_r0 + j * X_RSTEP;
-        x_ow[j] = m % a.W;
-        x_oh[j] = (m / a.W) % a.H;
-    }
     const int y_nq = tid % YQ, y_r0 = tid / YQ;
     const int y_n = n0 + y_nq * 4;
     const bool nvalid = y_n < a.N;
@@ -98,20 +100,20 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < X_N; j++) {
             const int m = mb + x_r0 + j * X_RSTEP;
-            const int ih = x_oh[j] + dh, iw = x_ow[j] + dw;
+            // pixel -> (oh, ow), exact while M * max(W, H) < 2^32 (checked on the host)
+            const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
+            const int ow = m - (int)t2 * a.W;
+            const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
+            const int ih = oh + dh, iw = ow + dw;
             const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            rx[j] = ok ? ldg4(a.x + ((long long)m * a.Cin + x_off)) : make_float4(0.f, 0.f, 0.f, 0.f);
-            // advance this row's pixel by BMR for the next step
-            x_ow[j] += BMR;
-            while (x_ow[j] >= a.W) {
-                x_ow[j] -= a.W;
-                if (++x_oh[j] == a.H) x_oh[j] = 0;
-            }
+            const unsigned off = (unsigned)(m * a.Cin + x_off) * 4u;
+            rx[j] = buf_ld4(xr, off | (ok ? 0u : kOOB));
         }
 #pragma unroll
         for (int j = 0; j < Y_N; j++) {
             const int m = mb + y_r0 + j * Y_RSTEP;
-            ry[j] = (nvalid && m < m_end) ? ldg4(a.dy + ((long long)m * a.N + y_n)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned off = (unsigned)(m * a.N + y_n) * 4u;
+            ry[j] = buf_ld4(yr, off | ((nvalid && m < m_end) ? 0u : kOOB));
         }
     };
     auto store_tiles = [&](int buf) {
@@ -136,29 +138,40 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgradArgs a) {
     const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BMR - 1) / BMR : 0;
     const int l31 = lane & 31, lh = lane >> 5;
     if (nsteps > 0) {
+        // same pipeline as the forward kernel: park the prefetched tile in the idle LDS buffer, re-issue the
+        // next global loads at once, multiply the current tile, one barrier per step.
         load_tiles(m_begin);
         store_tiles(0);
+        if (nsteps > 1) load_tiles(m_begin + BMR);
         __syncthreads();
         for (int s = 0; s < nsteps; s++) {
             const int cur = s & 1;
-            const bool more = s + 1 < nsteps;
-            if (more) load_tiles(m_begin + (s + 1) * BMR);
+            if (s + 1 < nsteps) store_tiles(cur ^ 1);
+            if (s + 2 < nsteps) load_tiles(m_begin + (s + 2) * BMR);
             const float *xs = Xs + cur * BMR * BKO + wk * WK + l31;
             const float *ys = Ys + cur * BMR * BN + wn * WN + l31;
+            float av[2][TK], bv[2][TN];
+#pragma unroll
+            for (int i = 0; i < TK; i++) av[0][i] = xs[lh * BKO + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; j++) bv[0][j] = ys[lh * BN + j * 32];
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
             for (int kk = 0; kk < BMR / 2; kk++) {
-                float av[TK], bv[TN];
+                if (kk + 1 < BMR / 2) {
 #pragma unroll
-                for (int i = 0; i < TK; i++) av[i] = xs[(kk * 2 + lh) * BKO + i * 32];
+                    for (int i = 0; i < TK; i++) av[(kk + 1) & 1][i] = xs[((kk + 1) * 2 + lh) * BKO + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; j++) bv[j] = ys[(kk * 2 + lh) * BN + j * 32];
+                    for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = ys[((kk + 1) * 2 + lh) * BN + j * 32];
+                }
 #pragma unroll
                 for (int i = 0; i < TK; i++)
 #pragma unroll
                     for (int j = 0; j < TN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
+                if (kk + 1 < BMR / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TK * TN, 0);
             }
-            if (more) store_tiles(cur ^ 1);
             __syncthreads();
         }
     }
@@ -208,8 +221,13 @@ int check_desc(const emadapt_conv_desc *d) {
         return EMADAPT_ERR_INVALID;
     if (d->Cin % 4 != 0 || d->Cout % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;
     if ((long long)d->B * d->H * d->W >= (1LL << 30)) return EMADAPT_ERR_UNSUPPORTED;
+    const long long M = (long long)d->B * d->H * d->W;
+    if (M * (d->Cin > d->Cout ? d->Cin : d->Cout) * 4 >= (1LL << 31)) return EMADAPT_ERR_UNSUPPORTED;  // 32-bit byte offsets
+    if (M * (d->W > d->H ? d->W : d->H) >= (1LL << 32)) return EMADAPT_ERR_UNSUPPORTED;                 // magic division range
     return EMADAPT_OK;
 }
+
+inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 
 template <int BN>
 int launch_wgrad(const WgradArgs &a, hipStream_t stream) {
@@ -260,6 +278,8 @@ int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *
     a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
     a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cin;
     a.tiles_k = p.tiles_k; a.tiles_n = p.tiles_n; a.splits = p.splits; a.rows_per_split = p.rows_per_split;
+    a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
+    a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
     rc = (p.bn == 64) ? launch_wgrad<64>(a, stream) : launch_wgrad<128>(a, stream);
     if (rc) return rc;
