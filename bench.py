@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--keep-prob", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = cgroup quota / affinity")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args()

@@ -19,6 +19,10 @@
 // buffers, one barrier per K step; two workgroups per CU.  blockIdx is remapped so that the eight
 // workgroups that share an XCD (and its L2) work on neighbouring tiles (8 M-tiles x all N-tiles).
 // Epilogue (bias / ReLU / dropout, or the ReLU-gradient gate for dgrad) is fused.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -43,6 +47,9 @@ struct IgemmArgs {
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes;  // extents for the bounds-checked buffer loads (< 2 GiB each)
     unsigned magic_cx, magic_kw;  // ceil(2^32/Cx), ceil(2^32/KW): k / Cx and tap / KW by one v_mul_hi_u32
+    int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
+    unsigned magic_nt;   // ceil(2^32/ntaps)
+    int ablate;  // diagnostics only (EMADAPT_ABLATE): 1 = no global loads, 2 = no LDS stores, 4 = no barrier
 };
 
 // 16-byte buffer load with hardware range checking: an offset at/after the end of the buffer returns 0,
@@ -135,71 +142,76 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
     const int b_nq = tid % QN, b_kr = tid / QN;       // !BT: float4 along n
     const int b_nr = tid / KQ;                        //  BT: float4 along k (same k quad as A)
 
-    float4 ra[A_N], rb[B_N];
+    // two register sets: while set P receives the global loads of tile kt+2, set P^1 (tile kt+1, loaded one
+    // iteration earlier) is parked in LDS -- a load has more than a full K step of MFMAs to land.
+    float4 ra[2][A_N], rb[2][B_N];
 
     // Out-of-range accesses are marked by setting bit 31 of the byte offset: every buffer is < 2 GiB, so the
     // hardware range check returns zeros for them -- no branch, no exec masking.
     constexpr unsigned kOOB = 0x80000000u;
-    auto load_tiles = [&](int kt) {
-        // this thread's k quad: k = kt*BK + a_kq*4 -> (tap = kh*KW + kw, channel c), exact for k < 2^20
-        const unsigned k = (unsigned)(kt * BK + a_kq * 4);
-        const unsigned tap = __umulhi(k, a.magic_cx);
-        const int c = (int)(k - tap * (unsigned)a.Cx);
-        const unsigned kh = __umulhi(tap, a.magic_kw);
-        const int kw = (int)(tap - kh * (unsigned)a.KW);
-        const bool kvalid = (int)tap < a.ntaps;
-        const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
-        const int dw = a.sign * (kw * a.dil - a.pad_w);
-        const int tap_off = (dh * a.W + dw) * a.Cx + c;
-#pragma unroll
-        for (int j = 0; j < A_N; j++) {
-            const int ih = a_oh[j] + dh, iw = a_ow[j] + dw;
-            const bool ok = kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            const unsigned off = (unsigned)(a_base[j] + tap_off) * 4u;
-            ra[j] = buf_ld4(xr, off | (ok ? 0u : kOOB));
-        }
-        if constexpr (!BT) {
-#pragma unroll
-            for (int j = 0; j < B_N; j++) {
-                const int kb = kt * BK + b_kr + j * B_KSTEP;
-                const int n = n0 + b_nq * 4;
-                const unsigned off = (unsigned)(kb * a.N + n) * 4u;
-                rb[j] = buf_ld4(wr, off | ((kb < a.K && n < a.N) ? 0u : kOOB));
-            }
+    struct Tap { unsigned tap; int c, dh, dw, off; bool valid; };
+    // this thread's k quad of K step kt: k = kt*BK + a_kq*4 -> (tap = kh*KW + kw, channel c), exact for k < 2^20
+    // K-step order.  Linear: k = kt*BK + .. = (tap, c) with the channel fastest.  tap_inner (Cx % BK == 0): K step
+    // kt = (channel chunk kt / ntaps, tap kt % ntaps): all taps of one 128-byte channel slice run back to back, so
+    // the slice of the tile's pixels (+halo) is fetched once and then hit in L1/L2 by the other taps.
+    auto tap_of = [&](int kt) {
+        Tap t;
+        if (a.tap_inner) {
+            const unsigned chunk = __umulhi((unsigned)kt, a.magic_nt);
+            t.tap = (unsigned)kt - chunk * (unsigned)a.ntaps;
+            t.c = (int)chunk * BK + a_kq * 4;
+            if ((int)chunk * BK >= a.Cx) t.tap = (unsigned)a.ntaps;  // past the end of K
         } else {
-#pragma unroll
-            for (int j = 0; j < B_N; j++) {
-                const int n = n0 + b_nr + j * A_RSTEP;
-                const unsigned off = (unsigned)(((int)tap * a.N + n) * a.Cx + c) * 4u;
-                rb[j] = buf_ld4(wr, off | ((kvalid && n < a.N) ? 0u : kOOB));
-            }
+            const unsigned k = (unsigned)(kt * BK + a_kq * 4);
+            t.tap = __umulhi(k, a.magic_cx);
+            t.c = (int)(k - t.tap * (unsigned)a.Cx);
+        }
+        const unsigned kh = __umulhi(t.tap, a.magic_kw);
+        const int kw = (int)(t.tap - kh * (unsigned)a.KW);
+        t.valid = (int)t.tap < a.ntaps;
+        t.dh = a.sign * ((int)kh * a.dil - a.pad_h);
+        t.dw = a.sign * (kw * a.dil - a.pad_w);
+        t.off = (t.dh * a.W + t.dw) * a.Cx + t.c;
+        return t;
+    };
+    auto load_a = [&](float4 &dst, int j, const Tap &t) {
+        const int ih = a_oh[j] + t.dh, iw = a_ow[j] + t.dw;
+        const bool ok = t.valid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        const unsigned off = (unsigned)(a_base[j] + t.off) * 4u;
+        dst = buf_ld4(xr, off | (ok ? 0u : kOOB));
+    };
+    auto load_b = [&](float4 &dst, int j, int kt, const Tap &t) {
+        if constexpr (!BT) {
+            // row of the [K][N] filter matrix: linear order kt*BK + r; tap-inner order tap*Cx + chunk*BK + r
+            const int r = b_kr + j * B_KSTEP;
+            const int kb = a.tap_inner ? (int)t.tap * a.Cx + (t.c - a_kq * 4) + r : kt * BK + r;
+            const int n = n0 + b_nq * 4;
+            const unsigned off = (unsigned)(kb * a.N + n) * 4u;
+            dst = buf_ld4(wr, off | ((kb < a.K && n < a.N) ? 0u : kOOB));
+        } else {
+            const int n = n0 + b_nr + j * A_RSTEP;
+            const unsigned off = (unsigned)(((int)t.tap * a.N + n) * a.Cx + t.c) * 4u;
+            dst = buf_ld4(wr, off | ((t.valid && n < a.N) ? 0u : kOOB));
         }
     };
-
-    auto store_tiles = [&](int buf) {
+    auto store_a = [&](int buf, int j, const float4 &v) {
         float *as = As + buf * BK * AS;
+        const int r = a_r0 + j * A_RSTEP;
+        as[(a_kq * 4 + 0) * AS + r] = v.x;
+        as[(a_kq * 4 + 1) * AS + r] = v.y;
+        as[(a_kq * 4 + 2) * AS + r] = v.z;
+        as[(a_kq * 4 + 3) * AS + r] = v.w;
+    };
+    auto store_b = [&](int buf, int j, const float4 &v) {
         float *bs = Bs + buf * BK * BS;
-#pragma unroll
-        for (int j = 0; j < A_N; j++) {
-            const int r = a_r0 + j * A_RSTEP;
-            as[(a_kq * 4 + 0) * AS + r] = ra[j].x;
-            as[(a_kq * 4 + 1) * AS + r] = ra[j].y;
-            as[(a_kq * 4 + 2) * AS + r] = ra[j].z;
-            as[(a_kq * 4 + 3) * AS + r] = ra[j].w;
-        }
         if constexpr (!BT) {
-#pragma unroll
-            for (int j = 0; j < B_N; j++)
-                *reinterpret_cast<float4 *>(&bs[(b_kr + j * B_KSTEP) * BS + b_nq * 4]) = rb[j];
+            *reinterpret_cast<float4 *>(&bs[(b_kr + j * B_KSTEP) * BS + b_nq * 4]) = v;
         } else {
-#pragma unroll
-            for (int j = 0; j < B_N; j++) {
-                const int n = b_nr + j * A_RSTEP;
-                bs[(a_kq * 4 + 0) * BS + n] = rb[j].x;
-                bs[(a_kq * 4 + 1) * BS + n] = rb[j].y;
-                bs[(a_kq * 4 + 2) * BS + n] = rb[j].z;
-                bs[(a_kq * 4 + 3) * BS + n] = rb[j].w;
-            }
+            const int n = b_nr + j * A_RSTEP;
+            bs[(a_kq * 4 + 0) * BS + n] = v.x;
+            bs[(a_kq * 4 + 1) * BS + n] = v.y;
+            bs[(a_kq * 4 + 2) * BS + n] = v.z;
+            bs[(a_kq * 4 + 3) * BS + n] = v.w;
         }
     };
 
@@ -211,47 +223,87 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    // Pipeline: registers always hold the tile AFTER the one being multiplied.  Each iteration first parks that
-    // tile in the idle LDS buffer, immediately re-issues the global loads for the tile after it (they get a whole
-    // iteration of MFMAs to land, so nothing waits in front of the barrier), then runs the MFMAs of the current tile.
+    // Software pipeline.  Inside the MFMA stream of K step kt -- NKK k-pairs of TM*TN MFMAs, 64 cycles each -- the
+    // tile movement is spread out in program order:
+    //   k-pairs 1 .. LD_END      : global loads of tile kt+2 into register set P (a few per pair, with their
+    //                              address arithmetic)
+    //   k-pairs ST0 .. NKK-1     : one part per pair of "park tile kt+1 (register set P^1) in the idle LDS buffer"
+    // so the LDS writes, VALU and VMEM issue in the shadow of the MFMAs instead of forming a phase of their own
+    // in which the matrix pipe idles.  Everything is unconditional (tiles past K are zero-filled by the range
+    // check and land in an LDS buffer nobody reads), so an iteration is one branch-free block, one barrier.
+    constexpr int NKK = BK / 2;
+    constexpr int NST = A_N + B_N;              // tile parts (one load / one LDS store each)
+    constexpr int ST0 = NKK - NST;              // first k-pair that stores
+    static_assert(ST0 >= 2, "K step too short for the software pipeline");
+    constexpr int LPK = (NST + (ST0 - 1) - 1) / (ST0 - 1);  // loads per k-pair, k-pairs 1..ST0-1
     const int nk = (a.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    if (nk > 1) load_tiles(1);
+    {
+        const Tap t0 = tap_of(0);
+#pragma unroll
+        for (int j = 0; j < A_N; j++) load_a(ra[0][j], j, t0);
+#pragma unroll
+        for (int j = 0; j < B_N; j++) load_b(rb[0][j], j, 0, t0);
+        const Tap t1 = tap_of(1);
+#pragma unroll
+        for (int j = 0; j < A_N; j++) load_a(ra[1][j], j, t1);
+#pragma unroll
+        for (int j = 0; j < B_N; j++) load_b(rb[1][j], j, 1, t1);
+#pragma unroll
+        for (int j = 0; j < A_N; j++) store_a(0, j, ra[0][j]);
+#pragma unroll
+        for (int j = 0; j < B_N; j++) store_b(0, j, rb[0][j]);
+    }
     __syncthreads();
 
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
-        if (kt + 2 < nk) load_tiles(kt + 2);
-        const float *as = As + cur * BK * AS + wm * WM + l31;
-        const float *bs = Bs + cur * BK * BS + wn * WN + l31;
+    auto k_step = [&](auto parity, int kt) {
+        constexpr int P = decltype(parity)::value;  // = kt & 1: LDS buffer being multiplied, register set being loaded
+        const float *as = As + P * BK * AS + wm * WM + l31;
+        const float *bs = Bs + P * BK * BS + wn * WN + l31;
+        Tap tnext = {};
         // LDS fragment reads run one k-pair ahead of the MFMAs that consume them
         float av[2][TM], bv[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; i++) av[0][i] = as[lh * AS + i * 32];
 #pragma unroll
         for (int j = 0; j < TN; j++) bv[0][j] = bs[lh * BS + j * 32];
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // fragment 0 (two ds_read2_b32)
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; kk++) {
-            if (kk + 1 < BK / 2) {
+        for (int kk = 0; kk < NKK; kk++) {
+            if (kk + 1 < NKK) {
 #pragma unroll
                 for (int i = 0; i < TM; i++) av[(kk + 1) & 1][i] = as[((kk + 1) * 2 + lh) * AS + i * 32];
 #pragma unroll
                 for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = bs[((kk + 1) * 2 + lh) * BS + j * 32];
             }
+            // hard scheduling fence: the reads above stay ahead of this k-pair's MFMAs (one k-pair of latency cover)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
-            // pin the order: fragment kk+1's LDS reads are issued before the MFMAs of fragment kk
-            if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            // tile movement slotted into this k-pair
+            if (kk >= 1 && kk < ST0 && !(a.ablate & 1)) {
+#pragma unroll
+                for (int q = 0; q < LPK; q++) {
+                    const int lidx = (kk - 1) * LPK + q;
+                    if (lidx == 0) tnext = tap_of(kt + 2);
+                    if (lidx < A_N) load_a(ra[P][lidx < A_N ? lidx : 0], lidx, tnext);
+                    else if (lidx < NST) load_b(rb[P][lidx - A_N < B_N && lidx >= A_N ? lidx - A_N : 0], lidx - A_N, kt + 2, tnext);
+                }
+            }
+            if (kk >= ST0 && !(a.ablate & 2)) {
+                const int sidx = kk - ST0;
+                if (sidx < A_N) store_a(P ^ 1, sidx, ra[P ^ 1][sidx < A_N ? sidx : 0]);
+                else store_b(P ^ 1, sidx - A_N, rb[P ^ 1][sidx >= A_N ? sidx - A_N : 0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        if (!(a.ablate & 4)) __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        k_step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < nk) k_step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
     // ---- fused epilogue; C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -303,6 +355,11 @@ int launch_igemm(IgemmArgs &a, hipStream_t stream) {
 
 template <bool BT>
 int dispatch_igemm(IgemmArgs &a, hipStream_t stream) {
+    static const int ablate = getenv("EMADAPT_ABLATE") ? atoi(getenv("EMADAPT_ABLATE")) : 0;
+    static const int no_tap_inner = getenv("EMADAPT_NO_TAP_INNER") ? 1 : 0;
+    a.ablate = ablate;
+    const int bk = a.N <= 64 ? 16 : 32;
+    a.tap_inner = (!no_tap_inner && a.ntaps > 1 && a.Cx % bk == 0) ? 1 : 0;
     if (a.N <= 64) return launch_igemm<256, 64, 16, BT>(a, stream);
     return launch_igemm<128, 128, 32, BT>(a, stream);
 }
@@ -353,7 +410,7 @@ int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w,
     a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cin;
     a.epi = epilogue; a.scale = 1.f; a.keep = keep_prob; a.seed = drop_seed;
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
-    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW);
+    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
     return dispatch_igemm<false>(a, stream);
@@ -373,7 +430,7 @@ int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float 
     a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cout;
     a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; a.keep = 1.f; a.seed = 0;
     a.x_bytes = (unsigned)((long long)a.M * d->Cout * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
-    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW);
+    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
     return dispatch_igemm<true>(a, stream);

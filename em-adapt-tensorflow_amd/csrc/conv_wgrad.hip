@@ -13,6 +13,8 @@
 // Layers whose [K x N] filter has few 128x128 tiles (conv1_x .. conv5_x) would leave most of the 256
 // CUs idle, so the pixel range is split across workgroups ("split-M"); each split writes an fp32
 // partial slab and a second kernel adds the slabs in a fixed order -- deterministic, no atomics.
+#include <type_traits>
+
 #include "common.h"
 
 namespace emadapt {
@@ -94,37 +96,31 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgradArgs a) {
     const int y_n = n0 + y_nq * 4;
     const bool nvalid = y_n < a.N;
 
-    float4 rx[X_N], ry[Y_N];
+    // two register sets, as in the forward kernel: set P receives the loads of step s+2 while set P^1 (step s+1)
+    // is parked in LDS.
+    float4 rx[2][X_N], ry[2][Y_N];
 
-    auto load_tiles = [&](int mb) {  // mb = first pixel of the step
-#pragma unroll
-        for (int j = 0; j < X_N; j++) {
-            const int m = mb + x_r0 + j * X_RSTEP;
-            // pixel -> (oh, ow), exact while M * max(W, H) < 2^32 (checked on the host)
-            const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
-            const int ow = m - (int)t2 * a.W;
-            const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
-            const int ih = oh + dh, iw = ow + dw;
-            const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            const unsigned off = (unsigned)(m * a.Cin + x_off) * 4u;
-            rx[j] = buf_ld4(xr, off | (ok ? 0u : kOOB));
-        }
-#pragma unroll
-        for (int j = 0; j < Y_N; j++) {
-            const int m = mb + y_r0 + j * Y_RSTEP;
-            const unsigned off = (unsigned)(m * a.N + y_n) * 4u;
-            ry[j] = buf_ld4(yr, off | ((nvalid && m < m_end) ? 0u : kOOB));
-        }
+    auto load_x = [&](float4 &dst, int j, int mb) {
+        const int m = mb + x_r0 + j * X_RSTEP;
+        // pixel -> (oh, ow), exact while M * max(W, H) < 2^32 (checked on the host)
+        const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
+        const int ow = m - (int)t2 * a.W;
+        const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
+        const int ih = oh + dh, iw = ow + dw;
+        const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        const unsigned off = (unsigned)(m * a.Cin + x_off) * 4u;
+        dst = buf_ld4(xr, off | (ok ? 0u : kOOB));
     };
-    auto store_tiles = [&](int buf) {
-        float *xs = Xs + buf * BMR * BKO;
-        float *ys = Ys + buf * BMR * BN;
-#pragma unroll
-        for (int j = 0; j < X_N; j++)
-            *reinterpret_cast<float4 *>(&xs[(x_r0 + j * X_RSTEP) * BKO + x_kq * 4]) = rx[j];
-#pragma unroll
-        for (int j = 0; j < Y_N; j++)
-            *reinterpret_cast<float4 *>(&ys[(y_r0 + j * Y_RSTEP) * BN + y_nq * 4]) = ry[j];
+    auto load_y = [&](float4 &dst, int j, int mb) {
+        const int m = mb + y_r0 + j * Y_RSTEP;
+        const unsigned off = (unsigned)(m * a.N + y_n) * 4u;
+        dst = buf_ld4(yr, off | ((nvalid && m < m_end) ? 0u : kOOB));
+    };
+    auto store_x = [&](int buf, int j, const float4 &v) {
+        *reinterpret_cast<float4 *>(&Xs[buf * BMR * BKO + (x_r0 + j * X_RSTEP) * BKO + x_kq * 4]) = v;
+    };
+    auto store_y = [&](int buf, int j, const float4 &v) {
+        *reinterpret_cast<float4 *>(&Ys[buf * BMR * BN + (y_r0 + j * Y_RSTEP) * BN + y_nq * 4]) = v;
     };
 
     f32x16 acc[TK][TN];
@@ -137,43 +133,71 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgradArgs a) {
 
     const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BMR - 1) / BMR : 0;
     const int l31 = lane & 31, lh = lane >> 5;
+    // software pipeline (see conv_igemm.hip): loads of step s+2 early in the MFMA stream, LDS stores of step s+1 late
+    constexpr int NKK = BMR / 2;
+    constexpr int NST = X_N + Y_N;
+    constexpr int ST0 = NKK - NST;
+    static_assert(ST0 >= 2, "reduction step too short for the software pipeline");
+    constexpr int LPK = (NST + (ST0 - 1) - 1) / (ST0 - 1);
     if (nsteps > 0) {
-        // same pipeline as the forward kernel: park the prefetched tile in the idle LDS buffer, re-issue the
-        // next global loads at once, multiply the current tile, one barrier per step.
-        load_tiles(m_begin);
-        store_tiles(0);
-        if (nsteps > 1) load_tiles(m_begin + BMR);
-        __syncthreads();
-        for (int s = 0; s < nsteps; s++) {
-            const int cur = s & 1;
-            if (s + 1 < nsteps) store_tiles(cur ^ 1);
-            if (s + 2 < nsteps) load_tiles(m_begin + (s + 2) * BMR);
-            const float *xs = Xs + cur * BMR * BKO + wk * WK + l31;
-            const float *ys = Ys + cur * BMR * BN + wn * WN + l31;
-            float av[2][TK], bv[2][TN];
 #pragma unroll
-            for (int i = 0; i < TK; i++) av[0][i] = xs[lh * BKO + i * 32];
+        for (int j = 0; j < X_N; j++) load_x(rx[0][j], j, m_begin);
 #pragma unroll
-            for (int j = 0; j < TN; j++) bv[0][j] = ys[lh * BN + j * 32];
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        for (int j = 0; j < Y_N; j++) load_y(ry[0][j], j, m_begin);
 #pragma unroll
-            for (int kk = 0; kk < BMR / 2; kk++) {
-                if (kk + 1 < BMR / 2) {
+        for (int j = 0; j < X_N; j++) load_x(rx[1][j], j, m_begin + BMR);
 #pragma unroll
-                    for (int i = 0; i < TK; i++) av[(kk + 1) & 1][i] = xs[((kk + 1) * 2 + lh) * BKO + i * 32];
+        for (int j = 0; j < Y_N; j++) load_y(ry[1][j], j, m_begin + BMR);
 #pragma unroll
-                    for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = ys[((kk + 1) * 2 + lh) * BN + j * 32];
-                }
+        for (int j = 0; j < X_N; j++) store_x(0, j, rx[0][j]);
 #pragma unroll
-                for (int i = 0; i < TK; i++)
+        for (int j = 0; j < Y_N; j++) store_y(0, j, ry[0][j]);
+    }
+    __syncthreads();
+    auto m_step = [&](auto parity, int st) {
+        constexpr int P = decltype(parity)::value;
+        const float *xs = Xs + P * BMR * BKO + wk * WK + l31;
+        const float *ys = Ys + P * BMR * BN + wn * WN + l31;
+        const int mb2 = m_begin + (st + 2) * BMR;  // rows >= m_end are zero-filled by the range check
+        float av[2][TK], bv[2][TN];
 #pragma unroll
-                    for (int j = 0; j < TN; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
-                if (kk + 1 < BMR / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, TK * TN, 0);
+        for (int i = 0; i < TK; i++) av[0][i] = xs[lh * BKO + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = ys[lh * BN + j * 32];
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk++) {
+            if (kk + 1 < NKK) {
+#pragma unroll
+                for (int i = 0; i < TK; i++) av[(kk + 1) & 1][i] = xs[((kk + 1) * 2 + lh) * BKO + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = ys[((kk + 1) * 2 + lh) * BN + j * 32];
             }
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TK; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
+            if (kk >= 1 && kk < ST0) {
+#pragma unroll
+                for (int q = 0; q < LPK; q++) {
+                    const int lidx = (kk - 1) * LPK + q;
+                    if (lidx < X_N) load_x(rx[P][lidx < X_N ? lidx : 0], lidx, mb2);
+                    else if (lidx < NST) load_y(ry[P][lidx >= X_N && lidx - X_N < Y_N ? lidx - X_N : 0], lidx - X_N, mb2);
+                }
+            }
+            if (kk >= ST0) {
+                const int sidx = kk - ST0;
+                if (sidx < X_N) store_x(P ^ 1, sidx, rx[P ^ 1][sidx < X_N ? sidx : 0]);
+                else store_y(P ^ 1, sidx - X_N, ry[P ^ 1][sidx >= X_N ? sidx - X_N : 0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();
+    };
+    for (int st = 0; st < nsteps; st += 2) {
+        m_step(std::integral_constant<int, 0>{}, st);
+        if (st + 1 < nsteps) m_step(std::integral_constant<int, 1>{}, st + 1);
     }
 
     float *out = a.out + (long long)split * a.K * a.N;

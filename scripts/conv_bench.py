@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Time single conv kernels (fwd / dgrad / wgrad) at DeepLab layer shapes.  usage: conv_bench.py [layer ...]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from em_adapt_tensorflow_amd import ops
+
+SHAPES = {  # name: (B, H, W, Cin, Cout, k, dil)
+    "fc6": (16, 41, 41, 512, 4096, 4, 4), "fc7": (16, 41, 41, 4096, 4096, 1, 1), "conv4_2": (16, 41, 41, 512, 512, 3, 1),
+    "conv5_2": (16, 41, 41, 512, 512, 3, 2), "conv3_2": (16, 81, 81, 256, 256, 3, 1), "conv2_2": (16, 161, 161, 128, 128, 3, 1),
+    "conv1_2": (16, 321, 321, 64, 64, 3, 1), "conv4_2x8": (128, 41, 41, 512, 512, 3, 1),
+    "fc7p": (16, 41, 41, 4096 + 64, 4096 + 64, 1, 1), "fc7h": (16, 41, 41, 2048, 2048, 1, 1), "fc7hp": (16, 41, 41, 2048 + 32, 2048 + 32, 1, 1),
+}
+
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+names = sys.argv[1:] or ["fc6", "conv4_2", "conv2_2"]
+for n in names:
+    B, H, W, Cin, Cout, k, dil = SHAPES[n]
+    x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
+    b = torch.zeros(Cout, device="cuda"); dy = torch.randn(B, H, W, Cout, device="cuda")
+    y = torch.empty(B, H, W, Cout, device="cuda"); dx = torch.empty_like(x); dw = torch.empty_like(w)
+    fl = 2.0 * B * H * W * k * k * Cin * Cout
+    for kind, fn in (("fwd", lambda: ops.conv_fwd(x, w, b, dil, out=y)), ("dgrad", lambda: ops.conv_dgrad(dy, w, dil, out=dx)),
+                     ("wgrad", lambda: ops.conv_wgrad(x, dy, k, k, dil, out=dw))):
+        ms = timeit(fn)
+        print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  ablate=%s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100,
+                                                                 os.environ.get("EMADAPT_ABLATE", "0")), flush=True)
