@@ -47,6 +47,8 @@ struct IgemmArgs {
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes;  // extents for the bounds-checked buffer loads (< 2 GiB each)
     unsigned magic_cx, magic_kw;  // ceil(2^32/Cx), ceil(2^32/KW): k / Cx and tap / KW by one v_mul_hi_u32
+    int splits;          // split-K: K steps are divided over `splits` workgroups per tile (partials -> slab)
+    float *slab;         // [splits][M][N] fp32 partials when splits > 1
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
     unsigned magic_nt;   // ceil(2^32/ntaps)
     int ablate;  // diagnostics only (EMADAPT_ABLATE): 1 = no global loads, 2 = no LDS stores, 4 = no barrier
@@ -71,6 +73,40 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float keep) {
     const unsigned u = (unsigned)(mix64(seed ^ (idx * 0xD1342543DE82EF95ull)) >> 40);
     return (float)u * (1.0f / 16777216.0f) < keep;
+}
+
+// bias / ReLU / dropout (tf.nn.dropout: x / keep_prob * mask) or the ReLU-gradient gate, on one output element.
+__device__ __forceinline__ float epilogue(const IgemmArgs &a, float v, int col, long long o) {
+    if (a.epi != EMADAPT_EPI_NONE && a.bias) v += a.bias[col];
+    if (a.epi == EMADAPT_EPI_BIAS_RELU) {
+        v = v > 0.f ? v : 0.f;
+        if (a.keep < 1.0f) {
+            const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
+            v = kp ? v / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
+        }
+    }
+    if (a.gate) v = a.gate[o] > 0.f ? v * a.scale : 0.f;
+    return v;
+}
+
+// split-K second stage: y = epilogue(sum_s slab[s]) with the partials added in ascending s (deterministic).
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(IgemmArgs a) {
+    const long long n4 = (long long)a.M * a.N / 4;
+    const long long mn = (long long)a.M * a.N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 v = *reinterpret_cast<const float4 *>(a.slab + i * 4);
+        for (int sp = 1; sp < a.splits; sp++) {
+            const float4 u = *reinterpret_cast<const float4 *>(a.slab + sp * mn + i * 4);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        const long long o = i * 4;
+        const int col = (int)(o % a.N);
+        v.x = epilogue(a, v.x, col + 0, o + 0);
+        v.y = epilogue(a, v.y, col + 1, o + 1);
+        v.z = epilogue(a, v.z, col + 2, o + 2);
+        v.w = epilogue(a, v.w, col + 3, o + 3);
+        *reinterpret_cast<float4 *>(a.y + o) = v;
+    }
 }
 
 template <int BM, int BN, int BK, bool BT>
@@ -100,12 +136,15 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
 
     // ---- XCD-aware tile order: blocks b, b+8, b+16.. share an XCD; give each XCD a contiguous run of
     //      tiles, ordered as groups of 8 M-tiles x all N-tiles (operands of neighbours hit in its L2).
-    int tile_m, tile_n;
+    int tile_m, tile_n, split;
     {
-        const int nblk = a.tiles_m * a.tiles_n;
+        const int ntile = a.tiles_m * a.tiles_n;
+        const int nblk = ntile * a.splits;
         const int bid = blockIdx.x;
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        split = t / ntile;  // all tiles of split 0 first, then split 1, ...
+        t -= split * ntile;
         constexpr int GM = 8;
         const int per_group = GM * a.tiles_n;
         const int g = t / per_group;
@@ -236,18 +275,20 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
     constexpr int ST0 = NKK - NST;              // first k-pair that stores
     static_assert(ST0 >= 2, "K step too short for the software pipeline");
     constexpr int LPK = (NST + (ST0 - 1) - 1) / (ST0 - 1);  // loads per k-pair, k-pairs 1..ST0-1
-    const int nk = (a.K + BK - 1) / BK;
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * split / a.splits);        // this workgroup's K steps [kt0, kt0 + nk)
+    const int nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
     {
-        const Tap t0 = tap_of(0);
+        const Tap t0 = tap_of(kt0);
 #pragma unroll
         for (int j = 0; j < A_N; j++) load_a(ra[0][j], j, t0);
 #pragma unroll
-        for (int j = 0; j < B_N; j++) load_b(rb[0][j], j, 0, t0);
-        const Tap t1 = tap_of(1);
+        for (int j = 0; j < B_N; j++) load_b(rb[0][j], j, kt0, t0);
+        const Tap t1 = tap_of(kt0 + 1);
 #pragma unroll
         for (int j = 0; j < A_N; j++) load_a(ra[1][j], j, t1);
 #pragma unroll
-        for (int j = 0; j < B_N; j++) load_b(rb[1][j], j, 1, t1);
+        for (int j = 0; j < B_N; j++) load_b(rb[1][j], j, kt0 + 1, t1);
 #pragma unroll
         for (int j = 0; j < A_N; j++) store_a(0, j, ra[0][j]);
 #pragma unroll
@@ -301,34 +342,26 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
         }
         if (!(a.ablate & 4)) __syncthreads();
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-        k_step(std::integral_constant<int, 0>{}, kt);
-        if (kt + 1 < nk) k_step(std::integral_constant<int, 1>{}, kt + 1);
+    for (int kt = 0; kt < nk; kt += 2) {  // k_step's argument is the absolute K step (the parity is relative)
+        k_step(std::integral_constant<int, 0>{}, kt0 + kt);
+        if (kt + 1 < nk) k_step(std::integral_constant<int, 1>{}, kt0 + kt + 1);
     }
 
     // ---- fused epilogue; C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float *slab = a.splits > 1 ? a.slab + (long long)split * a.M * a.N : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int col = n0 + wn * WN + j * 32 + l31;
             if (col >= a.N) continue;
-            const float bcol = (a.epi != EMADAPT_EPI_NONE && a.bias) ? a.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= a.M) continue;
                 const long long o = (long long)row * a.N + col;
-                float v = acc[i][j][r] + bcol;
-                if (a.epi == EMADAPT_EPI_BIAS_RELU) {
-                    v = v > 0.f ? v : 0.f;
-                    if (a.keep < 1.0f) {
-                        const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
-                        v = kp ? v / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
-                    }
-                }
-                if (a.gate) v = a.gate[o] > 0.f ? v * a.scale : 0.f;
-                a.y[o] = v;
+                if (slab) slab[o] = acc[i][j][r];
+                else a.y[o] = epilogue(a, acc[i][j][r], col, o);
             }
         }
     }
@@ -347,14 +380,57 @@ int launch_igemm(IgemmArgs &a, hipStream_t stream) {
     }
     a.tiles_m = (int)ceil_div(a.M, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
-    const long long nblk = (long long)a.tiles_m * a.tiles_n;
+    const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, BT>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    int rc = launch_status();
+    if (rc || a.splits <= 1) return rc;
+    long long g = ((long long)a.M * a.N / 4 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
     return launch_status();
 }
 
+// Split-K factor: with T tiles on 512 resident workgroup slots (256 CUs x 2) a launch runs ceil(T/512) rounds; when T
+// is a few hundred (the M = 26 896, N = 512 layers: 844 tiles -> 2 rounds at 82 %) splitting K by S makes
+// T*S workgroups fill whole rounds (S = 3 -> 4.95 of 5).  The price is one extra pass over S+1 output-sized
+// slabs, charged at ~3 TB/s against the kernel's time at ~110 TFLOP/s.
+int choose_splits(const IgemmArgs &a, int bm, int bn, int bk) {
+    static const int force = getenv("EMADAPT_SPLITK") ? atoi(getenv("EMADAPT_SPLITK")) : 0;
+    const long long tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
+    const int nk = (a.K + bk - 1) / bk;
+    if (force > 0) return force <= nk ? force : 1;
+    if (a.N % 4 != 0) return 1;
+    const double slots = 512.0;
+    const double t_kernel = 2.0 * a.M * (double)a.K * a.N / 110e12;
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= 8; s++) {
+        if (nk / s < 16) break;
+        const double rounds = (double)tiles * s / slots;
+        const double eff = rounds / (double)(long long)(rounds + 0.999999);
+        double t = t_kernel / eff;
+        if (s > 1) t += (double)(s + 1) * a.M * a.N * 4.0 / 3e12 + 3e-6;
+        if (t < best_t * 0.97) { best_t = t; best = s; }
+    }
+    return best;
+}
+
+size_t igemm_workspace_bytes(const IgemmArgs &a) {
+    const bool small_n = a.N <= 64;
+    const int s = choose_splits(a, small_n ? 256 : 128, small_n ? 64 : 128, small_n ? 16 : 32);
+    return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
+}
+
 template <bool BT>
-int dispatch_igemm(IgemmArgs &a, hipStream_t stream) {
+int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    {
+        const bool small_n = a.N <= 64;
+        int s = choose_splits(a, small_n ? 256 : 128, small_n ? 64 : 128, small_n ? 16 : 32);
+        if (s > 1 && (!workspace || workspace_bytes < (size_t)s * a.M * a.N * sizeof(float))) s = 1;  // no room: no split
+        a.splits = s;
+        a.slab = s > 1 ? static_cast<float *>(workspace) : nullptr;
+    }
     static const int ablate = getenv("EMADAPT_ABLATE") ? atoi(getenv("EMADAPT_ABLATE")) : 0;
     static const int no_tap_inner = getenv("EMADAPT_NO_TAP_INNER") ? 1 : 0;
     a.ablate = ablate;
@@ -390,10 +466,38 @@ namespace emadapt {
 int conv_pad_before(int k, int dil) { return ((k - 1) * dil) / 2; }
 }  // namespace emadapt
 
+namespace {
+// geometry shared by the launch and the workspace query
+void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
+    a.H = d->H; a.W = d->W; a.KW = d->KW; a.dil = d->dil; a.sign = dgrad ? -1 : 1;
+    a.Cx = dgrad ? d->Cout : d->Cin;
+    a.N = dgrad ? d->Cin : d->Cout;
+    a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
+    a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * a.Cx;
+    a.x_bytes = (unsigned)((long long)a.M * a.Cx * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
+    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
+}
+}  // namespace
+
 extern "C" {
 
+size_t emadapt_conv_fwd_workspace_bytes(const emadapt_conv_desc *d) {
+    if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
+    IgemmArgs a;
+    fill_geometry(a, d, false);
+    return igemm_workspace_bytes(a);
+}
+
+size_t emadapt_conv_dgrad_workspace_bytes(const emadapt_conv_desc *d) {
+    if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
+    IgemmArgs a;
+    fill_geometry(a, d, true);
+    return igemm_workspace_bytes(a);
+}
+
 int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
-                     int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed, void *stream_) {
+                     int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed, void *workspace,
+                     size_t workspace_bytes, void *stream_) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return EMADAPT_ERR_INVALID;
@@ -401,39 +505,31 @@ int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w,
     if (epilogue != EMADAPT_EPI_NONE && !bias) return EMADAPT_ERR_INVALID;
     if (!(keep_prob > 0.f) || keep_prob > 1.f) return EMADAPT_ERR_INVALID;
     if (keep_prob < 1.f && epilogue != EMADAPT_EPI_BIAS_RELU) return EMADAPT_ERR_INVALID;
-    if (!aligned16(x) || !aligned16(w) || !aligned16(y)) return EMADAPT_ERR_INVALID;
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
     if (d->B == 0) return EMADAPT_OK;
     IgemmArgs a;
+    fill_geometry(a, d, false);
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
-    a.H = d->H; a.W = d->W; a.Cx = d->Cin; a.N = d->Cout; a.KW = d->KW; a.dil = d->dil; a.sign = 1;
-    a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
-    a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cin;
     a.epi = epilogue; a.scale = 1.f; a.keep = keep_prob; a.seed = drop_seed;
-    a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
-    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    return dispatch_igemm<false>(a, stream);
+    return dispatch_igemm<false>(a, workspace, workspace_bytes, stream);
 }
 
 int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float *w, float *dx, const float *gate,
-                       float gate_scale, void *stream_) {
+                       float gate_scale, void *workspace, size_t workspace_bytes, void *stream_) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dy || !w || !dx) return EMADAPT_ERR_INVALID;
-    if (!aligned16(dy) || !aligned16(w) || !aligned16(dx)) return EMADAPT_ERR_INVALID;
+    if (!aligned16(dy) || !aligned16(w) || !aligned16(dx) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
     if (d->B == 0) return EMADAPT_OK;
     IgemmArgs a;
+    fill_geometry(a, d, true);
     a.x = dy; a.w = w; a.y = dx; a.bias = nullptr; a.gate = gate; a.mask = nullptr;
-    a.H = d->H; a.W = d->W; a.Cx = d->Cout; a.N = d->Cin; a.KW = d->KW; a.dil = d->dil; a.sign = -1;
-    a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
-    a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cout;
     a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; a.keep = 1.f; a.seed = 0;
-    a.x_bytes = (unsigned)((long long)a.M * d->Cout * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
-    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    return dispatch_igemm<true>(a, stream);
+    return dispatch_igemm<true>(a, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -127,29 +127,32 @@ __global__ void __launch_bounds__(256) final_sum_kernel(const float *__restrict_
 }
 
 // BiasAddGrad stage 1: partial[chunk][n] = sum over the chunk's rows of dy[m][n].
-// block = 64 column-quads x 4 row lanes.
+// block = CP column-quads x (256/CP) row lanes, CP = power of two >= min(N/4, 64): narrow layers (N = 64, 24)
+// spend their idle column lanes on more rows.
 __global__ void __launch_bounds__(256) bias_grad_partial_kernel(const float *__restrict__ dy, long long M, int N4,
-                                                              long long rows_per_chunk, float *__restrict__ partial) {
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int q = blockIdx.x * 64 + tx;
+                                                              int cp_log2, long long rows_per_chunk,
+                                                              float *__restrict__ partial) {
+    const int CP = 1 << cp_log2, RL = 256 >> cp_log2;
+    const int tx = threadIdx.x & (CP - 1), ty = threadIdx.x >> cp_log2;
+    const int q = blockIdx.x * CP + tx;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > M) r1 = M;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < N4) {
-        for (long long r = r0 + ty; r < r1; r += 4) {
+        for (long long r = r0 + ty; r < r1; r += RL) {
             const float4 v = ld4(dy + (r * N4 + q) * 4);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
-    __shared__ float4 sh[4][64];
-    sh[ty][tx] = acc;
+    __shared__ float4 sh[256];
+    sh[ty * CP + tx] = acc;
     __syncthreads();
     if (ty == 0 && q < N4) {
-        float4 s = sh[0][tx];
-#pragma unroll
-        for (int j = 1; j < 4; j++) {
-            s.x += sh[j][tx].x; s.y += sh[j][tx].y; s.z += sh[j][tx].z; s.w += sh[j][tx].w;
+        float4 s = sh[tx];
+        for (int j = 1; j < RL; j++) {
+            const float4 v = sh[j * CP + tx];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         st4(partial + ((long long)blockIdx.y * N4 + q) * 4, s);
     }
@@ -348,9 +351,16 @@ int emadapt_maxpool_bwd(const float *dy, const uint8_t *idx, const float *gate, 
     return launch_status();
 }
 
+static long long bias_grad_max_chunks(int N) {
+    long long c = 65536 / (N > 0 ? N : 1);  // narrow layers get more row chunks (same workspace)
+    if (c < 256) c = 256;
+    if (c > 1024) c = 1024;
+    return c;
+}
+
 size_t emadapt_bias_grad_workspace_bytes(int64_t M, int N) {
     (void)M;
-    return (size_t)256 * (size_t)(N > 0 ? N : 0) * sizeof(float) + 256;
+    return (size_t)bias_grad_max_chunks(N) * (size_t)(N > 0 ? N : 0) * sizeof(float) + 256;
 }
 
 int emadapt_bias_grad(const float *dy, int64_t M, int N, float *db, void *workspace, size_t workspace_bytes,
@@ -359,18 +369,22 @@ int emadapt_bias_grad(const float *dy, int64_t M, int N, float *db, void *worksp
     if (N % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < emadapt_bias_grad_workspace_bytes(M, N)) return EMADAPT_ERR_WORKSPACE;
     const int N4 = N / 4;
-    const int gx = (int)ceil_div(N4, 64);
-    long long chunks = 1024 / gx;
+    int cp_log2 = 0;
+    while ((1 << cp_log2) < N4 && cp_log2 < 6) cp_log2++;
+    const int CP = 1 << cp_log2;
+    const int gx = (int)ceil_div(N4, CP);
+    long long chunks = 2048 / gx;
     if (chunks < 1) chunks = 1;
-    if (chunks > 256) chunks = 256;
+    if (chunks > bias_grad_max_chunks(N)) chunks = bias_grad_max_chunks(N);
     long long rows_per_chunk = ceil_div(M, chunks);
-    if (rows_per_chunk < 16) rows_per_chunk = 16;
+    const int RL = 256 / CP;
+    if (rows_per_chunk < 4 * RL) rows_per_chunk = 4 * RL;
     chunks = ceil_div(M, rows_per_chunk);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)M * N * 4.0, stream);
     float *partial = static_cast<float *>(workspace);
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(gx, (unsigned)chunks), dim3(256), 0, stream, dy, (long long)M,
-                       N4, rows_per_chunk, partial);
+                       N4, cp_log2, rows_per_chunk, partial);
     int rc = launch_status();
     if (rc) return rc;
     return launch_slab_sum(partial, (int)chunks, N, db, stream);

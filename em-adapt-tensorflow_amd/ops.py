@@ -70,8 +70,10 @@ def conv_fwd(x, w, bias=None, dil=1, relu=True, keep_prob=1.0, drop_mask=None, d
     y = out if out is not None else torch.empty((d.B, d.H, d.W, d.Cout), dtype=torch.float32, device=x.device)
     _check(y, name="out")
     epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    nbytes = _lib.load().emadapt_conv_fwd_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, x.device) if nbytes else None
     _lib.call("emadapt_conv_fwd", ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), epi, float(keep_prob),
-              _p(drop_mask), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _stream())
+              _p(drop_mask), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(ws), ws.numel() if ws is not None else 0, _stream())
     return y
 
 
@@ -85,7 +87,10 @@ def conv_dgrad(dy, w, dil=1, gate=None, gate_scale=1.0, out=None):
     d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
     dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
     _check(dx, name="out")
-    _lib.call("emadapt_conv_dgrad", ctypes.byref(d), _p(dy), _p(w), _p(dx), _p(gate), float(gate_scale), _stream())
+    nbytes = _lib.load().emadapt_conv_dgrad_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, dy.device) if nbytes else None
+    _lib.call("emadapt_conv_dgrad", ctypes.byref(d), _p(dy), _p(w), _p(dx), _p(gate), float(gate_scale), _p(ws),
+              ws.numel() if ws is not None else 0, _stream())
     return dx
 
 

@@ -124,17 +124,24 @@ typedef struct emadapt_conv_desc {
  * bias f32 [Cout]; y f32 [B,H,W,Cout].  Dropout (only with EPI_BIAS_RELU): keep_prob < 1 scales kept
  * values by 1/keep_prob (tf.nn.dropout); the keep mask is drop_mask (uint8 [B,H,W,Cout], 1 = keep)
  * when non-NULL, else a counter-based hash of (drop_seed, element index). */
+size_t emadapt_conv_fwd_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w, const float *bias,
                      float *y, int epilogue, float keep_prob, const uint8_t *drop_mask,
-                     uint64_t drop_seed, void *stream);
+                     uint64_t drop_seed, void *workspace, size_t workspace_bytes, void *stream);
+/* workspace (fwd and dgrad): optional.  Layers whose output has only a few hundred 128x128 tiles are run
+ * split-K (fp32 partial slabs in the workspace + a fused, fixed-order reduce/epilogue kernel) so that the
+ * workgroups fill whole rounds of the 256 CUs; with workspace == NULL (or too small) the same result is
+ * produced unsplit.  *_workspace_bytes returns what the split plan for this shape needs (0 = none). */
 
 /* Data gradient (Conv2DBackpropInput of the autodiff in deeplab.py:192):
  *   dx[b,h,w,ci] = sum_{taps,co} dy[b,h-off,w-off,co] * w[tap,ci,co]
  * fused with the gradient of what precedes the conv: when `gate` is non-NULL (f32 [B,H,W,Cin], the
  * stored post-ReLU(/dropout) activation that fed this conv) dx = gate>0 ? dx*gate_scale : 0
  * (ReluGrad, and dropout's 1/keep_prob when the gate is a dropped activation). */
+size_t emadapt_conv_dgrad_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float *w, float *dx,
-                       const float *gate, float gate_scale, void *stream);
+                       const float *gate, float gate_scale, void *workspace, size_t workspace_bytes,
+                       void *stream);
 
 /* Filter gradient (Conv2DBackpropFilter): dw[tap,ci,co] = sum_{b,h,w} x[b,h+off,w+off,ci]*dy[b,h,w,co].
  * Deterministic: the pixel dimension is split over workgroups into fp32 partial slabs in `workspace`

@@ -68,7 +68,7 @@ def test_argument_validation_without_device(lib):
                              None) == -1
     assert lib.emadapt_maxpool_fwd(None, 1, 4, 4, 4, 2, None, None, None) == -1
     d = _lib.ConvDesc(1, 8, 8, 3, 8, 3, 3, 1)  # Cin not a multiple of 4
-    assert lib.emadapt_conv_fwd(ctypes.byref(d), 16, 16, None, 16, 0, 1.0, None, 0, None) == -2
+    assert lib.emadapt_conv_fwd(ctypes.byref(d), 16, 16, None, 16, 0, 1.0, None, 0, None, 0, None) == -2
     assert lib.emadapt_conv_wgrad_workspace_bytes(ctypes.byref(_lib.ConvDesc(16, 321, 321, 64, 64, 3, 3, 1))) > 0
     assert lib.emadapt_conv_wgrad_workspace_bytes(ctypes.byref(_lib.ConvDesc(16, 41, 41, 512, 4096, 4, 4, 4))) == 0
 

@@ -44,6 +44,8 @@ CONV_SHAPES = [
     (1, 33, 31, 4, 64, 3, 1),
     (2, 23, 23, 64, 256, 3, 2),
     (1, 41, 41, 24, 288, 1, 1),
+    (2, 49, 47, 256, 128, 3, 1),   # few tiles, long K: takes the split-K path (slabs + fused reduce/epilogue)
+    (1, 41, 41, 512, 136, 4, 4),   # fc6-like, split-K, N tail
 ]
 
 
@@ -120,6 +122,31 @@ def test_dropout_epilogue(env):
     assert abs(kept.mean() - 0.75) < 0.01
     assert np.array_equal(d1[kept], (ref / np.float32(0.75))[kept])
     del big
+
+
+def test_split_k_path_keeps_the_fused_epilogue(env):
+    """A shape the split-K heuristic splits: bias+ReLU+dropout(mask) and the dgrad gate must come out the same as
+    from the single-pass kernel (checked against the oracle)."""
+    ops, do, torch = env
+    from em_adapt_tensorflow_amd import _lib
+    import ctypes
+    rng = np.random.default_rng(12)
+    B, H, W, Cin, Cout, k, dil = 2, 49, 47, 256, 128, 3, 2
+    d = _lib.ConvDesc(B, H, W, Cin, Cout, k, k, dil)
+    assert _lib.load().emadapt_conv_fwd_workspace_bytes(ctypes.byref(d)) > 0, "expected a split-K plan for this shape"
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    w = rng.normal(0, 0.05, (k, k, Cin, Cout)).astype(np.float32)
+    b = rng.normal(0, 0.5, (Cout,)).astype(np.float32)
+    mask = (rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8)
+    y = do.conv_same(torch.tensor(x, dtype=torch.float64), torch.tensor(w, dtype=torch.float64),
+                     torch.tensor(b, dtype=torch.float64), dil)
+    want = torch.relu(y).numpy() / 0.5 * mask
+    got = ops.conv_fwd(_t(torch, x), _t(torch, w), _t(torch, b), dil, relu=True, keep_prob=0.5,
+                       drop_mask=_t(torch, mask, torch.uint8)).cpu().numpy()
+    assert _rel(got, want) < 2e-5
+    a = ops.conv_fwd(_t(torch, x), _t(torch, w), _t(torch, b), dil).cpu().numpy()
+    a2 = ops.conv_fwd(_t(torch, x), _t(torch, w), _t(torch, b), dil).cpu().numpy()
+    assert np.array_equal(a, a2), "split-K result must be bitwise reproducible"
 
 
 @pytest.mark.parametrize("shape", [(2, 21, 21, 8, 2), (1, 16, 18, 16, 2), (2, 11, 11, 12, 1), (1, 41, 41, 64, 1),
