@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = cgroup quota / affinity")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
+                                                      "for rehearsing the data-parallel flow on a single GPU)")
     return ap.parse_args()
 
 
@@ -122,12 +124,19 @@ def main():
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    if dev_index >= ndev:
+        raise SystemExit("rank %d needs GPU %d but only %d visible" % (rank, dev_index, ndev))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from em_adapt_tensorflow_amd import ops
     from em_adapt_tensorflow_amd.data import SyntheticData
@@ -157,6 +166,7 @@ def main():
         adapt.apply_update()
 
     def fence():
+        torch.cuda.synchronize(device)
         if distributed:
             dist.barrier()
         torch.cuda.synchronize(device)

@@ -51,7 +51,7 @@ struct IgemmArgs {
     float *slab;         // [splits][M][N] fp32 partials when splits > 1
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
     unsigned magic_nt;   // ceil(2^32/ntaps)
-    int ablate;  // diagnostics only (EMADAPT_ABLATE): 1 = no global loads, 2 = no LDS stores, 4 = no barrier
+    int ablate;  // diagnostics only (EMADAPT_ABLATE): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
 };
 
 // 16-byte buffer load with hardware range checking: an offset at/after the end of the buffer returns 0,
@@ -329,8 +329,8 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
                 for (int q = 0; q < LPK; q++) {
                     const int lidx = (kk - 1) * LPK + q;
                     if (lidx == 0) tnext = tap_of(kt + 2);
-                    if (lidx < A_N) load_a(ra[P][lidx < A_N ? lidx : 0], lidx, tnext);
-                    else if (lidx < NST) load_b(rb[P][lidx - A_N < B_N && lidx >= A_N ? lidx - A_N : 0], lidx - A_N, kt + 2, tnext);
+                    if (lidx < A_N) { if (!(a.ablate & 8)) load_a(ra[P][lidx < A_N ? lidx : 0], lidx, tnext); }
+                    else if (lidx < NST) { if (!(a.ablate & 16)) load_b(rb[P][lidx - A_N < B_N && lidx >= A_N ? lidx - A_N : 0], lidx - A_N, kt + 2, tnext); }
                 }
             }
             if (kk >= ST0 && !(a.ablate & 2)) {

@@ -1,0 +1,88 @@
+"""Data-parallel step on the GPU: two ranks (sharing the one visible GPU, gloo transport for the rehearsal --
+the production backend is nccl/RCCL, one rank per GPU) run micro_step on their half of a batch, exchange the
+accumulators through GradSync and apply Momentum; the weights must match a single-process run on the whole batch
+(the reference's ``accum += g/accum_num`` semantics with micro-batches mapped to ranks, deeplab.py:202)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = dict(size=65, C=5, width=8, B=2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs():
+    from oracle import deeplab_oracle as do
+    from oracle import estep_oracle as eo
+    images, labels = do.synthetic_batch(2 * CFG["B"], CFG["size"], CFG["C"], seed=31)
+    oracle = do.DeepLabOracle(category_num=CFG["C"], width=CFG["width"])
+    params = do.init_params(oracle.specs, seed=6, he=True)
+    return (images / 50).astype(np.float32), labels, params, eo.draw_perms(5, CFG["C"], seed=2)
+
+
+def _build(torch, params, B):
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    a = ADAPT({"input_size": (CFG["size"], CFG["size"]), "category_num": CFG["C"], "width": CFG["width"],
+               "batch_size": B, "accum_num": 1, "device": "cuda:0", "bucket_mb": 1})
+    a.build()
+    for layer, (w, b) in params.items():
+        a.weights[layer][0].copy_(torch.tensor(w).cuda())
+        a.weights[layer][1].copy_(torch.tensor(b).cuda())
+    a.pre_train(base_lr=1e-2, weight_decay=1e-3, momentum=0.9, batch_size=B)
+    return a
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    images, labels, params, perms = _inputs()
+    B = CFG["B"]
+    a = _build(torch, params, B)
+    assert a._gradsync is not None and a._gradsync.world_size == world and len(a._gradsync.buckets) > 1
+    sl = slice(rank * B, (rank + 1) * B)
+    for _ in range(2):  # two updates: the second exercises momentum and the re-armed GradSync
+        a.micro_step(images[sl], labels[sl], keep_prob=1.0, perms=perms)
+        a.apply_update()
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, "params%d.npy" % rank), a._flat["params"].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    p0 = np.load(tmp_path / "params0.npy")
+    p1 = np.load(tmp_path / "params1.npy")
+    assert np.array_equal(p0, p1), "ranks diverged"
+    # single process, whole batch
+    images, labels, params, perms = _inputs()
+    a = _build(torch, params, 2 * CFG["B"])
+    assert a._gradsync is None
+    for _ in range(2):
+        a.micro_step(images, labels, keep_prob=1.0, perms=perms)
+        a.apply_update()
+    torch.cuda.synchronize()
+    want = a._flat["params"].cpu().numpy()
+    err = np.abs(p0 - want).max() / np.abs(want).max()
+    assert err < 1e-5, err
