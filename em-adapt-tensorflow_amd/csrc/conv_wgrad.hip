@@ -219,6 +219,9 @@ struct Plan {
     int bn, tiles_k, tiles_n, splits, rows_per_split;
 };
 
+// Split-M plan.  T filter tiles x S pixel splits workgroups run in ceil(T*S/512) rounds on the 512 resident slots
+// (256 CUs x 2); S is chosen to fill whole rounds (e.g. conv4_x/conv5_x: T = 144, S = 7 -> 1008 = 1.97 rounds, or 14 ->
+// 3.94) while charging the extra pass over the S partial slabs (~3 TB/s) against the kernel time (~115 TFLOP/s).
 Plan make_plan(const emadapt_conv_desc *d) {
     Plan p;
     const long long M = (long long)d->B * d->H * d->W;
@@ -227,12 +230,20 @@ Plan make_plan(const emadapt_conv_desc *d) {
     p.tiles_k = (int)ceil_div(K, 128);
     p.tiles_n = (int)ceil_div(d->Cout, p.bn);
     const long long tiles = (long long)p.tiles_k * p.tiles_n;
-    long long splits = ceil_div(1024, tiles);           // aim for >= ~1024 workgroups (256 CUs x 2 x 2 waves of work)
-    const long long max_by_rows = ceil_div(M, 512);     // at least 512 pixels per split
-    if (splits > max_by_rows) splits = max_by_rows;
-    if (splits < 1) splits = 1;
-    if (splits > 2048) splits = 2048;
-    long long rps = ceil_div(M, splits);
+    const double t_kernel = 2.0 * (double)M * (p.tiles_k * 128.0) * (p.tiles_n * (double)p.bn) / 115e12;
+    const double kn_bytes = (double)K * d->Cout * 4.0;
+    long long best = 1;
+    double best_t = 1e30;
+    const long long max_s = ceil_div(M, 256) < 2048 ? ceil_div(M, 256) : 2048;  // >= 256 pixels per split
+    for (long long s = 1; s <= max_s; s++) {
+        const double rounds = (double)tiles * s / 512.0;
+        const double eff = rounds / (double)(long long)(rounds + 0.999999);
+        double t = t_kernel / eff + 2e-6 * (double)(long long)(rounds + 0.999999);  // + per-round turnover
+        if (s > 1) t += (double)(s + 1) * kn_bytes / 3e12 + 3e-6;
+        if (t < best_t * 0.995) { best_t = t; best = s; }
+        if (rounds > 24.0) break;
+    }
+    long long rps = ceil_div(M, best);
     rps = ceil_div(rps, BMR) * BMR;
     p.rows_per_split = (int)rps;
     p.splits = (int)ceil_div(M, rps);
