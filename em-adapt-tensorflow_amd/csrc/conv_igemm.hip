@@ -31,6 +31,14 @@ using namespace emadapt;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Ablation switches (EMADAPT_ABLATE env var) exist only in diagnostic builds (-DEMADAPT_ABLATE_BUILD): in the
+// shipped kernel they would put scalar branches into every k-pair of the MFMA stream.
+#ifdef EMADAPT_ABLATE_BUILD
+#define ABL(bit) (a.ablate & (bit))
+#else
+#define ABL(bit) 0
+#endif
+
 struct IgemmArgs {
     const float *x;     // activation to gather from: [B,H,W,Cx]
     const float *w;     // filter, HWIO
@@ -324,23 +332,23 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
                 for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
             // tile movement slotted into this k-pair
-            if (kk >= 1 && kk < ST0 && !(a.ablate & 1)) {
+            if (kk >= 1 && kk < ST0 && !ABL(1)) {
 #pragma unroll
                 for (int q = 0; q < LPK; q++) {
                     const int lidx = (kk - 1) * LPK + q;
                     if (lidx == 0) tnext = tap_of(kt + 2);
-                    if (lidx < A_N) { if (!(a.ablate & 8)) load_a(ra[P][lidx < A_N ? lidx : 0], lidx, tnext); }
-                    else if (lidx < NST) { if (!(a.ablate & 16)) load_b(rb[P][lidx - A_N < B_N && lidx >= A_N ? lidx - A_N : 0], lidx - A_N, kt + 2, tnext); }
+                    if (lidx < A_N) { if (!ABL(8)) load_a(ra[P][lidx < A_N ? lidx : 0], lidx, tnext); }
+                    else if (lidx < NST) { if (!ABL(16)) load_b(rb[P][lidx - A_N < B_N && lidx >= A_N ? lidx - A_N : 0], lidx - A_N, kt + 2, tnext); }
                 }
             }
-            if (kk >= ST0 && !(a.ablate & 2)) {
+            if (kk >= ST0 && !ABL(2)) {
                 const int sidx = kk - ST0;
                 if (sidx < A_N) store_a(P ^ 1, sidx, ra[P ^ 1][sidx < A_N ? sidx : 0]);
                 else store_b(P ^ 1, sidx - A_N, rb[P ^ 1][sidx >= A_N ? sidx - A_N : 0]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(a.ablate & 4)) __syncthreads();
+        if (!ABL(4)) __syncthreads();
     };
     for (int kt = 0; kt < nk; kt += 2) {  // k_step's argument is the absolute K step (the parity is relative)
         k_step(std::integral_constant<int, 0>{}, kt0 + kt);

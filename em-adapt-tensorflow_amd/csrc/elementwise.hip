@@ -158,17 +158,45 @@ __global__ void __launch_bounds__(256) bias_grad_partial_kernel(const float *__r
     }
 }
 
-// stage 2 (also used by the conv filter-gradient): out[i] = sum_s slab[s][i], s ascending.
+// stage 2 (also used by the conv filter-gradient): out[i] = sum_s slab[s][i].
+// block = 64 float4 columns x 4 slab lanes; lane g adds slabs g, g+4, g+8, .. (4 independent loads in flight per
+// step), then the four lane sums are combined as ((l0+l1)+(l2+l3)): a fixed tree -> bitwise reproducible.
 __global__ void __launch_bounds__(256) slab_sum_kernel(const float *__restrict__ slab, int nslab, long long n4,
                                                      float *__restrict__ out) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (long long)gridDim.x * blockDim.x) {
-        float4 s = ld4(slab + i * 4);
-        for (int k = 1; k < nslab; k++) {
-            const float4 v = ld4(slab + ((long long)k * n4 + i) * 4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    __shared__ float4 sh[4][64];
+    const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (long long i0 = (long long)blockIdx.x * 64; i0 < n4; i0 += (long long)gridDim.x * 64) {
+        const long long i = i0 + tx;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n4) {
+            int k = g;
+            for (; k + 12 < nslab; k += 16) {
+                const float4 v0 = ld4(slab + ((long long)k * n4 + i) * 4);
+                const float4 v1 = ld4(slab + ((long long)(k + 4) * n4 + i) * 4);
+                const float4 v2 = ld4(slab + ((long long)(k + 8) * n4 + i) * 4);
+                const float4 v3 = ld4(slab + ((long long)(k + 12) * n4 + i) * 4);
+                s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+                s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+                s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+                s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+            }
+            for (; k < nslab; k += 4) {
+                const float4 v = ld4(slab + ((long long)k * n4 + i) * 4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
         }
-        st4(out + i * 4, s);
+        sh[g][tx] = s;
+        __syncthreads();
+        if (g == 0 && i < n4) {
+            const float4 a = sh[0][tx], b = sh[1][tx], c = sh[2][tx], d = sh[3][tx];
+            float4 r;
+            r.x = (a.x + b.x) + (c.x + d.x);
+            r.y = (a.y + b.y) + (c.y + d.y);
+            r.z = (a.z + b.z) + (c.z + d.z);
+            r.w = (a.w + b.w) + (c.w + d.w);
+            st4(out + i * 4, r);
+        }
+        __syncthreads();
     }
 }
 
@@ -311,7 +339,7 @@ namespace emadapt {
 // used by conv_wgrad.hip
 int launch_slab_sum(const float *slab, int nslab, long long n, float *out, hipStream_t stream) {
     if (n % 4 != 0) return EMADAPT_ERR_INVALID;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, slab, nslab, n / 4, out);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 64, 4096)), dim3(256), 0, stream, slab, nslab, n / 4, out);
     return launch_status();
 }
 }  // namespace emadapt
