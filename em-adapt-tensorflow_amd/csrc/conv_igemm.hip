@@ -117,21 +117,28 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(IgemmArgs a) {
     }
 }
 
-template <int BM, int BN, int BK, bool BT>
-__global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
-    constexpr int WM = 64, WN = 64;                // per-wave accumulator block
+// Tile configurations: <BM, BN, BK, WN>.  Every wave owns a 64 x WN accumulator block (WN = 64: 64 VGPRs, WN = 128:
+// 128 VGPRs); THREADS = (BM/64)*(BN/WN)*64.
+//   128x128x32, WN 64,  256 threads, 2 workgroups/CU  -- default
+//   256x64x16,  WN 64,  256 threads                   -- N <= 64 layers
+//   256x256x32, WN 128, 512 threads, 1 workgroup/CU   -- N >= 1024 layers (fc6/fc7): half the global-load
+//                                                         instructions per MFMA of the 128x128 tile
+template <int BM, int BN, int BK, int WN, bool BT>
+__global__ void __launch_bounds__((BM / 64) * (BN / WN) * 64, 2) igemm_kernel(IgemmArgs a) {
+    constexpr int WM = 64;                         // per-wave accumulator block is WM x WN
     constexpr int WAVES_N = BN / WN;               // waves along N
-    static_assert((BM / WM) * (BN / WN) == 4, "4 wavefronts per workgroup");
+    constexpr int THREADS = (BM / WM) * (BN / WN) * 64;
+    static_assert(THREADS == 256 || THREADS == 512, "4 or 8 wavefronts per workgroup");
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int AS = BM + 1;                     // LDS pitch of the k-major A tile (odd: conflict-free transposing stores)
     constexpr int BS = BT ? BN + 1 : BN;
     constexpr int KQ = BK / 4;                     // float4 quads along k
-    constexpr int A_RSTEP = 256 / KQ;              // rows covered by one pass of the 256 threads
+    constexpr int A_RSTEP = THREADS / KQ;          // rows covered by one pass of the workgroup's threads
     constexpr int A_N = BM / A_RSTEP;              // A float4 loads per thread
     constexpr int QN = BN / 4;
-    constexpr int B_KSTEP = 256 / QN;
+    constexpr int B_KSTEP = THREADS / QN;
     constexpr int B_N = BT ? (BN / A_RSTEP) : (BK / B_KSTEP);
-    static_assert(A_N >= 1 && B_N >= 1, "tile too small for 256 threads");
+    static_assert(A_N >= 1 && B_N >= 1, "tile too small for the workgroup");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *As = lds;                        // [2][BK][AS]
@@ -278,11 +285,17 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
     // so the LDS writes, VALU and VMEM issue in the shadow of the MFMAs instead of forming a phase of their own
     // in which the matrix pipe idles.  Everything is unconditional (tiles past K are zero-filled by the range
     // check and land in an LDS buffer nobody reads), so an iteration is one branch-free block, one barrier.
+    // The 128-accumulator configuration (WN = 128) has no room for two register sets: it uses ONE set, stores first
+    // (k-pairs 1..NST), then re-loads (k-pairs NST+1..); its k-pairs are twice as long (8 MFMAs), so a load still
+    // has >= 2500 cycles before it is needed.
+    constexpr bool TWO_SETS = (WN == 64);
     constexpr int NKK = BK / 2;
     constexpr int NST = A_N + B_N;              // tile parts (one load / one LDS store each)
-    constexpr int ST0 = NKK - NST;              // first k-pair that stores
-    static_assert(ST0 >= 2, "K step too short for the software pipeline");
-    constexpr int LPK = (NST + (ST0 - 1) - 1) / (ST0 - 1);  // loads per k-pair, k-pairs 1..ST0-1
+    constexpr int ST0 = TWO_SETS ? NKK - NST : 1;            // first k-pair that stores
+    constexpr int LD0 = TWO_SETS ? 1 : 1 + NST;             // first k-pair that loads
+    constexpr int LDN = TWO_SETS ? ST0 - 1 : NKK - LD0;     // number of k-pairs that load
+    static_assert(ST0 >= 1 && LDN >= 1, "K step too short for the software pipeline");
+    constexpr int LPK = (NST + LDN - 1) / LDN;              // loads per k-pair
     const int nk_all = (a.K + BK - 1) / BK;
     const int kt0 = (int)((long long)nk_all * split / a.splits);        // this workgroup's K steps [kt0, kt0 + nk)
     const int nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
@@ -293,14 +306,22 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < B_N; j++) load_b(rb[0][j], j, kt0, t0);
         const Tap t1 = tap_of(kt0 + 1);
+        if constexpr (TWO_SETS) {
 #pragma unroll
-        for (int j = 0; j < A_N; j++) load_a(ra[1][j], j, t1);
+            for (int j = 0; j < A_N; j++) load_a(ra[1][j], j, t1);
 #pragma unroll
-        for (int j = 0; j < B_N; j++) load_b(rb[1][j], j, kt0 + 1, t1);
+            for (int j = 0; j < B_N; j++) load_b(rb[1][j], j, kt0 + 1, t1);
+        }
 #pragma unroll
         for (int j = 0; j < A_N; j++) store_a(0, j, ra[0][j]);
 #pragma unroll
         for (int j = 0; j < B_N; j++) store_b(0, j, rb[0][j]);
+        if constexpr (!TWO_SETS) {
+#pragma unroll
+            for (int j = 0; j < A_N; j++) load_a(ra[0][j], j, t1);
+#pragma unroll
+            for (int j = 0; j < B_N; j++) load_b(rb[0][j], j, kt0 + 1, t1);
+        }
     }
     __syncthreads();
 
@@ -331,20 +352,22 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
-            // tile movement slotted into this k-pair
-            if (kk >= 1 && kk < ST0 && !ABL(1)) {
+            // tile movement slotted into this k-pair (program order: a part's LDS store precedes its re-load)
+            constexpr int LS = TWO_SETS ? P : 0;      // register set receiving tile kt+2
+            constexpr int SS = TWO_SETS ? P ^ 1 : 0;  // register set holding tile kt+1
+            if (kk >= ST0 && kk < ST0 + NST && !ABL(2)) {
+                const int sidx = kk - ST0;
+                if (sidx < A_N) store_a(P ^ 1, sidx, ra[SS][sidx < A_N ? sidx : 0]);
+                else store_b(P ^ 1, sidx - A_N, rb[SS][sidx >= A_N && sidx - A_N < B_N ? sidx - A_N : 0]);
+            }
+            if (kk >= LD0 && kk < LD0 + LDN && !ABL(1)) {
 #pragma unroll
                 for (int q = 0; q < LPK; q++) {
-                    const int lidx = (kk - 1) * LPK + q;
+                    const int lidx = (kk - LD0) * LPK + q;
                     if (lidx == 0) tnext = tap_of(kt + 2);
-                    if (lidx < A_N) { if (!ABL(8)) load_a(ra[P][lidx < A_N ? lidx : 0], lidx, tnext); }
-                    else if (lidx < NST) { if (!ABL(16)) load_b(rb[P][lidx - A_N < B_N && lidx >= A_N ? lidx - A_N : 0], lidx - A_N, kt + 2, tnext); }
+                    if (lidx < A_N) { if (!ABL(8)) load_a(ra[LS][lidx < A_N ? lidx : 0], lidx, tnext); }
+                    else if (lidx < NST) { if (!ABL(16)) load_b(rb[LS][lidx - A_N < B_N && lidx >= A_N ? lidx - A_N : 0], lidx - A_N, kt + 2, tnext); }
                 }
-            }
-            if (kk >= ST0 && !ABL(2)) {
-                const int sidx = kk - ST0;
-                if (sidx < A_N) store_a(P ^ 1, sidx, ra[P ^ 1][sidx < A_N ? sidx : 0]);
-                else store_b(P ^ 1, sidx - A_N, rb[P ^ 1][sidx >= A_N ? sidx - A_N : 0]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -362,27 +385,30 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int col = n0 + wn * WN + j * 32 + l31;
-            if (col >= a.N) continue;
+            const bool col_ok = col < a.N;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= a.M) continue;
                 const long long o = (long long)row * a.N + col;
-                if (slab) slab[o] = acc[i][j][r];
-                else a.y[o] = epilogue(a, acc[i][j][r], col, o);
+                const float v = acc[i][j][r];
+                if (col_ok && row < a.M) {
+                    if (slab) slab[o] = v;
+                    else a.y[o] = epilogue(a, v, col, o);
+                }
             }
         }
     }
 }
 
-template <int BM, int BN, int BK, bool BT>
+template <int BM, int BN, int BK, int WN, bool BT>
 int launch_igemm(IgemmArgs &a, hipStream_t stream) {
+    constexpr int THREADS = (BM / 64) * (BN / WN) * 64;
     constexpr int AS = BM + 1, BS = BT ? BN + 1 : BN;
     constexpr size_t lds = sizeof(float) * 2 * BK * (AS + BS);
     static_assert((2 * BK * AS * 4) % 16 == 0, "B tile must stay 16-byte aligned");
     static bool attr_set = false;
     if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<BM, BN, BK, BT>),
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<BM, BN, BK, WN, BT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -390,7 +416,7 @@ int launch_igemm(IgemmArgs &a, hipStream_t stream) {
     a.tiles_n = (int)ceil_div(a.N, BN);
     const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, BT>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WN, BT>), dim3((unsigned)nblk), dim3(THREADS), lds, stream, a);
     int rc = launch_status();
     if (rc || a.splits <= 1) return rc;
     long long g = ((long long)a.M * a.N / 4 + 255) / 256;
@@ -403,13 +429,12 @@ int launch_igemm(IgemmArgs &a, hipStream_t stream) {
 // is a few hundred (the M = 26 896, N = 512 layers: 844 tiles -> 2 rounds at 82 %) splitting K by S makes
 // T*S workgroups fill whole rounds (S = 3 -> 4.95 of 5).  The price is one extra pass over S+1 output-sized
 // slabs, charged at ~3 TB/s against the kernel's time at ~110 TFLOP/s.
-int choose_splits(const IgemmArgs &a, int bm, int bn, int bk) {
+int choose_splits(const IgemmArgs &a, int bm, int bn, int bk, double slots = 512.0) {
     static const int force = getenv("EMADAPT_SPLITK") ? atoi(getenv("EMADAPT_SPLITK")) : 0;
     const long long tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
     const int nk = (a.K + bk - 1) / bk;
     if (force > 0) return force <= nk ? force : 1;
     if (a.N % 4 != 0) return 1;
-    const double slots = 512.0;
     const double t_kernel = 2.0 * a.M * (double)a.K * a.N / 110e12;
     int best = 1;
     double best_t = 1e30;
@@ -424,17 +449,31 @@ int choose_splits(const IgemmArgs &a, int bm, int bn, int bk) {
     return best;
 }
 
+// which tile configuration a launch uses: 0 = 128x128x32, 1 = 256x64x16 (N <= 64), 2 = 256x256x32 (wide N, many rows)
+int tile_config(const IgemmArgs &a) {
+    static const int no_big = getenv("EMADAPT_NO_BIG_TILES") ? 1 : 0;
+    if (a.N <= 64) return 1;
+    if (!no_big && a.N >= 1024 && a.M >= 8192) return 2;
+    return 0;
+}
+
+int plan_splits(const IgemmArgs &a) {
+    switch (tile_config(a)) {
+        case 1: return choose_splits(a, 256, 64, 16);
+        case 2: return 1;  // thousands of 256x256 tiles: whole rounds anyway, slabs would be output-sized
+        default: return choose_splits(a, 128, 128, 32);
+    }
+}
+
 size_t igemm_workspace_bytes(const IgemmArgs &a) {
-    const bool small_n = a.N <= 64;
-    const int s = choose_splits(a, small_n ? 256 : 128, small_n ? 64 : 128, small_n ? 16 : 32);
+    const int s = plan_splits(a);
     return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
 }
 
 template <bool BT>
 int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     {
-        const bool small_n = a.N <= 64;
-        int s = choose_splits(a, small_n ? 256 : 128, small_n ? 64 : 128, small_n ? 16 : 32);
+        int s = plan_splits(a);
         if (s > 1 && (!workspace || workspace_bytes < (size_t)s * a.M * a.N * sizeof(float))) s = 1;  // no room: no split
         a.splits = s;
         a.slab = s > 1 ? static_cast<float *>(workspace) : nullptr;
@@ -442,10 +481,13 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
     static const int ablate = getenv("EMADAPT_ABLATE") ? atoi(getenv("EMADAPT_ABLATE")) : 0;
     static const int no_tap_inner = getenv("EMADAPT_NO_TAP_INNER") ? 1 : 0;
     a.ablate = ablate;
-    const int bk = a.N <= 64 ? 16 : 32;
+    const int bk = tile_config(a) == 1 ? 16 : 32;
     a.tap_inner = (!no_tap_inner && a.ntaps > 1 && a.Cx % bk == 0) ? 1 : 0;
-    if (a.N <= 64) return launch_igemm<256, 64, 16, BT>(a, stream);
-    return launch_igemm<128, 128, 32, BT>(a, stream);
+    switch (tile_config(a)) {
+        case 1: return launch_igemm<256, 64, 16, 64, BT>(a, stream);
+        case 2: return launch_igemm<256, 256, 32, 128, BT>(a, stream);
+        default: return launch_igemm<128, 128, 32, 64, BT>(a, stream);
+    }
 }
 
 int check_desc(const emadapt_conv_desc *d) {

@@ -405,6 +405,44 @@ __global__ void resize_nearest_kernel(const float *__restrict__ in, int B, int H
     }
 }
 
+// Inference head of network.py:39-41: tf.image.resize_bilinear(output,(h,w)) (TF1 legacy mapping, align_corners
+// = False: src = dst * in/out, no half-pixel offset) followed by tf.argmax(axis=3).  One thread per output pixel;
+// the C interpolated logits are formed on the fly (optionally stored) and reduced to the first maximum.
+// fp contraction is switched off in the kernel body so that every multiply and add rounds separately, like the
+// restatement (and TF's CPU kernel).
+__global__ void __launch_bounds__(256) pred_bilinear_argmax_kernel(const float *__restrict__ logits, long long ldl, int B,
+                                                                 int IH, int IW, int C, int OH, int OW, float hs,
+                                                                 float ws, long long *__restrict__ pred,
+                                                                 float *__restrict__ rescale) {
+#pragma clang fp contract(off)  // no FMA: the restatement (and TF's CPU kernel) round the multiply and the add separately
+    const long long n = (long long)B * OH * OW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % OW);
+        const int y = (int)((idx / OW) % OH);
+        const int b = (int)(idx / ((long long)OW * OH));
+        const float fy = (float)y * hs, fx = (float)x * ws;
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+        const int y1 = y0 + 1 < IH ? y0 + 1 : IH - 1, x1 = x0 + 1 < IW ? x0 + 1 : IW - 1;
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float *tl = logits + (((long long)b * IH + y0) * IW + x0) * ldl;
+        const float *tr = logits + (((long long)b * IH + y0) * IW + x1) * ldl;
+        const float *bl = logits + (((long long)b * IH + y1) * IW + x0) * ldl;
+        const float *br = logits + (((long long)b * IH + y1) * IW + x1) * ldl;
+        int best = 0;
+        float bv = 0.f;
+        for (int c = 0; c < C; c++) {
+            // plain operators under `fp contract(off)`: each multiply and add rounds on its own
+            const float top = tl[c] + (tr[c] - tl[c]) * lx;
+            const float bot = bl[c] + (br[c] - bl[c]) * lx;
+            const float v = top + (bot - top) * ly;
+            if (rescale) rescale[idx * C + c] = v;
+            if (c == 0 || v > bv) { bv = v; best = c; }
+        }
+        pred[idx] = best;
+    }
+}
+
 std::mutex g_seed_mu;
 uint64_t g_seed_state = 0x9E3779B97F4A7C15ull;
 
@@ -489,6 +527,22 @@ int emadapt_resize_nearest(const float *in, int B, int H, int W, float *out, int
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 8.0, stream);
     hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid), dim3(256), 0, stream, in, B, H, W, out, oh, ow, hs, ws);
+    return launch_status();
+}
+
+int emadapt_pred_bilinear_argmax(const float *logits, int64_t ldl, int B, int IH, int IW, int C, int OH, int OW,
+                                 int64_t *pred, float *rescale_out, void *stream_) {
+    if (!logits || !pred || B < 0 || IH <= 0 || IW <= 0 || C <= 0 || OH <= 0 || OW <= 0 || ldl < C)
+        return EMADAPT_ERR_INVALID;
+    if (B == 0) return EMADAPT_OK;
+    const long long n = (long long)B * OH * OW;
+    int grid = (int)ceil_div(n, 256);
+    if (grid > 8192) grid = 8192;
+    const float hs = (float)IH / (float)OH, ws = (float)IW / (float)OW;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)B * IH * IW * C * 4.0 + (double)n * 8.0, stream);
+    hipLaunchKernelGGL(pred_bilinear_argmax_kernel, dim3(grid), dim3(256), 0, stream, logits, (long long)ldl, B, IH, IW,
+                       C, OH, OW, hs, ws, reinterpret_cast<long long *>(pred), rescale_out);
     return launch_status();
 }
 

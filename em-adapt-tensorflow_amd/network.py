@@ -57,10 +57,21 @@ class Network:
         return layer
 
     def pred(self):
-        """network.py:39-41: bilinear upsample to the input size + argmax.  Inference head -- listed as a
-        "next" row; the training hot path never evaluates it."""
+        """network.py:39-41: net["rescale_output"] = resize_bilinear(output,(h,w)); net["pred"] = argmax(axis=3).
+        Lazily evaluated by ``predict_labels``; the training hot path never runs it."""
         self.net["rescale_output"] = None
         self.net["pred"] = None
+
+    def predict_labels(self, logits=None, want_rescale=False):
+        """Evaluate the inference head on the current (or given) fc8 logits [B,s,s,ldl]: int64 [B,h,w]."""
+        if logits is None or logits is self.net.get("output"):
+            logits = self._bufs["act"][self._plan[-1].name]  # the class-padded fc8 buffer behind net["output"]
+        elif not logits.is_contiguous():
+            logits = logits.contiguous()
+        pred, resc = ops.pred_bilinear_argmax(logits, self.category_num, self.h, self.w, want_rescale)
+        self.net["pred"] = pred
+        self.net["rescale_output"] = resc
+        return pred
 
     def load_init_model(self):
         pass

@@ -164,6 +164,17 @@ def resize_nearest(label, oh, ow, out=None):
     return y
 
 
+def pred_bilinear_argmax(logits, num_classes, out_h, out_w, want_rescale=False):
+    """network.py:39-41: resize_bilinear to (out_h, out_w) + argmax over classes. logits f32 [B,h,w,ldl]."""
+    _check(logits, name="logits")
+    B, IH, IW, ldl = logits.shape
+    pred = torch.empty((B, out_h, out_w), dtype=torch.int64, device=logits.device)
+    resc = torch.empty((B, out_h, out_w, int(num_classes)), dtype=torch.float32, device=logits.device) if want_rescale else None
+    _lib.call("emadapt_pred_bilinear_argmax", _p(logits), ldl, B, IH, IW, int(num_classes), int(out_h), int(out_w),
+              _p(pred), _p(resc), _stream())
+    return pred, resc
+
+
 def estep_device(logits, label, perms, num_classes, suppress_others=True, num_iter=5, margin_others=1e-5,
                  bg_p=0.5, fg_p=0.25, label_kind=LABEL_F32, want_map=False, labels_out=None, map_out=None):
     """Device E-step (deeplab.py:109-124 without the host round trip).

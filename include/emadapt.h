@@ -104,6 +104,12 @@ int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label
  * in: f32 [B,H,W] (the trailing singleton channel of the placeholder dropped), out: f32 [B,oh,ow]. */
 int emadapt_resize_nearest(const float *in, int B, int H, int W, float *out, int oh, int ow, void *stream);
 
+/* Inference head, network.py:39-41: pred = argmax_c( resize_bilinear(logits, [OH,OW]) ), align_corners=False with
+ * TF1's legacy source mapping src = dst*in/out.  logits f32 [B,IH,IW][ldl] (first C used); pred int64 [B,OH,OW];
+ * rescale_out f32 [B,OH,OW,C] receives the interpolated logits when non-NULL (net["rescale_output"]). */
+int emadapt_pred_bilinear_argmax(const float *logits, int64_t ldl, int B, int IH, int IW, int C, int OH, int OW,
+                                 int64_t *pred, float *rescale_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution stack (DeepLab VGG-16 with dilation): implicit-GEMM on MFMA
  * ---------------------------------------------------------------------------------------- */

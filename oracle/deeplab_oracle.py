@@ -204,3 +204,23 @@ def synthetic_batch(B, size, category_num, seed=0, max_objects=3):
             labels[b, :, :brd] = 255
             labels[b, :, -brd:] = 255
     return images, labels
+
+
+def resize_bilinear_tf1(x, out_hw):
+    """tf.image.resize_bilinear(x, out_hw), align_corners=False, TF 1.x legacy kernel [TF-doc]: source coordinate =
+    dst * (in/out) (no half-pixel centre), lerp between floor and min(floor+1, in-1); fp32 arithmetic in this order:
+    top = tl + (tr - tl)*xl; bottom = bl + (br - bl)*xl; out = top + (bottom - top)*yl.  x: [B,H,W,C] float32."""
+    x = np.asarray(x, dtype=np.float32)
+    B, H, W, C = x.shape
+    oh, ow = out_hw
+    f32 = np.float32
+    ys = (np.arange(oh, dtype=np.float32) * (f32(H) / f32(oh))).astype(np.float32)
+    xs = (np.arange(ow, dtype=np.float32) * (f32(W) / f32(ow))).astype(np.float32)
+    y0 = np.floor(ys).astype(np.int64); x0 = np.floor(xs).astype(np.int64)
+    y1 = np.minimum(y0 + 1, H - 1); x1 = np.minimum(x0 + 1, W - 1)
+    yl = (ys - y0.astype(np.float32)).astype(np.float32)[None, :, None, None]
+    xl = (xs - x0.astype(np.float32)).astype(np.float32)[None, None, :, None]
+    tl = x[:, y0][:, :, x0]; tr = x[:, y0][:, :, x1]; bl = x[:, y1][:, :, x0]; br = x[:, y1][:, :, x1]
+    top = (tl + ((tr - tl) * xl).astype(np.float32)).astype(np.float32)
+    bot = (bl + ((br - bl) * xl).astype(np.float32)).astype(np.float32)
+    return (top + ((bot - top) * yl).astype(np.float32)).astype(np.float32)

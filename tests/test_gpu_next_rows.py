@@ -1,0 +1,69 @@
+"""GPU tests of the "next" rows of SURVEY section 8(f) that are built: f4 inference head (network.py:39-41) and
+f3 weights I/O (init.npy pickled dict, deeplab.py:126-129,155-167; checkpoints, network.py:100-110)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    from em_adapt_tensorflow_amd import ops
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from oracle import deeplab_oracle as do
+    return ops, ADAPT, do, torch
+
+
+@pytest.mark.parametrize("shape", [(2, 41, 41, 21, 24, 321), (1, 65, 65, 41, 44, 513), (3, 9, 7, 5, 8, 40)])
+def test_inference_head_bilinear_argmax(env, shape):
+    ops, ADAPT, do, torch = env
+    B, IH, IW, C, ldl, out = shape
+    rng = np.random.default_rng(sum(shape))
+    logits = np.full((B, IH, IW, ldl), 1e30, np.float32)
+    logits[..., :C] = rng.normal(0, 2, (B, IH, IW, C)).astype(np.float32)
+    want = do.resize_bilinear_tf1(logits[..., :C], (out, out))
+    pred, resc = ops.pred_bilinear_argmax(torch.tensor(logits, device="cuda:0"), C, out, out, want_rescale=True)
+    assert np.array_equal(resc.cpu().numpy(), want), "interpolated logits must be bit-identical to the restatement"
+    assert np.array_equal(pred.cpu().numpy(), np.argmax(want, axis=3))
+    pred2, none = ops.pred_bilinear_argmax(torch.tensor(logits, device="cuda:0"), C, out, out)
+    assert none is None and np.array_equal(pred2.cpu().numpy(), pred.cpu().numpy())
+
+
+def test_init_model_and_checkpoint_roundtrip(env, tmp_path):
+    ops, ADAPT, do, torch = env
+    cfg = {"input_size": (65, 65), "category_num": 21, "width": 8, "batch_size": 2, "accum_num": 1}
+    oracle = do.DeepLabOracle(category_num=21, width=8)
+    params = do.init_params(oracle.specs, seed=3, he=True)
+    # the EM-Adapt init model format: np.save of a dict {layer: {"w","b"}} (deeplab.py:128,160,166)
+    init_path = str(tmp_path / "init.npy")
+    np.save(init_path, {k: {"w": w, "b": b} for k, (w, b) in params.items()}, allow_pickle=True)
+    a = ADAPT(dict(cfg, init_model_path=init_path))
+    a.build()
+    for layer, (w, b) in params.items():
+        gw, gb = a.weights[layer][0].cpu().numpy(), a.weights[layer][1].cpu().numpy()
+        if layer == "fc8":  # Xavier-uniform for filter AND bias (deeplab.py:156-164), not the file's values
+            lim = (6.0 / (512 + 21)) ** 0.5
+            assert np.abs(gw).max() <= lim + 1e-6 and gw.std() > 0.3 * lim
+            assert np.abs(gb).max() <= (6.0 / 42) ** 0.5 + 1e-6 and np.abs(gb).max() > 0
+        else:
+            assert np.array_equal(gw, w) and np.array_equal(gb, b)
+    a.pre_train(1e-3, 1e-5, 0.9, 2)
+    images, labels = do.synthetic_batch(2, 65, 21, seed=1)
+    a.micro_step(images / 50, labels, keep_prob=1.0)
+    a.apply_update()
+    path = a.saver["norm"].save(None, str(tmp_path / "ckpt" / "norm"), global_step=7)
+    assert os.path.exists(path) and path.endswith("norm-7.npz")
+    before = a._flat["params"].clone()
+    mom = a._flat["momentum"].clone()
+    b2 = ADAPT(dict(cfg, model_path=path))
+    b2.build()
+    b2.pre_train(1e-3, 1e-5, 0.9, 2)
+    b2.restore_from_model(b2.saver["norm"], path)
+    assert torch.equal(b2._flat["params"], before), "weights must round-trip bit-exactly"
+    assert torch.equal(b2._flat["momentum"], mom), "momentum slots are saved too (the reference drops them)"
+    pred = b2.predict_labels(b2.forward(images / 50))
+    assert tuple(pred.shape) == (2, 65, 65) and pred.dtype == torch.int64
