@@ -56,6 +56,7 @@ PROTOTYPES = {
     "emadapt_estep": (c_int, [_vp, c_int64, _vp, c_int, c_int64, _vp, c_int, c_int, c_int, c_int, c_int, c_int,
                               c_float, c_int, c_int, _vp, _vp, _vp, c_size_t, _vp]),
     "emadapt_pred_bilinear_argmax": (c_int, [_vp, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _vp, _vp, _vp]),
+    "emadapt_bgr_mean_flip": (c_int, [_vp, _vp, c_int, c_int, c_int, POINTER(c_float), _vp, _vp, _vp, _vp]),
     "emadapt_resize_nearest": (c_int, [_vp, c_int, c_int, c_int, _vp, c_int, c_int, _vp]),
     "emadapt_conv_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "emadapt_conv_fwd": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_int, c_float, _vp, c_uint64, _vp, c_size_t,

@@ -439,7 +439,29 @@ __global__ void __launch_bounds__(256) pred_bilinear_argmax_kernel(const float *
             if (rescale) rescale[idx * C + c] = v;
             if (c == 0 || v > bv) { bv = v; best = c; }
         }
-        pred[idx] = best;
+        if (pred) pred[idx] = best;
+    }
+}
+
+// Tail of dataset.py:175-181: RGB -> BGR, subtract the per-channel mean (dataset.py:15-18), optional left-right flip
+// of image and label (image_flip, dataset.py:187-199).  in: f32 [B,H,W,3] RGB (the resized image), label f32 [B,H,W].
+__global__ void __launch_bounds__(256) bgr_mean_flip_kernel(const float *__restrict__ img, const float *__restrict__ lab,
+                                                          int B, int H, int W, float m0, float m1, float m2,
+                                                          const unsigned char *__restrict__ flip,
+                                                          float *__restrict__ img_out, float *__restrict__ lab_out) {
+    const long long n = (long long)B * H * W;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const long long row = idx / W;
+        const int b = (int)(row / H);
+        const int xs = (flip && flip[b]) ? W - 1 - x : x;
+        const long long src = row * W + xs;
+        const float r = img[src * 3 + 0], g = img[src * 3 + 1], bl = img[src * 3 + 2];
+        img_out[idx * 3 + 0] = bl - m0;
+        img_out[idx * 3 + 1] = g - m1;
+        img_out[idx * 3 + 2] = r - m2;
+        if (lab && lab_out) lab_out[idx] = lab[src];
     }
 }
 
@@ -532,7 +554,7 @@ int emadapt_resize_nearest(const float *in, int B, int H, int W, float *out, int
 
 int emadapt_pred_bilinear_argmax(const float *logits, int64_t ldl, int B, int IH, int IW, int C, int OH, int OW,
                                  int64_t *pred, float *rescale_out, void *stream_) {
-    if (!logits || !pred || B < 0 || IH <= 0 || IW <= 0 || C <= 0 || OH <= 0 || OW <= 0 || ldl < C)
+    if (!logits || (!pred && !rescale_out) || B < 0 || IH <= 0 || IW <= 0 || C <= 0 || OH <= 0 || OW <= 0 || ldl < C)
         return EMADAPT_ERR_INVALID;
     if (B == 0) return EMADAPT_OK;
     const long long n = (long long)B * OH * OW;
@@ -543,6 +565,20 @@ int emadapt_pred_bilinear_argmax(const float *logits, int64_t ldl, int B, int IH
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)B * IH * IW * C * 4.0 + (double)n * 8.0, stream);
     hipLaunchKernelGGL(pred_bilinear_argmax_kernel, dim3(grid), dim3(256), 0, stream, logits, (long long)ldl, B, IH, IW,
                        C, OH, OW, hs, ws, reinterpret_cast<long long *>(pred), rescale_out);
+    return launch_status();
+}
+
+int emadapt_bgr_mean_flip(const float *img_rgb, const float *label, int B, int H, int W, const float mean_bgr[3],
+                          const uint8_t *flip, float *img_out, float *label_out, void *stream_) {
+    if (!img_rgb || !img_out || !mean_bgr || B < 0 || H <= 0 || W <= 0) return EMADAPT_ERR_INVALID;
+    if (B == 0) return EMADAPT_OK;
+    const long long n = (long long)B * H * W;
+    int grid = (int)ceil_div(n, 256);
+    if (grid > 8192) grid = 8192;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 32.0, stream);
+    hipLaunchKernelGGL(bgr_mean_flip_kernel, dim3(grid), dim3(256), 0, stream, img_rgb, label, B, H, W, mean_bgr[0],
+                       mean_bgr[1], mean_bgr[2], flip, img_out, label_out);
     return launch_status();
 }
 

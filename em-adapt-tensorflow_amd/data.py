@@ -60,3 +60,27 @@ class SyntheticData:
         while True:
             yield pool[i % len(pool)]
             i += 1
+
+
+def image_preprocess(img_u8, label_u8, out_hw, scale=None, flip=False, device="cuda"):
+    """dataset.image_preprocess (dataset.py:147-185) for ONE decoded sample, on the device.
+
+    img_u8: uint8 [h0,w0,3] RGB, label_u8: uint8 [h0,w0] (or [h0,w0,1]); ``scale`` is the random factor the
+    reference draws from U[0.75,1.25) (None = no random scaling, the "val" branch), ``flip`` its coin toss.
+    Returns (image f32 [H,W,3] BGR minus mean, label f32 [H,W,1]) like the reference's tensors.  File listing and
+    JPEG/PNG decoding stay on the host (out of the hot path)."""
+    from . import ops
+    dev = torch.device(device)
+    img = torch.as_tensor(np.ascontiguousarray(img_u8)).to(dev, torch.float32).unsqueeze(0)
+    lab = torch.as_tensor(np.ascontiguousarray(label_u8)).to(dev, torch.float32).reshape(1, img.shape[1], img.shape[2])
+    if scale is not None:
+        # tf.to_int32(tf.to_float(h) * scale): fp32 product, truncation (dataset.py:154-155)
+        h_new = int(np.float32(img.shape[1]) * np.float32(scale))
+        w_new = int(np.float32(img.shape[2]) * np.float32(scale))
+        img = ops.resize_bilinear(img, h_new, w_new)
+        lab = ops.resize_nearest(lab, h_new, w_new)
+    img = ops.resize_bilinear(img.contiguous(), out_hw[0], out_hw[1])
+    lab = ops.resize_nearest(lab.contiguous(), out_hw[0], out_hw[1])
+    fl = torch.tensor([1 if flip else 0], dtype=torch.uint8, device=dev)
+    img, lab = ops.bgr_mean_flip(img, lab, fl)
+    return img[0], lab[0].unsqueeze(-1)

@@ -175,6 +175,29 @@ def pred_bilinear_argmax(logits, num_classes, out_h, out_w, want_rescale=False):
     return pred, resc
 
 
+def resize_bilinear(x, out_h, out_w):
+    """tf.image.resize_bilinear (TF1 legacy mapping, align_corners=False). x f32 [B,H,W,C]."""
+    _check(x, name="x")
+    B, IH, IW, C = x.shape
+    out = torch.empty((B, out_h, out_w, C), dtype=torch.float32, device=x.device)
+    _lib.call("emadapt_pred_bilinear_argmax", _p(x), C, B, IH, IW, C, int(out_h), int(out_w), None, _p(out), _stream())
+    return out
+
+
+IMG_MEAN_BGR = (104.00698793, 116.66876762, 122.67891434)  # dataset.py:16-18
+
+
+def bgr_mean_flip(img_rgb, label=None, flip=None, mean_bgr=IMG_MEAN_BGR):
+    """dataset.py:175-181 + image_flip: RGB->BGR, minus mean, optional per-image left-right flip (uint8 [B])."""
+    _check(img_rgb, name="img_rgb"); _check(label, name="label"); _check(flip, torch.uint8, "flip")
+    B, H, W, _ = img_rgb.shape
+    out = torch.empty_like(img_rgb)
+    lab_out = torch.empty_like(label) if label is not None else None
+    mean = (ctypes.c_float * 3)(*[float(m) for m in mean_bgr])
+    _lib.call("emadapt_bgr_mean_flip", _p(img_rgb), _p(label), B, H, W, mean, _p(flip), _p(out), _p(lab_out), _stream())
+    return out, lab_out
+
+
 def estep_device(logits, label, perms, num_classes, suppress_others=True, num_iter=5, margin_others=1e-5,
                  bg_p=0.5, fg_p=0.25, label_kind=LABEL_F32, want_map=False, labels_out=None, map_out=None):
     """Device E-step (deeplab.py:109-124 without the host round trip).

@@ -106,9 +106,17 @@ int emadapt_resize_nearest(const float *in, int B, int H, int W, float *out, int
 
 /* Inference head, network.py:39-41: pred = argmax_c( resize_bilinear(logits, [OH,OW]) ), align_corners=False with
  * TF1's legacy source mapping src = dst*in/out.  logits f32 [B,IH,IW][ldl] (first C used); pred int64 [B,OH,OW];
- * rescale_out f32 [B,OH,OW,C] receives the interpolated logits when non-NULL (net["rescale_output"]). */
+ * rescale_out f32 [B,OH,OW,C] receives the interpolated logits when non-NULL (net["rescale_output"]); pred may be
+ * NULL when only the resized tensor is wanted (plain tf.image.resize_bilinear). */
 int emadapt_pred_bilinear_argmax(const float *logits, int64_t ldl, int B, int IH, int IW, int C, int OH, int OW,
                                  int64_t *pred, float *rescale_out, void *stream);
+
+/* Input pipeline tail, dataset.py:175-181,187-199 (next row f1): RGB -> BGR, minus the per-channel mean
+ * (dataset.py:15-18), optional left-right flip of image and label (flip: uint8 [B], may be NULL).  The two resizes in
+ * front of it (dataset.py:153-173) are emadapt_pred_bilinear_argmax with pred == NULL (plain resize_bilinear of a
+ * C-channel image) and emadapt_resize_nearest.  img_rgb f32 [B,H,W,3]; label f32 [B,H,W] (may be NULL). */
+int emadapt_bgr_mean_flip(const float *img_rgb, const float *label, int B, int H, int W, const float mean_bgr[3],
+                          const uint8_t *flip, float *img_out, float *label_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution stack (DeepLab VGG-16 with dilation): implicit-GEMM on MFMA

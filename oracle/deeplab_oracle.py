@@ -224,3 +224,25 @@ def resize_bilinear_tf1(x, out_hw):
     top = (tl + ((tr - tl) * xl).astype(np.float32)).astype(np.float32)
     bot = (bl + ((br - bl) * xl).astype(np.float32)).astype(np.float32)
     return (top + ((bot - top) * yl).astype(np.float32)).astype(np.float32)
+
+
+def image_preprocess_oracle(img_u8, label_u8, out_hw, scale=None, flip=False):
+    """dataset.py:147-185 restated in NumPy (TF1 semantics [TF-doc]): optional random scale (bilinear image / nearest
+    label to int(h*scale), int(w*scale)), resize to out_hw, RGB->BGR, float32, minus mean, optional left-right flip.
+    The uint8 `label -= 255 ... += 255` wrap-around of the reference is the identity under nearest resizing."""
+    img = np.asarray(img_u8, dtype=np.float32)[None]
+    lab = np.asarray(label_u8, dtype=np.float32).reshape(1, img.shape[1], img.shape[2])
+    if scale is not None:
+        hn = int(np.float32(img.shape[1]) * np.float32(scale))
+        wn = int(np.float32(img.shape[2]) * np.float32(scale))
+        img = resize_bilinear_tf1(img, (hn, wn))
+        lab = _eo.resize_nearest_oracle(lab, (hn, wn))
+    img = resize_bilinear_tf1(img, out_hw)
+    lab = _eo.resize_nearest_oracle(lab, out_hw)
+    mean = np.array([104.00698793, 116.66876762, 122.67891434], np.float32)
+    out = img[0][:, :, ::-1].astype(np.float32) - mean
+    lab = lab[0].astype(np.float32)
+    if flip:
+        out = out[:, ::-1]
+        lab = lab[:, ::-1]
+    return np.ascontiguousarray(out, np.float32), np.ascontiguousarray(lab)[..., None]

@@ -67,3 +67,21 @@ def test_init_model_and_checkpoint_roundtrip(env, tmp_path):
     assert torch.equal(b2._flat["momentum"], mom), "momentum slots are saved too (the reference drops them)"
     pred = b2.predict_labels(b2.forward(images / 50))
     assert tuple(pred.shape) == (2, 65, 65) and pred.dtype == torch.int64
+
+
+@pytest.mark.parametrize("case", [(375, 500, 1.1337, True), (333, 500, 0.75, False), (281, 413, None, True),
+                                  (500, 375, 1.2499, False)])
+def test_input_pipeline_matches_restatement(env, case):
+    """f1: dataset.image_preprocess (dataset.py:147-185) on the device, randomness as explicit inputs."""
+    ops, ADAPT, do, torch = env
+    from em_adapt_tensorflow_amd.data import image_preprocess
+    h0, w0, scale, flip = case
+    rng = np.random.default_rng(h0 + w0)
+    img = rng.integers(0, 256, (h0, w0, 3), dtype=np.uint8)
+    lab = rng.integers(0, 21, (h0, w0), dtype=np.uint8)
+    lab[:5] = 255
+    want_img, want_lab = do.image_preprocess_oracle(img, lab, (321, 321), scale, flip)
+    got_img, got_lab = image_preprocess(img, lab, (321, 321), scale, flip, device="cuda:0")
+    assert tuple(got_img.shape) == (321, 321, 3) and tuple(got_lab.shape) == (321, 321, 1)
+    assert np.array_equal(got_lab.cpu().numpy(), want_lab)
+    assert np.array_equal(got_img.cpu().numpy(), want_img), np.abs(got_img.cpu().numpy() - want_img).max()
