@@ -7,10 +7,12 @@
 //     stays in registers, the channels of the classes present in the image stay in LDS
 //     ([slot][pixel], conflict-free for the pixel-strided access), so one (iteration, class) step
 //     never touches HBM;
-//   * the k-th smallest of (max - channel) -- np.partition in the reference -- is found exactly by a
-//     bitwise binary search on the raw IEEE bits (order-preserving for the non-negative differences):
-//     31 rounds of "count keys < candidate" done with wavefront ballots + s_bcnt1 (scalar pipe, no
-//     cross-lane shuffles) and one LDS word per wave per round; no sorting, no atomics;
+//   * when the whole [C][pixel] image fits in LDS (41x41x21 does: 141 KB) the logits are staged in ONCE with
+//     coalesced 16-byte loads and every later pass -- suppress, maxima, sweeps, argmax -- runs out of LDS;
+//   * the k-th smallest of (max - channel) -- np.partition in the reference -- is found exactly by a 3-pass
+//     radix select on the raw IEEE bits (order-preserving for the non-negative differences): 11+10+10 bits,
+//     each pass = LDS histogram (ds_add_u32) + a block-wide prefix scan (wavefront __shfl_up + one LDS word per
+//     wave) that locates the bin holding rank k; no sorting, 12 barriers per selection;
 //   * arithmetic is fp32 add / sub / compare only, in the reference's order, and the two np.mean()
 //     calls follow NumPy's pairwise summation tree, so label maps AND float maps are bit-identical;
 //   * the class visiting order (random.shuffle in the reference) is an input.
@@ -19,6 +21,7 @@
 // int64 label map is written once; the float map is written only when the caller asks for it.
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <vector>
@@ -29,12 +32,21 @@ namespace {
 
 using namespace emadapt;
 
+// Phase-timing exits (EMADAPT_ESTEP_STOP) exist only in diagnostic builds (-DEMADAPT_ABLATE_BUILD).
+#ifdef EMADAPT_ABLATE_BUILD
+#define ESTEP_STOP(n) if (a.stop_after == (n)) return
+#else
+#define ESTEP_STOP(n) do { } while (0)
+#endif
+
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxC = 256;       // classes
 constexpr int kMaxLeaves = 192;  // leaves of NumPy's pairwise-sum tree for HW <= 8192
 constexpr int kMaxEPT = 32;      // pixels per thread -> HW <= 8192
 constexpr size_t kLdsBudget = 160 * 1024;
+constexpr int kHistBins = 2048;  // 11-bit first radix pass
+constexpr int kPermCap = 1024;   // visiting-order entries (num_iter * (C-1)) staged in LDS; beyond that: read from HBM
 
 __device__ __forceinline__ unsigned f2key(float f) {
     unsigned u = __float_as_uint(f);
@@ -79,6 +91,8 @@ struct EstepArgs {
     long long *labels_out;
     int p_res;  // present-channel slots resident in LDS
     int hwp;    // HW rounded up to a multiple of 4 (LDS row pitch)
+    int full;   // 1: all C channels are staged into LDS, indexed by class (p_res == C)
+    int stop_after;  // diagnostics (EMADAPT_ESTEP_STOP): leave the kernel after phase n (0 = run everything)
 };
 
 // One leaf (n <= 128) of NumPy's float32 pairwise summation.
@@ -118,6 +132,9 @@ struct Lds {
     unsigned char *prog;  // [2*kMaxLeaves]  0 = push next leaf, 1 = add
     int *misc;        // [0]=P [1]=nleaf [2]=nprog
     float *scal;      // [0]=shift
+    unsigned *hist;   // [kHistBins] radix-select histogram
+    int *sel;         // [4] selected bin, remaining rank
+    unsigned short *perm;  // [kPermCap] class visiting order, staged once (a global load per visit would serialise)
 };
 
 __device__ __forceinline__ Lds carve(char *base, int hwp, int p_res) {
@@ -132,14 +149,17 @@ __device__ __forceinline__ Lds carve(char *base, int hwp, int p_res) {
     l.stk = l.leaf_n + kMaxLeaves;
     l.misc = l.stk + 48;
     l.scal = reinterpret_cast<float *>(l.misc + 4);
-    l.prog = reinterpret_cast<unsigned char *>(l.scal + 4);
+    l.hist = reinterpret_cast<unsigned *>(l.scal + 4);
+    l.sel = reinterpret_cast<int *>(l.hist + kHistBins);
+    l.perm = reinterpret_cast<unsigned short *>(l.sel + 4);
+    l.prog = reinterpret_cast<unsigned char *>(l.perm + kPermCap);
     return l;
 }
 
 size_t lds_bytes(int hwp, int p_res) {
     return sizeof(float) * ((size_t)hwp + (size_t)p_res * hwp) + sizeof(int) * (kMaxC + 2 * kWaves) +
            sizeof(float) * kMaxLeaves + sizeof(int) * (2 * kMaxLeaves + 48 + 4) + sizeof(float) * 4 +
-           2 * kMaxLeaves;
+           sizeof(unsigned) * kHistBins + sizeof(int) * 4 + sizeof(unsigned short) * kPermCap + 2 * kMaxLeaves;
 }
 
 // np.mean over l.mx[0..HW): leaves in parallel, then the combine program on thread 0.
@@ -167,6 +187,59 @@ __device__ float np_mean_lds(const Lds &l, int HW, int tid) {
     return res;
 }
 
+// k-th smallest (0-indexed) of the workgroup's keys, exact.  Valid keys are < 2^31 (bit patterns of non-negative
+// floats); unused slots hold 0xFFFFFFFF and never match a prefix.  Three passes over 11 + 10 + 10 bits from the top:
+// histogram the digit of every key that still matches the selected prefix, scan the histogram to find the bin
+// containing rank k, descend into it.  Every thread returns the same value.
+template <int EPT>
+__device__ unsigned radix_select(const unsigned (&key)[EPT], int k, const Lds &l, int tid, int lane, int wave) {
+    unsigned prefix = 0;
+    unsigned kk = (unsigned)k;
+    int shift = 31;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; pass++) {
+        const int bits = pass == 0 ? 11 : 10;
+        shift -= bits;  // 20, 10, 0
+        const int nb = 1 << bits;
+        for (int h = tid; h < nb; h += kThreads) l.hist[h] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const unsigned x = key[e];
+            if ((x >> (shift + bits)) == prefix) atomicAdd(&l.hist[(x >> shift) & (unsigned)(nb - 1)], 1u);
+        }
+        __syncthreads();
+        const int per = nb / kThreads;  // 8 or 4 consecutive bins per thread
+        unsigned local = 0;
+        for (int j = 0; j < per; j++) local += l.hist[tid * per + j];
+        unsigned incl = local;  // inclusive scan over the wavefront
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned n = __shfl_up(incl, d);
+            if (lane >= d) incl += n;
+        }
+        if (lane == 63) l.red[wave] = (int)incl;
+        __syncthreads();
+        unsigned base = 0;
+        for (int w = 0; w < wave; w++) base += (unsigned)l.red[w];
+        const unsigned excl = base + incl - local;
+        if (kk >= excl && kk < excl + local) {  // exactly one thread owns the bin that holds rank kk
+            unsigned c = excl;
+            int j = 0;
+            for (; j < per - 1; j++) {
+                const unsigned hc = l.hist[tid * per + j];
+                if (kk < c + hc) break;
+                c += hc;
+            }
+            l.sel[0] = tid * per + j;
+            l.sel[1] = (int)(kk - c);
+        }
+        __syncthreads();
+        prefix = (prefix << bits) | (unsigned)l.sel[0];
+        kk = (unsigned)l.sel[1];
+    }
+    return prefix;
+}
+
 template <int EPT>
 __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -176,6 +249,13 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
     const int wave = tid >> 6;
     const int b = blockIdx.x;
     const int HW = a.HW, C = a.C, hwp = a.hwp, p_res = a.p_res;
+    const bool full = a.full != 0;  // all channels LDS-resident, slot of class c == c
+
+    // ---- class visiting order -> LDS (one coalesced load instead of one dependent HBM load per visit) ----
+    const int nperm = a.num_iter * (C - 1);
+    const bool perm_lds = nperm <= kPermCap;
+    if (perm_lds)
+        for (int t = tid; t < nperm; t += kThreads) l.perm[t] = (unsigned short)a.perms[t];
 
     // ---- image-level label set (estep.py:35-44) ----
     for (int c = tid; c < kMaxC; c += kThreads) l.slot[c] = 0;
@@ -200,7 +280,11 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
     __syncthreads();
     if (tid == 0) {
         int P = 0;
-        for (int c = 0; c < C; c++) l.slot[c] = l.slot[c] ? P++ : -1;
+        for (int c = 0; c < C; c++) {
+            const bool present = l.slot[c] != 0;
+            l.slot[c] = present ? (full ? c : P) : -1;
+            P += present ? 1 : 0;
+        }
         l.misc[0] = P;
         // NumPy pairwise-sum tree for n = HW: leaves + post-order combine program.
         int nleaf = 0, nprog = 0, sp = 0;
@@ -232,10 +316,59 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
     }
     __syncthreads();
 
+    ESTEP_STOP(1);
     const float gmax = a.suppress ? key2f(*a.gmax_key) : 0.f;
     const bool suppress = a.suppress != 0;
     float mx[EPT];
 
+    if (full) {
+        // ---- stage the image's logits into LDS as [class][pixel]: coalesced HBM reads, read exactly once ----
+        const float *img = a.logits + (size_t)b * HW * a.ldl;
+        if ((a.ldl & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.logits) & 15) == 0)) {
+            const int q4 = (int)(a.ldl >> 2);
+            for (int g = tid; g < HW * q4; g += kThreads) {
+                const int row = g / q4, q = g - row * q4;
+                const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)g * 4);
+                const int c = q * 4;
+                if (c + 0 < C) l.chan[(size_t)(c + 0) * hwp + row] = v.x;
+                if (c + 1 < C) l.chan[(size_t)(c + 1) * hwp + row] = v.y;
+                if (c + 2 < C) l.chan[(size_t)(c + 2) * hwp + row] = v.z;
+                if (c + 3 < C) l.chan[(size_t)(c + 3) * hwp + row] = v.w;
+            }
+        } else {
+            for (int g = tid; g < HW * C; g += kThreads) {
+                const int row = g / C, c = g - row * C;
+                l.chan[(size_t)c * hwp + row] = img[(size_t)row * a.ldl + c];
+            }
+        }
+        __syncthreads();
+        // ---- suppress absent classes (estep.py:46-55) in place, per-pixel max ----
+#pragma unroll 1
+        for (int e = 0; e < EPT; e++) {
+            const int i = tid + e * kThreads;
+            if (i < HW) {
+                float m = FLT_MAX;
+                if (suppress) {
+                    for (int c = 0; c < C; c++) {
+                        const float v = l.chan[(size_t)c * hwp + i];
+                        const float t = (l.slot[c] >= 0) ? v : v + gmax;
+                        m = (t < m) ? t : m;
+                    }
+                }
+                const float repl = m - a.margin;
+                float mxv = 0.f;
+                for (int c = 0; c < C; c++) {
+                    float v = l.chan[(size_t)c * hwp + i];
+                    if (suppress && l.slot[c] < 0 && v > m) {
+                        v = repl;
+                        l.chan[(size_t)c * hwp + i] = v;
+                    }
+                    mxv = (c == 0 || v > mxv) ? v : mxv;
+                }
+                l.mx[i] = mxv;
+            }
+        }
+    } else
     // ---- suppress absent classes (estep.py:46-55), per-pixel max, present channels -> LDS ----
 #pragma unroll 1
     for (int e = 0; e < EPT; e++) {
@@ -270,13 +403,15 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
         mx[e] = (i < HW) ? l.mx[i] : 0.f;
     }
     __syncthreads();
+    ESTEP_STOP(2);
     const float mean0 = np_mean_lds(l, HW, tid);  // estep.py:56 (thread 0 holds it)
+    ESTEP_STOP(3);
 
     // ---- num_iter sweeps over the classes in the given order (estep.py:62-79) ----
-    int par = 0;
     for (int it = 0; it < a.num_iter; it++) {
         for (int q = 0; q < C; q++) {
-            const int j = (q == 0) ? 0 : a.perms[(size_t)it * (C - 1) + (q - 1)];
+            const int pi = it * (C - 1) + (q - 1);
+            const int j = (q == 0) ? 0 : (perm_lds ? (int)l.perm[pi] : a.perms[pi]);
             if ((unsigned)j >= (unsigned)C) continue;
             const int s = l.slot[j];
             if (s < 0) continue;
@@ -294,21 +429,7 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
                     key[e] = __float_as_uint(mx[e] - ch);  // >= +0: raw bits are order-preserving
                 }
             }
-            // k-th smallest key (0-indexed): largest r with #(key < r) <= k.
-            unsigned res = 0;
-            for (int bit = 30; bit >= 0; bit--) {
-                const unsigned cand = res | (1u << bit);
-                int cnt = 0;
-#pragma unroll
-                for (int e = 0; e < EPT; e++) cnt += __popcll(__ballot(key[e] < cand));
-                if (lane == 0) l.red[par * kWaves + wave] = cnt;
-                __syncthreads();
-                const int tot = l.red[par * kWaves + 0] + l.red[par * kWaves + 1] +
-                                l.red[par * kWaves + 2] + l.red[par * kWaves + 3];
-                par ^= 1;
-                if (tot <= k) res = cand;
-            }
-            const float t = __uint_as_float(res);
+            const float t = __uint_as_float(radix_select<EPT>(key, k, l, tid, lane, wave));  // np.partition(d, k)[k]
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
                 const int i = tid + e * kThreads;
@@ -322,6 +443,7 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
         }
     }
 
+    ESTEP_STOP(4);
     // ---- re-centre (estep.py:80-82) and argmax (deeplab.py:123) ----
 #pragma unroll
     for (int e = 0; e < EPT; e++) {
@@ -334,6 +456,29 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
     __syncthreads();
     const float shift = l.scal[0];
 
+    if (full) {
+#pragma unroll 1
+        for (int e = 0; e < EPT; e++) {
+            const int i = tid + e * kThreads;
+            if (i < HW) {
+                int best = 0;
+                float bv = 0.f;
+                for (int c = 0; c < C; c++) {
+                    const float v = l.chan[(size_t)c * hwp + i] + shift;
+                    if (c == 0 || v > bv) { bv = v; best = c; }
+                }
+                a.labels_out[(size_t)b * HW + i] = best;  // consecutive lanes -> consecutive int64: coalesced
+            }
+        }
+        if (a.map_out) {  // float map of estep.py:82, written with coalesced stores
+            float *mo = a.map_out + (size_t)b * HW * C;
+            for (int g = tid; g < HW * C; g += kThreads) {
+                const int row = g / C, c = g - row * C;
+                mo[g] = l.chan[(size_t)c * hwp + row] + shift;
+            }
+        }
+        return;
+    }
 #pragma unroll 1
     for (int e = 0; e < EPT; e++) {
         const int i = tid + e * kThreads;
@@ -531,6 +676,9 @@ int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label
     a.perms = perms; a.HW = (int)HW; a.C = C; a.suppress = suppress_others ? 1 : 0; a.num_iter = num_iter;
     a.margin = margin_others; a.k_bg = k_bg; a.k_fg = k_fg; a.gmax_key = gkey; a.map_out = map_out;
     a.labels_out = reinterpret_cast<long long *>(labels_out); a.p_res = p_res; a.hwp = hwp;
+    a.full = (p_res >= C) ? 1 : 0;
+    static const int stop_after = getenv("EMADAPT_ESTEP_STOP") ? atoi(getenv("EMADAPT_ESTEP_STOP")) : 0;
+    a.stop_after = stop_after;
     const size_t lds = align_up(lds_bytes(hwp, p_res), 16);
     const int ept = (int)ceil_div(HW, kThreads);
     if (ept <= 1) return launch_estep<1>(a, B, lds, stream);
