@@ -55,6 +55,7 @@ struct IgemmArgs {
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes;  // extents for the bounds-checked buffer loads (< 2 GiB each)
     unsigned magic_cx, magic_kw;  // ceil(2^32/Cx), ceil(2^32/KW): k / Cx and tap / KW by one v_mul_hi_u32
+    int m_begin, m_end;  // output rows (pixels) this launch covers: [m_begin, m_end)
     int splits;          // split-K: K steps are divided over `splits` workgroups per tile (partials -> slab)
     float *slab;         // [splits][M][N] fp32 partials when splits > 1
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
@@ -99,15 +100,16 @@ __device__ __forceinline__ float epilogue(const IgemmArgs &a, float v, int col, 
 
 // split-K second stage: y = epilogue(sum_s slab[s]) with the partials added in ascending s (deterministic).
 __global__ void __launch_bounds__(256) splitk_epilogue_kernel(IgemmArgs a) {
-    const long long n4 = (long long)a.M * a.N / 4;
-    const long long mn = (long long)a.M * a.N;
+    const long long mn = (long long)(a.m_end - a.m_begin) * a.N;  // one slab
+    const long long n4 = mn / 4;
+    const long long o0 = (long long)a.m_begin * a.N;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 v = *reinterpret_cast<const float4 *>(a.slab + i * 4);
         for (int sp = 1; sp < a.splits; sp++) {
             const float4 u = *reinterpret_cast<const float4 *>(a.slab + sp * mn + i * 4);
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
-        const long long o = i * 4;
+        const long long o = o0 + i * 4;
         const int col = (int)(o % a.N);
         v.x = epilogue(a, v.x, col + 0, o + 0);
         v.y = epilogue(a, v.y, col + 1, o + 1);
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__((BM / 64) * (BN / WN) * 64, 2) igemm_kernel(Ig
         tile_m = first_m + in_g % gsz;
         tile_n = in_g / gsz;
     }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-thread gather state for the A rows it loads ----
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__((BM / 64) * (BN / WN) * 64, 2) igemm_kernel(Ig
 #pragma unroll
     for (int j = 0; j < A_N; j++) {
         const int m = m0 + a_r0 + j * A_RSTEP;
-        if (m < a.M) {
+        if (m < a.m_end) {
             const int t2 = m / a.W;
             a_base[j] = m * a.Cx;
             a_oh[j] = t2 % a.H;
@@ -379,7 +381,8 @@ __global__ void __launch_bounds__((BM / 64) * (BN / WN) * 64, 2) igemm_kernel(Ig
     }
 
     // ---- fused epilogue; C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float *slab = a.splits > 1 ? a.slab + (long long)split * a.M * a.N : nullptr;
+    // split-K partials are stored compactly: slab[split][row - m_begin][col]
+    float *slab = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -391,13 +394,251 @@ __global__ void __launch_bounds__((BM / 64) * (BN / WN) * 64, 2) igemm_kernel(Ig
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const long long o = (long long)row * a.N + col;
                 const float v = acc[i][j][r];
-                if (col_ok && row < a.M) {
+                if (col_ok && row < a.m_end) {
                     if (slab) slab[o] = v;
                     else a.y[o] = epilogue(a, v, col, o);
                 }
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant of the 128x128x32 tile: 512 threads = 4 CONSUMER wavefronts (LDS fragment reads + MFMA,
+// nothing else in their instruction stream) + 4 PRODUCER wavefronts (im2col gather, filter loads, LDS stores).  A wave
+// issues in order, so in the unified kernel every global load / address computation / ds_write sits in front of that
+// wave's next MFMA; with the roles split the matrix pipe of a SIMD is fed by a wave that never waits on VMEM, while
+// the producer's VALU/VMEM/LDS work runs on the separate vector pipes.  The two roles live in disjoint branches, so the
+// register allocation is max(consumer, producer), not the sum (2 workgroups = 16 waves per CU need <= 128 VGPRs).
+// Same LDS layout, K order, split-K and epilogue as igemm_kernel; one barrier per K step joins both roles:
+//   producer, step kt : park tile kt+1 (registers) in LDS buffer (kt+1)&1, issue the loads of tile kt+2, barrier
+//   consumer, step kt : 64 MFMAs on LDS buffer kt&1, barrier
+template <bool BT>
+__global__ void __launch_bounds__(512, 4) igemm_ws_kernel(IgemmArgs a) {
+    constexpr int BM = 128, BN = 128, BK = 32, WM = 64, WN = 64;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int AS = BM + 1;
+    constexpr int BS = BT ? BN + 1 : BN;
+    constexpr int KQ = BK / 4;
+    constexpr int A_RSTEP = 256 / KQ;
+    constexpr int A_N = BM / A_RSTEP;
+    constexpr int QN = BN / 4;
+    constexpr int B_KSTEP = 256 / QN;
+    constexpr int B_N = BT ? (BN / A_RSTEP) : (BK / B_KSTEP);
+    constexpr int NKK = BK / 2;
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;
+    float *Bs = lds + 2 * BK * AS;
+
+    int tile_m, tile_n, split;
+    {
+        const int ntile = a.tiles_m * a.tiles_n;
+        const int nblk = ntile * a.splits;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        split = t / ntile;
+        t -= split * ntile;
+        constexpr int GM = 8;
+        const int per_group = GM * a.tiles_n;
+        const int g = t / per_group;
+        const int first_m = g * GM;
+        const int gsz = (a.tiles_m - first_m < GM) ? (a.tiles_m - first_m) : GM;
+        const int in_g = t - g * per_group;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
+    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * split / a.splits);
+    const int nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
+
+    if (threadIdx.x >= 256) {
+        // ================================ PRODUCER wavefronts ================================
+        const int tid = threadIdx.x - 256;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
+        constexpr unsigned kOOB = 0x80000000u;
+        const int a_kq = tid % KQ, a_r0 = tid / KQ;
+        int a_base[A_N], a_oh[A_N], a_ow[A_N];
+#pragma unroll
+        for (int j = 0; j < A_N; j++) {
+            const int m = m0 + a_r0 + j * A_RSTEP;
+            if (m < a.m_end) {
+                const int t2 = m / a.W;
+                a_base[j] = m * a.Cx;
+                a_oh[j] = t2 % a.H;
+                a_ow[j] = m - t2 * a.W;
+            } else {
+                a_base[j] = 0;
+                a_oh[j] = -(1 << 20);
+                a_ow[j] = -(1 << 20);
+            }
+        }
+        const int b_nq = tid % QN, b_kr = tid / QN;
+        const int b_nr = tid / KQ;
+        float4 ra[A_N], rb[B_N];
+
+        auto load_tile = [&](int kt) {
+            unsigned tap;
+            int c;
+            if (a.tap_inner) {
+                const unsigned chunk = __umulhi((unsigned)kt, a.magic_nt);
+                tap = (unsigned)kt - chunk * (unsigned)a.ntaps;
+                c = (int)chunk * BK + a_kq * 4;
+                if ((int)chunk * BK >= a.Cx) tap = (unsigned)a.ntaps;
+            } else {
+                const unsigned k = (unsigned)(kt * BK + a_kq * 4);
+                tap = __umulhi(k, a.magic_cx);
+                c = (int)(k - tap * (unsigned)a.Cx);
+            }
+            const unsigned kh = __umulhi(tap, a.magic_kw);
+            const int kw = (int)(tap - kh * (unsigned)a.KW);
+            const bool kvalid = (int)tap < a.ntaps;
+            const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
+            const int dw = a.sign * (kw * a.dil - a.pad_w);
+            const int toff = (dh * a.W + dw) * a.Cx + c;
+#pragma unroll
+            for (int j = 0; j < A_N; j++) {
+                const int ih = a_oh[j] + dh, iw = a_ow[j] + dw;
+                const bool ok = kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                ra[j] = buf_ld4(xr, ((unsigned)(a_base[j] + toff) * 4u) | (ok ? 0u : kOOB));
+            }
+#pragma unroll
+            for (int j = 0; j < B_N; j++) {
+                if constexpr (!BT) {
+                    const int r = b_kr + j * B_KSTEP;
+                    const int kb = a.tap_inner ? (int)tap * a.Cx + (c - a_kq * 4) + r : kt * BK + r;
+                    const int n = n0 + b_nq * 4;
+                    rb[j] = buf_ld4(wr, ((unsigned)(kb * a.N + n) * 4u) | ((kb < a.K && n < a.N) ? 0u : kOOB));
+                } else {
+                    const int n = n0 + b_nr + j * A_RSTEP;
+                    rb[j] = buf_ld4(wr, ((unsigned)(((int)tap * a.N + n) * a.Cx + c) * 4u) | ((kvalid && n < a.N) ? 0u : kOOB));
+                }
+            }
+        };
+        auto store_tile = [&](int buf) {
+            float *as = As + buf * BK * AS;
+            float *bs = Bs + buf * BK * BS;
+#pragma unroll
+            for (int j = 0; j < A_N; j++) {
+                const int r = a_r0 + j * A_RSTEP;
+                as[(a_kq * 4 + 0) * AS + r] = ra[j].x;
+                as[(a_kq * 4 + 1) * AS + r] = ra[j].y;
+                as[(a_kq * 4 + 2) * AS + r] = ra[j].z;
+                as[(a_kq * 4 + 3) * AS + r] = ra[j].w;
+            }
+#pragma unroll
+            for (int j = 0; j < B_N; j++) {
+                if constexpr (!BT) {
+                    *reinterpret_cast<float4 *>(&bs[(b_kr + j * B_KSTEP) * BS + b_nq * 4]) = rb[j];
+                } else {
+                    const int n = b_nr + j * A_RSTEP;
+                    bs[(a_kq * 4 + 0) * BS + n] = rb[j].x;
+                    bs[(a_kq * 4 + 1) * BS + n] = rb[j].y;
+                    bs[(a_kq * 4 + 2) * BS + n] = rb[j].z;
+                    bs[(a_kq * 4 + 3) * BS + n] = rb[j].w;
+                }
+            }
+        };
+        load_tile(kt0);
+        store_tile(0);
+        load_tile(kt0 + 1);  // K steps past the end are zero-filled by the range check
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            store_tile((kt + 1) & 1);
+            load_tile(kt0 + kt + 2);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================================ CONSUMER wavefronts ================================
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        const float *as = As + cur * BK * AS + wm * WM + l31;
+        const float *bs = Bs + cur * BK * BS + wn * WN + l31;
+        float av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[0][i] = as[lh * AS + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = bs[lh * BS + j * 32];
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk++) {
+            if (kk + 1 < NKK) {
+#pragma unroll
+                for (int i = 0; i < TM; i++) av[(kk + 1) & 1][i] = as[((kk + 1) * 2 + lh) * AS + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = bs[((kk + 1) * 2 + lh) * BS + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // split-K partials are stored compactly: slab[split][row - m_begin][col]
+    float *slab = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            const bool col_ok = col < a.N;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const long long o = (long long)row * a.N + col;
+                const float v = acc[i][j][r];
+                if (col_ok && row < a.m_end) {
+                    if (slab) slab[o] = v;
+                    else a.y[o] = epilogue(a, v, col, o);
+                }
+            }
+        }
+    }
+}
+
+template <bool BT>
+int launch_igemm_ws(IgemmArgs &a, hipStream_t stream) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int AS = BM + 1, BS = BT ? BN + 1 : BN;
+    constexpr size_t lds = sizeof(float) * 2 * BK * (AS + BS);
+    static bool attr_set = false;
+    if (!attr_set) {
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_ws_kernel<BT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, BM);
+    a.tiles_n = (int)ceil_div(a.N, BN);
+    const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
+    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((igemm_ws_kernel<BT>), dim3((unsigned)nblk), dim3(512), lds, stream, a);
+    int rc = launch_status();
+    if (rc || a.splits <= 1) return rc;
+    long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
+    return launch_status();
 }
 
 template <int BM, int BN, int BK, int WN, bool BT>
@@ -412,30 +653,30 @@ int launch_igemm(IgemmArgs &a, hipStream_t stream) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    a.tiles_m = (int)ceil_div(a.M, BM);
+    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
     const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WN, BT>), dim3((unsigned)nblk), dim3(THREADS), lds, stream, a);
     int rc = launch_status();
     if (rc || a.splits <= 1) return rc;
-    long long g = ((long long)a.M * a.N / 4 + 255) / 256;
+    long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
     return launch_status();
 }
 
-// Split-K factor: with T tiles on 512 resident workgroup slots (256 CUs x 2) a launch runs ceil(T/512) rounds; when T
-// is a few hundred (the M = 26 896, N = 512 layers: 844 tiles -> 2 rounds at 82 %) splitting K by S makes
-// T*S workgroups fill whole rounds (S = 3 -> 4.95 of 5).  The price is one extra pass over S+1 output-sized
-// slabs, charged at ~3 TB/s against the kernel's time at ~110 TFLOP/s.
-int choose_splits(const IgemmArgs &a, int bm, int bn, int bk, double slots = 512.0) {
+// Split-K factor: with T tiles on `slots` resident workgroup slots (256 CUs x 2) a launch runs ceil(T/slots) rounds;
+// when T is a few hundred (the M = 26 896, N = 512 layers: 844 tiles -> 2 rounds at 82 %) splitting K by S makes T*S
+// workgroups fill whole rounds (S = 3 -> 4.95 of 5).  The price is one extra pass over S+1 output-sized slabs,
+// charged at ~3 TB/s against the kernel's time at ~110 TFLOP/s.
+int choose_splits(long long M, int N, int K, int bm, int bn, int bk, double slots = 512.0) {
     static const int force = getenv("EMADAPT_SPLITK") ? atoi(getenv("EMADAPT_SPLITK")) : 0;
-    const long long tiles = ceil_div(a.M, bm) * ceil_div(a.N, bn);
-    const int nk = (a.K + bk - 1) / bk;
+    const long long tiles = ceil_div(M, bm) * ceil_div(N, bn);
+    const int nk = (K + bk - 1) / bk;
     if (force > 0) return force <= nk ? force : 1;
-    if (a.N % 4 != 0) return 1;
-    const double t_kernel = 2.0 * a.M * (double)a.K * a.N / 110e12;
+    if (N % 4 != 0) return 1;
+    const double t_kernel = 2.0 * M * (double)K * N / 110e12;
     int best = 1;
     double best_t = 1e30;
     for (int s = 1; s <= 8; s++) {
@@ -443,51 +684,88 @@ int choose_splits(const IgemmArgs &a, int bm, int bn, int bk, double slots = 512
         const double rounds = (double)tiles * s / slots;
         const double eff = rounds / (double)(long long)(rounds + 0.999999);
         double t = t_kernel / eff;
-        if (s > 1) t += (double)(s + 1) * a.M * a.N * 4.0 / 3e12 + 3e-6;
+        if (s > 1) t += (double)(s + 1) * M * N * 4.0 / 3e12 + 3e-6;
         if (t < best_t * 0.97) { best_t = t; best = s; }
     }
     return best;
 }
 
-// which tile configuration a launch uses: 0 = 128x128x32, 1 = 256x64x16 (N <= 64), 2 = 256x256x32 (wide N, many rows)
-int tile_config(const IgemmArgs &a) {
-    static const int no_big = getenv("EMADAPT_NO_BIG_TILES") ? 1 : 0;
-    if (a.N <= 64) return 1;
-    if (!no_big && a.N >= 1024 && a.M >= 8192) return 2;
-    return 0;
-}
+// How one convolution is launched.
+//   cfg 1: 256x64x16 tiles (N <= 64);  cfg 0: 128x128x32 tiles, wave-specialised (4 MFMA + 4 loader waves), split-K when
+//   the tile count is small;  cfg 2 (N >= 1024, many rows): 256x256x32 tiles for the rows that fill WHOLE rounds of the
+//   256 CUs, and the remaining rows (the partial last round: 160 of fc6's 1696 tiles) as a second launch of 128x128
+//   tiles with split-K, so that no CU idles while a handful of big tiles finish.
+struct LaunchPlan {
+    int cfg;         // configuration of the main launch
+    int main_rows;   // rows [0, main_rows) go to the main launch
+    int main_splits;
+    int tail_splits; // rows [main_rows, M) go to a cfg-0 launch with this split factor (0 = no tail)
+};
 
-int plan_splits(const IgemmArgs &a) {
-    switch (tile_config(a)) {
-        case 1: return choose_splits(a, 256, 64, 16);
-        case 2: return 1;  // thousands of 256x256 tiles: whole rounds anyway, slabs would be output-sized
-        default: return choose_splits(a, 128, 128, 32);
+LaunchPlan plan_launches(const IgemmArgs &a) {
+    static const int no_big = getenv("EMADAPT_NO_BIG_TILES") ? 1 : 0;
+    static const int no_tail = getenv("EMADAPT_NO_TAIL") ? 1 : 0;
+    LaunchPlan p;
+    p.main_rows = a.M;
+    p.tail_splits = 0;
+    p.main_splits = 1;
+    if (a.N <= 64) {
+        p.cfg = 1;
+        p.main_splits = choose_splits(a.M, a.N, a.K, 256, 64, 16);
+    } else if (!no_big && a.N >= 1024 && a.M >= 8192) {
+        p.cfg = 2;
+        const long long tn = ceil_div(a.N, 256), tm = ceil_div(a.M, 256);
+        const long long full = (tm * tn) / 256;  // whole rounds of one 256x256 workgroup per CU
+        if (!no_tail && full >= 1 && (tm * tn) % 256 != 0) {
+            const long long tm_full = full * 256 / tn;
+            if (tm_full >= 1 && tm_full < tm) {
+                p.main_rows = (int)(tm_full * 256);
+                p.tail_splits = choose_splits(a.M - p.main_rows, a.N, a.K, 128, 128, 32);
+            }
+        }
+    } else {
+        p.cfg = 0;
+        p.main_splits = choose_splits(a.M, a.N, a.K, 128, 128, 32);
     }
+    return p;
 }
 
 size_t igemm_workspace_bytes(const IgemmArgs &a) {
-    const int s = plan_splits(a);
-    return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
+    const LaunchPlan p = plan_launches(a);
+    size_t b = p.main_splits > 1 ? (size_t)p.main_splits * p.main_rows * a.N * sizeof(float) : 0;
+    if (p.tail_splits > 1) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
+    return b;
 }
 
 template <bool BT>
 int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    {
-        int s = plan_splits(a);
-        if (s > 1 && (!workspace || workspace_bytes < (size_t)s * a.M * a.N * sizeof(float))) s = 1;  // no room: no split
-        a.splits = s;
-        a.slab = s > 1 ? static_cast<float *>(workspace) : nullptr;
-    }
     static const int ablate = getenv("EMADAPT_ABLATE") ? atoi(getenv("EMADAPT_ABLATE")) : 0;
     static const int no_tap_inner = getenv("EMADAPT_NO_TAP_INNER") ? 1 : 0;
+    static const int no_ws = getenv("EMADAPT_NO_WS") ? 1 : 0;
     a.ablate = ablate;
-    const int bk = tile_config(a) == 1 ? 16 : 32;
-    a.tap_inner = (!no_tap_inner && a.ntaps > 1 && a.Cx % bk == 0) ? 1 : 0;
-    switch (tile_config(a)) {
-        case 1: return launch_igemm<256, 64, 16, 64, BT>(a, stream);
-        case 2: return launch_igemm<256, 256, 32, 128, BT>(a, stream);
-        default: return launch_igemm<128, 128, 32, 64, BT>(a, stream);
+    LaunchPlan p = plan_launches(a);
+    if (!workspace || workspace_bytes < igemm_workspace_bytes(a)) {  // no room for slabs: unsplit, same result
+        p.main_splits = 1;
+        if (p.tail_splits > 1) p.tail_splits = 1;
     }
+    a.tap_inner = (!no_tap_inner && a.ntaps > 1 && a.Cx % (p.cfg == 1 ? 16 : 32) == 0) ? 1 : 0;
+    a.m_begin = 0;
+    a.m_end = p.main_rows;
+    a.splits = p.main_splits;
+    a.slab = p.main_splits > 1 ? static_cast<float *>(workspace) : nullptr;
+    int rc;
+    switch (p.cfg) {
+        case 1: rc = launch_igemm<256, 64, 16, 64, BT>(a, stream); break;
+        case 2: rc = launch_igemm<256, 256, 32, 128, BT>(a, stream); break;
+        default: rc = no_ws ? launch_igemm<128, 128, 32, 64, BT>(a, stream) : launch_igemm_ws<BT>(a, stream); break;
+    }
+    if (rc || p.tail_splits == 0) return rc;
+    a.tap_inner = (!no_tap_inner && a.ntaps > 1 && a.Cx % 32 == 0) ? 1 : 0;
+    a.m_begin = p.main_rows;
+    a.m_end = a.M;
+    a.splits = p.tail_splits;
+    a.slab = p.tail_splits > 1 ? static_cast<float *>(workspace) : nullptr;  // the cfg-2 main launch uses no slab
+    return no_ws ? launch_igemm<128, 128, 32, 64, BT>(a, stream) : launch_igemm_ws<BT>(a, stream);
 }
 
 int check_desc(const emadapt_conv_desc *d) {
