@@ -13,6 +13,8 @@
 // Layers whose [K x N] filter has few 128x128 tiles (conv1_x .. conv5_x) would leave most of the 256
 // CUs idle, so the pixel range is split across workgroups ("split-M"); each split writes an fp32
 // partial slab and a second kernel adds the slabs in a fixed order -- deterministic, no atomics.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -215,6 +217,141 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgradArgs a) {
         }
 }
 
+// Wave-specialised variant (see igemm_ws_kernel in conv_igemm.hip): 512 threads = 4 consumer wavefronts (LDS fragment
+// reads + MFMA only) + 4 producer wavefronts (gather of x, rows of dy, LDS stores); one barrier per reduction step.
+template <int BN>
+__global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
+    constexpr int BKO = 128;
+    constexpr int WK = BKO / 2, WN = BN / 2;
+    constexpr int TK = WK / 32, TN = WN / 32;
+    constexpr int XQ = BKO / 4, X_RSTEP = 256 / XQ, X_N = BMR / X_RSTEP;
+    constexpr int YQ = BN / 4, Y_RSTEP = 256 / YQ, Y_N = BMR / Y_RSTEP;
+    constexpr int NKK = BMR / 2;
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Xs = lds;                    // [2][BMR][BKO]
+    float *Ys = lds + 2 * BMR * BKO;    // [2][BMR][BN]
+
+    int bid = blockIdx.x;
+    const int split = bid % a.splits;
+    bid /= a.splits;
+    const int tile_n = bid % a.tiles_n;
+    const int tile_k = bid / a.tiles_n;
+    const int k0 = tile_k * BKO, n0 = tile_n * BN;
+    const int m_begin = split * a.rows_per_split;
+    int m_end = m_begin + a.rows_per_split;
+    if (m_end > a.M) m_end = a.M;
+    const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BMR - 1) / BMR : 0;
+
+    if (threadIdx.x >= 256) {
+        // ================================ PRODUCER wavefronts ================================
+        const int tid = threadIdx.x - 256;
+        const int x_kq = tid % XQ, x_r0 = tid / XQ;
+        const int k = k0 + x_kq * 4;
+        const bool kvalid = k < a.K;
+        const int tap = kvalid ? k / a.Cin : 0;
+        const int c = kvalid ? k % a.Cin : 0;
+        const int dh = (tap / a.KW) * a.dil - a.pad_h;
+        const int dw = (tap % a.KW) * a.dil - a.pad_w;
+        const int x_off = (dh * a.W + dw) * a.Cin + c;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dy), 0, (int)a.y_bytes, 0x00020000);
+        constexpr unsigned kOOB = 0x80000000u;
+        const int y_nq = tid % YQ, y_r0 = tid / YQ;
+        const int y_n = n0 + y_nq * 4;
+        const bool nvalid = y_n < a.N;
+        float4 rx[X_N], ry[Y_N];
+        auto load_tile = [&](int mb) {
+#pragma unroll
+            for (int j = 0; j < X_N; j++) {
+                const int m = mb + x_r0 + j * X_RSTEP;
+                const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
+                const int ow = m - (int)t2 * a.W;
+                const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
+                const int ih = oh + dh, iw = ow + dw;
+                const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                rx[j] = buf_ld4(xr, ((unsigned)(m * a.Cin + x_off) * 4u) | (ok ? 0u : kOOB));
+            }
+#pragma unroll
+            for (int j = 0; j < Y_N; j++) {
+                const int m = mb + y_r0 + j * Y_RSTEP;
+                ry[j] = buf_ld4(yr, ((unsigned)(m * a.N + y_n) * 4u) | ((nvalid && m < m_end) ? 0u : kOOB));
+            }
+        };
+        auto store_tile = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < X_N; j++)
+                *reinterpret_cast<float4 *>(&Xs[buf * BMR * BKO + (x_r0 + j * X_RSTEP) * BKO + x_kq * 4]) = rx[j];
+#pragma unroll
+            for (int j = 0; j < Y_N; j++)
+                *reinterpret_cast<float4 *>(&Ys[buf * BMR * BN + (y_r0 + j * Y_RSTEP) * BN + y_nq * 4]) = ry[j];
+        };
+        load_tile(m_begin);
+        store_tile(0);
+        load_tile(m_begin + BMR);  // rows >= m_end are zero-filled by the range check
+        __syncthreads();
+        for (int st = 0; st < nsteps; st++) {
+            store_tile((st + 1) & 1);
+            load_tile(m_begin + (st + 2) * BMR);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================================ CONSUMER wavefronts ================================
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[TK][TN];
+#pragma unroll
+    for (int i = 0; i < TK; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    __syncthreads();
+    for (int st = 0; st < nsteps; st++) {
+        const int cur = st & 1;
+        const float *xs = Xs + cur * BMR * BKO + wk * WK + l31;
+        const float *ys = Ys + cur * BMR * BN + wn * WN + l31;
+        float av[2][TK], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TK; i++) av[0][i] = xs[lh * BKO + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = ys[lh * BN + j * 32];
+#pragma unroll
+        for (int kk = 0; kk < NKK; kk++) {
+            if (kk + 1 < NKK) {
+#pragma unroll
+                for (int i = 0; i < TK; i++) av[(kk + 1) & 1][i] = xs[((kk + 1) * 2 + lh) * BKO + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = ys[((kk + 1) * 2 + lh) * BN + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TK; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    float *out = a.out + (long long)split * a.K * a.N;
+#pragma unroll
+    for (int i = 0; i < TK; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            const bool col_ok = col < a.N;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = k0 + wk * WK + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (col_ok && row < a.K) out[(long long)row * a.N + col] = acc[i][j][r];
+            }
+        }
+}
+
 struct Plan {
     int bn, tiles_k, tiles_n, splits, rows_per_split;
 };
@@ -275,7 +412,18 @@ int launch_wgrad(const WgradArgs &a, hipStream_t stream) {
     }
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((wgrad_kernel<128, BN>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    static const int no_ws = getenv("EMADAPT_NO_WS") ? 1 : 0;
+    if (no_ws) {
+        hipLaunchKernelGGL((wgrad_kernel<128, BN>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
+    } else {
+        static bool ws_attr_set = false;
+        if (!ws_attr_set) {
+            EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_ws_kernel<BN>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ws_attr_set = true;
+        }
+        hipLaunchKernelGGL((wgrad_ws_kernel<BN>), dim3((unsigned)nblk), dim3(512), lds, stream, a);
+    }
     return launch_status();
 }
 
