@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/profiles_<round>/ (made by scripts/make_profiles.sh on the GPU box) into the small text/CSV
+summaries committed under profiles/.   usage: scripts/summarize_profiles.py r01"""
+import collections
+import csv
+import glob
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = "gpurun_out/profiles_%s" % R
+DST = "profiles"
+os.makedirs(DST, exist_ok=True)
+
+
+def short(name):
+    m = re.search(r"((?:igemm|wgrad)(?:_ws)?_kernel<[^>]*>|\w+_kernel\w*)", name)
+    return m.group(1) if m else name[:50]
+
+
+shutil.copy(glob.glob(SRC + "/trace/runc/*_kernel_stats.csv")[0], "%s/%s_bench_kernel_stats.csv" % (DST, R))
+shutil.copy(SRC + "/bench_line.json", "%s/%s_bench_line.json" % (DST, R))
+with open("%s/%s_bench_per_layer.txt" % (DST, R), "w") as f:
+    f.write(subprocess.check_output([sys.executable, "scripts/trace_layers.py", glob.glob(SRC + "/trace/runc/*_kernel_trace.csv")[0]]).decode())
+if os.path.exists(SRC + "/estep_bench.txt"):
+    shutil.copy(SRC + "/estep_bench.txt", "%s/%s_estep_bench.txt" % (DST, R))
+
+
+def load(path):
+    by = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        key = int(r["Dispatch_Id"])
+        d = by.setdefault(key, {"name": short(r["Kernel_Name"]), "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+        d[r["Counter_Name"]] = float(r["Counter_Value"])
+    return list(by.values())
+
+
+out = ["# rocprofv3 --pmc passes over `bench.py --steps 1 --warmup 1` (kernel-trace + counters only; one run per counter set).",
+       "# Aggregated over the LAST step's launches of each conv kernel. FETCH_SIZE/WRITE_SIZE are in KiB as reported;",
+       "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide coalesced reads by 2x -> hbm_read = 2*FETCH_SIZE*1024.", ""]
+agg = collections.OrderedDict()
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    rows = load(glob.glob("%s/%s/runc/*_counter_collection.csv" % (SRC, sub))[0])
+    conv = [r for r in rows if re.search(r"igemm|wgrad", r["name"])]
+    conv = conv[len(conv) // 2:]  # second (timed) step
+    for r in conv:
+        a = agg.setdefault(r["name"], collections.defaultdict(float))
+        a["launches_" + sub] += 1
+        a["ns_" + sub] += r["ns"]
+        for k, v in r.items():
+            if k not in ("name", "ns"):
+                a[k] += v
+for name, a in agg.items():
+    n = a["launches_pmc_sq"]
+    ms = a["ns_pmc_sq"] / 1e6
+    line = "%-44s launches/step %3d  time %7.3f ms" % (name, n, ms)
+    if a.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # busy cycles summed over the 1024 SIMDs; kernel cycles at the measured 2.4 GHz
+        line += "  mfma_pipe_busy %.1f%%" % (100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (a["ns_pmc_sq"] * 2.4))
+        wc = a["SQ_WAVE_CYCLES"]
+        line += "  wave: wait_any %.1f%% wait_inst %.1f%% active %.1f%%  lds_bank_conflict %d" % (
+            100 * a["SQ_WAIT_ANY"] / wc, 100 * a["SQ_WAIT_INST_ANY"] / wc, 100 * a["SQ_ACTIVE_INST_ANY"] / wc, a["SQ_LDS_BANK_CONFLICT"])
+    out.append(line)
+    if a.get("FETCH_SIZE") is not None:
+        rd = 2 * a["FETCH_SIZE"] * 1024
+        wr = a.get("WRITE_SIZE", 0.0) * 1024
+        hit = a["TCC_HIT_sum"] / max(a["TCC_HIT_sum"] + a["TCC_MISS_sum"], 1)
+        out.append("    HBM traffic/step: read %.2f GB (2 x FETCH_SIZE), write %.2f GB; per launch %.3f GB; L2 hit rate %.1f%%" % (
+            rd / 1e9, wr / 1e9, (rd + wr) / 1e9 / max(n, 1), 100 * hit))
+open("%s/%s_pmc_conv_kernels.txt" % (DST, R), "w").write("\n".join(out) + "\n")
+print("\n".join(out))

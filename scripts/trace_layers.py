@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Per-layer view of a rocprofv3 --kernel-trace CSV of bench.py: maps the conv kernels of the LAST step to
-DeepLab layers (launch order is fixed: forward conv1_1..fc8, backward fc8..conv1_1 as wgrad then dgrad) and
-prints duration, algorithmic TFLOP/s and fraction of the 157.3 TFLOP/s fp32-matrix peak per launch.
+"""Per-layer view of a rocprofv3 --kernel-trace CSV of bench.py: maps the conv kernels of the LAST step to DeepLab
+layers (launch order is fixed: forward conv1_1..fc8, backward fc8..conv1_1 as wgrad then dgrad; a 256x256 main
+launch is followed by its 128x128 tail launch for the rows of the partial last round) and prints duration,
+algorithmic TFLOP/s and the fraction of the 157.3 TFLOP/s fp32-matrix peak.
 
 usage: scripts/trace_layers.py <kernel_trace.csv> [batch] [size] [classes] [preset]
 """
 import csv
+import re
 import sys
 
 PEAK = 157.3e12
@@ -29,6 +31,11 @@ def layers(size=321, C=21, preset="ref", width=64):
     return out
 
 
+def short(name):
+    m = re.search(r"(igemm_ws_kernel<\w+>|wgrad_ws_kernel<\d+>|igemm_kernel<[^>]*>|wgrad_kernel<[^>]*>)", name)
+    return m.group(1) if m else name[:40]
+
+
 def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
@@ -36,25 +43,33 @@ def main():
     C = int(sys.argv[4]) if len(sys.argv) > 4 else 21
     preset = sys.argv[5] if len(sys.argv) > 5 else "ref"
     L = layers(size, C, preset)
-    rows = [r for r in csv.DictReader(open(path)) if "igemm_kernel" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if re.search(r"igemm(_ws)?_kernel|wgrad(_ws)?_kernel", r["Kernel_Name"])]
+    # group "256x256 main + igemm_ws tail" pairs into one logical launch
+    groups = []
+    i = 0
+    while i < len(rows):
+        g = [rows[i]]
+        if "igemm_kernel<256, 256" in rows[i]["Kernel_Name"] and i + 1 < len(rows) and "igemm_ws_kernel" in rows[i + 1]["Kernel_Name"]:
+            g.append(rows[i + 1])
+            i += 1
+        groups.append(g)
+        i += 1
     per_step = len(L) * 3 - 1  # conv1_1 has no dgrad
-    last = rows[-per_step:]
-    fwd = last[:len(L)]
-    bwd = last[len(L):]
+    last = groups[-per_step:]
+    fwd, bwd = last[:len(L)], last[len(L):]
     tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
 
-    def show(kind, name, r, flops):
-        ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    def show(kind, name, g, flops):
+        ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in g)
         tf = flops / ns * 1e9
         tot[kind][0] += ns
         tot[kind][1] += flops
-        kn = r["Kernel_Name"]
-        short = kn[kn.index("::") + 2:kn.index("(")].replace("(anonymous namespace)::", "")
-        print("%-6s %-8s %9.3f ms  %6.1f TF  %5.1f%%  grid %7d  %s" % (kind, name, ns / 1e6, tf / 1e12, 100 * tf / PEAK,
-                                                                     int(r["Grid_Size_X"]) // 256, short))
+        kn = " + ".join(short(r["Kernel_Name"]) for r in g)
+        wg = "+".join(str(int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])) for r in g)
+        print("%-6s %-8s %9.3f ms  %6.1f TF  %5.1f%%  wgs %-10s %s" % (kind, name, ns / 1e6, tf / 1e12, 100 * tf / PEAK, wg, kn))
 
-    for (name, h, k, cin, cout), r in zip(L, fwd):
-        show("fwd", name, r, 2.0 * B * h * h * k * k * cin * cout)
+    for (name, h, k, cin, cout), g in zip(L, fwd):
+        show("fwd", name, g, 2.0 * B * h * h * k * k * cin * cout)
     i = 0
     for (name, h, k, cin, cout) in reversed(L):
         fl = 2.0 * B * h * h * k * k * cin * cout
