@@ -32,6 +32,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MATRIX_TFLOPS = 2516.6  # dense bf16: v_mfma_f32_32x32x16_bf16, 32768 FLOP per 32 clk per SIMD x 1024 SIMDs x 2.4 GHz
 
 
 def parse():
@@ -45,6 +46,9 @@ def parse():
     ap.add_argument("--preset", default="ref", choices=["ref", "largefov"])
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--keep-prob", type=float, default=0.5)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="arithmetic of the conv inner products: fp32 (BASELINE configs[1], the headline) or bf16 "
+                         "operands with fp32 accumulation (configs[2]/[3]); everything else stays fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -146,7 +150,8 @@ def main():
     import random
 
     cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
-           "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device}
+           "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
+           "compute_dtype": args.dtype}
     data = SyntheticData(dict(cfg, seed=rank, unique_batches=2))
     adapt = ADAPT(dict(cfg, data=data))
     adapt.build()
@@ -209,13 +214,15 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "fp32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "DeepLab VGG-16 (%s preset: fc6 %s) %dx%d, %d classes, batch %d per GPU, fp32, "
+                "workload": "DeepLab VGG-16 (%s preset: fc6 %s) %dx%d, %d classes, batch %d per GPU, %s, "
                             "random-init N(0,0.01) weights, synthetic pixel labels, keep_prob %.2f, accum_num 1" % (
                                 args.preset, "4x4 rate 4 -> 4096" if args.preset == "ref" else "3x3 rate 12 -> 1024",
-                                args.size, args.size, args.classes, args.batch, args.keep_prob),
+                                args.size, args.size, args.classes, args.batch,
+                                "fp32" if args.dtype == "fp32" else "bf16 conv operands / fp32 accumulate, fp32 master "
+                                "weights, activations, gradients and optimizer", args.keep_prob),
                 "global_batch": global_batch,
                 "parallelism": "dp%d" % world,
                 "gflop_per_image_fwd_bwd": round(fb_flops / 1e9, 1),
@@ -230,13 +237,14 @@ def main():
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
             all_flops = sum(v["flops"] for v in conv.values())
             all_ms = sum(v["ms"] for v in conv.values())
+            peak = PEAK_FP32_MATRIX_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": dom,
                 "achieved": round(tf, 2),
-                "peak": PEAK_FP32_MATRIX_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "frac": round(tf / peak, 4),
                 "traffic": None,
                 "launches": d["launches"],
                 "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),

@@ -1,0 +1,652 @@
+// bf16-compute variants of the three convolution GEMMs (configurations C3/C4: "bf16 compute,
+// fp32 master weights and accumulators").  Same call surface, layouts, epilogues and split-K/split-M machinery as
+// the fp32 kernels (conv_igemm.hip, conv_wgrad.hip); what changes is the arithmetic of the inner product:
+//
+//   operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32), products are exact, sums are fp32
+//   (v_mfma_f32_32x32x16_bf16: 16 k per instruction at half the cycles of the fp32 32x32x2 form -> 16x the rate).
+//
+// Activations and gradients stay fp32 in HBM; the PRODUCER wavefronts convert them on their way into LDS.  The
+// filters are converted once per optimizer step into two bf16 images whose reduction axis is contiguous, so that
+// the forward pass and the data gradient read them with plain 16-byte loads and store them untransposed:
+//     fwd image   [tap][co][ci8]   (ci padded to a multiple of 8, zero filled)   k = (tap, ci), n = co
+//     dgrad image [tap][ci][co8]   (the HWIO filter itself, co padded to 8)      k = (tap, co), n = ci
+//
+// LDS tiles are [row][k] bf16 with a 144-byte row pitch: the 16-lane groups of ds_read_b128 then touch 16 different
+// 16-byte slots of the 256-byte bank row (9 r mod 16 is a bijection on each group's rows) -- conflict-free without a
+// swizzle -- and the producers' ds_write_b64 / ds_write_b128 cover contiguous 128-byte runs.
+//
+// The filter gradient reduces over pixels, the axis along which neither operand is contiguous; its LDS tiles are
+// [pixel][k] and [pixel][n] exactly as loaded, and the MFMA fragments are gathered with the gfx950 transposing read
+// ds_read_b64_tr_b16 (4 pixels x 16 columns per 16-lane group, delivered column-major).  Row pitch 320 bytes: the four
+// pixel rows of one read sit 16 banks apart (80 dwords mod 64), so the 32-lane halves are conflict-free.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "igemm_common.h"
+
+namespace emadapt {
+int launch_slab_sum(const float *slab, int nslab, long long n, float *out, hipStream_t stream);
+}
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+inline int round_up8(int v) { return (v + 7) & ~7; }
+
+__device__ __forceinline__ uint2 cvt4(float4 v) {
+    bf16x4 c;
+    c[0] = (__bf16)v.x; c[1] = (__bf16)v.y; c[2] = (__bf16)v.z; c[3] = (__bf16)v.w;
+    return *reinterpret_cast<uint2 *>(&c);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Filter conversion: fp32 HWIO -> the two bf16 images.  One 32x32 (ci, co) tile per workgroup, transposed through LDS.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) weights_to_bf16_kernel(const float *__restrict__ w, __bf16 *__restrict__ wf,
+                                                              __bf16 *__restrict__ wd, int Cin, int Cout, int Cip,
+                                                              int Cop, int tiles_ci, int tiles_co) {
+    __shared__ float tile[32][33];
+    int bid = blockIdx.x;
+    const int tco = bid % tiles_co;
+    bid /= tiles_co;
+    const int tci = bid % tiles_ci;
+    const int tap = bid / tiles_ci;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int ci0 = tci * 32, co0 = tco * 32;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int ci = ci0 + ty + 8 * r, co = co0 + tx;
+        const float v = (ci < Cin && co < Cout) ? w[((long long)tap * Cin + ci) * Cout + co] : 0.f;
+        tile[ty + 8 * r][tx] = v;
+        if (wd && ci < Cin && co < Cop) wd[((long long)tap * Cin + ci) * Cop + co] = (__bf16)v;
+    }
+    __syncthreads();
+    if (!wf) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int co = co0 + ty + 8 * r, ci = ci0 + tx;
+        if (co < Cout && ci < Cip) wf[((long long)tap * Cout + co) * Cip + ci] = (__bf16)tile[tx][ty + 8 * r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward / data-gradient: out[m][n] = sum_k A[m][k] Bw[n][k], 128x128x64 tiles, 4 consumer + 4 producer wavefronts.
+// IgemmArgs is used as in the fp32 kernel with: w = bf16 image [tap][N][Cxp], Cxp = round_up(Cx, 8) = the k pitch of
+// a tap (K = ntaps * Cxp; channels Cx..Cxp-1 are zero on both sides), magic_cx = magic(Cxp).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kPitchG = 144;  // bytes per LDS row of 64 bf16 (+8 pad)
+
+__global__ void __launch_bounds__(512, 4) igemm_bf16_kernel(IgemmArgs a, int Cxp) {
+    constexpr int BM = 128, BN = 128, BK = 64, WM = 64, WN = 64;
+    constexpr int TM = 2, TN = 2;
+    constexpr int KQ = BK / 4;             // 16 fp32 quads per A row
+    constexpr int A_RSTEP = 256 / KQ;      // 16
+    constexpr int A_N = BM / A_RSTEP;      // 8
+    constexpr int KC = BK / 8;             // 8 bf16 chunks (16 B) per B row
+    constexpr int B_RSTEP = 256 / KC;      // 32
+    constexpr int B_N = BN / B_RSTEP;      // 4
+    constexpr int TILE = BM * kPitchG;     // bytes per operand tile
+
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char *As = ldsb;               // [2][BM][kPitchG]
+    char *Bs = ldsb + 2 * TILE;    // [2][BN][kPitchG]
+
+    int tile_m, tile_n, split;
+    {
+        const int ntile = a.tiles_m * a.tiles_n;
+        const int nblk = ntile * a.splits;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        split = t / ntile;
+        t -= split * ntile;
+        constexpr int GM = 8;
+        const int per_group = GM * a.tiles_n;
+        const int g = t / per_group;
+        const int first_m = g * GM;
+        const int gsz = (a.tiles_m - first_m < GM) ? (a.tiles_m - first_m) : GM;
+        const int in_g = t - g * per_group;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
+    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
+    const int nk_all = (a.K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * split / a.splits);
+    const int nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
+
+    if (threadIdx.x >= 256) {
+        // ================================ PRODUCER wavefronts ================================
+        const int tid = threadIdx.x - 256;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
+        constexpr unsigned kOOB = 0x80000000u;
+        const int a_kq = tid % KQ, a_r0 = tid / KQ;
+        int a_base[A_N], a_oh[A_N], a_ow[A_N];
+#pragma unroll
+        for (int j = 0; j < A_N; j++) {
+            const int m = m0 + a_r0 + j * A_RSTEP;
+            if (m < a.m_end) {
+                const int t2 = m / a.W;
+                a_base[j] = m * a.Cx;
+                a_oh[j] = t2 % a.H;
+                a_ow[j] = m - t2 * a.W;
+            } else {
+                a_base[j] = 0;
+                a_oh[j] = -(1 << 20);
+                a_ow[j] = -(1 << 20);
+            }
+        }
+        const int b_kc = tid % KC, b_r0 = tid / KC;
+        float4 ra[A_N];
+        u32x4 rb[B_N];
+
+        auto load_tile = [&](int kt) {
+            unsigned tap, tapb;
+            int c, cb;
+            if (a.tap_inner) {  // Cxp % BK == 0: the whole K step lies in one tap
+                const unsigned chunk = __umulhi((unsigned)kt, a.magic_nt);
+                tap = (unsigned)kt - chunk * (unsigned)a.ntaps;
+                if ((int)chunk * BK >= Cxp) tap = (unsigned)a.ntaps;
+                tapb = tap;
+                c = (int)chunk * BK + a_kq * 4;
+                cb = (int)chunk * BK + b_kc * 8;
+            } else {
+                const unsigned k = (unsigned)(kt * BK + a_kq * 4);
+                tap = __umulhi(k, a.magic_cx);
+                c = (int)(k - tap * (unsigned)Cxp);
+                const unsigned kb = (unsigned)(kt * BK + b_kc * 8);
+                tapb = __umulhi(kb, a.magic_cx);
+                cb = (int)(kb - tapb * (unsigned)Cxp);
+            }
+            const unsigned kh = __umulhi(tap, a.magic_kw);
+            const int kw = (int)(tap - kh * (unsigned)a.KW);
+            const bool kvalid = (int)tap < a.ntaps && c < a.Cx;
+            const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
+            const int dw = a.sign * (kw * a.dil - a.pad_w);
+            const int toff = (dh * a.W + dw) * a.Cx + c;
+#pragma unroll
+            for (int j = 0; j < A_N; j++) {
+                const int ih = a_oh[j] + dh, iw = a_ow[j] + dw;
+                const bool ok = kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                ra[j] = buf_ld4(xr, ((unsigned)(a_base[j] + toff) * 4u) | (ok ? 0u : kOOB));
+            }
+            const bool bvalid = (int)tapb < a.ntaps;
+#pragma unroll
+            for (int j = 0; j < B_N; j++) {
+                const int n = n0 + b_r0 + j * B_RSTEP;
+                const unsigned off = (unsigned)(((int)tapb * a.N + n) * Cxp + cb) * 2u;
+                rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(off | ((bvalid && n < a.N) ? 0u : kOOB)), 0, 0);
+            }
+        };
+        auto store_tile = [&](int buf) {
+            char *as = As + buf * TILE;
+            char *bs = Bs + buf * TILE;
+#pragma unroll
+            for (int j = 0; j < A_N; j++)
+                *reinterpret_cast<uint2 *>(as + (a_r0 + j * A_RSTEP) * kPitchG + a_kq * 8) = cvt4(ra[j]);
+#pragma unroll
+            for (int j = 0; j < B_N; j++)
+                *reinterpret_cast<u32x4 *>(bs + (b_r0 + j * B_RSTEP) * kPitchG + b_kc * 16) = rb[j];
+        };
+        load_tile(kt0);
+        store_tile(0);
+        load_tile(kt0 + 1);  // K steps past the end are zero-filled by the range check
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt++) {
+            store_tile((kt + 1) & 1);
+            load_tile(kt0 + kt + 2);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================================ CONSUMER wavefronts ================================
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt & 1;
+        const char *as = As + cur * TILE + (wm * WM + l31) * kPitchG + lh * 16;
+        const char *bs = Bs + cur * TILE + (wn * WN + l31) * kPitchG + lh * 16;
+        bf16x8 av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[0][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * kPitchG);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ks++) {
+            if (ks + 1 < BK / 16) {
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+                    av[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG + (ks + 1) * 32);
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    bv[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * kPitchG + (ks + 1) * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    float *slab = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            const bool col_ok = col < a.N;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const long long o = (long long)row * a.N + col;
+                const float v = acc[i][j][r];
+                if (col_ok && row < a.m_end) {
+                    if (slab) slab[o] = v;
+                    else a.y[o] = epilogue(a, v, col, o);
+                }
+            }
+        }
+    }
+}
+
+void fill_geometry_bf16(IgemmArgs &a, int &Cxp, const emadapt_conv_desc *d, bool dgrad) {
+    fill_geometry(a, d, dgrad);
+    Cxp = round_up8(a.Cx);
+    a.K = a.ntaps * Cxp;
+    a.w_bytes = (unsigned)((long long)a.ntaps * a.N * Cxp * 2);
+    a.magic_cx = magic_u32(Cxp);
+}
+
+int bf16_splits(const IgemmArgs &a) { return choose_splits(a.M, a.N, a.K, 128, 128, 64, 512.0, 450e12); }
+
+size_t igemm_bf16_workspace_bytes(const IgemmArgs &a) {
+    const int s = bf16_splits(a);
+    return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
+}
+
+int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    constexpr size_t lds = 4 * 128 * kPitchG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_bf16_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    int splits = bf16_splits(a);
+    if (splits > 1 && (!workspace || workspace_bytes < igemm_bf16_workspace_bytes(a))) splits = 1;
+    a.ablate = 0;
+    a.tap_inner = (a.ntaps > 1 && Cxp % 64 == 0) ? 1 : 0;
+    a.m_begin = 0;
+    a.m_end = a.M;
+    a.splits = splits;
+    a.slab = splits > 1 ? static_cast<float *>(workspace) : nullptr;
+    a.tiles_m = (int)ceil_div(a.M, 128);
+    a.tiles_n = (int)ceil_div(a.N, 128);
+    const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
+    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(igemm_bf16_kernel, dim3((unsigned)nblk), dim3(512), lds, stream, a, Cxp);
+    int rc = launch_status();
+    if (rc || a.splits <= 1) return rc;
+    long long g = ((long long)a.M * a.N / 4 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Filter gradient: dw[k][n] = sum_m A[m][k] dy[m][n]; 128 x BN filter tiles, 64 pixels per reduction step, split-M.
+// ------------------------------------------------------------------------------------------------------------------
+struct WgradBf16Args {
+    const float *x;   // [B,H,W,Cin]
+    const float *dy;  // [M][N]
+    float *out;       // dw or slab base: [splits][K][N]
+    int H, W, Cin, N, KW, dil, pad_h, pad_w;
+    int M, K, ntaps;
+    int tiles_k, tiles_n, splits;
+    int rows_per_split;  // multiple of kBMR
+    unsigned x_bytes, y_bytes;
+    unsigned magic_w, magic_h;
+};
+
+constexpr int kBMR = 64;      // pixels per reduction step (4 MFMA k-steps of 16)
+constexpr int kPitchW = 320;  // bytes per LDS pixel row of 128 bf16 (+32 pad)
+
+__device__ __forceinline__ bf16x8 tr_frag(const char *p0, const char *p1) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p0));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p1));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int BN>
+__global__ void __launch_bounds__(512, 4) wgrad_bf16_kernel(WgradBf16Args a) {
+    constexpr int BKO = 128;
+    constexpr int WK = BKO / 2, WN = BN / 2;
+    constexpr int TK = WK / 32, TN = WN / 32;
+    constexpr int XQ = BKO / 4, X_RSTEP = 256 / XQ, X_N = kBMR / X_RSTEP;  // 32, 8, 8
+    constexpr int YQ = BN / 4, Y_RSTEP = 256 / YQ, Y_N = kBMR / Y_RSTEP;   // BN 128: 32, 8, 8; BN 64: 16, 16, 4
+    constexpr int TILE = kBMR * kPitchW;
+
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+    char *Xs = ldsb;              // [2][kBMR][kPitchW]
+    char *Ys = ldsb + 2 * TILE;   // [2][kBMR][kPitchW]
+
+    int bid = blockIdx.x;
+    const int split = bid % a.splits;
+    bid /= a.splits;
+    const int tile_n = bid % a.tiles_n;
+    const int tile_k = bid / a.tiles_n;
+    const int k0 = tile_k * BKO, n0 = tile_n * BN;
+    const int m_begin = split * a.rows_per_split;
+    int m_end = m_begin + a.rows_per_split;
+    if (m_end > a.M) m_end = a.M;
+    const int nsteps = (m_end > m_begin) ? (m_end - m_begin + kBMR - 1) / kBMR : 0;
+
+    if (threadIdx.x >= 256) {
+        // ================================ PRODUCER wavefronts ================================
+        const int tid = threadIdx.x - 256;
+        const int x_kq = tid % XQ, x_r0 = tid / XQ;
+        const int k = k0 + x_kq * 4;
+        const bool kvalid = k < a.K;
+        const int tap = kvalid ? k / a.Cin : 0;
+        const int c = kvalid ? k % a.Cin : 0;
+        const int dh = (tap / a.KW) * a.dil - a.pad_h;
+        const int dw = (tap % a.KW) * a.dil - a.pad_w;
+        const int x_off = (dh * a.W + dw) * a.Cin + c;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dy), 0, (int)a.y_bytes, 0x00020000);
+        constexpr unsigned kOOB = 0x80000000u;
+        const int y_nq = tid % YQ, y_r0 = tid / YQ;
+        const int y_n = n0 + y_nq * 4;
+        const bool nvalid = y_n < a.N;
+        float4 rx[X_N], ry[Y_N];
+        auto load_tile = [&](int mb) {
+#pragma unroll
+            for (int j = 0; j < X_N; j++) {
+                const int m = mb + x_r0 + j * X_RSTEP;
+                const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
+                const int ow = m - (int)t2 * a.W;
+                const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
+                const int ih = oh + dh, iw = ow + dw;
+                const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                rx[j] = buf_ld4(xr, ((unsigned)(m * a.Cin + x_off) * 4u) | (ok ? 0u : kOOB));
+            }
+#pragma unroll
+            for (int j = 0; j < Y_N; j++) {
+                const int m = mb + y_r0 + j * Y_RSTEP;
+                ry[j] = buf_ld4(yr, ((unsigned)(m * a.N + y_n) * 4u) | ((nvalid && m < m_end) ? 0u : kOOB));
+            }
+        };
+        auto store_tile = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < X_N; j++)
+                *reinterpret_cast<uint2 *>(Xs + buf * TILE + (x_r0 + j * X_RSTEP) * kPitchW + x_kq * 8) = cvt4(rx[j]);
+#pragma unroll
+            for (int j = 0; j < Y_N; j++)
+                *reinterpret_cast<uint2 *>(Ys + buf * TILE + (y_r0 + j * Y_RSTEP) * kPitchW + y_nq * 8) = cvt4(ry[j]);
+        };
+        load_tile(m_begin);
+        store_tile(0);
+        load_tile(m_begin + kBMR);  // rows >= m_end are zero-filled by the range check
+        __syncthreads();
+        for (int st = 0; st < nsteps; st++) {
+            store_tile((st + 1) & 1);
+            load_tile(m_begin + (st + 2) * kBMR);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================================ CONSUMER wavefronts ================================
+    // Transposing read: in the 16-lane group g = lane>>4, lane 4q+p supplies the address of pixel row q, columns
+    // 4p..4p+3 of the group's 16 columns, and receives column (lane&15) of the four rows.  For the 32x32x16 operand
+    // lane l holds column l&31 and pixels 8*(l>>5) + 0..7: group g covers columns 16*(g&1).. and pixel half g>>1.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int frag_off = ((grp >> 1) * 8 + q) * kPitchW + ((grp & 1) * 16 + p * 4) * 2;  // bytes; + 4 pixel rows for the upper half
+    f32x16 acc[TK][TN];
+#pragma unroll
+    for (int i = 0; i < TK; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    __syncthreads();
+    for (int st = 0; st < nsteps; st++) {
+        const int cur = st & 1;
+        const char *xs = Xs + cur * TILE + frag_off + (wk * WK) * 2;
+        const char *ys = Ys + cur * TILE + frag_off + (wn * WN) * 2;
+        bf16x8 av[2][TK], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TK; i++) av[0][i] = tr_frag(xs + i * 64, xs + i * 64 + 4 * kPitchW);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bv[0][j] = tr_frag(ys + j * 64, ys + j * 64 + 4 * kPitchW);
+#pragma unroll
+        for (int ms = 0; ms < kBMR / 16; ms++) {
+            if (ms + 1 < kBMR / 16) {
+                const int o = (ms + 1) * 16 * kPitchW;
+#pragma unroll
+                for (int i = 0; i < TK; i++) av[(ms + 1) & 1][i] = tr_frag(xs + o + i * 64, xs + o + i * 64 + 4 * kPitchW);
+#pragma unroll
+                for (int j = 0; j < TN; j++) bv[(ms + 1) & 1][j] = tr_frag(ys + o + j * 64, ys + o + j * 64 + 4 * kPitchW);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TK; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ms & 1][i], bv[ms & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    float *out = a.out + (long long)split * a.K * a.N;
+#pragma unroll
+    for (int i = 0; i < TK; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            const bool col_ok = col < a.N;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = k0 + wk * WK + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (col_ok && row < a.K) out[(long long)row * a.N + col] = acc[i][j][r];
+            }
+        }
+}
+
+struct PlanW {
+    int bn, tiles_k, tiles_n, splits, rows_per_split;
+};
+
+// Split-M plan as in conv_wgrad.hip, with the bf16 kernel's rate.
+PlanW make_plan_bf16(const emadapt_conv_desc *d) {
+    PlanW p;
+    const long long M = (long long)d->B * d->H * d->W;
+    const int K = d->KH * d->KW * d->Cin;
+    p.bn = d->Cout <= 64 ? 64 : 128;
+    p.tiles_k = (int)ceil_div(K, 128);
+    p.tiles_n = (int)ceil_div(d->Cout, p.bn);
+    const long long tiles = (long long)p.tiles_k * p.tiles_n;
+    const double t_kernel = 2.0 * (double)M * (p.tiles_k * 128.0) * (p.tiles_n * (double)p.bn) / 400e12;
+    const double kn_bytes = (double)K * d->Cout * 4.0;
+    long long best = 1;
+    double best_t = 1e30;
+    const long long max_s = ceil_div(M, 512) < 2048 ? ceil_div(M, 512) : 2048;
+    for (long long s = 1; s <= max_s; s++) {
+        const double rounds = (double)tiles * s / 512.0;
+        const double eff = rounds / (double)(long long)(rounds + 0.999999);
+        double t = t_kernel / eff + 2e-6 * (double)(long long)(rounds + 0.999999);
+        if (s > 1) t += (double)(s + 1) * kn_bytes / 3e12 + 3e-6;
+        if (t < best_t * 0.995) { best_t = t; best = s; }
+        if (rounds > 24.0) break;
+    }
+    long long rps = ceil_div(M, best);
+    rps = ceil_div(rps, kBMR) * kBMR;
+    p.rows_per_split = (int)rps;
+    p.splits = (int)ceil_div(M, rps);
+    return p;
+}
+
+int check_desc_wgrad(const emadapt_conv_desc *d) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    const long long M = (long long)d->B * d->H * d->W;
+    if (M * (d->W > d->H ? d->W : d->H) >= (1LL << 32)) return EMADAPT_ERR_UNSUPPORTED;  // magic division range
+    return EMADAPT_OK;
+}
+
+template <int BN>
+int launch_wgrad_bf16(const WgradBf16Args &a, hipStream_t stream) {
+    constexpr size_t lds = 4 * kBMR * kPitchW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<BN>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
+    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((wgrad_bf16_kernel<BN>), dim3((unsigned)nblk), dim3(512), lds, stream, a);
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t emadapt_weights_bf16_bytes(const emadapt_conv_desc *d, int which) {
+    if (check_desc(d) != EMADAPT_OK) return 0;
+    const size_t taps = (size_t)d->KH * d->KW;
+    return which == 0 ? taps * d->Cout * round_up8(d->Cin) * 2 : taps * d->Cin * round_up8(d->Cout) * 2;
+}
+
+int emadapt_weights_to_bf16(const emadapt_conv_desc *d, const float *w, void *w_fwd_bf16, void *w_dgrad_bf16,
+                            void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!w || (!w_fwd_bf16 && !w_dgrad_bf16)) return EMADAPT_ERR_INVALID;
+    if (!aligned16(w) || !aligned16(w_fwd_bf16) || !aligned16(w_dgrad_bf16)) return EMADAPT_ERR_INVALID;
+    const int Cip = round_up8(d->Cin), Cop = round_up8(d->Cout);
+    const int tiles_ci = (int)ceil_div(Cip, 32), tiles_co = (int)ceil_div(Cop, 32);
+    const long long nblk = (long long)d->KH * d->KW * tiles_ci * tiles_co;
+    hipLaunchKernelGGL(weights_to_bf16_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream_), w,
+                       static_cast<__bf16 *>(w_fwd_bf16), static_cast<__bf16 *>(w_dgrad_bf16), d->Cin, d->Cout, Cip,
+                       Cop, tiles_ci, tiles_co);
+    return launch_status();
+}
+
+size_t emadapt_conv_fwd_bf16_workspace_bytes(const emadapt_conv_desc *d) {
+    if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
+    IgemmArgs a;
+    int Cxp;
+    fill_geometry_bf16(a, Cxp, d, false);
+    return igemm_bf16_workspace_bytes(a);
+}
+
+size_t emadapt_conv_dgrad_bf16_workspace_bytes(const emadapt_conv_desc *d) {
+    if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
+    IgemmArgs a;
+    int Cxp;
+    fill_geometry_bf16(a, Cxp, d, true);
+    return igemm_bf16_workspace_bytes(a);
+}
+
+int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const float *x, const void *w_fwd_bf16, const float *bias,
+                          float *y, int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed,
+                          void *workspace, size_t workspace_bytes, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x || !w_fwd_bf16 || !y) return EMADAPT_ERR_INVALID;
+    if (epilogue < EMADAPT_EPI_NONE || epilogue > EMADAPT_EPI_BIAS_RELU) return EMADAPT_ERR_INVALID;
+    if (epilogue != EMADAPT_EPI_NONE && !bias) return EMADAPT_ERR_INVALID;
+    if (!(keep_prob > 0.f) || keep_prob > 1.f) return EMADAPT_ERR_INVALID;
+    if (keep_prob < 1.f && epilogue != EMADAPT_EPI_BIAS_RELU) return EMADAPT_ERR_INVALID;
+    if (!aligned16(x) || !aligned16(w_fwd_bf16) || !aligned16(y) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
+    if (d->B == 0) return EMADAPT_OK;
+    IgemmArgs a;
+    int Cxp;
+    fill_geometry_bf16(a, Cxp, d, false);
+    a.x = x; a.w = static_cast<const float *>(w_fwd_bf16); a.y = y; a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
+    a.epi = epilogue; a.scale = 1.f; a.keep = keep_prob; a.seed = drop_seed;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N, 0.0, stream);
+    return dispatch_igemm_bf16(a, Cxp, workspace, workspace_bytes, stream);
+}
+
+int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const float *dy, const void *w_dgrad_bf16, float *dx,
+                            const float *gate, float gate_scale, void *workspace, size_t workspace_bytes,
+                            void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dy || !w_dgrad_bf16 || !dx) return EMADAPT_ERR_INVALID;
+    if (!aligned16(dy) || !aligned16(w_dgrad_bf16) || !aligned16(dx) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
+    if (d->B == 0) return EMADAPT_OK;
+    IgemmArgs a;
+    int Cxp;
+    fill_geometry_bf16(a, Cxp, d, true);
+    a.x = dy; a.w = static_cast<const float *>(w_dgrad_bf16); a.y = dx; a.bias = nullptr; a.gate = gate; a.mask = nullptr;
+    a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; a.keep = 1.f; a.seed = 0;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N, 0.0, stream);
+    return dispatch_igemm_bf16(a, Cxp, workspace, workspace_bytes, stream);
+}
+
+size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d) {
+    if (check_desc_wgrad(d) != EMADAPT_OK || d->B == 0) return 0;
+    const PlanW p = make_plan_bf16(d);
+    if (p.splits <= 1) return 0;
+    return (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+}
+
+int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, void *workspace,
+                            size_t workspace_bytes, void *stream_) {
+    int rc = check_desc_wgrad(d);
+    if (rc) return rc;
+    if (!x || !dy || !dw) return EMADAPT_ERR_INVALID;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
+    hipStream_t stream = as_stream(stream_);
+    const long long KN = (long long)d->KH * d->KW * d->Cin * d->Cout;
+    if (d->B == 0) {
+        EMADAPT_HIP_TRY(hipMemsetAsync(dw, 0, KN * sizeof(float), stream));
+        return EMADAPT_OK;
+    }
+    const PlanW p = make_plan_bf16(d);
+    if (p.splits > 1 && (!workspace || workspace_bytes < emadapt_conv_wgrad_bf16_workspace_bytes(d)))
+        return EMADAPT_ERR_WORKSPACE;
+    WgradBf16Args a;
+    a.x = x; a.dy = dy; a.out = p.splits > 1 ? static_cast<float *>(workspace) : dw;
+    a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.N = d->Cout; a.KW = d->KW; a.dil = d->dil;
+    a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
+    a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cin;
+    a.tiles_k = p.tiles_k; a.tiles_n = p.tiles_n; a.splits = p.splits; a.rows_per_split = p.rows_per_split;
+    a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
+    a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
+    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    rc = (p.bn == 64) ? launch_wgrad_bf16<64>(a, stream) : launch_wgrad_bf16<128>(a, stream);
+    if (rc) return rc;
+    if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// Shared pieces of the implicit-GEMM convolution kernels (fp32: conv_igemm.hip, bf16: conv_bf16.hip):
+// launch arguments, bounds-checked loads, the fused epilogue, the split-K second stage and its cost model.
+#pragma once
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace emadapt {
+int conv_pad_before(int k, int dil);
+}
+
+namespace {
+
+using namespace emadapt;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Ablation switches (EMADAPT_ABLATE env var) exist only in diagnostic builds (-DEMADAPT_ABLATE_BUILD): in the
+// shipped kernel they would put scalar branches into every k-pair of the MFMA stream.
+#ifdef EMADAPT_ABLATE_BUILD
+#define ABL(bit) (a.ablate & (bit))
+#else
+#define ABL(bit) 0
+#endif
+
+struct IgemmArgs {
+    const float *x;     // activation to gather from: [B,H,W,Cx]
+    const float *w;     // filter, HWIO
+    float *y;           // [M][N]
+    const float *bias;  // [N] or null
+    const float *gate;  // [M][N] or null (dgrad: stored activation; out = gate>0 ? out*scale : 0)
+    const unsigned char *mask;  // [M][N] keep mask or null
+    int H, W, Cx, N, KW, dil, sign, pad_h, pad_w;
+    int M, K, ntaps;
+    int epi;            // EMADAPT_EPI_*
+    float scale;        // gate scale
+    float keep;         // dropout keep probability (1 = off)
+    unsigned long long seed;
+    int tiles_m, tiles_n;
+    unsigned x_bytes, w_bytes;  // extents for the bounds-checked buffer loads (< 2 GiB each)
+    unsigned magic_cx, magic_kw;  // ceil(2^32/Cx), ceil(2^32/KW): k / Cx and tap / KW by one v_mul_hi_u32
+    int m_begin, m_end;  // output rows (pixels) this launch covers: [m_begin, m_end)
+    int splits;          // split-K: K steps are divided over `splits` workgroups per tile (partials -> slab)
+    float *slab;         // [splits][M][N] fp32 partials when splits > 1
+    int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
+    unsigned magic_nt;   // ceil(2^32/ntaps)
+    int ablate;  // diagnostics only (EMADAPT_ABLATE): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
+};
+
+// 16-byte buffer load with hardware range checking: an offset at/after the end of the buffer returns 0,
+// which is how out-of-image taps, K/M/N tails are zero-filled without any branch or exec masking.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// keep decision of the built-in dropout generator: uniform 24-bit draw per (seed, element).
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float keep) {
+    const unsigned u = (unsigned)(mix64(seed ^ (idx * 0xD1342543DE82EF95ull)) >> 40);
+    return (float)u * (1.0f / 16777216.0f) < keep;
+}
+
+// bias / ReLU / dropout (tf.nn.dropout: x / keep_prob * mask) or the ReLU-gradient gate, on one output element.
+__device__ __forceinline__ float epilogue(const IgemmArgs &a, float v, int col, long long o) {
+    if (a.epi != EMADAPT_EPI_NONE && a.bias) v += a.bias[col];
+    if (a.epi == EMADAPT_EPI_BIAS_RELU) {
+        v = v > 0.f ? v : 0.f;
+        if (a.keep < 1.0f) {
+            const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
+            v = kp ? v / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
+        }
+    }
+    if (a.gate) v = a.gate[o] > 0.f ? v * a.scale : 0.f;
+    return v;
+}
+
+// split-K second stage: y = epilogue(sum_s slab[s]) with the partials added in ascending s (deterministic).
+__global__ void __launch_bounds__(256) splitk_epilogue_kernel(IgemmArgs a) {
+    const long long mn = (long long)(a.m_end - a.m_begin) * a.N;  // one slab
+    const long long n4 = mn / 4;
+    const long long o0 = (long long)a.m_begin * a.N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 v = *reinterpret_cast<const float4 *>(a.slab + i * 4);
+        for (int sp = 1; sp < a.splits; sp++) {
+            const float4 u = *reinterpret_cast<const float4 *>(a.slab + sp * mn + i * 4);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        const long long o = o0 + i * 4;
+        const int col = (int)(o % a.N);
+        v.x = epilogue(a, v.x, col + 0, o + 0);
+        v.y = epilogue(a, v.y, col + 1, o + 1);
+        v.z = epilogue(a, v.z, col + 2, o + 2);
+        v.w = epilogue(a, v.w, col + 3, o + 3);
+        *reinterpret_cast<float4 *>(a.y + o) = v;
+    }
+}
+
+// Split-K factor: with T tiles on `slots` resident workgroup slots (256 CUs x 2) a launch runs ceil(T/slots) rounds;
+// when T is a few hundred (the M = 26 896, N = 512 layers: 844 tiles -> 2 rounds at 82 %) splitting K by S makes T*S
+// workgroups fill whole rounds (S = 3 -> 4.95 of 5).  The price is one extra pass over S+1 output-sized slabs,
+// charged at ~3 TB/s against the kernel's time at ~110 TFLOP/s.
+int choose_splits(long long M, int N, int K, int bm, int bn, int bk, double slots = 512.0, double rate = 110e12) {
+    static const int force = getenv("EMADAPT_SPLITK") ? atoi(getenv("EMADAPT_SPLITK")) : 0;
+    const long long tiles = ceil_div(M, bm) * ceil_div(N, bn);
+    const int nk = (K + bk - 1) / bk;
+    if (force > 0) return force <= nk ? force : 1;
+    if (N % 4 != 0) return 1;
+    const double t_kernel = 2.0 * M * (double)K * N / rate;
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= 8; s++) {
+        if (nk / s < 16) break;
+        const double rounds = (double)tiles * s / slots;
+        const double eff = rounds / (double)(long long)(rounds + 0.999999);
+        double t = t_kernel / eff;
+        if (s > 1) t += (double)(s + 1) * M * N * 4.0 / 3e12 + 3e-6;
+        if (t < best_t * 0.97) { best_t = t; best = s; }
+    }
+    return best;
+}
+
+int check_desc(const emadapt_conv_desc *d) {
+    if (!d) return EMADAPT_ERR_INVALID;
+    if (d->B < 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->dil <= 0)
+        return EMADAPT_ERR_INVALID;
+    if (d->Cin % 4 != 0 || d->Cout % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;
+    if ((long long)d->B * d->H * d->W >= (1LL << 30)) return EMADAPT_ERR_UNSUPPORTED;
+    // activations and filters are addressed with 32-bit byte offsets (bounds-checked buffer loads)
+    if ((long long)d->B * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) * 4 >= (1LL << 31)) return EMADAPT_ERR_UNSUPPORTED;
+    if ((long long)d->KH * d->KW * d->Cin * d->Cout * 4 >= (1LL << 31)) return EMADAPT_ERR_UNSUPPORTED;
+    return EMADAPT_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ceil(2^32 / d) for d >= 2: __umulhi(n, magic) == n / d exactly for n < 2^20, d <= 4096 (d == 1 -> identity
+// is handled by the 0 encoding below: __umulhi(n, 0xFFFFFFFF) = n - 1 for n >= 1, so d == 1 uses its own path).
+inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
+
+
+// geometry shared by the launch and the workspace query
+void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
+    a.H = d->H; a.W = d->W; a.KW = d->KW; a.dil = d->dil; a.sign = dgrad ? -1 : 1;
+    a.Cx = dgrad ? d->Cout : d->Cin;
+    a.N = dgrad ? d->Cin : d->Cout;
+    a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
+    a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * a.Cx;
+    a.x_bytes = (unsigned)((long long)a.M * a.Cx * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
+    a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
+}
+
+}  // namespace

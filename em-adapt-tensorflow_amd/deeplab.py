@@ -63,6 +63,12 @@ class ADAPT(Network):
         self.fc_width = int(fcw) if fcw is not None else (4096 if self.preset == "ref" else 1024) * self.width // 64
         self.seed = int(self.config.get("seed", 2))
         self.input_channel = int(self.config.get("input_channel", 3))
+        # "fp32" (reference numerics, BASELINE configs C1/C2/C5) or "bf16" (C3/C4: bf16 MFMA operands, fp32 accumulation,
+        # fp32 master weights / gradients / optimizer state)
+        self.compute_dtype = str(self.config.get("compute_dtype", "fp32"))
+        if self.compute_dtype not in ("fp32", "bf16"):
+            raise ValueError("compute_dtype must be 'fp32' or 'bf16', got %r" % self.compute_dtype)
+        self._w16_seen = None
         self._plan = []
         self._shapes = {}
         self._dry = False
@@ -289,6 +295,22 @@ class ADAPT(Network):
                 bp = self._flat[buf][s + nw:s + nw + nb]
                 seg[prefix + "w_pad"], seg[prefix + "b_pad"] = wp, bp
                 seg[prefix + "w"], seg[prefix + "b"] = wp[:, :, :cin, :cout], bp[:cout]
+        if self.compute_dtype == "bf16":
+            # bf16 filter images (include/emadapt.h, "bf16-compute variants"), one flat buffer per image kind
+            offs, nf, nd = {}, 0, 0
+            for layer, seg in self._segments.items():
+                kh, kw, cin_p, cout_p = seg["pshape"]
+                sf, sd = kh * kw * cout_p * round_up(cin_p, 8), kh * kw * cin_p * round_up(cout_p, 8)
+                offs[layer] = (nf, sf, nd, sd)
+                nf, nd = round_up(nf + sf, 128), round_up(nd + sd, 128)
+            self._flat["wf16"] = torch.zeros(nf, dtype=torch.bfloat16, device=dev)
+            self._flat["wd16"] = torch.zeros(nd, dtype=torch.bfloat16, device=dev)
+            for layer, seg in self._segments.items():
+                kh, kw, cin_p, cout_p = seg["pshape"]
+                of, sf, od, sd = offs[layer]
+                seg["wf16"] = self._flat["wf16"][of:of + sf].view(kh * kw, cout_p, round_up(cin_p, 8))
+                seg["wd16"] = self._flat["wd16"][od:od + sd].view(kh * kw, cin_p, round_up(cout_p, 8))
+            self._w16_seen = None
 
     def _finish_plan(self):
         h, w = self.h, self.w
@@ -350,9 +372,24 @@ class ADAPT(Network):
             return a.to(device=self.device, dtype=dtype, non_blocking=True).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype, non_blocking=True)
 
+    def refresh_bf16_weights(self, force=False):
+        """Re-derive the bf16 filter images when the fp32 master weights changed (torch in-place ops bump the flat
+        buffer's version counter; the optimizer kernel, which torch does not see, resets ``_w16_seen`` itself)."""
+        if self.compute_dtype != "bf16":
+            return
+        ver = self._flat["params"]._version
+        if not force and self._w16_seen == ver:
+            return
+        for op in self._plan:
+            if op.kind == "conv":
+                ops.weights_to_bf16(op.w_pad, op.seg["wf16"], op.seg["wd16"])
+        self._w16_seen = ver
+
     def forward(self, images, keep_prob=1.0, drop_masks=None):
         """The conv stack (deeplab.py:35-49). images [B,H,W,3]; returns the fc8 logits view [B,S,S,C]."""
         images = self._to_dev(images)
+        self.refresh_bf16_weights()
+        bf16 = self.compute_dtype == "bf16"
         B = images.shape[0]
         bufs = self._alloc(B)
         self.net["input"] = images
@@ -369,8 +406,13 @@ class ADAPT(Network):
                 mask = None
                 if op.drop and kp < 1.0 and drop_masks is not None:
                     mask = self._pad_mask(drop_masks[op.name], op)
-                ops.conv_fwd(x, op.w_pad, op.b_pad, op.rate, relu=op.relu, keep_prob=kp, drop_mask=mask,
-                             drop_seed=(self.seed << 32) + self._micro * 64 + op.index, out=out)
+                seed = (self.seed << 32) + self._micro * 64 + op.index
+                if bf16:
+                    ops.conv_fwd_bf16(x, op.seg["wf16"], (op.k, op.k), op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
+                                      drop_mask=mask, drop_seed=seed, out=out)
+                else:
+                    ops.conv_fwd(x, op.w_pad, op.b_pad, op.rate, relu=op.relu, keep_prob=kp, drop_mask=mask,
+                                 drop_seed=seed, out=out)
             else:
                 ops.maxpool_fwd(x, op.stride, out=out, idx=bufs["idx"][op.name])
             x = out
@@ -470,12 +512,16 @@ class ADAPT(Network):
         cur, other = bufs["gA"], bufs["gB"]
         inv_accum = 1.0 / float(self.accum_num)
         plan = self._plan
+        bf16 = self.compute_dtype == "bf16"
         for i in range(len(plan) - 1, -1, -1):
             op = plan[i]
             prev = plan[i - 1] if i > 0 else None
             if op.kind == "conv":
                 x_in = bufs["act"][prev.name] if prev is not None else bufs["x_in"]
-                ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
+                if bf16:
+                    ops.conv_wgrad_bf16(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
+                else:
+                    ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
                 ops.bias_grad(d, out=op.gb_pad)
                 seg = op.seg
                 s, n = seg["start"], seg["nw"] + seg["nb"]
@@ -486,11 +532,14 @@ class ADAPT(Network):
                 if prev is None:
                     break
                 out = other[:x_in.numel()].view(x_in.shape)
+                gate, scale = None, 1.0
                 if prev.kind == "conv" and prev.relu:
+                    gate = x_in
                     scale = (1.0 / keep) if (prev.drop and keep < 1.0) else 1.0
-                    d = ops.conv_dgrad(d, op.w_pad, op.rate, gate=x_in, gate_scale=scale, out=out)
+                if bf16:
+                    d = ops.conv_dgrad_bf16(d, op.seg["wd16"], (op.k, op.k), op.rate, gate=gate, gate_scale=scale, out=out)
                 else:
-                    d = ops.conv_dgrad(d, op.w_pad, op.rate, out=out)
+                    d = ops.conv_dgrad(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
             else:
                 x_in = bufs["act"][prev.name]
                 gate = x_in if (prev.kind == "conv" and prev.relu) else None
@@ -517,6 +566,7 @@ class ADAPT(Network):
             scale = 1.0 / self._gradsync.world_size
         f = self._flat
         ops.sgd_momentum(f["params"], f["momentum"], f["accum"], self.net["lr"], self._momentum, scale)
+        self._w16_seen = None  # the master weights moved: the bf16 images are refreshed by the next forward
         self._step += 1
 
     def eval_loss(self, images, labels, keep_prob=0.5, perms=None, drop_masks=None):

@@ -108,6 +108,84 @@ def conv_wgrad(x, dy, KH, KW, dil=1, out=None):
     return dw
 
 
+# ---- bf16-compute variants (include/emadapt.h "bf16-compute variants"): f32 tensors in, f32 out; filters come from the
+# two bf16 images made by weights_to_bf16 (fwd: [taps, Cout, round8(Cin)], dgrad: [taps, Cin, round8(Cout)]).
+def _round8(v):
+    return (int(v) + 7) // 8 * 8
+
+
+def weights_to_bf16(w, fwd_out=None, dgrad_out=None, want_fwd=True, want_dgrad=True):
+    """Derive the bf16 filter images from the f32 HWIO master copy; returns (fwd_image, dgrad_image)."""
+    _check(w, name="w")
+    KH, KW, Cin, Cout = w.shape
+    d = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+    wf = wd = None
+    if want_fwd:
+        wf = fwd_out if fwd_out is not None else torch.empty((KH * KW, Cout, _round8(Cin)), dtype=torch.bfloat16, device=w.device)
+        _check(wf, torch.bfloat16, "fwd_out")
+        if wf.numel() != KH * KW * Cout * _round8(Cin):
+            raise ValueError("fwd_out has the wrong size")
+    if want_dgrad:
+        wd = dgrad_out if dgrad_out is not None else torch.empty((KH * KW, Cin, _round8(Cout)), dtype=torch.bfloat16, device=w.device)
+        _check(wd, torch.bfloat16, "dgrad_out")
+        if wd.numel() != KH * KW * Cin * _round8(Cout):
+            raise ValueError("dgrad_out has the wrong size")
+    _lib.call("emadapt_weights_to_bf16", ctypes.byref(d), _p(w), _p(wf), _p(wd), _stream())
+    return wf, wd
+
+
+def conv_fwd_bf16(x, wf, ksize, bias=None, dil=1, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None):
+    """conv_fwd with bf16 operands / fp32 accumulation; wf = forward image of weights_to_bf16, ksize = (KH, KW)."""
+    _check(x, name="x"); _check(wf, torch.bfloat16, "wf"); _check(bias, name="bias")
+    _check(drop_mask, torch.uint8, "drop_mask")
+    B, H, W, Cin = x.shape
+    KH, KW = ksize
+    taps, Cout, Cip = wf.shape
+    if taps != KH * KW or Cip != _round8(Cin):
+        raise ValueError("forward filter image %s does not match x channels %d / ksize %s" % (tuple(wf.shape), Cin, ksize))
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    y = out if out is not None else torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    _check(y, name="out")
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    nbytes = _lib.load().emadapt_conv_fwd_bf16_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, x.device) if nbytes else None
+    _lib.call("emadapt_conv_fwd_bf16", ctypes.byref(d), _p(x), _p(wf), _p(bias), _p(y), epi, float(keep_prob),
+              _p(drop_mask), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(ws), ws.numel() if ws is not None else 0, _stream())
+    return y
+
+
+def conv_dgrad_bf16(dy, wd, ksize, dil=1, gate=None, gate_scale=1.0, out=None):
+    """conv_dgrad with bf16 operands / fp32 accumulation; wd = dgrad image of weights_to_bf16."""
+    _check(dy, name="dy"); _check(wd, torch.bfloat16, "wd"); _check(gate, name="gate")
+    B, H, W, Cout = dy.shape
+    KH, KW = ksize
+    taps, Cin, Cop = wd.shape
+    if taps != KH * KW or Cop != _round8(Cout):
+        raise ValueError("dgrad filter image %s does not match dy channels %d / ksize %s" % (tuple(wd.shape), Cout, ksize))
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
+    _check(dx, name="out")
+    nbytes = _lib.load().emadapt_conv_dgrad_bf16_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, dy.device) if nbytes else None
+    _lib.call("emadapt_conv_dgrad_bf16", ctypes.byref(d), _p(dy), _p(wd), _p(dx), _p(gate), float(gate_scale), _p(ws),
+              ws.numel() if ws is not None else 0, _stream())
+    return dx
+
+
+def conv_wgrad_bf16(x, dy, KH, KW, dil=1, out=None):
+    """conv_wgrad with bf16 operands / fp32 accumulation (f32 HWIO result)."""
+    _check(x, name="x"); _check(dy, name="dy")
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    dw = out if out is not None else torch.empty((KH, KW, Cin, Cout), dtype=torch.float32, device=x.device)
+    _check(dw, name="out")
+    nbytes = _lib.load().emadapt_conv_wgrad_bf16_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, x.device)
+    _lib.call("emadapt_conv_wgrad_bf16", ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream())
+    return dw
+
+
 def bias_grad(dy, out=None):
     _check(dy, name="dy")
     N = dy.shape[-1]

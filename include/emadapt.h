@@ -164,6 +164,29 @@ size_t emadapt_conv_wgrad_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- bf16-compute variants (configurations C3/C4: bf16 compute, fp32 master weights
+ * and fp32 accumulation).  Same semantics, shapes and epilogues as the fp32 entry points above; the operands
+ * of every inner product are rounded to bf16 (round-to-nearest-even), products and sums are fp32
+ * (v_mfma_f32_32x32x16_bf16).  Activations and gradients stay f32 in memory.  The filters are read from two
+ * bf16 images that emadapt_weights_to_bf16 derives from the f32 HWIO master copy (once per optimizer step):
+ *   which = 0, forward image  [KH*KW][Cout][round8(Cin)]   (reduction axis ci contiguous, zero padded)
+ *   which = 1, dgrad image    [KH*KW][Cin][round8(Cout)]   (the HWIO filter with co padded to 8)
+ * The filter gradient needs no image; dw is written f32 HWIO. */
+size_t emadapt_weights_bf16_bytes(const emadapt_conv_desc *d, int which);
+int emadapt_weights_to_bf16(const emadapt_conv_desc *d, const float *w, void *w_fwd_bf16, void *w_dgrad_bf16,
+                            void *stream); /* either image pointer may be NULL */
+size_t emadapt_conv_fwd_bf16_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const float *x, const void *w_fwd_bf16, const float *bias,
+                          float *y, int epilogue, float keep_prob, const uint8_t *drop_mask,
+                          uint64_t drop_seed, void *workspace, size_t workspace_bytes, void *stream);
+size_t emadapt_conv_dgrad_bf16_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const float *dy, const void *w_dgrad_bf16, float *dx,
+                            const float *gate, float gate_scale, void *workspace, size_t workspace_bytes,
+                            void *stream);
+size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 /* BiasAddGrad: db[n] = sum_m dy[m,n]; dy f32 [M,N].  Deterministic two-stage reduction. */
 size_t emadapt_bias_grad_workspace_bytes(int64_t M, int N);
 int emadapt_bias_grad(const float *dy, int64_t M, int N, float *db, void *workspace,

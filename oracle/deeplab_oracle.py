@@ -89,6 +89,38 @@ def conv_same(x, w, b, rate):
     return y.permute(0, 2, 3, 1)
 
 
+def _bf16_round(t):
+    """Round to bf16 (round-to-nearest-even, as v_cvt_pk_bf16_f32) and return in t's dtype."""
+    return t.to(torch.float32).bfloat16().to(t.dtype)
+
+
+class _ConvBf16(torch.autograd.Function):
+    """Arithmetic model of the bf16-compute kernels (csrc/conv_bf16.hip): every inner product -- forward, data gradient
+    and filter gradient -- takes both operands rounded to bf16 and accumulates exactly (here: in the tensor dtype)."""
+
+    @staticmethod
+    def forward(ctx, x, w, rate):
+        ctx.save_for_backward(x, w)
+        ctx.rate = rate
+        return conv_same(_bf16_round(x), _bf16_round(w), None, rate)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dyr = _bf16_round(dy)
+        with torch.enable_grad():
+            xr = _bf16_round(x).detach().requires_grad_(True)
+            wr = _bf16_round(w).detach().requires_grad_(True)
+            y = conv_same(xr, wr, None, ctx.rate)
+            dx, dw = torch.autograd.grad(y, (xr, wr), dyr)
+        return dx, dw, None
+
+
+def conv_same_bf16(x, w, b, rate):
+    y = _ConvBf16.apply(x, w, rate)
+    return y if b is None else y + b
+
+
 def maxpool_same(x, stride):
     B, H, W, C = x.shape
     oh, ow = -(-H // stride), -(-W // stride)
@@ -111,8 +143,9 @@ class DeepLabOracle:
     """Forward / loss / backward / update of one micro-step, on the CPU."""
 
     def __init__(self, category_num=21, preset="ref", width=64, fc_width=None, input_channel=3,
-                 dtype=torch.float32):
+                 dtype=torch.float32, compute_dtype="fp32"):
         self.C = category_num
+        self.conv = conv_same_bf16 if compute_dtype == "bf16" else conv_same
         self.specs = layer_specs(category_num, preset, width, fc_width, input_channel)
         self.dtype = dtype
         self.estep_args = dict(bg_p=0.4, fg_p=0.2, num_iter=5, suppress_others=True, margin_others=1e-5)  # deeplab.py:181
@@ -131,7 +164,7 @@ class DeepLabOracle:
         for name, kind, p in self.specs:
             if kind == "conv":
                 w, b = tparams[name]
-                x = conv_same(x, w, b, p["rate"])
+                x = self.conv(x, w, b, p["rate"])
                 if p.get("relu"):
                     x = torch.relu(x)
                 if p.get("drop") and keep_prob < 1.0:

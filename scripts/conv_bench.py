@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time single conv kernels (fwd / dgrad / wgrad) at DeepLab layer shapes.  usage: conv_bench.py [layer ...]"""
+"""Time single conv kernels (fwd / dgrad / wgrad) at DeepLab layer shapes.  usage: conv_bench.py [--bf16] [layer ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,15 +20,26 @@ def timeit(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
-names = sys.argv[1:] or ["fc6", "conv4_2", "conv2_2"]
+BF16 = "--bf16" in sys.argv
+names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fc6", "conv4_2", "conv2_2"]
 for n in names:
     B, H, W, Cin, Cout, k, dil = SHAPES[n]
     x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
     b = torch.zeros(Cout, device="cuda"); dy = torch.randn(B, H, W, Cout, device="cuda")
     y = torch.empty(B, H, W, Cout, device="cuda"); dx = torch.empty_like(x); dw = torch.empty_like(w)
     fl = 2.0 * B * H * W * k * k * Cin * Cout
-    for kind, fn in (("fwd", lambda: ops.conv_fwd(x, w, b, dil, out=y)), ("dgrad", lambda: ops.conv_dgrad(dy, w, dil, out=dx)),
-                     ("wgrad", lambda: ops.conv_wgrad(x, dy, k, k, dil, out=dw))):
+    if BF16:
+        wf, wd = ops.weights_to_bf16(w)
+        kinds = (("fwd", lambda: ops.conv_fwd_bf16(x, wf, (k, k), b, dil, out=y)),
+                 ("dgrad", lambda: ops.conv_dgrad_bf16(dy, wd, (k, k), dil, out=dx)),
+                 ("wgrad", lambda: ops.conv_wgrad_bf16(x, dy, k, k, dil, out=dw)),
+                 ("cvt", lambda: ops.weights_to_bf16(w, wf, wd)))
+        peak = 2516.6  # dense bf16 MFMA peak, TFLOP/s
+    else:
+        kinds = (("fwd", lambda: ops.conv_fwd(x, w, b, dil, out=y)), ("dgrad", lambda: ops.conv_dgrad(dy, w, dil, out=dx)),
+                 ("wgrad", lambda: ops.conv_wgrad(x, dy, k, k, dil, out=dw)))
+        peak = 157.3
+    for kind, fn in kinds:
         ms = timeit(fn)
-        print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  ablate=%s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / 157.3 * 100,
-                                                                 os.environ.get("EMADAPT_ABLATE", "0")), flush=True)
+        print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  %s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / peak * 100,
+                                                           "bf16" if BF16 else "fp32"), flush=True)

@@ -1,0 +1,212 @@
+"""GPU parity of the bf16-compute convolution kernels (bf16 compute, fp32 accumulate).
+
+The kernels round every operand of an inner product to bf16 (round-to-nearest-even) and then multiply/accumulate in
+fp32.  bf16 x bf16 products are exact in fp32, so against an fp64 oracle fed with the SAME rounded operands the only
+error left is the fp32 summation: the bar is 2e-5 of the tensor's max magnitude, as for the fp32 kernels.  A second,
+looser check against the unrounded fp64 result documents the bf16 quantisation itself (about 2^-8 per operand).
+All calls go through the C ABI.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import em_adapt_tensorflow_amd.ops as ops
+    from oracle import deeplab_oracle as do
+    return ops, do, torch
+
+
+def _rel(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def _l2(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+
+
+def _t(torch, a, dtype=None):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype or torch.float32, device="cuda:0")
+
+
+def _bf(torch, a):
+    """fp32 array rounded to bf16 (RNE), back as fp64 tensor."""
+    return torch.tensor(a, dtype=torch.float32).bfloat16().double()
+
+
+# (B, H, W, Cin, Cout, k, dil): channel counts that are / are not multiples of 8 (4 -> padded RGB, 12, 44 -> 41 classes),
+# Cin % 64 == 0 (whole K step inside one tap) and not, N <= 64 and N > 128, K and M tails, long-K split-K shapes.
+SHAPES = [
+    (1, 7, 9, 4, 8, 3, 1),
+    (2, 13, 11, 8, 16, 3, 1),
+    (2, 12, 12, 12, 64, 3, 2),
+    (1, 19, 17, 16, 136, 3, 1),
+    (2, 11, 11, 32, 160, 4, 4),
+    (1, 25, 25, 24, 44, 3, 12),
+    (3, 9, 9, 160, 24, 1, 1),
+    (1, 33, 31, 4, 64, 3, 1),
+    (2, 23, 23, 64, 256, 3, 2),
+    (1, 41, 41, 24, 288, 1, 1),
+    (2, 49, 47, 256, 128, 3, 1),
+    (1, 41, 41, 512, 136, 4, 4),
+    (1, 41, 41, 128, 44, 1, 1),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_bf16_conv_fwd_dgrad_wgrad(env, shape):
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    rng = np.random.default_rng(hash(shape) % (1 << 31))
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    w = rng.normal(0, 0.2, (k, k, Cin, Cout)).astype(np.float32)
+    b = rng.normal(0, 0.5, (Cout,)).astype(np.float32)
+    dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
+
+    # oracle on bf16-rounded operands, fp64 arithmetic
+    xr = _bf(torch, x).requires_grad_(True)
+    wr = _bf(torch, w).requires_grad_(True)
+    bt = torch.tensor(b, dtype=torch.float64)
+    y = do.conv_same(xr, wr, bt, dil)
+    y.backward(_bf(torch, dy))
+    # and on the unrounded operands (quantisation check)
+    y_full = do.conv_same(torch.tensor(x, dtype=torch.float64), torch.tensor(w, dtype=torch.float64), bt, dil)
+
+    xg, wg, bg, dyg = _t(torch, x), _t(torch, w), _t(torch, b), _t(torch, dy)
+    wf, wd = ops.weights_to_bf16(wg)
+    # the filter images are the RNE-rounded filter, re-laid-out and zero padded
+    wb = wg.bfloat16().reshape(k * k, Cin, Cout)
+    assert torch.equal(wd[:, :, :Cout], wb)
+    assert torch.equal(wf[:, :, :Cin], wb.permute(0, 2, 1))
+    assert not wd[:, :, Cout:].any() and not wf[:, :, Cin:].any()
+
+    got = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=False).cpu()
+    assert _rel(got, y.detach()) < 2e-5
+    assert _rel(got, y_full) < 2e-2
+    assert _rel(ops.conv_fwd_bf16(xg, wf, (k, k), None, dil).cpu(), (y - bt).detach()) < 2e-5
+    assert _rel(ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=True).cpu(), torch.relu(y).detach()) < 2e-5
+
+    assert _rel(ops.conv_dgrad_bf16(dyg, wd, (k, k), dil).cpu(), xr.grad) < 2e-5
+    gate = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    want = np.where(gate > 0, xr.grad.numpy() * 2.0, 0.0)
+    assert _rel(ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=_t(torch, gate), gate_scale=2.0).cpu(), want) < 2e-5
+
+    assert _rel(ops.conv_wgrad_bf16(xg, dyg, k, k, dil).cpu(), wr.grad) < 2e-5
+
+
+def test_bf16_wgrad_split_m_is_deterministic_and_right(env):
+    ops, do, torch = env
+    rng = np.random.default_rng(5)
+    B, H, W, Cin, Cout, k = 2, 97, 95, 8, 64, 3
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
+    wt = torch.zeros((k, k, Cin, Cout), dtype=torch.float64, requires_grad=True)
+    y = do.conv_same(_bf(torch, x), wt, torch.zeros(Cout, dtype=torch.float64), 1)
+    y.backward(_bf(torch, dy))
+    xg, dyg = _t(torch, x), _t(torch, dy)
+    a = ops.conv_wgrad_bf16(xg, dyg, k, k, 1).cpu().numpy()
+    b = ops.conv_wgrad_bf16(xg, dyg, k, k, 1).cpu().numpy()
+    assert np.array_equal(a, b), "filter gradient must be bitwise reproducible"
+    assert _rel(a, wt.grad) < 2e-5
+
+
+def test_bf16_dropout_epilogue_matches_fp32_kernel_mask(env):
+    """The counter-based dropout mask depends only on (seed, element index): the bf16 and fp32 kernels drop the same
+    elements, and kept values are relu(conv)/keep."""
+    ops, do, torch = env
+    rng = np.random.default_rng(9)
+    x = _t(torch, rng.normal(0, 1, (2, 21, 21, 64)).astype(np.float32))
+    w = _t(torch, rng.normal(0, 0.1, (3, 3, 64, 136)).astype(np.float32))
+    b = _t(torch, rng.normal(0.5, 0.5, (136,)).astype(np.float32))
+    wf, _ = ops.weights_to_bf16(w, want_dgrad=False)
+    y0 = ops.conv_fwd_bf16(x, wf, (3, 3), b, 1, relu=True)
+    y1 = ops.conv_fwd_bf16(x, wf, (3, 3), b, 1, relu=True, keep_prob=0.5, drop_seed=77)
+    y32 = ops.conv_fwd(x, w, b, 1, relu=True, keep_prob=0.5, drop_seed=77)
+    kept = y1 != 0
+    assert torch.equal(y1[kept], (y0 / 0.5)[kept])
+    pos = (y0 > 0) & (ops.conv_fwd(x, w, b, 1, relu=True) > 0)
+    assert torch.equal((y1 != 0) & pos, (y32 != 0) & pos)
+    frac = kept.sum().item() / max((y0 > 0).sum().item(), 1)
+    assert 0.45 < frac < 0.55
+
+
+def test_bf16_micro_step_tracks_the_bf16_oracle():
+    """ADAPT(compute_dtype="bf16"): forward, E-step, backward, accumulate and update against the oracle's bf16
+    arithmetic model (operands of every conv inner product rounded to bf16, exact accumulation; fp64 elsewhere).
+    Two bf16 computations that differ only in summation order agree to ~1e-7 until the first activation lands close
+    enough to a bf16 rounding boundary to round the other way; from there they decorrelate to the bf16 noise floor
+    (a relative perturbation e becomes ~sqrt(e)/16 after one rounding, fixed point 2^-8): measured 4e-3 on the logits.
+    In backward, ReLU gates of near-zero activations flip for that fraction of elements, an L2 error of
+    sqrt(fraction): measured <= 4e-2 per layer, while the bf16 model itself sits 4..24 % from the fp32 graph.
+    Bars: logits 1e-2 (max), loss 5e-3, gradients 8e-2 (relative L2) per layer and 5e-2 on average.  The kernels
+    themselves are held to 2e-5 above.  Label maps must be bit-identical to the oracle E-step on the GPU's logits."""
+    import torch
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from oracle import deeplab_oracle as do
+    from oracle import estep_oracle as eo
+    B, width, size, C = 2, 8, 65, 5
+    adapt = ADAPT({"input_size": (size, size), "category_num": C, "width": width, "accum_num": 1, "batch_size": B,
+                   "compute_dtype": "bf16"})
+    adapt.build()
+    oracle = do.DeepLabOracle(category_num=C, width=width, dtype=torch.float64, compute_dtype="bf16")
+    oracle32 = do.DeepLabOracle(category_num=C, width=width, dtype=torch.float64)
+    params = do.init_params(oracle.specs, seed=11, he=True)
+    for layer, (w, b) in params.items():
+        adapt.weights[layer][0].copy_(torch.tensor(w).to(adapt.device))
+        adapt.weights[layer][1].copy_(torch.tensor(b).to(adapt.device))
+    adapt.pre_train(base_lr=1e-3, weight_decay=1e-2, momentum=0.9, batch_size=B)
+    images, labels = do.synthetic_batch(B, size, C, seed=5)
+    images = (images / 50.0).astype(np.float32)
+    S = adapt.out_hw[0]
+    rng = np.random.default_rng(1)
+    masks = {l: (rng.random((B, S, S, adapt.weights[l][1].shape[0])) < 0.5).astype(np.uint8) for l in ("fc6", "fc7")}
+    perms = eo.draw_perms(5, C, seed=77)
+
+    logits = adapt.forward(images, keep_prob=0.5, drop_masks=masks).cpu().numpy()
+    want = oracle.forward(oracle.tensors(params, requires_grad=False), images, 0.5, masks)["output"].numpy()
+    full = oracle32.forward(oracle32.tensors(params, requires_grad=False), images, 0.5, masks)["output"].numpy()
+    assert _rel(logits, want) < 1e-2
+    assert _rel(logits, full) < 5e-2        # bf16 quantisation against the fp32-semantics graph
+    assert _rel(want, full) > 1e-5          # ... and the bf16 model really is a different arithmetic
+
+    # the filter images follow the master weights
+    w6 = adapt._segments["fc6"]
+    assert torch.equal(w6["wd16"][:, :, :w6["pshape"][3]], w6["w_pad"].bfloat16().reshape(w6["wd16"].shape[0], w6["pshape"][2], -1))
+
+    adapt.micro_step(images, labels, keep_prob=0.5, perms=perms, drop_masks=masks)
+    torch.cuda.synchronize()
+    got_labels = adapt.net["e_argmax"].cpu().numpy()
+    want_labels, _ = oracle.estep_labels(logits, labels, perms)
+    assert np.array_equal(got_labels, want_labels)
+
+    ref = oracle.micro_step(params, images, labels, perms, weight_decay=1e-2, keep_prob=0.5, masks=masks,
+                            labels_override=want_labels)
+    assert abs(float(adapt.loss["norm"].cpu()) - ref["loss_norm"]) / abs(ref["loss_norm"]) < 5e-3
+    errs = []
+    for layer, (dw, db) in ref["grads"].items():
+        seg = adapt._segments[layer]
+        s, nw = seg["start"], seg["nw"]
+        kh, kw, cin, cout = seg["shape"]
+        acc_w = adapt._flat["accum"][s:s + nw].view(seg["pshape"])[:, :, :cin, :cout].cpu().numpy()
+        acc_b = adapt._flat["accum"][s + nw:s + nw + cout].cpu().numpy()
+        errs.append(_l2(acc_w, dw))
+        assert errs[-1] < 8e-2, layer
+        assert _l2(acc_b, db) < 8e-2, layer
+    assert np.mean(errs) < 5e-2
+
+    before = adapt._segments["fc8"]["wf16"].clone()
+    adapt.apply_update()
+    adapt.forward(images, keep_prob=1.0)
+    torch.cuda.synchronize()
+    seg = adapt._segments["fc8"]
+    assert not torch.equal(before, seg["wf16"]), "the bf16 images must be refreshed after the optimizer step"
+    kh, kw, cin_p, cout_p = seg["pshape"]
+    assert torch.equal(seg["wf16"][:, :, :cin_p], seg["w_pad"].bfloat16().reshape(1, cin_p, cout_p).permute(0, 2, 1))
