@@ -74,26 +74,36 @@ __global__ void __launch_bounds__(256) weights_to_bf16_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Forward / data-gradient: out[m][n] = sum_k A[m][k] Bw[n][k], 128x128x64 tiles, 4 consumer + 4 producer wavefronts.
+// Forward / data-gradient: out[m][n] = sum_k A[m][k] Bw[n][k].
 // IgemmArgs is used as in the fp32 kernel with: w = bf16 image [tap][N][Cxp], Cxp = round_up(Cx, 8) = the k pitch of
 // a tap (K = ntaps * Cxp; channels Cx..Cxp-1 are zero on both sides), magic_cx = magic(Cxp).
+//
+// Tile configurations <BM, BN, WN> (BK = 64; every consumer wave owns a 64 x WN block; 4 producer waves):
+//   128x128, WN 64  : 4 + 4 waves, 2 workgroups/CU, 128 registers/wave
+//   256x256, WN 128 : 8 + 4 waves, 1 workgroup/CU, 168 registers/wave.  What bounds these kernels is the delivery rate
+//                     of the vector memory path (~70 GB/s per CU from L2, MI355X_MICROARCH.md "gather into LDS"), i.e.
+//                     bytes per FLOP: 48 KB of operands per 128x128x64 step = 94 B/clk to keep the MFMAs busy against
+//                     ~29 B/clk delivered (31 %); the 256x256 tile moves 96 KB per 4x the FLOPs (47 B/clk, 62 %).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kPitchG = 144;  // bytes per LDS row of 64 bf16 (+8 pad)
 
-__global__ void __launch_bounds__(512, 4) igemm_bf16_kernel(IgemmArgs a, int Cxp) {
-    constexpr int BM = 128, BN = 128, BK = 64, WM = 64, WN = 64;
-    constexpr int TM = 2, TN = 2;
+template <int BM, int BN, int WN>
+__global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 4 : 3) igemm_bf16_kernel(IgemmArgs a, int Cxp) {
+    constexpr int BK = 64, WM = 64;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int CTHREADS = (BM / WM) * WAVES_N * 64;  // consumer threads; the 256 producer threads follow
+    constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int KQ = BK / 4;             // 16 fp32 quads per A row
-    constexpr int A_RSTEP = 256 / KQ;      // 16
-    constexpr int A_N = BM / A_RSTEP;      // 8
+    constexpr int A_RSTEP = 256 / KQ;      // 16 rows per pass of the producers
+    constexpr int A_N = BM / A_RSTEP;      // A loads per producer thread and K step
     constexpr int KC = BK / 8;             // 8 bf16 chunks (16 B) per B row
     constexpr int B_RSTEP = 256 / KC;      // 32
-    constexpr int B_N = BN / B_RSTEP;      // 4
-    constexpr int TILE = BM * kPitchG;     // bytes per operand tile
+    constexpr int B_N = BN / B_RSTEP;
+    constexpr int TILE_A = BM * kPitchG, TILE_B = BN * kPitchG;  // bytes per operand tile
 
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
-    char *As = ldsb;               // [2][BM][kPitchG]
-    char *Bs = ldsb + 2 * TILE;    // [2][BN][kPitchG]
+    char *As = ldsb;                 // [2][BM][kPitchG]
+    char *Bs = ldsb + 2 * TILE_A;    // [2][BN][kPitchG]
 
     int tile_m, tile_n, split;
     {
@@ -104,7 +114,7 @@ __global__ void __launch_bounds__(512, 4) igemm_bf16_kernel(IgemmArgs a, int Cxp
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         split = t / ntile;
         t -= split * ntile;
-        constexpr int GM = 8;
+        constexpr int GM = BM == 128 ? 8 : 4;  // M-tiles per group: the XCD's co-resident workgroups form a square-ish block
         const int per_group = GM * a.tiles_n;
         const int g = t / per_group;
         const int first_m = g * GM;
@@ -118,33 +128,36 @@ __global__ void __launch_bounds__(512, 4) igemm_bf16_kernel(IgemmArgs a, int Cxp
     const int kt0 = (int)((long long)nk_all * split / a.splits);
     const int nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
 
-    if (threadIdx.x >= 256) {
+    if (threadIdx.x >= CTHREADS) {
         // ================================ PRODUCER wavefronts ================================
-        const int tid = threadIdx.x - 256;
+        const int tid = threadIdx.x - CTHREADS;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
         constexpr unsigned kOOB = 0x80000000u;
         const int a_kq = tid % KQ, a_r0 = tid / KQ;
-        int a_base[A_N], a_oh[A_N], a_ow[A_N];
+        // per-row pixel coordinates, packed (oh << 16 | ow); rows past m_end get oh = 0x4000 and fail every bounds check
+        unsigned a_hw[A_N];
 #pragma unroll
         for (int j = 0; j < A_N; j++) {
             const int m = m0 + a_r0 + j * A_RSTEP;
             if (m < a.m_end) {
                 const int t2 = m / a.W;
-                a_base[j] = m * a.Cx;
-                a_oh[j] = t2 % a.H;
-                a_ow[j] = m - t2 * a.W;
+                a_hw[j] = ((unsigned)(t2 % a.H) << 16) | (unsigned)(m - t2 * a.W);
             } else {
-                a_base[j] = 0;
-                a_oh[j] = -(1 << 20);
-                a_ow[j] = -(1 << 20);
+                a_hw[j] = 0x40000000u;
             }
         }
+        const int a_base0 = (m0 + a_r0) * a.Cx;
+        const int a_rstride = A_RSTEP * a.Cx;
         const int b_kc = tid % KC, b_r0 = tid / KC;
         float4 ra[A_N];
         u32x4 rb[B_N];
 
-        auto load_tile = [&](int kt) {
+        // per-K-step addressing, shared by the loads of a step
+        int toff, dh, dw;
+        bool kvalid, bvalid;
+        unsigned boff;
+        auto step_setup = [&](int kt) {
             unsigned tap, tapb;
             int c, cb;
             if (a.tap_inner) {  // Cxp % BK == 0: the whole K step lies in one tap
@@ -164,41 +177,49 @@ __global__ void __launch_bounds__(512, 4) igemm_bf16_kernel(IgemmArgs a, int Cxp
             }
             const unsigned kh = __umulhi(tap, a.magic_kw);
             const int kw = (int)(tap - kh * (unsigned)a.KW);
-            const bool kvalid = (int)tap < a.ntaps && c < a.Cx;
-            const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
-            const int dw = a.sign * (kw * a.dil - a.pad_w);
-            const int toff = (dh * a.W + dw) * a.Cx + c;
-#pragma unroll
-            for (int j = 0; j < A_N; j++) {
-                const int ih = a_oh[j] + dh, iw = a_ow[j] + dw;
-                const bool ok = kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-                ra[j] = buf_ld4(xr, ((unsigned)(a_base[j] + toff) * 4u) | (ok ? 0u : kOOB));
-            }
-            const bool bvalid = (int)tapb < a.ntaps;
-#pragma unroll
-            for (int j = 0; j < B_N; j++) {
-                const int n = n0 + b_r0 + j * B_RSTEP;
-                const unsigned off = (unsigned)(((int)tapb * a.N + n) * Cxp + cb) * 2u;
-                rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(off | ((bvalid && n < a.N) ? 0u : kOOB)), 0, 0);
-            }
+            kvalid = (int)tap < a.ntaps && c < a.Cx;
+            dh = a.sign * ((int)kh * a.dil - a.pad_h);
+            dw = a.sign * (kw * a.dil - a.pad_w);
+            toff = a_base0 + (dh * a.W + dw) * a.Cx + c;
+            bvalid = (int)tapb < a.ntaps;
+            boff = (unsigned)(((int)tapb * a.N + n0 + b_r0) * Cxp + cb) * 2u;
         };
-        auto store_tile = [&](int buf) {
-            char *as = As + buf * TILE;
-            char *bs = Bs + buf * TILE;
-#pragma unroll
-            for (int j = 0; j < A_N; j++)
-                *reinterpret_cast<uint2 *>(as + (a_r0 + j * A_RSTEP) * kPitchG + a_kq * 8) = cvt4(ra[j]);
-#pragma unroll
-            for (int j = 0; j < B_N; j++)
-                *reinterpret_cast<u32x4 *>(bs + (b_r0 + j * B_RSTEP) * kPitchG + b_kc * 16) = rb[j];
+        auto load_a = [&](int j) {
+            const int ih = (int)(a_hw[j] >> 16) + dh, iw = (int)(a_hw[j] & 0xffffu) + dw;
+            const bool ok = kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            ra[j] = buf_ld4(xr, ((unsigned)(toff + j * a_rstride) * 4u) | (ok ? 0u : kOOB));
         };
-        load_tile(kt0);
-        store_tile(0);
-        load_tile(kt0 + 1);  // K steps past the end are zero-filled by the range check
+        auto load_b = [&](int j) {
+            const int n = n0 + b_r0 + j * B_RSTEP;
+            const unsigned off = boff + (unsigned)(j * B_RSTEP * Cxp) * 2u;
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(off | ((bvalid && n < a.N) ? 0u : kOOB)), 0, 0);
+        };
+        auto store_a = [&](int buf, int j) {
+            *reinterpret_cast<uint2 *>(As + buf * TILE_A + (a_r0 + j * A_RSTEP) * kPitchG + a_kq * 8) = cvt4(ra[j]);
+        };
+        auto store_b = [&](int buf, int j) {
+            *reinterpret_cast<u32x4 *>(Bs + buf * TILE_B + (b_r0 + j * B_RSTEP) * kPitchG + b_kc * 16) = rb[j];
+        };
+        step_setup(kt0);
+#pragma unroll
+        for (int j = 0; j < A_N; j++) load_a(j);
+#pragma unroll
+        for (int j = 0; j < B_N; j++) load_b(j);
+        step_setup(kt0 + 1);  // K steps past the end are zero-filled by the range check
+#pragma unroll
+        for (int j = 0; j < A_N; j++) { store_a(0, j); load_a(j); }
+#pragma unroll
+        for (int j = 0; j < B_N; j++) { store_b(0, j); load_b(j); }
         __syncthreads();
+        // steady state: register j is parked in LDS and immediately re-armed with the load of the step after next, so
+        // the vector-memory pipe always has all but one of this thread's loads in flight
         for (int kt = 0; kt < nk; kt++) {
-            store_tile((kt + 1) & 1);
-            load_tile(kt0 + kt + 2);
+            const int buf = (kt + 1) & 1;
+            step_setup(kt0 + kt + 2);
+#pragma unroll
+            for (int j = 0; j < A_N; j++) { store_a(buf, j); load_a(j); }
+#pragma unroll
+            for (int j = 0; j < B_N; j++) { store_b(buf, j); load_b(j); }
             __syncthreads();
         }
         return;
@@ -207,7 +228,7 @@ __global__ void __launch_bounds__(512, 4) igemm_bf16_kernel(IgemmArgs a, int Cxp
     // ================================ CONSUMER wavefronts ================================
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int l31 = lane & 31, lh = lane >> 5;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -219,30 +240,54 @@ __global__ void __launch_bounds__(512, 4) igemm_bf16_kernel(IgemmArgs a, int Cxp
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
-        const char *as = As + cur * TILE + (wm * WM + l31) * kPitchG + lh * 16;
-        const char *bs = Bs + cur * TILE + (wn * WN + l31) * kPitchG + lh * 16;
-        bf16x8 av[2][TM], bv[2][TN];
+        const char *as = As + cur * TILE_A + (wm * WM + l31) * kPitchG + lh * 16;
+        const char *bs = Bs + cur * TILE_B + (wn * WN + l31) * kPitchG + lh * 16;
+        if constexpr (BM == 128) {
+            // fragments of k-step ks+1 are fetched while the MFMAs of ks run
+            bf16x8 av[2][TM], bv[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; i++) av[0][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG);
+            for (int i = 0; i < TM; i++) av[0][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG);
 #pragma unroll
-        for (int j = 0; j < TN; j++) bv[0][j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * kPitchG);
+            for (int j = 0; j < TN; j++) bv[0][j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * kPitchG);
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ks++) {
-            if (ks + 1 < BK / 16) {
+            for (int ks = 0; ks < BK / 16; ks++) {
+                if (ks + 1 < BK / 16) {
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+                        av[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG + (ks + 1) * 32);
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        bv[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * kPitchG + (ks + 1) * 32);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; i++)
-                    av[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG + (ks + 1) * 32);
 #pragma unroll
-                for (int j = 0; j < TN; j++)
-                    bv[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * kPitchG + (ks + 1) * 32);
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // 128 accumulator registers leave room for one fragment set plus the next step's A fragments; the second
+            // consumer wave of the SIMD covers the LDS latency of the B fragments
+            bf16x8 av[2][TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+            for (int i = 0; i < TM; i++) av[0][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ks++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * kPitchG + ks * 32);
+                if (ks + 1 < BK / 16) {
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+                        av[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG + (ks + 1) * 32);
+                }
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks & 1][i], bv[ks & 1][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < TM; i++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks & 1][i], bv[j], acc[i][j], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -275,35 +320,58 @@ void fill_geometry_bf16(IgemmArgs &a, int &Cxp, const emadapt_conv_desc *d, bool
     a.magic_cx = magic_u32(Cxp);
 }
 
-int bf16_splits(const IgemmArgs &a) { return choose_splits(a.M, a.N, a.K, 128, 128, 64, 512.0, 450e12); }
+// Launch plan: the 256x256 tile (one workgroup per CU) when the output is wide and tall enough to fill the chip with
+// it, else 128x128 tiles (two per CU) with split-K when the tile count is small.
+struct PlanG {
+    int big;     // 1: 256x256 tiles
+    int splits;
+};
+
+PlanG plan_bf16(const IgemmArgs &a) {
+    // EMADAPT_BF16_TILE=128|256 forces a configuration (read per call: the parity tests run both on small shapes)
+    const char *force = getenv("EMADAPT_BF16_TILE");
+    PlanG p;
+    const long long t256 = ceil_div(a.M, 256) * ceil_div(a.N, 256);
+    p.big = (a.N >= 256 && t256 >= 192) ? 1 : 0;
+    if (force) p.big = atoi(force) == 256 ? 1 : 0;
+    p.splits = p.big ? choose_splits(a.M, a.N, a.K, 256, 256, 64, 256.0, 1000e12)
+                     : choose_splits(a.M, a.N, a.K, 128, 128, 64, 512.0, 450e12);
+    return p;
+}
 
 size_t igemm_bf16_workspace_bytes(const IgemmArgs &a) {
-    const int s = bf16_splits(a);
+    const int s = plan_bf16(a).splits;
     return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
 }
 
-int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr size_t lds = 4 * 128 * kPitchG;
+template <int BM, int BN, int WN>
+int launch_igemm_bf16(IgemmArgs &a, int Cxp, hipStream_t stream) {
+    constexpr size_t lds = 2 * (BM + BN) * kPitchG;
+    constexpr int threads = ((BM / 64) * (BN / WN) + 4) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_bf16_kernel),
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_bf16_kernel<BM, BN, WN>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    int splits = bf16_splits(a);
-    if (splits > 1 && (!workspace || workspace_bytes < igemm_bf16_workspace_bytes(a))) splits = 1;
+    a.tiles_m = (int)ceil_div(a.M, BM);
+    a.tiles_n = (int)ceil_div(a.N, BN);
+    const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
+    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WN>), dim3((unsigned)nblk), dim3(threads), lds, stream, a, Cxp);
+    return launch_status();
+}
+
+int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    PlanG p = plan_bf16(a);
+    if (p.splits > 1 && (!workspace || workspace_bytes < igemm_bf16_workspace_bytes(a))) p.splits = 1;
     a.ablate = 0;
     a.tap_inner = (a.ntaps > 1 && Cxp % 64 == 0) ? 1 : 0;
     a.m_begin = 0;
     a.m_end = a.M;
-    a.splits = splits;
-    a.slab = splits > 1 ? static_cast<float *>(workspace) : nullptr;
-    a.tiles_m = (int)ceil_div(a.M, 128);
-    a.tiles_n = (int)ceil_div(a.N, 128);
-    const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
-    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(igemm_bf16_kernel, dim3((unsigned)nblk), dim3(512), lds, stream, a, Cxp);
-    int rc = launch_status();
+    a.splits = p.splits;
+    a.slab = p.splits > 1 ? static_cast<float *>(workspace) : nullptr;
+    int rc = p.big ? launch_igemm_bf16<256, 256, 128>(a, Cxp, stream) : launch_igemm_bf16<128, 128, 64>(a, Cxp, stream);
     if (rc || a.splits <= 1) return rc;
     long long g = ((long long)a.M * a.N / 4 + 255) / 256;
     if (g > 8192) g = 8192;
@@ -321,13 +389,12 @@ struct WgradBf16Args {
     int H, W, Cin, N, KW, dil, pad_h, pad_w;
     int M, K, ntaps;
     int tiles_k, tiles_n, splits;
-    int rows_per_split;  // multiple of kBMR
+    int rows_per_split;  // multiple of kRowsUnit
     unsigned x_bytes, y_bytes;
     unsigned magic_w, magic_h;
 };
 
-constexpr int kBMR = 64;      // pixels per reduction step (4 MFMA k-steps of 16)
-constexpr int kPitchW = 320;  // bytes per LDS pixel row of 128 bf16 (+32 pad)
+constexpr int kRowsUnit = 64;  // rows_per_split is a multiple of this (covers both reduction step sizes)
 
 __device__ __forceinline__ bf16x8 tr_frag(const char *p0, const char *p1) {
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -336,33 +403,56 @@ __device__ __forceinline__ bf16x8 tr_frag(const char *p0, const char *p1) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int BN>
-__global__ void __launch_bounds__(512, 4) wgrad_bf16_kernel(WgradBf16Args a) {
-    constexpr int BKO = 128;
-    constexpr int WK = BKO / 2, WN = BN / 2;
+// Tile configurations <BKO, BN, BMR>: BKO x BN filter tile, BMR pixels per reduction step; consumer waves own 64 x BN/2
+// blocks ((BKO/64) x 2 of them), 4 producer waves.  LDS rows are pixels: pitch = columns*2 + 64 bytes, so that the four
+// pixel rows of one transposing read sit 16 banks apart.
+//   128 x 64|128, 64 px : 4 + 4 waves, 2 workgroups/CU
+//   256 x 256,    32 px : 8 + 4 waves, 1 workgroup/CU (168 registers/wave) -- half the operand bytes per FLOP
+template <int BKO, int BN, int BMR>
+__global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) wgrad_bf16_kernel(WgradBf16Args a) {
+    constexpr int WK = 64, WN = BN / 2;
     constexpr int TK = WK / 32, TN = WN / 32;
-    constexpr int XQ = BKO / 4, X_RSTEP = 256 / XQ, X_N = kBMR / X_RSTEP;  // 32, 8, 8
-    constexpr int YQ = BN / 4, Y_RSTEP = 256 / YQ, Y_N = kBMR / Y_RSTEP;   // BN 128: 32, 8, 8; BN 64: 16, 16, 4
-    constexpr int TILE = kBMR * kPitchW;
+    constexpr int CTHREADS = (BKO / WK) * 2 * 64;
+    constexpr int XQ = BKO / 4, X_RSTEP = 256 / XQ, X_N = BMR / X_RSTEP;
+    constexpr int YQ = BN / 4, Y_RSTEP = 256 / YQ, Y_N = BMR / Y_RSTEP;
+    constexpr int PX = BKO * 2 + 64, PY = BN * 2 + 64;  // LDS row pitches in bytes
+    constexpr int TILE_X = BMR * PX, TILE_Y = BMR * PY;
+    static_assert(X_N >= 1 && Y_N >= 1, "tile too small for the producers");
 
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
-    char *Xs = ldsb;              // [2][kBMR][kPitchW]
-    char *Ys = ldsb + 2 * TILE;   // [2][kBMR][kPitchW]
+    char *Xs = ldsb;                // [2][BMR][PX]
+    char *Ys = ldsb + 2 * TILE_X;   // [2][BMR][PY]
 
-    int bid = blockIdx.x;
-    const int split = bid % a.splits;
-    bid /= a.splits;
-    const int tile_n = bid % a.tiles_n;
-    const int tile_k = bid / a.tiles_n;
+    // XCD-aware block order (blocks b, b+8, .. share an XCD and its L2): each XCD takes a contiguous run of logical
+    // blocks in split-major order -- so the workgroups of one XCD stream the SAME pixel range -- and inside a split
+    // the filter tiles go in groups of GK k-tiles x all n-tiles (k fastest).
+    int tile_k, tile_n, split;
+    {
+        const int ntile = a.tiles_k * a.tiles_n;
+        const int nblk = ntile * a.splits;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        split = t / ntile;
+        t -= split * ntile;
+        constexpr int GK = BKO == 128 ? 8 : 4;
+        const int per_group = GK * a.tiles_n;
+        const int g = t / per_group;
+        const int first_k = g * GK;
+        const int gsz = (a.tiles_k - first_k < GK) ? (a.tiles_k - first_k) : GK;
+        const int in_g = t - g * per_group;
+        tile_k = first_k + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
     const int k0 = tile_k * BKO, n0 = tile_n * BN;
     const int m_begin = split * a.rows_per_split;
     int m_end = m_begin + a.rows_per_split;
     if (m_end > a.M) m_end = a.M;
-    const int nsteps = (m_end > m_begin) ? (m_end - m_begin + kBMR - 1) / kBMR : 0;
+    const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BMR - 1) / BMR : 0;
 
-    if (threadIdx.x >= 256) {
+    if (threadIdx.x >= CTHREADS) {
         // ================================ PRODUCER wavefronts ================================
-        const int tid = threadIdx.x - 256;
+        const int tid = threadIdx.x - CTHREADS;
         const int x_kq = tid % XQ, x_r0 = tid / XQ;
         const int k = k0 + x_kq * 4;
         const bool kvalid = k < a.K;
@@ -378,38 +468,42 @@ __global__ void __launch_bounds__(512, 4) wgrad_bf16_kernel(WgradBf16Args a) {
         const int y_n = n0 + y_nq * 4;
         const bool nvalid = y_n < a.N;
         float4 rx[X_N], ry[Y_N];
-        auto load_tile = [&](int mb) {
-#pragma unroll
-            for (int j = 0; j < X_N; j++) {
-                const int m = mb + x_r0 + j * X_RSTEP;
-                const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
-                const int ow = m - (int)t2 * a.W;
-                const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
-                const int ih = oh + dh, iw = ow + dw;
-                const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-                rx[j] = buf_ld4(xr, ((unsigned)(m * a.Cin + x_off) * 4u) | (ok ? 0u : kOOB));
-            }
-#pragma unroll
-            for (int j = 0; j < Y_N; j++) {
-                const int m = mb + y_r0 + j * Y_RSTEP;
-                ry[j] = buf_ld4(yr, ((unsigned)(m * a.N + y_n) * 4u) | ((nvalid && m < m_end) ? 0u : kOOB));
-            }
+        auto load_x = [&](int mb, int j) {
+            const int m = mb + x_r0 + j * X_RSTEP;
+            const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
+            const int ow = m - (int)t2 * a.W;
+            const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
+            const int ih = oh + dh, iw = ow + dw;
+            const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            rx[j] = buf_ld4(xr, ((unsigned)(m * a.Cin + x_off) * 4u) | (ok ? 0u : kOOB));
         };
-        auto store_tile = [&](int buf) {
-#pragma unroll
-            for (int j = 0; j < X_N; j++)
-                *reinterpret_cast<uint2 *>(Xs + buf * TILE + (x_r0 + j * X_RSTEP) * kPitchW + x_kq * 8) = cvt4(rx[j]);
-#pragma unroll
-            for (int j = 0; j < Y_N; j++)
-                *reinterpret_cast<uint2 *>(Ys + buf * TILE + (y_r0 + j * Y_RSTEP) * kPitchW + y_nq * 8) = cvt4(ry[j]);
+        auto load_y = [&](int mb, int j) {
+            const int m = mb + y_r0 + j * Y_RSTEP;
+            ry[j] = buf_ld4(yr, ((unsigned)(m * a.N + y_n) * 4u) | ((nvalid && m < m_end) ? 0u : kOOB));
         };
-        load_tile(m_begin);
-        store_tile(0);
-        load_tile(m_begin + kBMR);  // rows >= m_end are zero-filled by the range check
+        auto store_x = [&](int buf, int j) {
+            *reinterpret_cast<uint2 *>(Xs + buf * TILE_X + (x_r0 + j * X_RSTEP) * PX + x_kq * 8) = cvt4(rx[j]);
+        };
+        auto store_y = [&](int buf, int j) {
+            *reinterpret_cast<uint2 *>(Ys + buf * TILE_Y + (y_r0 + j * Y_RSTEP) * PY + y_nq * 8) = cvt4(ry[j]);
+        };
+#pragma unroll
+        for (int j = 0; j < X_N; j++) load_x(m_begin, j);
+#pragma unroll
+        for (int j = 0; j < Y_N; j++) load_y(m_begin, j);
+#pragma unroll
+        for (int j = 0; j < X_N; j++) { store_x(0, j); load_x(m_begin + BMR, j); }  // rows >= m_end: zero-filled
+#pragma unroll
+        for (int j = 0; j < Y_N; j++) { store_y(0, j); load_y(m_begin + BMR, j); }
         __syncthreads();
+        // steady state: park register j in LDS, re-arm it with the load of the step after next (loads stay in flight)
         for (int st = 0; st < nsteps; st++) {
-            store_tile((st + 1) & 1);
-            load_tile(m_begin + (st + 2) * kBMR);
+            const int buf = (st + 1) & 1;
+            const int mb = m_begin + (st + 2) * BMR;
+#pragma unroll
+            for (int j = 0; j < X_N; j++) { store_x(buf, j); load_x(mb, j); }
+#pragma unroll
+            for (int j = 0; j < Y_N; j++) { store_y(buf, j); load_y(mb, j); }
             __syncthreads();
         }
         return;
@@ -423,7 +517,8 @@ __global__ void __launch_bounds__(512, 4) wgrad_bf16_kernel(WgradBf16Args a) {
     const int wk = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
     const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int frag_off = ((grp >> 1) * 8 + q) * kPitchW + ((grp & 1) * 16 + p * 4) * 2;  // bytes; + 4 pixel rows for the upper half
+    const int frow = (grp >> 1) * 8 + q;              // pixel row inside a 16-pixel MFMA step (+4 for the upper half)
+    const int fcol = ((grp & 1) * 16 + p * 4) * 2;    // byte offset of the lane's 4 columns
     f32x16 acc[TK][TN];
 #pragma unroll
     for (int i = 0; i < TK; i++)
@@ -434,29 +529,25 @@ __global__ void __launch_bounds__(512, 4) wgrad_bf16_kernel(WgradBf16Args a) {
     __syncthreads();
     for (int st = 0; st < nsteps; st++) {
         const int cur = st & 1;
-        const char *xs = Xs + cur * TILE + frag_off + (wk * WK) * 2;
-        const char *ys = Ys + cur * TILE + frag_off + (wn * WN) * 2;
-        bf16x8 av[2][TK], bv[2][TN];
+        const char *xs = Xs + cur * TILE_X + frow * PX + fcol + (wk * WK) * 2;
+        const char *ys = Ys + cur * TILE_Y + frow * PY + fcol + (wn * WN) * 2;
+        bf16x8 av[2][TK], bv[TN];
 #pragma unroll
-        for (int i = 0; i < TK; i++) av[0][i] = tr_frag(xs + i * 64, xs + i * 64 + 4 * kPitchW);
+        for (int i = 0; i < TK; i++) av[0][i] = tr_frag(xs + i * 64, xs + i * 64 + 4 * PX);
 #pragma unroll
-        for (int j = 0; j < TN; j++) bv[0][j] = tr_frag(ys + j * 64, ys + j * 64 + 4 * kPitchW);
+        for (int ms = 0; ms < BMR / 16; ms++) {
 #pragma unroll
-        for (int ms = 0; ms < kBMR / 16; ms++) {
-            if (ms + 1 < kBMR / 16) {
-                const int o = (ms + 1) * 16 * kPitchW;
+            for (int j = 0; j < TN; j++) bv[j] = tr_frag(ys + ms * 16 * PY + j * 64, ys + ms * 16 * PY + j * 64 + 4 * PY);
+            if (ms + 1 < BMR / 16) {
+                const int o = (ms + 1) * 16 * PX;
 #pragma unroll
-                for (int i = 0; i < TK; i++) av[(ms + 1) & 1][i] = tr_frag(xs + o + i * 64, xs + o + i * 64 + 4 * kPitchW);
-#pragma unroll
-                for (int j = 0; j < TN; j++) bv[(ms + 1) & 1][j] = tr_frag(ys + o + j * 64, ys + o + j * 64 + 4 * kPitchW);
+                for (int i = 0; i < TK; i++) av[(ms + 1) & 1][i] = tr_frag(xs + o + i * 64, xs + o + i * 64 + 4 * PX);
             }
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TK; i++)
+            for (int j = 0; j < TN; j++)
 #pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ms & 1][i], bv[ms & 1][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < TK; i++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ms & 1][i], bv[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -476,25 +567,32 @@ __global__ void __launch_bounds__(512, 4) wgrad_bf16_kernel(WgradBf16Args a) {
 }
 
 struct PlanW {
-    int bn, tiles_k, tiles_n, splits, rows_per_split;
+    int bko, bn, tiles_k, tiles_n, splits, rows_per_split;
 };
 
-// Split-M plan as in conv_wgrad.hip, with the bf16 kernel's rate.
+// Split-M plan as in conv_wgrad.hip, with the bf16 kernels' rates; the 256x256 filter tile when the filter is at
+// least that large (conv3_x .. fc7).
 PlanW make_plan_bf16(const emadapt_conv_desc *d) {
     PlanW p;
     const long long M = (long long)d->B * d->H * d->W;
     const int K = d->KH * d->KW * d->Cin;
-    p.bn = d->Cout <= 64 ? 64 : 128;
-    p.tiles_k = (int)ceil_div(K, 128);
+    const char *force = getenv("EMADAPT_BF16_TILE");  // 128|256, read per call (parity tests run both)
+    bool big = K >= 256 && d->Cout >= 256;
+    if (force) big = atoi(force) == 256;
+    p.bko = big ? 256 : 128;
+    p.bn = big ? 256 : (d->Cout <= 64 ? 64 : 128);
+    p.tiles_k = (int)ceil_div(K, p.bko);
     p.tiles_n = (int)ceil_div(d->Cout, p.bn);
     const long long tiles = (long long)p.tiles_k * p.tiles_n;
-    const double t_kernel = 2.0 * (double)M * (p.tiles_k * 128.0) * (p.tiles_n * (double)p.bn) / 400e12;
+    const double slots = big ? 256.0 : 512.0;
+    const double rate = big ? 800e12 : 450e12;
+    const double t_kernel = 2.0 * (double)M * (p.tiles_k * (double)p.bko) * (p.tiles_n * (double)p.bn) / rate;
     const double kn_bytes = (double)K * d->Cout * 4.0;
     long long best = 1;
     double best_t = 1e30;
     const long long max_s = ceil_div(M, 512) < 2048 ? ceil_div(M, 512) : 2048;
     for (long long s = 1; s <= max_s; s++) {
-        const double rounds = (double)tiles * s / 512.0;
+        const double rounds = (double)tiles * s / slots;
         const double eff = rounds / (double)(long long)(rounds + 0.999999);
         double t = t_kernel / eff + 2e-6 * (double)(long long)(rounds + 0.999999);
         if (s > 1) t += (double)(s + 1) * kn_bytes / 3e12 + 3e-6;
@@ -502,7 +600,7 @@ PlanW make_plan_bf16(const emadapt_conv_desc *d) {
         if (rounds > 24.0) break;
     }
     long long rps = ceil_div(M, best);
-    rps = ceil_div(rps, kBMR) * kBMR;
+    rps = ceil_div(rps, kRowsUnit) * kRowsUnit;
     p.rows_per_split = (int)rps;
     p.splits = (int)ceil_div(M, rps);
     return p;
@@ -516,18 +614,19 @@ int check_desc_wgrad(const emadapt_conv_desc *d) {
     return EMADAPT_OK;
 }
 
-template <int BN>
+template <int BKO, int BN, int BMR>
 int launch_wgrad_bf16(const WgradBf16Args &a, hipStream_t stream) {
-    constexpr size_t lds = 4 * kBMR * kPitchW;
+    constexpr size_t lds = 2 * BMR * (BKO * 2 + 64 + BN * 2 + 64);
+    constexpr int threads = (BKO / 64 * 2 + 4) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<BN>),
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<BKO, BN, BMR>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((wgrad_bf16_kernel<BN>), dim3((unsigned)nblk), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((wgrad_bf16_kernel<BKO, BN, BMR>), dim3((unsigned)nblk), dim3(threads), lds, stream, a);
     return launch_status();
 }
 
@@ -643,7 +742,9 @@ int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const float *x, const fl
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    rc = (p.bn == 64) ? launch_wgrad_bf16<64>(a, stream) : launch_wgrad_bf16<128>(a, stream);
+    rc = p.bko == 256 ? launch_wgrad_bf16<256, 256, 32>(a, stream)
+       : p.bn == 64  ? launch_wgrad_bf16<128, 64, 64>(a, stream)
+                     : launch_wgrad_bf16<128, 128, 64>(a, stream);
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
     return rc;

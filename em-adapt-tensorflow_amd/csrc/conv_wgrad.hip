@@ -71,11 +71,28 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave >> 1, wn = wave & 1;
 
-    int bid = blockIdx.x;
-    const int split = bid % a.splits;
-    bid /= a.splits;
-    const int tile_n = bid % a.tiles_n;
-    const int tile_k = bid / a.tiles_n;
+    // XCD-aware block order (blocks b, b+8, .. share an XCD and its L2): each XCD takes a contiguous run of logical
+    // blocks in split-major order -- so the workgroups of one XCD stream the SAME pixel range -- and inside a split
+    // the filter tiles go in groups of 8 k-tiles x all n-tiles (k fastest): 64 co-resident workgroups then share
+    // 8 x-panels and 8 dy-panels instead of 2 and 32.
+    int tile_k, tile_n, split;
+    {
+        const int ntile = a.tiles_k * a.tiles_n;
+        const int nblk = ntile * a.splits;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        split = t / ntile;
+        t -= split * ntile;
+        constexpr int GK = 8;
+        const int per_group = GK * a.tiles_n;
+        const int g = t / per_group;
+        const int first_k = g * GK;
+        const int gsz = (a.tiles_k - first_k < GK) ? (a.tiles_k - first_k) : GK;
+        const int in_g = t - g * per_group;
+        tile_k = first_k + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
     const int k0 = tile_k * BKO, n0 = tile_n * BN;
     const int m_begin = split * a.rows_per_split;
     int m_end = m_begin + a.rows_per_split;
@@ -232,11 +249,28 @@ __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
     float *Xs = lds;                    // [2][BMR][BKO]
     float *Ys = lds + 2 * BMR * BKO;    // [2][BMR][BN]
 
-    int bid = blockIdx.x;
-    const int split = bid % a.splits;
-    bid /= a.splits;
-    const int tile_n = bid % a.tiles_n;
-    const int tile_k = bid / a.tiles_n;
+    // XCD-aware block order (blocks b, b+8, .. share an XCD and its L2): each XCD takes a contiguous run of logical
+    // blocks in split-major order -- so the workgroups of one XCD stream the SAME pixel range -- and inside a split
+    // the filter tiles go in groups of 8 k-tiles x all n-tiles (k fastest): 64 co-resident workgroups then share
+    // 8 x-panels and 8 dy-panels instead of 2 and 32.
+    int tile_k, tile_n, split;
+    {
+        const int ntile = a.tiles_k * a.tiles_n;
+        const int nblk = ntile * a.splits;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        split = t / ntile;
+        t -= split * ntile;
+        constexpr int GK = 8;
+        const int per_group = GK * a.tiles_n;
+        const int g = t / per_group;
+        const int first_k = g * GK;
+        const int gsz = (a.tiles_k - first_k < GK) ? (a.tiles_k - first_k) : GK;
+        const int in_g = t - g * per_group;
+        tile_k = first_k + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
     const int k0 = tile_k * BKO, n0 = tile_n * BN;
     const int m_begin = split * a.rows_per_split;
     int m_end = m_begin + a.rows_per_split;

@@ -32,7 +32,7 @@ def layers(size=321, C=21, preset="ref", width=64):
 
 
 def short(name):
-    m = re.search(r"(igemm_ws_kernel<\w+>|wgrad_ws_kernel<\d+>|igemm_kernel<[^>]*>|wgrad_kernel<[^>]*>)", name)
+    m = re.search(r"(igemm_ws_kernel<\w+>|wgrad_ws_kernel<\d+>|igemm_kernel<[^>]*>|wgrad_kernel<[^>]*>|igemm_bf16_kernel|wgrad_bf16_kernel<\d+>)", name)
     return m.group(1) if m else name[:40]
 
 
@@ -43,7 +43,7 @@ def main():
     C = int(sys.argv[4]) if len(sys.argv) > 4 else 21
     preset = sys.argv[5] if len(sys.argv) > 5 else "ref"
     L = layers(size, C, preset)
-    rows = [r for r in csv.DictReader(open(path)) if re.search(r"igemm(_ws)?_kernel|wgrad(_ws)?_kernel", r["Kernel_Name"])]
+    rows = [r for r in csv.DictReader(open(path)) if re.search(r"igemm(_ws|_bf16)?_kernel|wgrad(_ws|_bf16)?_kernel", r["Kernel_Name"])]
     # group "256x256 main + igemm_ws tail" pairs into one logical launch
     groups = []
     i = 0
