@@ -65,15 +65,20 @@ PROTOTYPES = {
     "emadapt_conv_dgrad": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_float, _vp, c_size_t, _vp]),
     "emadapt_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "emadapt_conv_wgrad": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_size_t, _vp]),
+    "emadapt_maxpool_fwd_dt": (c_int, [_vp, c_int, c_int, c_int, c_int, c_int, c_int, _vp, _vp, _vp]),
+    "emadapt_maxpool_bwd_dt": (c_int, [_vp, _vp, _vp, c_int, c_int, c_int, c_int, c_int, c_int, _vp, _vp]),
+    "emadapt_bias_grad_dt": (c_int, [_vp, c_int, c_int64, c_int, _vp, _vp, c_size_t, _vp]),
+    "emadapt_softmax_ce_dt": (c_int, [_vp, c_int64, _vp, c_int64, c_int, c_float, _vp, c_int, _vp, _vp, c_size_t, _vp]),
     "emadapt_weights_bf16_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "emadapt_weights_to_bf16": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "emadapt_conv_fwd_bf16_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
-    "emadapt_conv_fwd_bf16": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_int, c_float, _vp, c_uint64, _vp,
-                                      c_size_t, _vp]),
+    "emadapt_conv_fwd_bf16": (c_int, [POINTER(ConvDesc), _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_float, _vp, c_uint64,
+                                      _vp, c_size_t, _vp]),
     "emadapt_conv_dgrad_bf16_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
-    "emadapt_conv_dgrad_bf16": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_float, _vp, c_size_t, _vp]),
+    "emadapt_conv_dgrad_bf16": (c_int, [POINTER(ConvDesc), _vp, c_int, _vp, _vp, c_int, _vp, c_float, _vp, c_size_t,
+                                        _vp]),
     "emadapt_conv_wgrad_bf16_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
-    "emadapt_conv_wgrad_bf16": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_size_t, _vp]),
+    "emadapt_conv_wgrad_bf16": (c_int, [POINTER(ConvDesc), _vp, c_int, _vp, c_int, _vp, _vp, c_size_t, _vp]),
     "emadapt_bias_grad_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "emadapt_bias_grad": (c_int, [_vp, c_int64, c_int, _vp, _vp, c_size_t, _vp]),
     "emadapt_maxpool_fwd": (c_int, [_vp, c_int, c_int, c_int, c_int, c_int, _vp, _vp, _vp]),

@@ -87,16 +87,65 @@ __global__ void __launch_bounds__(256) weights_to_bf16_kernel(const float *__res
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kPitchG = 144;  // bytes per LDS row of 64 bf16 (+8 pad)
 
-template <int BM, int BN, int WN>
+// bias / ReLU / dropout, or the ReLU-gradient gate (stored activation, bf16 when GBF), on one output element.
+template <bool GBF>
+__device__ __forceinline__ float epilogue_t(const IgemmArgs &a, float v, int col, long long o) {
+    if (a.epi != EMADAPT_EPI_NONE && a.bias) v += a.bias[col];
+    if (a.epi == EMADAPT_EPI_BIAS_RELU) {
+        v = v > 0.f ? v : 0.f;
+        if (a.keep < 1.0f) {
+            const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
+            v = kp ? v / a.keep : 0.f;
+        }
+    }
+    if (a.gate) {
+        const float g = GBF ? (float)reinterpret_cast<const __bf16 *>(a.gate)[o] : a.gate[o];
+        v = g > 0.f ? v * a.scale : 0.f;
+    }
+    return v;
+}
+
+template <bool YBF>
+__device__ __forceinline__ void store_out(const IgemmArgs &a, long long o, float v) {
+    if constexpr (YBF) reinterpret_cast<__bf16 *>(a.y)[o] = (__bf16)v;
+    else a.y[o] = v;
+}
+
+// split-K second stage for the bf16-storage variants (the fp32-storage one is splitk_epilogue_kernel).
+template <bool YBF>
+__global__ void __launch_bounds__(256) splitk_epilogue_t_kernel(IgemmArgs a) {
+    const long long mn = (long long)(a.m_end - a.m_begin) * a.N;
+    const long long n4 = mn / 4;
+    const long long o0 = (long long)a.m_begin * a.N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 v = *reinterpret_cast<const float4 *>(a.slab + i * 4);
+        for (int sp = 1; sp < a.splits; sp++) {
+            const float4 u = *reinterpret_cast<const float4 *>(a.slab + sp * mn + i * 4);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        const long long o = o0 + i * 4;
+        const int col = (int)(o % a.N);
+        v.x = epilogue_t<YBF>(a, v.x, col + 0, o + 0);
+        v.y = epilogue_t<YBF>(a, v.y, col + 1, o + 1);
+        v.z = epilogue_t<YBF>(a, v.z, col + 2, o + 2);
+        v.w = epilogue_t<YBF>(a, v.w, col + 3, o + 3);
+        if constexpr (YBF) *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(a.y) + o) = cvt4(v);
+        else *reinterpret_cast<float4 *>(a.y + o) = v;
+    }
+}
+
+// Storage types: XBF = the gathered activation (x, or dy for the data gradient) is bf16 in memory (Cx % 8 == 0; 16-byte
+// loads carry 8 channels and go to LDS unconverted); YBF = the output (and the gate of the data gradient) is bf16.
+template <int BM, int BN, int WN, bool XBF, bool YBF>
 __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 4 : 3) igemm_bf16_kernel(IgemmArgs a, int Cxp) {
     constexpr int BK = 64, WM = 64;
     constexpr int WAVES_N = BN / WN;
     constexpr int CTHREADS = (BM / WM) * WAVES_N * 64;  // consumer threads; the 256 producer threads follow
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int KQ = BK / 4;             // 16 fp32 quads per A row
-    constexpr int A_RSTEP = 256 / KQ;      // 16 rows per pass of the producers
+    constexpr int KC = BK / 8;             // 8 bf16 chunks (16 B) per row
+    constexpr int KQ = XBF ? KC : BK / 4;  // 16-byte pieces per A row: 8 bf16 chunks or 16 fp32 quads
+    constexpr int A_RSTEP = 256 / KQ;      // rows per pass of the producers
     constexpr int A_N = BM / A_RSTEP;      // A loads per producer thread and K step
-    constexpr int KC = BK / 8;             // 8 bf16 chunks (16 B) per B row
     constexpr int B_RSTEP = 256 / KC;      // 32
     constexpr int B_N = BN / B_RSTEP;
     constexpr int TILE_A = BM * kPitchG, TILE_B = BN * kPitchG;  // bytes per operand tile
@@ -150,8 +199,10 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
         const int a_base0 = (m0 + a_r0) * a.Cx;
         const int a_rstride = A_RSTEP * a.Cx;
         const int b_kc = tid % KC, b_r0 = tid / KC;
-        float4 ra[A_N];
+        u32x4 ra[A_N];
         u32x4 rb[B_N];
+        constexpr int AEL = XBF ? 8 : 4;   // channels per A piece
+        constexpr unsigned ABY = XBF ? 2u : 4u;
 
         // per-K-step addressing, shared by the loads of a step
         int toff, dh, dw;
@@ -165,10 +216,10 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
                 tap = (unsigned)kt - chunk * (unsigned)a.ntaps;
                 if ((int)chunk * BK >= Cxp) tap = (unsigned)a.ntaps;
                 tapb = tap;
-                c = (int)chunk * BK + a_kq * 4;
+                c = (int)chunk * BK + a_kq * AEL;
                 cb = (int)chunk * BK + b_kc * 8;
             } else {
-                const unsigned k = (unsigned)(kt * BK + a_kq * 4);
+                const unsigned k = (unsigned)(kt * BK + a_kq * AEL);
                 tap = __umulhi(k, a.magic_cx);
                 c = (int)(k - tap * (unsigned)Cxp);
                 const unsigned kb = (unsigned)(kt * BK + b_kc * 8);
@@ -187,7 +238,7 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
         auto load_a = [&](int j) {
             const int ih = (int)(a_hw[j] >> 16) + dh, iw = (int)(a_hw[j] & 0xffffu) + dw;
             const bool ok = kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            ra[j] = buf_ld4(xr, ((unsigned)(toff + j * a_rstride) * 4u) | (ok ? 0u : kOOB));
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(((unsigned)(toff + j * a_rstride) * ABY) | (ok ? 0u : kOOB)), 0, 0);
         };
         auto load_b = [&](int j) {
             const int n = n0 + b_r0 + j * B_RSTEP;
@@ -195,7 +246,13 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
             rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(off | ((bvalid && n < a.N) ? 0u : kOOB)), 0, 0);
         };
         auto store_a = [&](int buf, int j) {
-            *reinterpret_cast<uint2 *>(As + buf * TILE_A + (a_r0 + j * A_RSTEP) * kPitchG + a_kq * 8) = cvt4(ra[j]);
+            if constexpr (XBF) {
+                *reinterpret_cast<u32x4 *>(As + buf * TILE_A + (a_r0 + j * A_RSTEP) * kPitchG + a_kq * 16) = ra[j];
+            } else {
+                const float4 f = make_float4(__uint_as_float(ra[j].x), __uint_as_float(ra[j].y), __uint_as_float(ra[j].z),
+                                             __uint_as_float(ra[j].w));
+                *reinterpret_cast<uint2 *>(As + buf * TILE_A + (a_r0 + j * A_RSTEP) * kPitchG + a_kq * 8) = cvt4(f);
+            }
         };
         auto store_b = [&](int buf, int j) {
             *reinterpret_cast<u32x4 *>(Bs + buf * TILE_B + (b_r0 + j * B_RSTEP) * kPitchG + b_kc * 16) = rb[j];
@@ -305,7 +362,7 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
                 const float v = acc[i][j][r];
                 if (col_ok && row < a.m_end) {
                     if (slab) slab[o] = v;
-                    else a.y[o] = epilogue(a, v, col, o);
+                    else store_out<YBF>(a, o, epilogue_t<YBF>(a, v, col, o));
                 }
             }
         }
@@ -344,13 +401,13 @@ size_t igemm_bf16_workspace_bytes(const IgemmArgs &a) {
     return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
 }
 
-template <int BM, int BN, int WN>
+template <int BM, int BN, int WN, bool XBF, bool YBF>
 int launch_igemm_bf16(IgemmArgs &a, int Cxp, hipStream_t stream) {
     constexpr size_t lds = 2 * (BM + BN) * kPitchG;
     constexpr int threads = ((BM / 64) * (BN / WN) + 4) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_bf16_kernel<BM, BN, WN>),
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_bf16_kernel<BM, BN, WN, XBF, YBF>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -358,10 +415,16 @@ int launch_igemm_bf16(IgemmArgs &a, int Cxp, hipStream_t stream) {
     a.tiles_n = (int)ceil_div(a.N, BN);
     const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WN>), dim3((unsigned)nblk), dim3(threads), lds, stream, a, Cxp);
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WN, XBF, YBF>), dim3((unsigned)nblk), dim3(threads), lds, stream, a, Cxp);
+    int rc = launch_status();
+    if (rc || a.splits <= 1) return rc;
+    long long g = ((long long)a.M * a.N / 4 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(splitk_epilogue_t_kernel<YBF>, dim3((unsigned)g), dim3(256), 0, stream, a);
     return launch_status();
 }
 
+template <bool XBF, bool YBF>
 int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     PlanG p = plan_bf16(a);
     if (p.splits > 1 && (!workspace || workspace_bytes < igemm_bf16_workspace_bytes(a))) p.splits = 1;
@@ -371,12 +434,21 @@ int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace
     a.m_end = a.M;
     a.splits = p.splits;
     a.slab = p.splits > 1 ? static_cast<float *>(workspace) : nullptr;
-    int rc = p.big ? launch_igemm_bf16<256, 256, 128>(a, Cxp, stream) : launch_igemm_bf16<128, 128, 64>(a, Cxp, stream);
-    if (rc || a.splits <= 1) return rc;
-    long long g = ((long long)a.M * a.N / 4 + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
-    return launch_status();
+    return p.big ? launch_igemm_bf16<256, 256, 128, XBF, YBF>(a, Cxp, stream)
+                 : launch_igemm_bf16<128, 128, 64, XBF, YBF>(a, Cxp, stream);
+}
+
+// storage-type dispatch: (x, y) in {f32, bf16}^2
+int dispatch_igemm_bf16_dt(IgemmArgs &a, int Cxp, int x_bf16, int y_bf16, void *workspace, size_t workspace_bytes,
+                           hipStream_t stream) {
+    if (x_bf16) {
+        if (a.Cx % 8 != 0) return EMADAPT_ERR_UNSUPPORTED;  // 16-byte loads of 8 bf16 channels
+        a.x_bytes = (unsigned)((long long)a.M * a.Cx * 2);
+        return y_bf16 ? dispatch_igemm_bf16<true, true>(a, Cxp, workspace, workspace_bytes, stream)
+                      : dispatch_igemm_bf16<true, false>(a, Cxp, workspace, workspace_bytes, stream);
+    }
+    return y_bf16 ? dispatch_igemm_bf16<false, true>(a, Cxp, workspace, workspace_bytes, stream)
+                  : dispatch_igemm_bf16<false, false>(a, Cxp, workspace, workspace_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -408,13 +480,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char *p0, const char *p1) {
 // pixel rows of one transposing read sit 16 banks apart.
 //   128 x 64|128, 64 px : 4 + 4 waves, 2 workgroups/CU
 //   256 x 256,    32 px : 8 + 4 waves, 1 workgroup/CU (168 registers/wave) -- half the operand bytes per FLOP
-template <int BKO, int BN, int BMR>
+// Storage types: XBF / DBF = x / dy are bf16 in memory (Cin resp. Cout % 8 == 0; 16-byte loads carry 8 channels).
+template <int BKO, int BN, int BMR, bool XBF, bool DBF>
 __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) wgrad_bf16_kernel(WgradBf16Args a) {
     constexpr int WK = 64, WN = BN / 2;
     constexpr int TK = WK / 32, TN = WN / 32;
     constexpr int CTHREADS = (BKO / WK) * 2 * 64;
-    constexpr int XQ = BKO / 4, X_RSTEP = 256 / XQ, X_N = BMR / X_RSTEP;
-    constexpr int YQ = BN / 4, Y_RSTEP = 256 / YQ, Y_N = BMR / Y_RSTEP;
+    constexpr int XE = XBF ? 8 : 4, YE = DBF ? 8 : 4;  // channels per 16-byte piece
+    constexpr int XQ = BKO / XE, X_RSTEP = 256 / XQ, X_N = BMR / X_RSTEP;
+    constexpr int YQ = BN / YE, Y_RSTEP = 256 / YQ, Y_N = BMR / Y_RSTEP;
     constexpr int PX = BKO * 2 + 64, PY = BN * 2 + 64;  // LDS row pitches in bytes
     constexpr int TILE_X = BMR * PX, TILE_Y = BMR * PY;
     static_assert(X_N >= 1 && Y_N >= 1, "tile too small for the producers");
@@ -454,7 +528,7 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
         // ================================ PRODUCER wavefronts ================================
         const int tid = threadIdx.x - CTHREADS;
         const int x_kq = tid % XQ, x_r0 = tid / XQ;
-        const int k = k0 + x_kq * 4;
+        const int k = k0 + x_kq * XE;
         const bool kvalid = k < a.K;
         const int tap = kvalid ? k / a.Cin : 0;
         const int c = kvalid ? k % a.Cin : 0;
@@ -465,9 +539,12 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dy), 0, (int)a.y_bytes, 0x00020000);
         constexpr unsigned kOOB = 0x80000000u;
         const int y_nq = tid % YQ, y_r0 = tid / YQ;
-        const int y_n = n0 + y_nq * 4;
+        const int y_n = n0 + y_nq * YE;
         const bool nvalid = y_n < a.N;
-        float4 rx[X_N], ry[Y_N];
+        u32x4 rx[X_N], ry[Y_N];
+        auto as_f4 = [](const u32x4 &v) {
+            return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        };
         auto load_x = [&](int mb, int j) {
             const int m = mb + x_r0 + j * X_RSTEP;
             const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
@@ -475,17 +552,21 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
             const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
             const int ih = oh + dh, iw = ow + dw;
             const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            rx[j] = buf_ld4(xr, ((unsigned)(m * a.Cin + x_off) * 4u) | (ok ? 0u : kOOB));
+            rx[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(((unsigned)(m * a.Cin + x_off) * (XBF ? 2u : 4u)) | (ok ? 0u : kOOB)), 0, 0);
         };
         auto load_y = [&](int mb, int j) {
             const int m = mb + y_r0 + j * Y_RSTEP;
-            ry[j] = buf_ld4(yr, ((unsigned)(m * a.N + y_n) * 4u) | ((nvalid && m < m_end) ? 0u : kOOB));
+            ry[j] = __builtin_amdgcn_raw_buffer_load_b128(yr, (int)(((unsigned)(m * a.N + y_n) * (DBF ? 2u : 4u)) | ((nvalid && m < m_end) ? 0u : kOOB)), 0, 0);
         };
         auto store_x = [&](int buf, int j) {
-            *reinterpret_cast<uint2 *>(Xs + buf * TILE_X + (x_r0 + j * X_RSTEP) * PX + x_kq * 8) = cvt4(rx[j]);
+            char *d = Xs + buf * TILE_X + (x_r0 + j * X_RSTEP) * PX + x_kq * (XE * 2);
+            if constexpr (XBF) *reinterpret_cast<u32x4 *>(d) = rx[j];
+            else *reinterpret_cast<uint2 *>(d) = cvt4(as_f4(rx[j]));
         };
         auto store_y = [&](int buf, int j) {
-            *reinterpret_cast<uint2 *>(Ys + buf * TILE_Y + (y_r0 + j * Y_RSTEP) * PY + y_nq * 8) = cvt4(ry[j]);
+            char *d = Ys + buf * TILE_Y + (y_r0 + j * Y_RSTEP) * PY + y_nq * (YE * 2);
+            if constexpr (DBF) *reinterpret_cast<u32x4 *>(d) = ry[j];
+            else *reinterpret_cast<uint2 *>(d) = cvt4(as_f4(ry[j]));
         };
 #pragma unroll
         for (int j = 0; j < X_N; j++) load_x(m_begin, j);
@@ -614,20 +695,27 @@ int check_desc_wgrad(const emadapt_conv_desc *d) {
     return EMADAPT_OK;
 }
 
-template <int BKO, int BN, int BMR>
+template <int BKO, int BN, int BMR, bool XBF, bool DBF>
 int launch_wgrad_bf16(const WgradBf16Args &a, hipStream_t stream) {
     constexpr size_t lds = 2 * BMR * (BKO * 2 + 64 + BN * 2 + 64);
     constexpr int threads = (BKO / 64 * 2 + 4) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<BKO, BN, BMR>),
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<BKO, BN, BMR, XBF, DBF>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((wgrad_bf16_kernel<BKO, BN, BMR>), dim3((unsigned)nblk), dim3(threads), lds, stream, a);
+    hipLaunchKernelGGL((wgrad_bf16_kernel<BKO, BN, BMR, XBF, DBF>), dim3((unsigned)nblk), dim3(threads), lds, stream, a);
     return launch_status();
+}
+
+template <bool XBF, bool DBF>
+int launch_wgrad_bf16_plan(const PlanW &p, const WgradBf16Args &a, hipStream_t stream) {
+    return p.bko == 256 ? launch_wgrad_bf16<256, 256, 32, XBF, DBF>(a, stream)
+         : p.bn == 64   ? launch_wgrad_bf16<128, 64, 64, XBF, DBF>(a, stream)
+                        : launch_wgrad_bf16<128, 128, 64, XBF, DBF>(a, stream);
 }
 
 }  // namespace
@@ -671,12 +759,14 @@ size_t emadapt_conv_dgrad_bf16_workspace_bytes(const emadapt_conv_desc *d) {
     return igemm_bf16_workspace_bytes(a);
 }
 
-int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const float *x, const void *w_fwd_bf16, const float *bias,
-                          float *y, int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed,
-                          void *workspace, size_t workspace_bytes, void *stream_) {
+int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *w_fwd_bf16,
+                          const float *bias, void *y, int y_dtype, int epilogue, float keep_prob,
+                          const uint8_t *drop_mask, uint64_t drop_seed, void *workspace, size_t workspace_bytes,
+                          void *stream_) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !w_fwd_bf16 || !y) return EMADAPT_ERR_INVALID;
+    if ((x_dtype | y_dtype) & ~1) return EMADAPT_ERR_INVALID;
     if (epilogue < EMADAPT_EPI_NONE || epilogue > EMADAPT_EPI_BIAS_RELU) return EMADAPT_ERR_INVALID;
     if (epilogue != EMADAPT_EPI_NONE && !bias) return EMADAPT_ERR_INVALID;
     if (!(keep_prob > 0.f) || keep_prob > 1.f) return EMADAPT_ERR_INVALID;
@@ -686,29 +776,32 @@ int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const float *x, const void
     IgemmArgs a;
     int Cxp;
     fill_geometry_bf16(a, Cxp, d, false);
-    a.x = x; a.w = static_cast<const float *>(w_fwd_bf16); a.y = y; a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
+    a.x = static_cast<const float *>(x); a.w = static_cast<const float *>(w_fwd_bf16); a.y = static_cast<float *>(y);
+    a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
     a.epi = epilogue; a.scale = 1.f; a.keep = keep_prob; a.seed = drop_seed;
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N, 0.0, stream);
-    return dispatch_igemm_bf16(a, Cxp, workspace, workspace_bytes, stream);
+    return dispatch_igemm_bf16_dt(a, Cxp, x_dtype, y_dtype, workspace, workspace_bytes, stream);
 }
 
-int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const float *dy, const void *w_dgrad_bf16, float *dx,
-                            const float *gate, float gate_scale, void *workspace, size_t workspace_bytes,
-                            void *stream_) {
+int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const void *dy, int dy_dtype, const void *w_dgrad_bf16,
+                            void *dx, int dx_dtype, const void *gate, float gate_scale, void *workspace,
+                            size_t workspace_bytes, void *stream_) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!dy || !w_dgrad_bf16 || !dx) return EMADAPT_ERR_INVALID;
+    if ((dy_dtype | dx_dtype) & ~1) return EMADAPT_ERR_INVALID;
     if (!aligned16(dy) || !aligned16(w_dgrad_bf16) || !aligned16(dx) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
     if (d->B == 0) return EMADAPT_OK;
     IgemmArgs a;
     int Cxp;
     fill_geometry_bf16(a, Cxp, d, true);
-    a.x = dy; a.w = static_cast<const float *>(w_dgrad_bf16); a.y = dx; a.bias = nullptr; a.gate = gate; a.mask = nullptr;
+    a.x = static_cast<const float *>(dy); a.w = static_cast<const float *>(w_dgrad_bf16); a.y = static_cast<float *>(dx);
+    a.bias = nullptr; a.gate = static_cast<const float *>(gate); a.mask = nullptr;
     a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; a.keep = 1.f; a.seed = 0;
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N, 0.0, stream);
-    return dispatch_igemm_bf16(a, Cxp, workspace, workspace_bytes, stream);
+    return dispatch_igemm_bf16_dt(a, Cxp, dy_dtype, dx_dtype, workspace, workspace_bytes, stream);
 }
 
 size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d) {
@@ -718,11 +811,13 @@ size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d) {
     return (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
 }
 
-int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, void *workspace,
-                            size_t workspace_bytes, void *stream_) {
+int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
+                            float *dw, void *workspace, size_t workspace_bytes, void *stream_) {
     int rc = check_desc_wgrad(d);
     if (rc) return rc;
     if (!x || !dy || !dw) return EMADAPT_ERR_INVALID;
+    if ((x_dtype | dy_dtype) & ~1) return EMADAPT_ERR_INVALID;
+    if ((x_dtype && d->Cin % 8 != 0) || (dy_dtype && d->Cout % 8 != 0)) return EMADAPT_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
     hipStream_t stream = as_stream(stream_);
     const long long KN = (long long)d->KH * d->KW * d->Cin * d->Cout;
@@ -734,17 +829,18 @@ int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const float *x, const fl
     if (p.splits > 1 && (!workspace || workspace_bytes < emadapt_conv_wgrad_bf16_workspace_bytes(d)))
         return EMADAPT_ERR_WORKSPACE;
     WgradBf16Args a;
-    a.x = x; a.dy = dy; a.out = p.splits > 1 ? static_cast<float *>(workspace) : dw;
+    a.x = static_cast<const float *>(x); a.dy = static_cast<const float *>(dy);
+    a.out = p.splits > 1 ? static_cast<float *>(workspace) : dw;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.N = d->Cout; a.KW = d->KW; a.dil = d->dil;
     a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
     a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cin;
     a.tiles_k = p.tiles_k; a.tiles_n = p.tiles_n; a.splits = p.splits; a.rows_per_split = p.rows_per_split;
-    a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
+    a.x_bytes = (unsigned)((long long)a.M * d->Cin * (x_dtype ? 2 : 4));
+    a.y_bytes = (unsigned)((long long)a.M * d->Cout * (dy_dtype ? 2 : 4));
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    rc = p.bko == 256 ? launch_wgrad_bf16<256, 256, 32>(a, stream)
-       : p.bn == 64  ? launch_wgrad_bf16<128, 64, 64>(a, stream)
-                     : launch_wgrad_bf16<128, 128, 64>(a, stream);
+    rc = x_dtype ? (dy_dtype ? launch_wgrad_bf16_plan<true, true>(p, a, stream) : launch_wgrad_bf16_plan<true, false>(p, a, stream))
+                 : (dy_dtype ? launch_wgrad_bf16_plan<false, true>(p, a, stream) : launch_wgrad_bf16_plan<false, false>(p, a, stream));
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
     return rc;

@@ -17,12 +17,26 @@ using namespace emadapt;
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
+// The same 4-channel accessors for bf16 storage (include/emadapt.h "Storage types"): 8-byte vectors, values widened
+// to fp32 in registers and rounded to nearest-even on the way out.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const __bf16 *p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4 *>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(__bf16 *p, float4 v) {
+    bf16x4 c;
+    c[0] = (__bf16)v.x; c[1] = (__bf16)v.y; c[2] = (__bf16)v.z; c[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4 *>(p) = c;
+}
+
 // ------------------------------------------------------------------------------------------
 // tf.nn.max_pool 3x3, SAME (deeplab.py:77,82)
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float *__restrict__ x, int B, int H, int W, int C4,
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ x, int B, int H, int W, int C4,
                                                         int stride, int OH, int OW, int pt, int pl,
-                                                        float *__restrict__ y, unsigned char *__restrict__ idx) {
+                                                        T *__restrict__ y, unsigned char *__restrict__ idx) {
     const long long n = (long long)B * OH * OW * C4;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
          t += (long long)gridDim.x * blockDim.x) {
@@ -56,11 +70,12 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float *__restric
 }
 
 // MaxPoolGrad (+ ReluGrad of the producing layer): gather form, one thread per input pixel x 4 channels.
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float *__restrict__ dy,
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ dy,
                                                         const unsigned char *__restrict__ idx,
-                                                        const float *__restrict__ gate, int B, int H, int W, int C4,
+                                                        const T *__restrict__ gate, int B, int H, int W, int C4,
                                                         int stride, int OH, int OW, int pt, int pl,
-                                                        float *__restrict__ dx) {
+                                                        T *__restrict__ dx) {
     const long long n = (long long)B * H * W * C4;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
          t += (long long)gridDim.x * blockDim.x) {
@@ -129,7 +144,8 @@ __global__ void __launch_bounds__(256) final_sum_kernel(const float *__restrict_
 // BiasAddGrad stage 1: partial[chunk][n] = sum over the chunk's rows of dy[m][n].
 // block = CP column-quads x (256/CP) row lanes, CP = power of two >= min(N/4, 64): narrow layers (N = 64, 24)
 // spend their idle column lanes on more rows.
-__global__ void __launch_bounds__(256) bias_grad_partial_kernel(const float *__restrict__ dy, long long M, int N4,
+template <typename T>
+__global__ void __launch_bounds__(256) bias_grad_partial_kernel(const T *__restrict__ dy, long long M, int N4,
                                                               int cp_log2, long long rows_per_chunk,
                                                               float *__restrict__ partial) {
     const int CP = 1 << cp_log2, RL = 256 >> cp_log2;
@@ -203,9 +219,10 @@ __global__ void __launch_bounds__(256) slab_sum_kernel(const float *__restrict__
 // ------------------------------------------------------------------------------------------
 // sparse softmax cross-entropy + gradient (deeplab.py:182); one thread per pixel row
 // ------------------------------------------------------------------------------------------
+template <typename TD>
 __global__ void __launch_bounds__(256) softmax_ce_kernel(const float *__restrict__ logits, long long ldl,
                                                        const long long *__restrict__ labels, long long M, int C,
-                                                       float grad_scale, float *__restrict__ dlogits,
+                                                       float grad_scale, TD *__restrict__ dlogits,
                                                        float *__restrict__ partial) {
     __shared__ float sh[4];
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,13 +237,13 @@ __global__ void __launch_bounds__(256) softmax_ce_kernel(const float *__restrict
         const float lse = logf(s);
         if (lab >= 0 && lab < C) loss = lse - (p[lab] - mx);
         if (dlogits) {
-            float *d = dlogits + r * ldl;
+            TD *d = dlogits + r * ldl;
             const float inv = 1.0f / s;
             for (int c = 0; c < C; c++) {
                 const float sm = expf(p[c] - mx) * inv;
-                d[c] = (sm - (c == lab ? 1.f : 0.f)) * grad_scale;
+                d[c] = (TD)((sm - (c == lab ? 1.f : 0.f)) * grad_scale);
             }
-            for (int c = C; c < ldl; c++) d[c] = 0.f;
+            for (int c = C; c < ldl; c++) d[c] = (TD)0.f;
         }
     }
     loss = block_sum_256(loss, sh);
@@ -344,10 +361,10 @@ int launch_slab_sum(const float *slab, int nslab, long long n, float *out, hipSt
 }
 }  // namespace emadapt
 
-extern "C" {
+namespace {
 
-int emadapt_maxpool_fwd(const float *x, int B, int H, int W, int C, int stride, float *y, uint8_t *idx,
-                        void *stream_) {
+template <typename T>
+int maxpool_fwd_t(const T *x, int B, int H, int W, int C, int stride, T *y, uint8_t *idx, void *stream_) {
     if (!x || !y || B < 0 || H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
     if (C % 4 != 0 || (stride != 1 && stride != 2)) return EMADAPT_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(y)) return EMADAPT_ERR_INVALID;
@@ -357,14 +374,15 @@ int emadapt_maxpool_fwd(const float *x, int B, int H, int W, int C, int stride, 
     same_pad(W, stride, &OW, &pl);
     const long long n = (long long)B * OH * OW * (C / 4);
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)B * H * W * C * 4.0 + (double)n * 20.0, stream);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W, C / 4,
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)B * H * W * C * sizeof(T) + (double)n * (4.0 * sizeof(T) + 4.0), stream);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W, C / 4,
                        stride, OH, OW, pt, pl, y, idx);
     return launch_status();
 }
 
-int emadapt_maxpool_bwd(const float *dy, const uint8_t *idx, const float *gate, int B, int H, int W, int C,
-                        int stride, float *dx, void *stream_) {
+template <typename T>
+int maxpool_bwd_t(const T *dy, const uint8_t *idx, const T *gate, int B, int H, int W, int C, int stride, T *dx,
+                  void *stream_) {
     if (!dy || !idx || !dx || B < 0 || H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
     if (C % 4 != 0 || (stride != 1 && stride != 2)) return EMADAPT_ERR_UNSUPPORTED;
     if (B == 0) return EMADAPT_OK;
@@ -373,10 +391,44 @@ int emadapt_maxpool_bwd(const float *dy, const uint8_t *idx, const float *gate, 
     same_pad(W, stride, &OW, &pl);
     const long long n = (long long)B * H * W * (C / 4);
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 16.0 * (gate ? 2.0 : 1.0) + (double)B * OH * OW * C * 5.0, stream);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, dy, idx, gate, B, H,
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 4.0 * sizeof(T) * (gate ? 2.0 : 1.0) + (double)B * OH * OW * C * (sizeof(T) + 1.0), stream);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, dy, idx, gate, B, H,
                        W, C / 4, stride, OH, OW, pt, pl, dx);
     return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int emadapt_maxpool_fwd(const float *x, int B, int H, int W, int C, int stride, float *y, uint8_t *idx,
+                        void *stream_) {
+    return maxpool_fwd_t<float>(x, B, H, W, C, stride, y, idx, stream_);
+}
+
+int emadapt_maxpool_bwd(const float *dy, const uint8_t *idx, const float *gate, int B, int H, int W, int C,
+                        int stride, float *dx, void *stream_) {
+    return maxpool_bwd_t<float>(dy, idx, gate, B, H, W, C, stride, dx, stream_);
+}
+
+int emadapt_maxpool_fwd_dt(const void *x, int dtype, int B, int H, int W, int C, int stride, void *y, uint8_t *idx,
+                           void *stream_) {
+    if (dtype == EMADAPT_DT_F32)
+        return maxpool_fwd_t<float>(static_cast<const float *>(x), B, H, W, C, stride, static_cast<float *>(y), idx, stream_);
+    if (dtype == EMADAPT_DT_BF16)
+        return maxpool_fwd_t<__bf16>(static_cast<const __bf16 *>(x), B, H, W, C, stride, static_cast<__bf16 *>(y), idx, stream_);
+    return EMADAPT_ERR_INVALID;
+}
+
+int emadapt_maxpool_bwd_dt(const void *dy, const uint8_t *idx, const void *gate, int dtype, int B, int H, int W, int C,
+                           int stride, void *dx, void *stream_) {
+    if (dtype == EMADAPT_DT_F32)
+        return maxpool_bwd_t<float>(static_cast<const float *>(dy), idx, static_cast<const float *>(gate), B, H, W, C, stride,
+                                    static_cast<float *>(dx), stream_);
+    if (dtype == EMADAPT_DT_BF16)
+        return maxpool_bwd_t<__bf16>(static_cast<const __bf16 *>(dy), idx, static_cast<const __bf16 *>(gate), B, H, W, C,
+                                     stride, static_cast<__bf16 *>(dx), stream_);
+    return EMADAPT_ERR_INVALID;
 }
 
 static long long bias_grad_max_chunks(int N) {
@@ -391,8 +443,11 @@ size_t emadapt_bias_grad_workspace_bytes(int64_t M, int N) {
     return (size_t)bias_grad_max_chunks(N) * (size_t)(N > 0 ? N : 0) * sizeof(float) + 256;
 }
 
-int emadapt_bias_grad(const float *dy, int64_t M, int N, float *db, void *workspace, size_t workspace_bytes,
-                      void *stream_) {
+}  // extern "C"
+
+template <typename T>
+static int bias_grad_t(const T *dy, int64_t M, int N, float *db, void *workspace, size_t workspace_bytes,
+                       void *stream_) {
     if (!dy || !db || M <= 0 || N <= 0) return EMADAPT_ERR_INVALID;
     if (N % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < emadapt_bias_grad_workspace_bytes(M, N)) return EMADAPT_ERR_WORKSPACE;
@@ -409,19 +464,36 @@ int emadapt_bias_grad(const float *dy, int64_t M, int N, float *db, void *worksp
     if (rows_per_chunk < 4 * RL) rows_per_chunk = 4 * RL;
     chunks = ceil_div(M, rows_per_chunk);
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)M * N * 4.0, stream);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)M * N * sizeof(T), stream);
     float *partial = static_cast<float *>(workspace);
-    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(gx, (unsigned)chunks), dim3(256), 0, stream, dy, (long long)M,
+    hipLaunchKernelGGL(bias_grad_partial_kernel<T>, dim3(gx, (unsigned)chunks), dim3(256), 0, stream, dy, (long long)M,
                        N4, cp_log2, rows_per_chunk, partial);
     int rc = launch_status();
     if (rc) return rc;
     return launch_slab_sum(partial, (int)chunks, N, db, stream);
 }
 
+extern "C" {
+
+int emadapt_bias_grad(const float *dy, int64_t M, int N, float *db, void *workspace, size_t workspace_bytes,
+                      void *stream_) {
+    return bias_grad_t<float>(dy, M, N, db, workspace, workspace_bytes, stream_);
+}
+
+int emadapt_bias_grad_dt(const void *dy, int dtype, int64_t M, int N, float *db, void *workspace,
+                         size_t workspace_bytes, void *stream_) {
+    if (dtype == EMADAPT_DT_F32) return bias_grad_t<float>(static_cast<const float *>(dy), M, N, db, workspace, workspace_bytes, stream_);
+    if (dtype == EMADAPT_DT_BF16) return bias_grad_t<__bf16>(static_cast<const __bf16 *>(dy), M, N, db, workspace, workspace_bytes, stream_);
+    return EMADAPT_ERR_INVALID;
+}
+
 size_t emadapt_softmax_ce_workspace_bytes(int64_t M) { return (size_t)(ceil_div(M > 0 ? M : 1, 256)) * 4 + 256; }
 
-int emadapt_softmax_ce(const float *logits, int64_t ldl, const int64_t *labels, int64_t M, int C, float grad_scale,
-                       float *dlogits, float *loss_sum, void *workspace, size_t workspace_bytes, void *stream_) {
+}  // extern "C"
+
+template <typename TD>
+static int softmax_ce_t(const float *logits, int64_t ldl, const int64_t *labels, int64_t M, int C, float grad_scale,
+                        TD *dlogits, float *loss_sum, void *workspace, size_t workspace_bytes, void *stream_) {
     if (!logits || !labels || M <= 0 || C <= 0 || ldl < C) return EMADAPT_ERR_INVALID;
     if (loss_sum && (!workspace || workspace_bytes < emadapt_softmax_ce_workspace_bytes(M)))
         return EMADAPT_ERR_WORKSPACE;
@@ -429,12 +501,29 @@ int emadapt_softmax_ce(const float *logits, int64_t ldl, const int64_t *labels, 
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)M * (ldl * 8.0 + 8.0), stream);
     float *partial = loss_sum ? static_cast<float *>(workspace) : nullptr;
-    hipLaunchKernelGGL(softmax_ce_kernel, dim3(grid), dim3(256), 0, stream, logits, (long long)ldl,
+    hipLaunchKernelGGL(softmax_ce_kernel<TD>, dim3(grid), dim3(256), 0, stream, logits, (long long)ldl,
                        reinterpret_cast<const long long *>(labels), (long long)M, C, grad_scale, dlogits, partial);
     int rc = launch_status();
     if (rc || !loss_sum) return rc;
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, stream, partial, grid, 1.0f, loss_sum);
     return launch_status();
+}
+
+extern "C" {
+
+int emadapt_softmax_ce(const float *logits, int64_t ldl, const int64_t *labels, int64_t M, int C, float grad_scale,
+                       float *dlogits, float *loss_sum, void *workspace, size_t workspace_bytes, void *stream_) {
+    return softmax_ce_t<float>(logits, ldl, labels, M, C, grad_scale, dlogits, loss_sum, workspace, workspace_bytes, stream_);
+}
+
+int emadapt_softmax_ce_dt(const float *logits, int64_t ldl, const int64_t *labels, int64_t M, int C, float grad_scale,
+                          void *dlogits, int dlogits_dtype, float *loss_sum, void *workspace, size_t workspace_bytes,
+                          void *stream_) {
+    if (dlogits_dtype == EMADAPT_DT_F32)
+        return softmax_ce_t<float>(logits, ldl, labels, M, C, grad_scale, static_cast<float *>(dlogits), loss_sum, workspace, workspace_bytes, stream_);
+    if (dlogits_dtype == EMADAPT_DT_BF16)
+        return softmax_ce_t<__bf16>(logits, ldl, labels, M, C, grad_scale, static_cast<__bf16 *>(dlogits), loss_sum, workspace, workspace_bytes, stream_);
+    return EMADAPT_ERR_INVALID;
 }
 
 size_t emadapt_l2_loss_workspace_bytes(int64_t n) {

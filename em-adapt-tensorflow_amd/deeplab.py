@@ -68,6 +68,14 @@ class ADAPT(Network):
         self.compute_dtype = str(self.config.get("compute_dtype", "fp32"))
         if self.compute_dtype not in ("fp32", "bf16"):
             raise ValueError("compute_dtype must be 'fp32' or 'bf16', got %r" % self.compute_dtype)
+        # storage type of activations / activation gradients: defaults to the compute type.  bf16 storage holds the very
+        # values the bf16 kernels would round an f32 tensor to, at half the bytes (include/emadapt.h "Storage types");
+        # the input image, the fc8 logits (E-step / loss input), weights, gradients and optimizer state stay f32.
+        act = str(self.config.get("act_dtype", self.compute_dtype))
+        if act not in ("fp32", "bf16") or (act == "bf16" and self.compute_dtype != "bf16"):
+            raise ValueError("act_dtype must be 'fp32', or 'bf16' together with compute_dtype 'bf16'")
+        self.act_dtype = torch.bfloat16 if act == "bf16" else torch.float32
+        self._cpad = 8 if act == "bf16" else 4   # channel padding of the buffers (16-byte vectors)
         self._w16_seen = None
         self._plan = []
         self._shapes = {}
@@ -246,11 +254,15 @@ class ADAPT(Network):
     def _add_conv(self, layer, k, rate):
         kh, kw, cin, cout = self._shapes[layer]
         op = _Op(name=layer, kind="conv", out_name=layer, k=k, rate=rate, relu=False, drop=False, cin=cin, cout=cout,
-                 cin_p=round_up(cin, 4), cout_p=round_up(cout, 4), index=len(self._plan))
+                 cin_p=self._pad_cin(layer, cin), cout_p=round_up(cout, self._cpad), index=len(self._plan))
         if not self._dry:
             seg = self._segments[layer]
             op.seg, op.w_pad, op.b_pad, op.gw_pad, op.gb_pad = seg, seg["w_pad"], seg["b_pad"], seg["gw_pad"], seg["gb_pad"]
         self._plan.append(op)
+
+    def _pad_cin(self, layer, cin):
+        # the image keeps its 3 -> 4 padding (conv1_1 always gathers it as f32); every other input is an activation
+        return round_up(cin, 4) if layer == "conv1_1" else round_up(cin, self._cpad)
 
     def _add_pool(self, layer, stride):
         self._plan.append(_Op(name=layer, kind="pool", out_name=layer, stride=stride, index=len(self._plan)))
@@ -272,7 +284,7 @@ class ADAPT(Network):
         off = 0
         for layer in reversed(order):
             kh, kw, cin, cout = self._shapes[layer]
-            cin_p, cout_p = round_up(cin, 4), round_up(cout, 4)
+            cin_p, cout_p = self._pad_cin(layer, cin), round_up(cout, self._cpad)
             nw, nb = kh * kw * cin_p * cout_p, cout_p
             start = off
             self._segments[layer] = dict(start=start, nw=nw, nb=nb, shape=(kh, kw, cin, cout), pshape=(kh, kw, cin_p, cout_p))
@@ -320,7 +332,7 @@ class ADAPT(Network):
                 h, w = ops.pool_out_size(h, op.stride), ops.pool_out_size(w, op.stride)
             op.out_hw = (h, w)
         self.out_hw = (h, w)
-        self.c_pad = round_up(self.category_num, 4)
+        self.c_pad = round_up(self.category_num, self._cpad)
 
     def parameter_count(self):
         return sum(int(np.prod(s["shape"])) + s["shape"][3] for s in self._segments.values())
@@ -342,18 +354,20 @@ class ADAPT(Network):
         bufs["x4"] = torch.zeros((B, self.h, self.w, round_up(self.input_channel, 4)), dtype=f32, device=dev)
         maxn = bufs["x4"].numel()
         c = bufs["x4"].shape[3]
+        adt = self.act_dtype
         for op in self._plan:
             oh, ow = op.out_hw
             if op.kind == "conv":
                 c = op.cout_p
-                bufs["act"][op.name] = torch.empty((B, oh, ow, c), dtype=f32, device=dev)
+                dt = f32 if op is self._plan[-1] else adt   # the logits feed the E-step and the loss: always f32
+                bufs["act"][op.name] = torch.empty((B, oh, ow, c), dtype=dt, device=dev)
             else:
-                bufs["act"][op.name] = torch.empty((B, oh, ow, c), dtype=f32, device=dev)
+                bufs["act"][op.name] = torch.empty((B, oh, ow, c), dtype=adt, device=dev)
                 bufs["idx"][op.name] = torch.empty((B, oh, ow, c), dtype=torch.uint8, device=dev)
             maxn = max(maxn, bufs["act"][op.name].numel())
             self.net[op.out_name] = bufs["act"][op.name]
-        bufs["gA"] = torch.empty(maxn, dtype=f32, device=dev)
-        bufs["gB"] = torch.empty(maxn, dtype=f32, device=dev)
+        bufs["gA"] = torch.empty(maxn, dtype=adt, device=dev)   # activation gradients ping-pong between these two
+        bufs["gB"] = torch.empty(maxn, dtype=adt, device=dev)
         S1, S2 = self.out_hw
         bufs["shrink"] = torch.empty((B, S1, S2), dtype=f32, device=dev)
         bufs["labels"] = torch.empty((B, S1, S2), dtype=torch.int64, device=dev)

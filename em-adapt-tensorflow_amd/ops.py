@@ -31,6 +31,24 @@ def _check(t, dtype=torch.float32, name="tensor"):
         raise ValueError("%s must be contiguous" % name)
 
 
+DT_F32, DT_BF16 = 0, 1  # EMADAPT_DT_*: storage type of an activation / activation-gradient tensor
+
+
+def _act(t, name="tensor"):
+    """Validate an activation tensor that may be stored f32 or bf16; returns its EMADAPT_DT_* code."""
+    if t is None:
+        return DT_F32
+    if t.dtype == torch.float32:
+        _check(t, torch.float32, name)
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        _check(t, torch.bfloat16, name)
+        if t.shape[-1] % 8 != 0:
+            raise ValueError("%s: bf16 tensors need a channel count that is a multiple of 8" % name)
+        return DT_BF16
+    raise TypeError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
+
+
 class Workspace:
     """Grow-only scratch buffer per device (partial slabs of the deterministic reductions)."""
 
@@ -134,9 +152,11 @@ def weights_to_bf16(w, fwd_out=None, dgrad_out=None, want_fwd=True, want_dgrad=T
     return wf, wd
 
 
-def conv_fwd_bf16(x, wf, ksize, bias=None, dil=1, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None):
-    """conv_fwd with bf16 operands / fp32 accumulation; wf = forward image of weights_to_bf16, ksize = (KH, KW)."""
-    _check(x, name="x"); _check(wf, torch.bfloat16, "wf"); _check(bias, name="bias")
+def conv_fwd_bf16(x, wf, ksize, bias=None, dil=1, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None,
+                  out_dtype=None):
+    """conv_fwd with bf16 operands / fp32 accumulation; wf = forward image of weights_to_bf16, ksize = (KH, KW).
+    x may be stored f32 or bf16; the output is f32 unless out / out_dtype say bf16."""
+    xdt = _act(x, "x"); _check(wf, torch.bfloat16, "wf"); _check(bias, name="bias")
     _check(drop_mask, torch.uint8, "drop_mask")
     B, H, W, Cin = x.shape
     KH, KW = ksize
@@ -144,37 +164,42 @@ def conv_fwd_bf16(x, wf, ksize, bias=None, dil=1, relu=True, keep_prob=1.0, drop
     if taps != KH * KW or Cip != _round8(Cin):
         raise ValueError("forward filter image %s does not match x channels %d / ksize %s" % (tuple(wf.shape), Cin, ksize))
     d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
-    y = out if out is not None else torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    _check(y, name="out")
+    y = out if out is not None else torch.empty((B, H, W, Cout), dtype=out_dtype or torch.float32, device=x.device)
+    ydt = _act(y, "out")
     epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
     nbytes = _lib.load().emadapt_conv_fwd_bf16_workspace_bytes(ctypes.byref(d))
     ws = _WS.get(nbytes, x.device) if nbytes else None
-    _lib.call("emadapt_conv_fwd_bf16", ctypes.byref(d), _p(x), _p(wf), _p(bias), _p(y), epi, float(keep_prob),
+    _lib.call("emadapt_conv_fwd_bf16", ctypes.byref(d), _p(x), xdt, _p(wf), _p(bias), _p(y), ydt, epi, float(keep_prob),
               _p(drop_mask), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(ws), ws.numel() if ws is not None else 0, _stream())
     return y
 
 
-def conv_dgrad_bf16(dy, wd, ksize, dil=1, gate=None, gate_scale=1.0, out=None):
-    """conv_dgrad with bf16 operands / fp32 accumulation; wd = dgrad image of weights_to_bf16."""
-    _check(dy, name="dy"); _check(wd, torch.bfloat16, "wd"); _check(gate, name="gate")
+def conv_dgrad_bf16(dy, wd, ksize, dil=1, gate=None, gate_scale=1.0, out=None, out_dtype=None):
+    """conv_dgrad with bf16 operands / fp32 accumulation; wd = dgrad image of weights_to_bf16.
+    dy may be stored f32 or bf16; dx (and the gate, the stored activation) are f32 or both bf16."""
+    ddt = _act(dy, "dy"); _check(wd, torch.bfloat16, "wd"); gdt = _act(gate, "gate")
     B, H, W, Cout = dy.shape
     KH, KW = ksize
     taps, Cin, Cop = wd.shape
     if taps != KH * KW or Cop != _round8(Cout):
         raise ValueError("dgrad filter image %s does not match dy channels %d / ksize %s" % (tuple(wd.shape), Cout, ksize))
     d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
-    dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
-    _check(dx, name="out")
+    if out is None:
+        out_dtype = out_dtype or (gate.dtype if gate is not None else torch.float32)
+    dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=out_dtype, device=dy.device)
+    xdt = _act(dx, "out")
+    if gate is not None and gdt != xdt:
+        raise TypeError("gate and dx must have the same storage type")
     nbytes = _lib.load().emadapt_conv_dgrad_bf16_workspace_bytes(ctypes.byref(d))
     ws = _WS.get(nbytes, dy.device) if nbytes else None
-    _lib.call("emadapt_conv_dgrad_bf16", ctypes.byref(d), _p(dy), _p(wd), _p(dx), _p(gate), float(gate_scale), _p(ws),
-              ws.numel() if ws is not None else 0, _stream())
+    _lib.call("emadapt_conv_dgrad_bf16", ctypes.byref(d), _p(dy), ddt, _p(wd), _p(dx), xdt, _p(gate), float(gate_scale),
+              _p(ws), ws.numel() if ws is not None else 0, _stream())
     return dx
 
 
 def conv_wgrad_bf16(x, dy, KH, KW, dil=1, out=None):
-    """conv_wgrad with bf16 operands / fp32 accumulation (f32 HWIO result)."""
-    _check(x, name="x"); _check(dy, name="dy")
+    """conv_wgrad with bf16 operands / fp32 accumulation (f32 HWIO result); x and dy stored f32 or bf16."""
+    xdt = _act(x, "x"); ddt = _act(dy, "dy")
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
@@ -182,18 +207,21 @@ def conv_wgrad_bf16(x, dy, KH, KW, dil=1, out=None):
     _check(dw, name="out")
     nbytes = _lib.load().emadapt_conv_wgrad_bf16_workspace_bytes(ctypes.byref(d))
     ws = _WS.get(nbytes, x.device)
-    _lib.call("emadapt_conv_wgrad_bf16", ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream())
+    _lib.call("emadapt_conv_wgrad_bf16", ctypes.byref(d), _p(x), xdt, _p(dy), ddt, _p(dw), _p(ws), ws.numel(), _stream())
     return dw
 
 
 def bias_grad(dy, out=None):
-    _check(dy, name="dy")
+    dt = _act(dy, "dy")
     N = dy.shape[-1]
     M = dy.numel() // N
     db = out if out is not None else torch.empty((N,), dtype=torch.float32, device=dy.device)
     nbytes = _lib.load().emadapt_bias_grad_workspace_bytes(M, N)
     ws = _WS.get(nbytes, dy.device)
-    _lib.call("emadapt_bias_grad", _p(dy), M, N, _p(db), _p(ws), ws.numel(), _stream())
+    if dt == DT_F32:
+        _lib.call("emadapt_bias_grad", _p(dy), M, N, _p(db), _p(ws), ws.numel(), _stream())
+    else:
+        _lib.call("emadapt_bias_grad_dt", _p(dy), dt, M, N, _p(db), _p(ws), ws.numel(), _stream())
     return db
 
 
@@ -203,21 +231,31 @@ def pool_out_size(n, stride):
 
 def maxpool_fwd(x, stride, out=None, idx=None):
     """3x3 max-pool, SAME (deeplab.py:77,82). Returns (y, idx) with idx the winning tap (uint8)."""
-    _check(x, name="x")
+    dt = _act(x, "x")
     B, H, W, C = x.shape
     OH, OW = pool_out_size(H, stride), pool_out_size(W, stride)
-    y = out if out is not None else torch.empty((B, OH, OW, C), dtype=torch.float32, device=x.device)
+    y = out if out is not None else torch.empty((B, OH, OW, C), dtype=x.dtype, device=x.device)
+    if _act(y, "out") != dt:
+        raise TypeError("max-pool input and output must have the same storage type")
     if idx is None:
         idx = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=x.device)
-    _lib.call("emadapt_maxpool_fwd", _p(x), B, H, W, C, int(stride), _p(y), _p(idx), _stream())
+    if dt == DT_F32:
+        _lib.call("emadapt_maxpool_fwd", _p(x), B, H, W, C, int(stride), _p(y), _p(idx), _stream())
+    else:
+        _lib.call("emadapt_maxpool_fwd_dt", _p(x), dt, B, H, W, C, int(stride), _p(y), _p(idx), _stream())
     return y, idx
 
 
 def maxpool_bwd(dy, idx, in_shape, stride, gate=None, out=None):
-    _check(dy, name="dy"); _check(idx, torch.uint8, "idx"); _check(gate, name="gate")
+    dt = _act(dy, "dy"); _check(idx, torch.uint8, "idx"); _act(gate, "gate")
     B, H, W, C = in_shape
-    dx = out if out is not None else torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
-    _lib.call("emadapt_maxpool_bwd", _p(dy), _p(idx), _p(gate), B, H, W, C, int(stride), _p(dx), _stream())
+    dx = out if out is not None else torch.empty((B, H, W, C), dtype=dy.dtype, device=dy.device)
+    if _act(dx, "out") != dt or (gate is not None and gate.dtype != dy.dtype):
+        raise TypeError("max-pool gradient, gate and output must have the same storage type")
+    if dt == DT_F32:
+        _lib.call("emadapt_maxpool_bwd", _p(dy), _p(idx), _p(gate), B, H, W, C, int(stride), _p(dx), _stream())
+    else:
+        _lib.call("emadapt_maxpool_bwd_dt", _p(dy), _p(idx), _p(gate), dt, B, H, W, C, int(stride), _p(dx), _stream())
     return dx
 
 
@@ -318,11 +356,16 @@ def softmax_ce(logits, labels, num_classes, grad_scale=None, want_grad=True, wan
         grad_scale = 1.0 / M
     if want_grad and dlogits is None:
         dlogits = torch.empty_like(logits)
+    ddt = _act(dlogits, "dlogits") if want_grad else DT_F32
     loss = torch.empty((1,), dtype=torch.float32, device=logits.device) if want_loss else None
     nbytes = _lib.load().emadapt_softmax_ce_workspace_bytes(M)
     ws = _WS.get(nbytes, logits.device)
-    _lib.call("emadapt_softmax_ce", _p(logits), ldl, _p(labels), M, int(num_classes), float(grad_scale),
-              _p(dlogits) if want_grad else None, _p(loss), _p(ws), ws.numel(), _stream())
+    if ddt == DT_F32:
+        _lib.call("emadapt_softmax_ce", _p(logits), ldl, _p(labels), M, int(num_classes), float(grad_scale),
+                  _p(dlogits) if want_grad else None, _p(loss), _p(ws), ws.numel(), _stream())
+    else:  # gradient stored bf16 (consumed by the bf16-compute fc8 kernels)
+        _lib.call("emadapt_softmax_ce_dt", _p(logits), ldl, _p(labels), M, int(num_classes), float(grad_scale),
+                  _p(dlogits), ddt, _p(loss), _p(ws), ws.numel(), _stream())
     return loss, (dlogits if want_grad else None)
 
 

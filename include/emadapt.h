@@ -166,26 +166,51 @@ int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *
 
 /* ---- bf16-compute variants (configurations C3/C4: bf16 compute, fp32 master weights
  * and fp32 accumulation).  Same semantics, shapes and epilogues as the fp32 entry points above; the operands
- * of every inner product are rounded to bf16 (round-to-nearest-even), products and sums are fp32
- * (v_mfma_f32_32x32x16_bf16).  Activations and gradients stay f32 in memory.  The filters are read from two
- * bf16 images that emadapt_weights_to_bf16 derives from the f32 HWIO master copy (once per optimizer step):
+ * of every inner product are bf16 (round-to-nearest-even), products and sums are fp32
+ * (v_mfma_f32_32x32x16_bf16).
+ *
+ * Storage types.  Each activation / activation-gradient tensor is EMADAPT_DT_F32 or EMADAPT_DT_BF16 in memory
+ * (the *_dtype argument next to its pointer).  An f32 tensor is rounded to bf16 by the kernel that consumes
+ * it; a bf16 tensor was rounded once by the kernel that produced it (after bias/ReLU/dropout resp. the
+ * ReLU-gradient gate, which are evaluated in fp32) -- the same values either way, at half the bytes.  bf16
+ * tensors need a channel count that is a multiple of 8 (16-byte vectors).  Bias, filter gradients, logits
+ * consumed by the E-step and all optimizer state are always f32.
+ *
+ * The filters are read from two bf16 images that emadapt_weights_to_bf16 derives from the f32 HWIO master copy
+ * (once per optimizer step):
  *   which = 0, forward image  [KH*KW][Cout][round8(Cin)]   (reduction axis ci contiguous, zero padded)
  *   which = 1, dgrad image    [KH*KW][Cin][round8(Cout)]   (the HWIO filter with co padded to 8)
  * The filter gradient needs no image; dw is written f32 HWIO. */
+#define EMADAPT_DT_F32 0
+#define EMADAPT_DT_BF16 1
 size_t emadapt_weights_bf16_bytes(const emadapt_conv_desc *d, int which);
 int emadapt_weights_to_bf16(const emadapt_conv_desc *d, const float *w, void *w_fwd_bf16, void *w_dgrad_bf16,
                             void *stream); /* either image pointer may be NULL */
 size_t emadapt_conv_fwd_bf16_workspace_bytes(const emadapt_conv_desc *d);
-int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const float *x, const void *w_fwd_bf16, const float *bias,
-                          float *y, int epilogue, float keep_prob, const uint8_t *drop_mask,
-                          uint64_t drop_seed, void *workspace, size_t workspace_bytes, void *stream);
+int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *w_fwd_bf16,
+                          const float *bias, void *y, int y_dtype, int epilogue, float keep_prob,
+                          const uint8_t *drop_mask, uint64_t drop_seed, void *workspace, size_t workspace_bytes,
+                          void *stream);
 size_t emadapt_conv_dgrad_bf16_workspace_bytes(const emadapt_conv_desc *d);
-int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const float *dy, const void *w_dgrad_bf16, float *dx,
-                            const float *gate, float gate_scale, void *workspace, size_t workspace_bytes,
-                            void *stream);
+/* gate (the stored activation that fed the conv) has the storage type of dx */
+int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const void *dy, int dy_dtype, const void *w_dgrad_bf16,
+                            void *dx, int dx_dtype, const void *gate, float gate_scale, void *workspace,
+                            size_t workspace_bytes, void *stream);
 size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d);
-int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw,
-                            void *workspace, size_t workspace_bytes, void *stream);
+int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
+                            float *dw, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The HBM-bound kernels of the step on either storage type (dtype = EMADAPT_DT_*; same semantics as the f32
+ * entry points below, arithmetic in fp32 registers, results rounded to nearest-even when the output is bf16). */
+int emadapt_maxpool_fwd_dt(const void *x, int dtype, int B, int H, int W, int C, int stride, void *y, uint8_t *idx,
+                           void *stream);
+int emadapt_maxpool_bwd_dt(const void *dy, const uint8_t *idx, const void *gate, int dtype, int B, int H, int W,
+                           int C, int stride, void *dx, void *stream);
+int emadapt_bias_grad_dt(const void *dy, int dtype, int64_t M, int N, float *db, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int emadapt_softmax_ce_dt(const float *logits, int64_t ldl, const int64_t *labels, int64_t M, int C,
+                          float grad_scale, void *dlogits, int dlogits_dtype, float *loss_sum, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 /* BiasAddGrad: db[n] = sum_m dy[m,n]; dy f32 [M,N].  Deterministic two-stage reduction. */
 size_t emadapt_bias_grad_workspace_bytes(int64_t M, int N);

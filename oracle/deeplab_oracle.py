@@ -116,6 +116,30 @@ class _ConvBf16(torch.autograd.Function):
         return dx, dw, None
 
 
+class _RoundFwd(torch.autograd.Function):
+    """An activation stored as bf16: rounded on the way forward, gradient passes unchanged."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16_round(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """An activation GRADIENT stored as bf16: identity forward, the gradient is rounded on the way back."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16_round(g)
+
+
 def conv_same_bf16(x, w, b, rate):
     y = _ConvBf16.apply(x, w, rate)
     return y if b is None else y + b
@@ -143,9 +167,12 @@ class DeepLabOracle:
     """Forward / loss / backward / update of one micro-step, on the CPU."""
 
     def __init__(self, category_num=21, preset="ref", width=64, fc_width=None, input_channel=3,
-                 dtype=torch.float32, compute_dtype="fp32"):
+                 dtype=torch.float32, compute_dtype="fp32", act_dtype=None):
         self.C = category_num
         self.conv = conv_same_bf16 if compute_dtype == "bf16" else conv_same
+        # act_dtype "bf16" (default with bf16 compute): activations are rounded when stored (after bias/ReLU/dropout), and
+        # activation gradients when stored (after the ReLU / dropout gate); the logits stay unrounded, their gradient not
+        self.store_bf16 = (act_dtype or compute_dtype) == "bf16"
         self.specs = layer_specs(category_num, preset, width, fc_width, input_channel)
         self.dtype = dtype
         self.estep_args = dict(bg_p=0.4, fg_p=0.2, num_iter=5, suppress_others=True, margin_others=1e-5)  # deeplab.py:181
@@ -161,15 +188,20 @@ class DeepLabOracle:
         """images [B,H,W,3]; masks {"fc6": uint8/bool [B,h,w,C], "fc7": ...} injected keep masks."""
         x = torch.as_tensor(images, dtype=self.dtype)
         acts = {"input": x}
+        last = self.specs[-1][0]
         for name, kind, p in self.specs:
             if kind == "conv":
                 w, b = tparams[name]
                 x = self.conv(x, w, b, p["rate"])
+                if self.store_bf16:
+                    x = _RoundBwd.apply(x)
                 if p.get("relu"):
                     x = torch.relu(x)
                 if p.get("drop") and keep_prob < 1.0:
                     m = torch.as_tensor(np.asarray(masks[name]), dtype=self.dtype)
                     x = x / keep_prob * m  # tf.nn.dropout: div then multiply by the binary mask
+                if self.store_bf16 and name != last:
+                    x = _RoundFwd.apply(x)
             else:
                 x = maxpool_same(x, p["stride"])
             if keep_all:

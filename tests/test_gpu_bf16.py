@@ -110,6 +110,75 @@ def test_bf16_conv_fwd_dgrad_wgrad(env, shape, tile):
     assert _rel(ops.conv_wgrad_bf16(xg, dyg, k, k, dil).cpu(), wr.grad) < 2e-5
 
 
+def _within_bf16_ulp(got, want, slack=1e-5):
+    """|got - want| <= one bf16 ulp of want (2^-8 relative) + slack * max|want|: what a correctly rounded bf16 store of
+    an fp32-accumulated value can differ from the fp64 result by."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    return bool(np.all(np.abs(got - want) <= np.abs(want) * 2.0 ** -8 + slack * np.abs(want).max()))
+
+
+@pytest.mark.parametrize("shape", [sh for sh in SHAPES if sh[3] % 8 == 0 and sh[4] % 8 == 0])
+def test_bf16_storage_variants(env, shape, tile):
+    """Activations / gradients stored as bf16 (include/emadapt.h "Storage types"): bf16 in -> same sums as f32 in holding
+    the same values; bf16 out -> the f32 result rounded once."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    rng = np.random.default_rng(hash(shape) % (1 << 31) + 1)
+    x = _t(torch, rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)).bfloat16()
+    w = _t(torch, rng.normal(0, 0.2, (k, k, Cin, Cout)).astype(np.float32))
+    b = _t(torch, rng.normal(0, 0.5, (Cout,)).astype(np.float32))
+    dy = _t(torch, rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)).bfloat16()
+    gate = _t(torch, rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)).bfloat16()
+    wf, wd = ops.weights_to_bf16(w)
+    # bf16-stored inputs, f32 outputs: bit-identical to the f32-stored path on the same values
+    y32 = ops.conv_fwd_bf16(x.float(), wf, (k, k), b, dil, relu=True)
+    assert torch.equal(ops.conv_fwd_bf16(x, wf, (k, k), b, dil, relu=True), y32)
+    dx32 = ops.conv_dgrad_bf16(dy.float(), wd, (k, k), dil, gate=gate.float(), gate_scale=2.0)
+    assert torch.equal(ops.conv_dgrad_bf16(dy, wd, (k, k), dil, gate=gate.float(), gate_scale=2.0), dx32)
+    dw32 = ops.conv_wgrad_bf16(x.float(), dy.float(), k, k, dil)
+    assert torch.equal(ops.conv_wgrad_bf16(x, dy, k, k, dil), dw32)
+    assert torch.equal(ops.conv_wgrad_bf16(x.float(), dy, k, k, dil), dw32)
+    assert torch.equal(ops.conv_wgrad_bf16(x, dy.float(), k, k, dil), dw32)
+    # bf16 outputs: the same values rounded to nearest-even
+    assert torch.equal(ops.conv_fwd_bf16(x, wf, (k, k), b, dil, relu=True, out_dtype=torch.bfloat16), y32.bfloat16())
+    assert torch.equal(ops.conv_dgrad_bf16(dy, wd, (k, k), dil, gate=gate, gate_scale=2.0), dx32.bfloat16())
+    # and against the fp64 oracle
+    xr = x.cpu().double().requires_grad_(True)
+    wr = w.bfloat16().cpu().double().requires_grad_(True)
+    yo = do.conv_same(xr, wr, b.cpu().double(), dil)
+    yo.backward(dy.cpu().double())
+    got = ops.conv_fwd_bf16(x, wf, (k, k), b, dil, relu=False, out_dtype=torch.bfloat16).float().cpu()
+    assert _within_bf16_ulp(got, yo.detach())
+    assert _within_bf16_ulp(ops.conv_dgrad_bf16(dy, wd, (k, k), dil, out_dtype=torch.bfloat16).float().cpu(), xr.grad)
+    assert _rel(dw32.cpu(), wr.grad) < 2e-5
+
+
+def test_bf16_elementwise_kernels(env):
+    """max-pool forward/backward, bias gradient and the softmax-CE gradient on bf16-stored tensors."""
+    ops, do, torch = env
+    rng = np.random.default_rng(21)
+    for (B, H, W, C, stride) in [(2, 21, 21, 8, 2), (1, 16, 18, 16, 1), (2, 11, 13, 24, 2)]:
+        x = _t(torch, rng.normal(0, 1, (B, H, W, C)).astype(np.float32)).bfloat16()
+        y, idx = ops.maxpool_fwd(x, stride)
+        y32, idx32 = ops.maxpool_fwd(x.float(), stride)
+        assert y.dtype == torch.bfloat16 and torch.equal(y.float(), y32) and torch.equal(idx, idx32)
+        want = do.maxpool_same(x.cpu().double(), stride)
+        assert np.array_equal(y.float().cpu().numpy(), want.numpy())
+        dy = _t(torch, rng.normal(0, 1, tuple(y.shape)).astype(np.float32)).bfloat16()
+        gate = _t(torch, rng.normal(0, 1, (B, H, W, C)).astype(np.float32)).bfloat16()
+        dx = ops.maxpool_bwd(dy, idx, (B, H, W, C), stride, gate=gate)
+        dx32 = ops.maxpool_bwd(dy.float(), idx32, (B, H, W, C), stride, gate=gate.float())
+        assert dx.dtype == torch.bfloat16 and torch.equal(dx, dx32.bfloat16())
+    dyb = _t(torch, rng.normal(0, 1, (3, 17, 19, 40)).astype(np.float32)).bfloat16()
+    assert _rel(ops.bias_grad(dyb).cpu(), dyb.cpu().double().sum(dim=(0, 1, 2))) < 2e-5
+    logits = _t(torch, rng.normal(0, 2, (2, 9, 9, 24)).astype(np.float32))
+    labels = torch.tensor(rng.integers(0, 21, (2, 9, 9)), dtype=torch.int64, device="cuda:0")
+    l32, d32 = ops.softmax_ce(logits, labels, 21)
+    l16, d16 = ops.softmax_ce(logits, labels, 21, dlogits=torch.empty((2, 9, 9, 24), dtype=torch.bfloat16, device="cuda:0"))
+    assert torch.equal(l16, l32) and torch.equal(d16, d32.bfloat16())
+
+
 def test_bf16_wgrad_split_m_is_deterministic_and_right(env):
     ops, do, torch = env
     rng = np.random.default_rng(5)
@@ -146,7 +215,8 @@ def test_bf16_dropout_epilogue_matches_fp32_kernel_mask(env):
     assert 0.45 < frac < 0.55
 
 
-def test_bf16_micro_step_tracks_the_bf16_oracle():
+@pytest.mark.parametrize("act", ["bf16", "fp32"])
+def test_bf16_micro_step_tracks_the_bf16_oracle(act):
     """ADAPT(compute_dtype="bf16"): forward, E-step, backward, accumulate and update against the oracle's bf16
     arithmetic model (operands of every conv inner product rounded to bf16, exact accumulation; fp64 elsewhere).
     Two bf16 computations that differ only in summation order agree to ~1e-7 until the first activation lands close
@@ -162,9 +232,9 @@ def test_bf16_micro_step_tracks_the_bf16_oracle():
     from oracle import estep_oracle as eo
     B, width, size, C = 2, 8, 65, 5
     adapt = ADAPT({"input_size": (size, size), "category_num": C, "width": width, "accum_num": 1, "batch_size": B,
-                   "compute_dtype": "bf16"})
+                   "compute_dtype": "bf16", "act_dtype": act})
     adapt.build()
-    oracle = do.DeepLabOracle(category_num=C, width=width, dtype=torch.float64, compute_dtype="bf16")
+    oracle = do.DeepLabOracle(category_num=C, width=width, dtype=torch.float64, compute_dtype="bf16", act_dtype=act)
     oracle32 = do.DeepLabOracle(category_num=C, width=width, dtype=torch.float64)
     params = do.init_params(oracle.specs, seed=11, he=True)
     for layer, (w, b) in params.items():
@@ -179,6 +249,8 @@ def test_bf16_micro_step_tracks_the_bf16_oracle():
     perms = eo.draw_perms(5, C, seed=77)
 
     logits = adapt.forward(images, keep_prob=0.5, drop_masks=masks).cpu().numpy()
+    assert adapt.net["relu4_2"].dtype == (torch.bfloat16 if act == "bf16" else torch.float32)
+    assert adapt.net["output"].dtype == torch.float32
     want = oracle.forward(oracle.tensors(params, requires_grad=False), images, 0.5, masks)["output"].numpy()
     full = oracle32.forward(oracle32.tensors(params, requires_grad=False), images, 0.5, masks)["output"].numpy()
     assert _rel(logits, want) < 1e-2
