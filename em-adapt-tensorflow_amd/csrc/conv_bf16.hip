@@ -348,87 +348,11 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
         }
         __syncthreads();
     }
-    // ---- epilogue.  The operand tiles are dead after the last barrier, so every consumer wave takes a private LDS
-    //      region, parks a 32 x WN slab of its accumulators there ([row][col] fp32) and reads it back as 8 consecutive
-    //      columns per lane: bias / ReLU / dropout / gate run on 8 values, and the gate loads and the output stores are
-    //      16-byte vectors covering 256 contiguous bytes (bf16) per 16 lanes instead of 2-byte scalars.
-    constexpr int SP = WN + 4;                 // slab pitch in floats (rows stay 16-byte aligned)
-    constexpr int CPR = WN / 8;                // 8-column chunks per slab row
-    static_assert(32 * SP * 4 * (BM / WM) * WAVES_N <= 2 * (BM + BN) * kPitchG, "epilogue slabs must fit in the tile LDS");
-    float *stage = reinterpret_cast<float *>(ldsb) + wave * (32 * SP);
+    // ---- epilogue through LDS (igemm_common.h: store_acc_tile): the operand tiles are dead after the last barrier
+    constexpr int SLAB = 32 * (WN + 4);  // floats per wave
+    static_assert(SLAB * 4 * (BM / WM) * WAVES_N <= 2 * (BM + BN) * kPitchG, "epilogue slabs must fit in the tile LDS");
     float *slab = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
-#pragma unroll
-    for (int i = 0; i < TM; i++) {  // (fully unrolled: a dynamic index would move the accumulators to scratch)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SP + j * 32 + l31] = acc[i][j][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int it = 0; it < CPR / 2; it++) {   // 32 * CPR chunks, 64 lanes
-            const int idx = it * 64 + lane;
-            const int row_l = idx / CPR, ch = idx % CPR;
-            const int row = m0 + wm * WM + i * 32 + row_l;
-            const int col = n0 + wn * WN + ch * 8;
-            const float4 v0 = *reinterpret_cast<const float4 *>(stage + row_l * SP + ch * 8);
-            const float4 v1 = *reinterpret_cast<const float4 *>(stage + row_l * SP + ch * 8 + 4);
-            if (row >= a.m_end || col >= a.N) continue;
-            const bool hi = col + 4 < a.N;   // N % 4 == 0: the chunk holds one or two whole quads
-            const long long o = (long long)row * a.N + col;
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            if (slab) {
-                *reinterpret_cast<float4 *>(slab + o) = v0;
-                if (hi) *reinterpret_cast<float4 *>(slab + o + 4) = v1;
-                continue;
-            }
-            if (a.epi != EMADAPT_EPI_NONE && a.bias) {
-                const float4 b0 = *reinterpret_cast<const float4 *>(a.bias + col);
-                const float4 b1 = hi ? *reinterpret_cast<const float4 *>(a.bias + col + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-            }
-            if (a.epi == EMADAPT_EPI_BIAS_RELU) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                if (a.keep < 1.0f) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        if (e >= 4 && !hi) break;
-                        const bool kp = a.mask ? (a.mask[o + e] != 0) : dropout_keep(a.seed, (unsigned long long)(o + e), a.keep);
-                        v[e] = kp ? v[e] / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
-                    }
-                }
-            }
-            if (a.gate) {
-                float g[8];
-                if constexpr (YBF) {  // the gate has the storage type of the output; bf16 tensors have N % 8 == 0
-                    const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(reinterpret_cast<const __bf16 *>(a.gate) + o);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) g[e] = (float)gv[e];
-                } else {
-                    const float4 g0 = *reinterpret_cast<const float4 *>(a.gate + o);
-                    const float4 g1 = hi ? *reinterpret_cast<const float4 *>(a.gate + o + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = g[e] > 0.f ? v[e] * a.scale : 0.f;
-            }
-            if constexpr (YBF) {
-                bf16x8 ov;
-#pragma unroll
-                for (int e = 0; e < 8; e++) ov[e] = (__bf16)v[e];
-                *reinterpret_cast<bf16x8 *>(reinterpret_cast<__bf16 *>(a.y) + o) = ov;
-            } else {
-                *reinterpret_cast<float4 *>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
-                if (hi) *reinterpret_cast<float4 *>(a.y + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    store_acc_tile<TM, TN, 32, YBF>(a, acc, reinterpret_cast<float *>(ldsb) + wave * SLAB, lane, m0 + wm * WM, n0 + wn * WN, slab);
 }
 
 void fill_geometry_bf16(IgemmArgs &a, int &Cxp, const emadapt_conv_desc *d, bool dgrad) {

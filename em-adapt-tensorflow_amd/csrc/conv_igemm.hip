@@ -288,27 +288,13 @@ __global__ void __launch_bounds__((BM / 64) * (BN / WN) * 64, 2) igemm_kernel(Ig
         if (kt + 1 < nk) k_step(std::integral_constant<int, 1>{}, kt0 + kt + 1);
     }
 
-    // ---- fused epilogue; C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- fused epilogue through LDS (igemm_common.h: store_acc_tile): the tiles are dead after the last barrier.
     // split-K partials are stored compactly: slab[split][row - m_begin][col]
+    constexpr int LDS_FLOATS = 2 * BK * (AS + BS);
+    constexpr int ROWS = ((THREADS / 64) * 32 * (WN + 4) <= LDS_FLOATS) ? 32 : 16;
+    static_assert((THREADS / 64) * ROWS * (WN + 4) <= LDS_FLOATS, "epilogue slabs must fit in the tile LDS");
     float *slab = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int col = n0 + wn * WN + j * 32 + l31;
-            const bool col_ok = col < a.N;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const long long o = (long long)row * a.N + col;
-                const float v = acc[i][j][r];
-                if (col_ok && row < a.m_end) {
-                    if (slab) slab[o] = v;
-                    else a.y[o] = epilogue(a, v, col, o);
-                }
-            }
-        }
-    }
+    store_acc_tile<TM, TN, ROWS, false>(a, acc, lds + wave * (ROWS * (WN + 4)), lane, m0 + wm * WM, n0 + wn * WN, slab);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -503,26 +489,10 @@ __global__ void __launch_bounds__(512, 4) igemm_ws_kernel(IgemmArgs a) {
         }
         __syncthreads();
     }
-    // split-K partials are stored compactly: slab[split][row - m_begin][col]
+    // epilogue through LDS (igemm_common.h: store_acc_tile); split-K partials: slab[split][row - m_begin][col]
+    static_assert(4 * 32 * (WN + 4) <= 2 * BK * (AS + BS), "epilogue slabs must fit in the tile LDS");
     float *slab = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int col = n0 + wn * WN + j * 32 + l31;
-            const bool col_ok = col < a.N;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const long long o = (long long)row * a.N + col;
-                const float v = acc[i][j][r];
-                if (col_ok && row < a.m_end) {
-                    if (slab) slab[o] = v;
-                    else a.y[o] = epilogue(a, v, col, o);
-                }
-            }
-        }
-    }
+    store_acc_tile<TM, TN, 32, false>(a, acc, lds + wave * (32 * (WN + 4)), lane, m0 + wm * WM, n0 + wn * WN, slab);
 }
 
 template <bool BT>

@@ -82,6 +82,104 @@ __device__ __forceinline__ float epilogue(const IgemmArgs &a, float v, int col, 
     return v;
 }
 
+// Tile epilogue through LDS, shared by the fp32 and bf16 kernels.  The operand tiles are dead after the main loop's
+// last barrier, so every MFMA wave takes a private LDS region (`stage`, ROWS x (TN*32 + 4) floats), parks ROWS rows of
+// its accumulator block there ([row][col] fp32; C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) +
+// 4*(lane>>5)) and reads them back as 8 consecutive columns per lane.  Bias / ReLU / dropout / gate then run on 8
+// values, and the gate loads and output stores are 16-byte vectors over contiguous rows instead of one scalar per
+// lane and accumulator register.  Same arithmetic, element for element, as epilogue() above.
+//   ROWS = 32 or 16 (16 when 32-row slabs of all waves would not fit in the kernel's tile LDS)
+//   YBF  = output (and gate) stored as bf16 (N % 8 == 0), else f32 (N % 4 == 0)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <int TM, int TN, int ROWS, bool YBF>
+__device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 (&acc)[TM][TN], float *stage, int lane,
+                                               int row0, int col0, float *slab) {
+    constexpr int WN = TN * 32;
+    constexpr int SP = WN + 4;   // slab pitch in floats (rows stay 16-byte aligned)
+    constexpr int CPR = WN / 8;  // 8-column chunks per slab row
+    static_assert(ROWS == 32 || ROWS == 16, "slab height");
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {  // (fully unrolled: a dynamic index would move the accumulators to scratch)
+#pragma unroll
+        for (int h = 0; h < 32 / ROWS; h++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int rr = 0; rr < ROWS / 2; rr++) {
+                    const int r = h * (ROWS / 2) + rr;  // accumulator register; its row inside the slab:
+                    stage[((r & 3) + 8 * ((r >> 2) % (ROWS / 8)) + 4 * lh) * SP + j * 32 + l31] = acc[i][j][r];
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < ROWS * CPR / 64; it++) {
+                const int idx = it * 64 + lane;
+                const int row_l = idx / CPR, ch = idx % CPR;
+                const int row = row0 + i * 32 + h * ROWS + row_l;
+                const int col = col0 + ch * 8;
+                const float4 v0 = *reinterpret_cast<const float4 *>(stage + row_l * SP + ch * 8);
+                const float4 v1 = *reinterpret_cast<const float4 *>(stage + row_l * SP + ch * 8 + 4);
+                if (row >= a.m_end || col >= a.N) continue;
+                const bool hi = col + 4 < a.N;  // N % 4 == 0: the chunk holds one or two whole quads
+                const long long o = (long long)row * a.N + col;
+                if (slab) {
+                    *reinterpret_cast<float4 *>(slab + o) = v0;
+                    if (hi) *reinterpret_cast<float4 *>(slab + o + 4) = v1;
+                    continue;
+                }
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (a.epi != EMADAPT_EPI_NONE && a.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4 *>(a.bias + col);
+                    const float4 b1 = hi ? *reinterpret_cast<const float4 *>(a.bias + col + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (a.epi == EMADAPT_EPI_BIAS_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    if (a.keep < 1.0f) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            if (e >= 4 && !hi) break;
+                            const bool kp = a.mask ? (a.mask[o + e] != 0) : dropout_keep(a.seed, (unsigned long long)(o + e), a.keep);
+                            v[e] = kp ? v[e] / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
+                        }
+                    }
+                }
+                if (a.gate) {
+                    float g[8];
+                    if constexpr (YBF) {  // the gate has the storage type of the output
+                        const bf16x8_t gv = *reinterpret_cast<const bf16x8_t *>(reinterpret_cast<const __bf16 *>(a.gate) + o);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) g[e] = (float)gv[e];
+                    } else {
+                        const float4 g0 = *reinterpret_cast<const float4 *>(a.gate + o);
+                        const float4 g1 = hi ? *reinterpret_cast<const float4 *>(a.gate + o + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = g[e] > 0.f ? v[e] * a.scale : 0.f;
+                }
+                if constexpr (YBF) {
+                    bf16x8_t ov;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) ov[e] = (__bf16)v[e];
+                    *reinterpret_cast<bf16x8_t *>(reinterpret_cast<__bf16 *>(a.y) + o) = ov;
+                } else {
+                    *reinterpret_cast<float4 *>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (hi) *reinterpret_cast<float4 *>(a.y + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
 // split-K second stage: y = epilogue(sum_s slab[s]) with the partials added in ascending s (deterministic).
 __global__ void __launch_bounds__(256) splitk_epilogue_kernel(IgemmArgs a) {
     const long long mn = (long long)(a.m_end - a.m_begin) * a.N;  // one slab
