@@ -5,10 +5,16 @@ import collections
 import csv
 import glob
 import os
+import os
 import re
 import shutil
 import subprocess
 import sys
+
+def newest(pattern):
+    """Newest file matching pattern (gpurun merges every run into the same local directory)."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = "gpurun_out/profiles_%s" % R
@@ -21,10 +27,10 @@ def short(name):
     return m.group(1) if m else name[:50]
 
 
-shutil.copy(glob.glob(SRC + "/trace/runc/*_kernel_stats.csv")[0], "%s/%s_bench_kernel_stats.csv" % (DST, R))
+shutil.copy(newest(SRC + "/trace/runc/*_kernel_stats.csv"), "%s/%s_bench_kernel_stats.csv" % (DST, R))
 shutil.copy(SRC + "/bench_line.json", "%s/%s_bench_line.json" % (DST, R))
 with open("%s/%s_bench_per_layer.txt" % (DST, R), "w") as f:
-    f.write(subprocess.check_output([sys.executable, "scripts/trace_layers.py", glob.glob(SRC + "/trace/runc/*_kernel_trace.csv")[0]]).decode())
+    f.write(subprocess.check_output([sys.executable, "scripts/trace_layers.py", newest(SRC + "/trace/runc/*_kernel_trace.csv")]).decode())
 if os.path.exists(SRC + "/estep_bench.txt"):
     shutil.copy(SRC + "/estep_bench.txt", "%s/%s_estep_bench.txt" % (DST, R))
 
@@ -43,7 +49,7 @@ out = ["# rocprofv3 --pmc passes over `bench.py --steps 1 --warmup 1` (kernel-tr
        "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide coalesced reads by 2x -> hbm_read = 2*FETCH_SIZE*1024.", ""]
 agg = collections.OrderedDict()
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
-    rows = load(glob.glob("%s/%s/runc/*_counter_collection.csv" % (SRC, sub))[0])
+    rows = load(newest("%s/%s/runc/*_counter_collection.csv" % (SRC, sub)))
     conv = [r for r in rows if re.search(r"igemm|wgrad", r["name"])]
     conv = conv[len(conv) // 2:]  # second (timed) step
     for r in conv:
