@@ -290,3 +290,40 @@ def test_bf16_micro_step_tracks_the_bf16_oracle(act):
     assert not torch.equal(before, seg["wf16"]), "the bf16 images must be refreshed after the optimizer step"
     kh, kw, cin_p, cout_p = seg["pshape"]
     assert torch.equal(seg["wf16"][:, :, :cin_p], seg["w_pad"].bfloat16().reshape(1, cin_p, cout_p).permute(0, 2, 1))
+
+
+def test_bf16_training_tracks_fp32_training():
+    """40 optimizer steps of the EM-Adapt loop on a fixed synthetic batch, once in fp32 and once in bf16 (same weights,
+    data, E-step visiting orders and dropout masks): both must learn, and the bf16 loss must stay close to the fp32 loss.
+    Also exercises the refresh of the bf16 filter images after every update and accum_num > 1."""
+    import random
+    import torch
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from oracle import deeplab_oracle as do
+    B, width, size, C = 4, 16, 65, 5
+    images, labels = do.synthetic_batch(B, size, C, seed=3)
+    images = (images / 50.0).astype(np.float32)
+    losses = {}
+    for mode in ("fp32", "bf16"):
+        random.seed(5)   # E-step visiting orders are drawn from Python's global generator (estep.py:64-66)
+        adapt = ADAPT({"input_size": (size, size), "category_num": C, "width": width, "accum_num": 2, "batch_size": B,
+                       "compute_dtype": mode, "seed": 7})
+        adapt.build()
+        params = do.init_params(do.layer_specs(C, "ref", width), seed=11, he=True)
+        for layer, (w, b) in params.items():
+            adapt.weights[layer][0].copy_(torch.tensor(w).to(adapt.device))
+            adapt.weights[layer][1].copy_(torch.tensor(b).to(adapt.device))
+        adapt.pre_train(base_lr=2e-3, weight_decay=1e-5, momentum=0.9, batch_size=B)
+        trace = []
+        for it in range(80):
+            loss = adapt.micro_step(images, labels, keep_prob=0.5)
+            if it % 2 == 1:
+                adapt.apply_update()
+            trace.append(float(loss.cpu()))
+        losses[mode] = np.array(trace)
+        assert np.all(np.isfinite(trace))
+    f, h = losses["fp32"], losses["bf16"]
+    assert f[-10:].mean() < 0.7 * f[:4].mean(), "fp32 run did not learn: %s" % f[::8]
+    assert h[-10:].mean() < 0.7 * h[:4].mean(), "bf16 run did not learn: %s" % h[::8]
+    assert abs(h[0] - f[0]) / f[0] < 2e-2                       # same start (one bf16 forward of difference)
+    assert abs(h[-10:].mean() - f[-10:].mean()) / f[-10:].mean() < 0.25, (f[::8], h[::8])
