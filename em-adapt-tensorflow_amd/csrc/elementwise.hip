@@ -30,24 +30,50 @@ __device__ __forceinline__ void st4(__bf16 *p, float4 v) {
     *reinterpret_cast<bf16x4 *>(p) = c;
 }
 
+// 16 bytes per thread for either storage type: VW<T> channels (4 f32 or 8 bf16), widened to fp32 in registers.
+template <typename T> struct VW { static constexpr int N = 16 / (int)sizeof(T); };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void ldv(const float *p, float (&v)[4]) {
+    const float4 t = ld4(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void stv(float *p, const float (&v)[4]) { st4(p, make_float4(v[0], v[1], v[2], v[3])); }
+__device__ __forceinline__ void ldv(const __bf16 *p, float (&v)[8]) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8 *>(p);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void stv(__bf16 *p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; e++) t[e] = (__bf16)v[e];
+    *reinterpret_cast<bf16x8 *>(p) = t;
+}
+template <int N> struct ByteVec;
+template <> struct ByteVec<4> { typedef unsigned int type; };
+template <> struct ByteVec<8> { typedef unsigned long long type; };
+
 // ------------------------------------------------------------------------------------------
 // tf.nn.max_pool 3x3, SAME (deeplab.py:77,82)
 // ------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ x, int B, int H, int W, int C4,
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ x, int B, int H, int W, int CV,
                                                         int stride, int OH, int OW, int pt, int pl,
                                                         T *__restrict__ y, unsigned char *__restrict__ idx) {
-    const long long n = (long long)B * OH * OW * C4;
+    constexpr int N = VW<T>::N;  // channels per thread; CV = C / N
+    const long long n = (long long)B * OH * OW * CV;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
          t += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(t % C4);
-        long long r = t / C4;
+        const int cv = (int)(t % CV);
+        long long r = t / CV;
         const int ow = (int)(r % OW);
         r /= OW;
         const int oh = (int)(r % OH);
         const int b = (int)(r / OH);
-        float4 best = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-        int bi0 = -1, bi1 = -1, bi2 = -1, bi3 = -1;
+        float best[N];
+        int bi[N];
+#pragma unroll
+        for (int e = 0; e < N; e++) { best[e] = -FLT_MAX; bi[e] = -1; }
 #pragma unroll
         for (int kh = 0; kh < 3; kh++) {
             const int h = oh * stride - pt + kh;
@@ -56,16 +82,21 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ 
             for (int kw = 0; kw < 3; kw++) {
                 const int w = ow * stride - pl + kw;
                 if ((unsigned)w >= (unsigned)W) continue;
-                const float4 v = ld4(x + (((long long)b * H + h) * W + w) * C4 * 4 + c4 * 4);
+                float v[N];
+                ldv(x + ((((long long)b * H + h) * W + w) * CV + cv) * N, v);
                 const int tap = kh * 3 + kw;
-                if (bi0 < 0 || v.x > best.x) { best.x = v.x; bi0 = tap; }
-                if (bi1 < 0 || v.y > best.y) { best.y = v.y; bi1 = tap; }
-                if (bi2 < 0 || v.z > best.z) { best.z = v.z; bi2 = tap; }
-                if (bi3 < 0 || v.w > best.w) { best.w = v.w; bi3 = tap; }
+#pragma unroll
+                for (int e = 0; e < N; e++)
+                    if (bi[e] < 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = tap; }  // first maximum wins
             }
         }
-        st4(y + t * 4, best);
-        if (idx) *reinterpret_cast<uchar4 *>(idx + t * 4) = make_uchar4(bi0, bi1, bi2, bi3);
+        stv(y + t * N, best);
+        if (idx) {
+            typename ByteVec<N>::type pk = 0;
+#pragma unroll
+            for (int e = 0; e < N; e++) pk |= (typename ByteVec<N>::type)(unsigned char)bi[e] << (8 * e);
+            *reinterpret_cast<typename ByteVec<N>::type *>(idx + t * N) = pk;
+        }
     }
 }
 
@@ -73,19 +104,22 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ dy,
                                                         const unsigned char *__restrict__ idx,
-                                                        const T *__restrict__ gate, int B, int H, int W, int C4,
+                                                        const T *__restrict__ gate, int B, int H, int W, int CV,
                                                         int stride, int OH, int OW, int pt, int pl,
                                                         T *__restrict__ dx) {
-    const long long n = (long long)B * H * W * C4;
+    constexpr int N = VW<T>::N;
+    const long long n = (long long)B * H * W * CV;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
          t += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(t % C4);
-        long long r = t / C4;
+        const int cv = (int)(t % CV);
+        long long r = t / CV;
         const int w = (int)(r % W);
         r /= W;
         const int h = (int)(r % H);
         const int b = (int)(r / H);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float acc[N];
+#pragma unroll
+        for (int e = 0; e < N; e++) acc[e] = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 3; kh++) {
             const int th = h + pt - kh;
@@ -98,24 +132,23 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ 
                 if (tw < 0 || tw % stride != 0) continue;
                 const int ow = tw / stride;
                 if (ow >= OW) continue;
-                const long long o = ((((long long)b * OH + oh) * OW + ow) * C4 + c4) * 4;
-                const uchar4 id = *reinterpret_cast<const uchar4 *>(idx + o);
-                const float4 g = ld4(dy + o);
-                const int tap = kh * 3 + kw;
-                if (id.x == tap) acc.x += g.x;
-                if (id.y == tap) acc.y += g.y;
-                if (id.z == tap) acc.z += g.z;
-                if (id.w == tap) acc.w += g.w;
+                const long long o = ((((long long)b * OH + oh) * OW + ow) * CV + cv) * N;
+                const typename ByteVec<N>::type id = *reinterpret_cast<const typename ByteVec<N>::type *>(idx + o);
+                float g[N];
+                ldv(dy + o, g);
+                const unsigned tap = kh * 3 + kw;
+#pragma unroll
+                for (int e = 0; e < N; e++)
+                    if (((unsigned)(id >> (8 * e)) & 0xffu) == tap) acc[e] += g[e];
             }
         }
         if (gate) {
-            const float4 a = ld4(gate + t * 4);
-            acc.x = a.x > 0.f ? acc.x : 0.f;
-            acc.y = a.y > 0.f ? acc.y : 0.f;
-            acc.z = a.z > 0.f ? acc.z : 0.f;
-            acc.w = a.w > 0.f ? acc.w : 0.f;
+            float a[N];
+            ldv(gate + t * N, a);
+#pragma unroll
+            for (int e = 0; e < N; e++) acc[e] = a[e] > 0.f ? acc[e] : 0.f;
         }
-        st4(dx + t * 4, acc);
+        stv(dx + t * N, acc);
     }
 }
 
@@ -142,35 +175,41 @@ __global__ void __launch_bounds__(256) final_sum_kernel(const float *__restrict_
 }
 
 // BiasAddGrad stage 1: partial[chunk][n] = sum over the chunk's rows of dy[m][n].
-// block = CP column-quads x (256/CP) row lanes, CP = power of two >= min(N/4, 64): narrow layers (N = 64, 24)
-// spend their idle column lanes on more rows.
+// block = CP column-vectors (16 bytes: 4 f32 or 8 bf16 channels) x (256/CP) row lanes, CP = power of two >=
+// min(N/VW, 64): narrow layers (N = 64, 24) spend their idle column lanes on more rows.
 template <typename T>
-__global__ void __launch_bounds__(256) bias_grad_partial_kernel(const T *__restrict__ dy, long long M, int N4,
+__global__ void __launch_bounds__(256) bias_grad_partial_kernel(const T *__restrict__ dy, long long M, int NV,
                                                               int cp_log2, long long rows_per_chunk,
                                                               float *__restrict__ partial) {
+    constexpr int N = VW<T>::N;
     const int CP = 1 << cp_log2, RL = 256 >> cp_log2;
     const int tx = threadIdx.x & (CP - 1), ty = threadIdx.x >> cp_log2;
     const int q = blockIdx.x * CP + tx;
     const long long r0 = (long long)blockIdx.y * rows_per_chunk;
     long long r1 = r0 + rows_per_chunk;
     if (r1 > M) r1 = M;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < N4) {
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; e++) acc[e] = 0.f;
+    if (q < NV) {
         for (long long r = r0 + ty; r < r1; r += RL) {
-            const float4 v = ld4(dy + (r * N4 + q) * 4);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            float v[N];
+            ldv(dy + (r * NV + q) * N, v);
+#pragma unroll
+            for (int e = 0; e < N; e++) acc[e] += v[e];
         }
     }
-    __shared__ float4 sh[256];
-    sh[ty * CP + tx] = acc;
+    __shared__ float sh[256][N + 1];
+#pragma unroll
+    for (int e = 0; e < N; e++) sh[ty * CP + tx][e] = acc[e];
     __syncthreads();
-    if (ty == 0 && q < N4) {
-        float4 s = sh[tx];
-        for (int j = 1; j < RL; j++) {
-            const float4 v = sh[j * CP + tx];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if (ty == 0 && q < NV) {
+#pragma unroll
+        for (int e = 0; e < N; e++) {
+            float sum = sh[tx][e];
+            for (int j = 1; j < RL; j++) sum += sh[j * CP + tx][e];
+            partial[((long long)blockIdx.y * NV + q) * N + e] = sum;
         }
-        st4(partial + ((long long)blockIdx.y * N4 + q) * 4, s);
     }
 }
 
@@ -366,16 +405,17 @@ namespace {
 template <typename T>
 int maxpool_fwd_t(const T *x, int B, int H, int W, int C, int stride, T *y, uint8_t *idx, void *stream_) {
     if (!x || !y || B < 0 || H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
-    if (C % 4 != 0 || (stride != 1 && stride != 2)) return EMADAPT_ERR_UNSUPPORTED;
+    constexpr int N = VW<T>::N;
+    if (C % N != 0 || (stride != 1 && stride != 2)) return EMADAPT_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(y)) return EMADAPT_ERR_INVALID;
     if (B == 0) return EMADAPT_OK;
     int OH, OW, pt, pl;
     same_pad(H, stride, &OH, &pt);
     same_pad(W, stride, &OW, &pl);
-    const long long n = (long long)B * OH * OW * (C / 4);
+    const long long n = (long long)B * OH * OW * (C / N);
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)B * H * W * C * sizeof(T) + (double)n * (4.0 * sizeof(T) + 4.0), stream);
-    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W, C / 4,
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)B * H * W * C * sizeof(T) + (double)n * N * (sizeof(T) + 1.0), stream);
+    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W, C / N,
                        stride, OH, OW, pt, pl, y, idx);
     return launch_status();
 }
@@ -383,17 +423,18 @@ int maxpool_fwd_t(const T *x, int B, int H, int W, int C, int stride, T *y, uint
 template <typename T>
 int maxpool_bwd_t(const T *dy, const uint8_t *idx, const T *gate, int B, int H, int W, int C, int stride, T *dx,
                   void *stream_) {
+    constexpr int N = VW<T>::N;
     if (!dy || !idx || !dx || B < 0 || H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
-    if (C % 4 != 0 || (stride != 1 && stride != 2)) return EMADAPT_ERR_UNSUPPORTED;
+    if (C % N != 0 || (stride != 1 && stride != 2)) return EMADAPT_ERR_UNSUPPORTED;
     if (B == 0) return EMADAPT_OK;
     int OH, OW, pt, pl;
     same_pad(H, stride, &OH, &pt);
     same_pad(W, stride, &OW, &pl);
-    const long long n = (long long)B * H * W * (C / 4);
+    const long long n = (long long)B * H * W * (C / N);
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 4.0 * sizeof(T) * (gate ? 2.0 : 1.0) + (double)B * OH * OW * C * (sizeof(T) + 1.0), stream);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * N * sizeof(T) * (gate ? 2.0 : 1.0) + (double)B * OH * OW * C * (sizeof(T) + 1.0), stream);
     hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, dy, idx, gate, B, H,
-                       W, C / 4, stride, OH, OW, pt, pl, dx);
+                       W, C / N, stride, OH, OW, pt, pl, dx);
     return launch_status();
 }
 
@@ -448,10 +489,11 @@ size_t emadapt_bias_grad_workspace_bytes(int64_t M, int N) {
 template <typename T>
 static int bias_grad_t(const T *dy, int64_t M, int N, float *db, void *workspace, size_t workspace_bytes,
                        void *stream_) {
+    constexpr int NC = VW<T>::N;
     if (!dy || !db || M <= 0 || N <= 0) return EMADAPT_ERR_INVALID;
-    if (N % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;
+    if (N % NC != 0) return EMADAPT_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < emadapt_bias_grad_workspace_bytes(M, N)) return EMADAPT_ERR_WORKSPACE;
-    const int N4 = N / 4;
+    const int N4 = N / NC;  // 16-byte column vectors per row
     int cp_log2 = 0;
     while ((1 << cp_log2) < N4 && cp_log2 < 6) cp_log2++;
     const int CP = 1 << cp_log2;
