@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = cgroup quota / affinity")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise torch.distributed and the gradient exchange even with one rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the data-parallel flow on a single GPU)")
     return ap.parse_args()
@@ -120,7 +122,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if args.gpus != world and rank == 0 and distributed:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if args.gpus > 1 and not distributed:
@@ -136,11 +138,23 @@ def main():
     device = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
+        # stdout carries exactly one JSON line: RCCL prints its NCCL_DEBUG=VERSION banner (set on the GPU boxes) with a
+        # bare printf when the communicator is created, so file descriptor 1 points at stderr while that happens
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)
-        else:
-            dist.init_process_group(backend=args.backend)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=device)
+            else:
+                dist.init_process_group(backend=args.backend)
+            dist.barrier()
+            torch.cuda.synchronize(device)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from em_adapt_tensorflow_amd import ops
     from em_adapt_tensorflow_amd.data import SyntheticData
@@ -151,7 +165,7 @@ def main():
 
     cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
-           "compute_dtype": args.dtype}
+           "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist)}
     data = SyntheticData(dict(cfg, seed=rank, unique_batches=2))
     adapt = ADAPT(dict(cfg, data=data))
     adapt.build()

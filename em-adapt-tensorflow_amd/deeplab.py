@@ -499,7 +499,7 @@ class ADAPT(Network):
         self.net["train_op"] = self.apply_update
         self.net["g"] = 1.0
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-                torch.distributed.get_world_size() > 1:
+                (torch.distributed.get_world_size() > 1 or self.config.get("force_gradsync", False)):
             from .dist import GradSync
             self._gradsync = GradSync(self._flat["accum"], [(s["start"], s["end"]) for s in self._bucket_order()],
                                       bucket_bytes=int(self.config.get("bucket_mb", 64)) << 20)
