@@ -259,13 +259,27 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": round(tf / peak, 4),
-                "traffic": None,
+                "traffic": None,   # filled below from the committed PMC passes when they cover this workload
                 "launches": d["launches"],
                 "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                 "flop_per_launch": d["flops"] / max(d["launches"], 1),
                 "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None,
                 "step_tflops": round(fb_flops * args.batch / (ms * 1e-3) / 1e12, 2),
             }
+            # HBM (L2-miss) bytes per launch of the dominant class: PMC counters need their own rocprofv3 passes
+            # (scripts/make_profiles.sh); their per-class summary is committed under profiles/ and used when it was taken
+            # on exactly this workload
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                 "r01_traffic.json" if args.dtype == "fp32" else "r01_bf16_traffic.json")
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == out["config"]["workload"] and tj.get("dtype") == args.dtype:
+                    per_step = tj["per_step"][dom]
+                    calls = d["launches"] / max(args.steps, 1)
+                    out["roofline"]["traffic"] = round((per_step["read_bytes"] + per_step["write_bytes"]) / max(calls, 1))
+                    out["roofline"]["traffic_unit"] = "bytes per launch (HBM-side reads + writes, %s)" % os.path.relpath(tpath, os.path.dirname(os.path.abspath(__file__)))
+            except (OSError, KeyError, ValueError):
+                pass
             out["kernel_ms_per_step"] = {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in prof.items()}
             e = prof["estep"]
             if e["ms"] > 0:

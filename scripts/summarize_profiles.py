@@ -77,4 +77,39 @@ for name, a in agg.items():
         out.append("    HBM traffic/step: read %.2f GB (2 x FETCH_SIZE), write %.2f GB; per launch %.3f GB; L2 hit rate %.1f%%" % (
             rd / 1e9, wr / 1e9, (rd + wr) / 1e9 / max(n, 1), 100 * hit))
 open("%s/%s_pmc_conv_kernels.txt" % (DST, R), "w").write("\n".join(out) + "\n")
+
+# HBM bytes per step and kernel class (bench.py's roofline.traffic): the class of a launch is in its name for the fp32
+# kernels (BT = true -> data gradient); the bf16 forward and data-gradient launches share one symbol and are told apart
+# by position (forward launches come first: one per conv layer = as many as there are filter-gradient launches).
+import json
+
+
+def classes_of(rows):
+    nw = sum(1 for r in rows if "wgrad" in r["name"])
+    out, seen_bf16 = [], 0
+    for r in rows:
+        n = r["name"]
+        if "wgrad" in n:
+            out.append("igemm_wgrad")
+        elif "igemm_bf16" in n:
+            out.append("igemm_fwd" if seen_bf16 < nw else "igemm_dgrad")
+            seen_bf16 += 1
+        else:
+            out.append("igemm_dgrad" if re.search(r"true>", n) else "igemm_fwd")
+    return out
+
+
+traffic = {c: {"read_bytes": 0.0, "write_bytes": 0.0} for c in ("igemm_fwd", "igemm_dgrad", "igemm_wgrad")}
+for sub, counter, key, mult in (("pmc_fetch", "FETCH_SIZE", "read_bytes", 2 * 1024.0), ("pmc_write", "WRITE_SIZE", "write_bytes", 1024.0)):
+    rows = load(newest("%s/%s/runc/*_counter_collection.csv" % (SRC, sub)))
+    conv = [r for r in rows if re.search(r"igemm|wgrad", r["name"]) and "splitk" not in r["name"]]
+    conv = conv[len(conv) // 2:]
+    for r, c in zip(conv, classes_of(conv)):
+        traffic[c][key] += r.get(counter, 0.0) * mult
+line = json.load(open(SRC + "/bench_line.json"))
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/make_profiles.sh over bench.py --steps 1 --warmup 1; "
+                     "read = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md), write = WRITE_SIZE KiB; "
+                     "L2-miss (fabric) traffic, Infinity-Cache hits included",
+           "dtype": line["dtype"], "workload": line["config"]["workload"], "per_step": traffic},
+          open("%s/%s_traffic.json" % (DST, R), "w"), indent=1)
 print("\n".join(out))
