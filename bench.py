@@ -73,6 +73,16 @@ def host_cores():
     return max(1, min(n, 64))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
     """Time the CPU oracle on a bounded sample of the same workload (test infrastructure used as a baseline)."""
     import numpy as np
@@ -108,6 +118,7 @@ def cpu_baseline(args):
         "value": round(B * args.cpu_steps / dt, 4),
         "unit": "images/s",
         "cores": int(torch.get_num_threads()),
+        "cpu_model": cpu_model(),
         "kind": "port",
         "sample": "%d images/step x %d timed steps (after 1 warm-up) of the same step: %dx%d, %d classes, preset %s, "
                   "fp32, PyTorch-CPU convs + NumPy E-step oracle; %.1f s" % (B, args.cpu_steps, args.size, args.size,
