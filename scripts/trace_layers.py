@@ -2,7 +2,8 @@
 """Per-layer view of a rocprofv3 --kernel-trace CSV of bench.py: maps the conv kernels of the LAST step to DeepLab
 layers (launch order is fixed: forward conv1_1..fc8, backward fc8..conv1_1 as wgrad then dgrad; a 256x256 main
 launch is followed by its 128x128 tail launch for the rows of the partial last round) and prints duration,
-algorithmic TFLOP/s and the fraction of the 157.3 TFLOP/s fp32-matrix peak.
+algorithmic TFLOP/s and the fraction of the matrix peak (157.3 TFLOP/s fp32; 2516.6 TFLOP/s dense bf16 when the trace
+holds the bf16 kernels).
 
 usage: scripts/trace_layers.py <kernel_trace.csv> [batch] [size] [classes] [preset]
 """
@@ -10,7 +11,7 @@ import csv
 import re
 import sys
 
-PEAK = 157.3e12
+PEAK = 157.3e12  # replaced by the bf16 peak in main() when the trace holds bf16 kernels
 
 
 def layers(size=321, C=21, preset="ref", width=64):
@@ -44,6 +45,9 @@ def main():
     preset = sys.argv[5] if len(sys.argv) > 5 else "ref"
     L = layers(size, C, preset)
     rows = [r for r in csv.DictReader(open(path)) if re.search(r"igemm(_ws|_bf16)?_kernel|wgrad(_ws|_bf16)?_kernel", r["Kernel_Name"])]
+    global PEAK
+    if any("bf16" in r["Kernel_Name"] for r in rows):
+        PEAK = 2516.6e12
     # group "256x256 main + igemm_ws tail" pairs into one logical launch
     groups = []
     i = 0
