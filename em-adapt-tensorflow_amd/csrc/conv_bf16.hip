@@ -5,7 +5,11 @@
 //   operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32), products are exact, sums are fp32
 //   (v_mfma_f32_32x32x16_bf16: 16 k per instruction at half the cycles of the fp32 32x32x2 form -> 16x the rate).
 //
-// Activations and gradients stay fp32 in HBM; the PRODUCER wavefronts convert them on their way into LDS.  The
+// Activations and activation gradients are stored f32 or bf16 (template parameters XBF / YBF / DBF, EMADAPT_DT_* in the
+// ABI): a bf16 tensor holds the values an f32 tensor would be rounded to, was rounded once by the epilogue that wrote it,
+// and is copied into LDS as 16-byte vectors; an f32 tensor is converted by the PRODUCER wavefronts on its way into LDS.
+// With the matrix pipe this fast the kernels are bound by operand bytes (L2->CU delivery, ~70 GB/s per CU), hence bf16
+// storage, 256x256 tiles and vector epilogues.  The
 // filters are converted once per optimizer step into two bf16 images whose reduction axis is contiguous, so that
 // the forward pass and the data gradient read them with plain 16-byte loads and store them untransposed:
 //     fwd image   [tap][co][ci8]   (ci padded to a multiple of 8, zero filled)   k = (tap, ci), n = co
@@ -17,8 +21,8 @@
 //
 // The filter gradient reduces over pixels, the axis along which neither operand is contiguous; its LDS tiles are
 // [pixel][k] and [pixel][n] exactly as loaded, and the MFMA fragments are gathered with the gfx950 transposing read
-// ds_read_b64_tr_b16 (4 pixels x 16 columns per 16-lane group, delivered column-major).  Row pitch 320 bytes: the four
-// pixel rows of one read sit 16 banks apart (80 dwords mod 64), so the 32-lane halves are conflict-free.
+// ds_read_b64_tr_b16 (4 pixels x 16 columns per 16-lane group, delivered column-major).  Row pitch = columns*2 + 64
+// bytes: the four pixel rows of one read sit 16 banks apart, so the 32-lane halves are conflict-free.
 #include <stdlib.h>
 
 #include <type_traits>
