@@ -46,9 +46,10 @@ def parse():
     ap.add_argument("--preset", default="ref", choices=["ref", "largefov"])
     ap.add_argument("--width", type=int, default=64)
     ap.add_argument("--keep-prob", type=float, default=0.5)
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
-                    help="arithmetic of the conv inner products: fp32 (BASELINE configs[1], the headline) or bf16 "
-                         "operands with fp32 accumulation (configs[2]/[3]); everything else stays fp32")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "bf16x6"],
+                    help="arithmetic of the conv inner products: fp32 = native fp32 MFMA (BASELINE configs[1], the "
+                         "headline); bf16 = bf16 operands with fp32 accumulation (configs[2]/[3]); bf16x6 = fp32-grade "
+                         "results from six bf16 MFMAs per product over the exact 3-way bf16 split of both fp32 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -246,8 +247,9 @@ def main():
                             "random-init N(0,0.01) weights, synthetic pixel labels, keep_prob %.2f, accum_num 1" % (
                                 args.preset, "4x4 rate 4 -> 4096" if args.preset == "ref" else "3x3 rate 12 -> 1024",
                                 args.size, args.size, args.classes, args.batch,
-                                "fp32" if args.dtype == "fp32" else "bf16 conv operands / fp32 accumulate, fp32 master "
-                                "weights, activations, gradients and optimizer", args.keep_prob),
+                                {"fp32": "fp32", "bf16": "bf16 conv operands / fp32 accumulate, fp32 master weights, bf16 activation storage",
+                                 "bf16x6": "fp32 tensors, conv products as six bf16 MFMAs over the exact 3-way bf16 split "
+                                           "(fp32-grade), fp32 accumulate"}[args.dtype], args.keep_prob),
                 "global_batch": global_batch,
                 "parallelism": "dp%d" % world,
                 "gflop_per_image_fwd_bwd": round(fb_flops / 1e9, 1),
@@ -262,7 +264,8 @@ def main():
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
             all_flops = sum(v["flops"] for v in conv.values())
             all_ms = sum(v["ms"] for v in conv.values())
-            peak = PEAK_FP32_MATRIX_TFLOPS if args.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
+            peak = {"fp32": PEAK_FP32_MATRIX_TFLOPS, "bf16": PEAK_BF16_MATRIX_TFLOPS,
+                    "bf16x6": round(PEAK_BF16_MATRIX_TFLOPS / 6, 1)}[args.dtype]
             out["roofline"] = {
                 "bound": "mfma",
                 "kernel": dom,
@@ -281,7 +284,7 @@ def main():
             # (scripts/make_profiles.sh); their per-class summary is committed under profiles/ and used when it was taken
             # on exactly this workload
             tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                 "r01_traffic.json" if args.dtype == "fp32" else "r01_bf16_traffic.json")
+                                 {"fp32": "r01_traffic.json", "bf16": "r01_bf16_traffic.json"}.get(args.dtype, "none.json"))
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == out["config"]["workload"] and tj.get("dtype") == args.dtype:

@@ -66,12 +66,13 @@ class ADAPT(Network):
         # "fp32" (reference numerics, BASELINE configs C1/C2/C5) or "bf16" (C3/C4: bf16 MFMA operands, fp32 accumulation,
         # fp32 master weights / gradients / optimizer state)
         self.compute_dtype = str(self.config.get("compute_dtype", "fp32"))
-        if self.compute_dtype not in ("fp32", "bf16"):
-            raise ValueError("compute_dtype must be 'fp32' or 'bf16', got %r" % self.compute_dtype)
+        # "bf16x6": fp32-grade results on the bf16 matrix pipe (exact 3-way split, six products; all tensors f32)
+        if self.compute_dtype not in ("fp32", "bf16", "bf16x6"):
+            raise ValueError("compute_dtype must be 'fp32', 'bf16' or 'bf16x6', got %r" % self.compute_dtype)
         # storage type of activations / activation gradients: defaults to the compute type.  bf16 storage holds the very
         # values the bf16 kernels would round an f32 tensor to, at half the bytes (include/emadapt.h "Storage types");
         # the input image, the fc8 logits (E-step / loss input), weights, gradients and optimizer state stay f32.
-        act = str(self.config.get("act_dtype", self.compute_dtype))
+        act = str(self.config.get("act_dtype", "bf16" if self.compute_dtype == "bf16" else "fp32"))
         if act not in ("fp32", "bf16") or (act == "bf16" and self.compute_dtype != "bf16"):
             raise ValueError("act_dtype must be 'fp32', or 'bf16' together with compute_dtype 'bf16'")
         self.act_dtype = torch.bfloat16 if act == "bf16" else torch.float32
@@ -307,6 +308,13 @@ class ADAPT(Network):
                 bp = self._flat[buf][s + nw:s + nw + nb]
                 seg[prefix + "w_pad"], seg[prefix + "b_pad"] = wp, bp
                 seg[prefix + "w"], seg[prefix + "b"] = wp[:, :, :cin, :cout], bp[:cout]
+        if self.compute_dtype == "bf16x6":
+            # k-contiguous f32 image of every filter for the forward pass (include/emadapt.h "bf16x6")
+            self._flat["wk32"] = torch.zeros(total, dtype=torch.float32, device=dev)
+            for layer, seg in self._segments.items():
+                kh, kw, cin_p, cout_p = seg["pshape"]
+                seg["wk32"] = self._flat["wk32"][seg["start"]:seg["start"] + seg["nw"]].view(kh * kw, cout_p, cin_p)
+            self._w16_seen = None
         if self.compute_dtype == "bf16":
             # bf16 filter images (include/emadapt.h, "bf16-compute variants"), one flat buffer per image kind
             offs, nf, nd = {}, 0, 0
@@ -389,14 +397,17 @@ class ADAPT(Network):
     def refresh_bf16_weights(self, force=False):
         """Re-derive the bf16 filter images when the fp32 master weights changed (torch in-place ops bump the flat
         buffer's version counter; the optimizer kernel, which torch does not see, resets ``_w16_seen`` itself)."""
-        if self.compute_dtype != "bf16":
+        if self.compute_dtype == "fp32":
             return
         ver = self._flat["params"]._version
         if not force and self._w16_seen == ver:
             return
         for op in self._plan:
             if op.kind == "conv":
-                ops.weights_to_bf16(op.w_pad, op.seg["wf16"], op.seg["wd16"])
+                if self.compute_dtype == "bf16":
+                    ops.weights_to_bf16(op.w_pad, op.seg["wf16"], op.seg["wd16"])
+                else:
+                    ops.filter_kmajor(op.w_pad, op.seg["wk32"])
         self._w16_seen = ver
 
     def forward(self, images, keep_prob=1.0, drop_masks=None):
@@ -404,6 +415,7 @@ class ADAPT(Network):
         images = self._to_dev(images)
         self.refresh_bf16_weights()
         bf16 = self.compute_dtype == "bf16"
+        x6 = self.compute_dtype == "bf16x6"
         B = images.shape[0]
         bufs = self._alloc(B)
         self.net["input"] = images
@@ -424,6 +436,9 @@ class ADAPT(Network):
                 if bf16:
                     ops.conv_fwd_bf16(x, op.seg["wf16"], (op.k, op.k), op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
                                       drop_mask=mask, drop_seed=seed, out=out)
+                elif x6:
+                    ops.conv_fwd_x6(x, op.seg["wk32"], (op.k, op.k), op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
+                                    drop_mask=mask, drop_seed=seed, out=out)
                 else:
                     ops.conv_fwd(x, op.w_pad, op.b_pad, op.rate, relu=op.relu, keep_prob=kp, drop_mask=mask,
                                  drop_seed=seed, out=out)
@@ -527,6 +542,7 @@ class ADAPT(Network):
         inv_accum = 1.0 / float(self.accum_num)
         plan = self._plan
         bf16 = self.compute_dtype == "bf16"
+        x6 = self.compute_dtype == "bf16x6"
         for i in range(len(plan) - 1, -1, -1):
             op = plan[i]
             prev = plan[i - 1] if i > 0 else None
@@ -534,6 +550,8 @@ class ADAPT(Network):
                 x_in = bufs["act"][prev.name] if prev is not None else bufs["x_in"]
                 if bf16:
                     ops.conv_wgrad_bf16(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
+                elif x6:
+                    ops.conv_wgrad_x6(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
                 else:
                     ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
                 ops.bias_grad(d, out=op.gb_pad)
@@ -552,6 +570,8 @@ class ADAPT(Network):
                     scale = (1.0 / keep) if (prev.drop and keep < 1.0) else 1.0
                 if bf16:
                     d = ops.conv_dgrad_bf16(d, op.seg["wd16"], (op.k, op.k), op.rate, gate=gate, gate_scale=scale, out=out)
+                elif x6:
+                    d = ops.conv_dgrad_x6(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
                 else:
                     d = ops.conv_dgrad(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
             else:

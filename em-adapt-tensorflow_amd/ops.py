@@ -211,6 +211,68 @@ def conv_wgrad_bf16(x, dy, KH, KW, dil=1, out=None):
     return dw
 
 
+# ---- fp32-grade GEMMs on the bf16 matrix pipe (include/emadapt.h "bf16x6"): all tensors f32
+def filter_kmajor(w, out=None):
+    """k-contiguous f32 image [KH*KW, Cout, Cin] of the HWIO filter (what conv_fwd_x6 reads)."""
+    _check(w, name="w")
+    KH, KW, Cin, Cout = w.shape
+    d = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+    wk = out if out is not None else torch.empty((KH * KW, Cout, Cin), dtype=torch.float32, device=w.device)
+    _check(wk, name="out")
+    if wk.numel() != w.numel():
+        raise ValueError("out has the wrong size")
+    _lib.call("emadapt_filter_kmajor", ctypes.byref(d), _p(w), _p(wk), _stream())
+    return wk
+
+
+def conv_fwd_x6(x, wk, ksize, bias=None, dil=1, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None):
+    """conv_fwd computed as six bf16 MFMAs per product over the exact 3-way bf16 split of both operands."""
+    _check(x, name="x"); _check(wk, name="wk"); _check(bias, name="bias"); _check(drop_mask, torch.uint8, "drop_mask")
+    B, H, W, Cin = x.shape
+    KH, KW = ksize
+    taps, Cout, Ci = wk.shape
+    if taps != KH * KW or Ci != Cin:
+        raise ValueError("k-major filter image %s does not match x channels %d / ksize %s" % (tuple(wk.shape), Cin, ksize))
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    y = out if out is not None else torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    _check(y, name="out")
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    nbytes = _lib.load().emadapt_conv_fwd_x6_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, x.device) if nbytes else None
+    _lib.call("emadapt_conv_fwd_x6", ctypes.byref(d), _p(x), _p(wk), _p(bias), _p(y), epi, float(keep_prob),
+              _p(drop_mask), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(ws), ws.numel() if ws is not None else 0, _stream())
+    return y
+
+
+def conv_dgrad_x6(dy, w, dil=1, gate=None, gate_scale=1.0, out=None):
+    _check(dy, name="dy"); _check(w, name="w"); _check(gate, name="gate")
+    B, H, W, Cout = dy.shape
+    KH, KW, Cin, Co = w.shape
+    if Co != Cout:
+        raise ValueError("filter Cout %d != dy channels %d" % (Co, Cout))
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=torch.float32, device=dy.device)
+    _check(dx, name="out")
+    nbytes = _lib.load().emadapt_conv_dgrad_x6_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, dy.device) if nbytes else None
+    _lib.call("emadapt_conv_dgrad_x6", ctypes.byref(d), _p(dy), _p(w), _p(dx), _p(gate), float(gate_scale), _p(ws),
+              ws.numel() if ws is not None else 0, _stream())
+    return dx
+
+
+def conv_wgrad_x6(x, dy, KH, KW, dil=1, out=None):
+    _check(x, name="x"); _check(dy, name="dy")
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    dw = out if out is not None else torch.empty((KH, KW, Cin, Cout), dtype=torch.float32, device=x.device)
+    _check(dw, name="out")
+    nbytes = _lib.load().emadapt_conv_wgrad_x6_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, x.device)
+    _lib.call("emadapt_conv_wgrad_x6", ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream())
+    return dw
+
+
 def bias_grad(dy, out=None):
     dt = _act(dy, "dy")
     N = dy.shape[-1]

@@ -200,6 +200,25 @@ size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
                             float *dw, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- fp32-grade GEMMs on the bf16 matrix pipe ("bf16x6", opt-in).  Every fp32 operand is split exactly into
+ * three bf16 pieces (x = p0 + p1 + p2: 8+8+8 mantissa bits) and each product is formed from the six piece pairs
+ * that matter (the dropped ones are below 2^-25 of the product), accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16: fp32-grade results (same parity bar as the native fp32 kernels) at 16/6 of the native
+ * fp32 matrix rate.  All tensors are f32 in memory, shapes / epilogues / determinism as for the fp32 entry points.
+ * The forward pass reads the filter from a k-contiguous f32 image [KH*KW][Cout][Cin] (emadapt_filter_kmajor, same
+ * byte size as the HWIO filter, refreshed when the weights change); dgrad and wgrad read the HWIO master copy. */
+int emadapt_filter_kmajor(const emadapt_conv_desc *d, const float *w, float *w_kmajor, void *stream);
+size_t emadapt_conv_fwd_x6_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_fwd_x6(const emadapt_conv_desc *d, const float *x, const float *w_kmajor, const float *bias,
+                        float *y, int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed,
+                        void *workspace, size_t workspace_bytes, void *stream);
+size_t emadapt_conv_dgrad_x6_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_dgrad_x6(const emadapt_conv_desc *d, const float *dy, const float *w, float *dx, const float *gate,
+                          float gate_scale, void *workspace, size_t workspace_bytes, void *stream);
+size_t emadapt_conv_wgrad_x6_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_wgrad_x6(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
 /* The HBM-bound kernels of the step on either storage type (dtype = EMADAPT_DT_*; same semantics as the f32
  * entry points below, arithmetic in fp32 registers, results rounded to nearest-even when the output is bf16). */
 int emadapt_maxpool_fwd_dt(const void *x, int dtype, int B, int H, int W, int C, int stride, void *y, uint8_t *idx,

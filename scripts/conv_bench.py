@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time single conv kernels (fwd / dgrad / wgrad) at DeepLab layer shapes.  usage: conv_bench.py [--bf16] [layer ...]"""
+"""Time single conv kernels (fwd / dgrad / wgrad) at DeepLab layer shapes.  usage: conv_bench.py [--bf16|--x6] [layer ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,6 +21,7 @@ def timeit(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 BF16 = "--bf16" in sys.argv
+X6 = "--x6" in sys.argv
 names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fc6", "conv4_2", "conv2_2"]
 for n in names:
     B, H, W, Cin, Cout, k, dil = SHAPES[n]
@@ -35,6 +36,13 @@ for n in names:
                  ("wgrad", lambda: ops.conv_wgrad_bf16(x, dy, k, k, dil, out=dw)),
                  ("cvt", lambda: ops.weights_to_bf16(w, wf, wd)))
         peak = 2516.6  # dense bf16 MFMA peak, TFLOP/s
+    elif X6:
+        wk = ops.filter_kmajor(w)
+        kinds = (("fwd", lambda: ops.conv_fwd_x6(x, wk, (k, k), b, dil, out=y)),
+                 ("dgrad", lambda: ops.conv_dgrad_x6(dy, w, dil, out=dx)),
+                 ("wgrad", lambda: ops.conv_wgrad_x6(x, dy, k, k, dil, out=dw)),
+                 ("kmaj", lambda: ops.filter_kmajor(w, wk)))
+        peak = 2516.6 / 6  # six bf16 MFMAs per fp32 product
     else:
         kinds = (("fwd", lambda: ops.conv_fwd(x, w, b, dil, out=y)), ("dgrad", lambda: ops.conv_dgrad(dy, w, dil, out=dx)),
                  ("wgrad", lambda: ops.conv_wgrad(x, dy, k, k, dil, out=dw)))
@@ -42,4 +50,4 @@ for n in names:
     for kind, fn in kinds:
         ms = timeit(fn)
         print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  %s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / peak * 100,
-                                                           "bf16" if BF16 else "fp32"), flush=True)
+                                                           "bf16" if BF16 else "bf16x6" if X6 else "fp32"), flush=True)
