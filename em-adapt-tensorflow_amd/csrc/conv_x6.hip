@@ -51,8 +51,10 @@ __device__ __forceinline__ void split3(const float4 v, uint2 &p0, uint2 &p1, uin
     p2 = *reinterpret_cast<uint2 *>(&c);
 }
 
-// The six plane pairs, smallest products first.
-#define X6_PAIRS(F) F(0, 2) F(2, 0) F(1, 1) F(0, 1) F(1, 0) F(0, 0)
+// The six plane pairs, in the order their fragments arrive from LDS (planes are loaded 0, 1, 2), so the first MFMAs of a K
+// step start after 4 of its 12 fragment loads.  The order has no bearing on accuracy: the accumulator already carries
+// the running sum of the previous K steps.
+#define X6_PAIRS(F) F(0, 0) F(0, 1) F(1, 0) F(1, 1) F(0, 2) F(2, 0)
 
 // ------------------------------------------------------------------------------------------------------------------
 // k-contiguous fp32 image of the filter for the forward pass: HWIO [tap][ci][co] -> [tap][co][ci]
