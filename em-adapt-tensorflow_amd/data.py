@@ -1,8 +1,8 @@
-"""Synthetic input source with the call shape the training loop expects from ``dataset``
-(reference dataset.py:107-145: ``next_batch(category, batch_size, epoches)`` and ``get_data_len()``).
+"""Input sources with the call shape the training loop expects from the reference's ``dataset``
+(dataset.py:107-145: ``next_batch(category, batch_size, epoches)`` and ``get_data_len()``).
 
-The reference's real pipeline (VOC file lists, tf.data decode/scale/flip) is outside the hot path and is
-not rebuilt here (section 8 f1 lists it as the next row).  This class
+``dataset`` (below) is the reference's class surface over real VOC-style files: host decode, device
+scale/resize/BGR-mean/flip.  ``SyntheticData``
 produces the benchmark inputs of SURVEY section 8(d) directly in HBM: images ~ N(0, 50^2) (the scale of
 BGR-mean-subtracted pixels, dataset.py:15-18,177) and pixel label maps made of background, 1-3 rectangles
 of random foreground classes and a 4-pixel void (255) border.
@@ -71,8 +71,8 @@ def image_preprocess(img_u8, label_u8, out_hw, scale=None, flip=False, device="c
     JPEG/PNG decoding stay on the host (out of the hot path)."""
     from . import ops
     dev = torch.device(device)
-    img = torch.as_tensor(np.ascontiguousarray(img_u8)).to(dev, torch.float32).unsqueeze(0)
-    lab = torch.as_tensor(np.ascontiguousarray(label_u8)).to(dev, torch.float32).reshape(1, img.shape[1], img.shape[2])
+    img = torch.as_tensor(np.array(img_u8, copy=True)).to(dev, torch.float32).unsqueeze(0)
+    lab = torch.as_tensor(np.array(label_u8, copy=True)).to(dev, torch.float32).reshape(1, img.shape[1], img.shape[2])
     if scale is not None:
         # tf.to_int32(tf.to_float(h) * scale): fp32 product, truncation (dataset.py:154-155)
         h_new = int(np.float32(img.shape[1]) * np.float32(scale))
@@ -84,3 +84,159 @@ def image_preprocess(img_u8, label_u8, out_hw, scale=None, flip=False, device="c
     fl = torch.tensor([1 if flip else 0], dtype=torch.uint8, device=dev)
     img, lab = ops.bgr_mean_flip(img, lab, fl)
     return img[0], lab[0].unsqueeze(-1)
+
+
+# VOC palette of the reference's label2rgb / rgb2label (dataset.py:78-84, 91-97)
+VOC_COLORS = [(0, 0, 0), (128, 0, 0), (0, 128, 0), (128, 128, 0), (0, 0, 128), (128, 0, 128), (0, 128, 128),
+              (128, 128, 128), (64, 0, 0), (192, 0, 0), (64, 128, 0), (192, 128, 0), (64, 0, 128), (192, 0, 128),
+              (64, 128, 128), (192, 128, 128), (0, 64, 0), (128, 64, 0), (0, 192, 0), (128, 192, 0), (0, 64, 128)]
+
+
+class dataset:
+    """The reference's ``dataset`` class (dataset.py:6-145) with the same config keys, attributes and methods, feeding
+    the device pipeline instead of tf.data:
+
+      * file lists: ``<list_path>/<category>.txt`` (default ``pascal/txt``, dataset.py:32) holding one id per line;
+        images ``<main_path>/JPEGImages/<id>.jpg``, labels ``<main_path>/SegmentationClassAug/<id>.png``
+        (dataset.py:35-37); ``config["length"]`` truncates every list (dataset.py:38-42);
+      * ``next_batch(category, batch_size, epoches)`` (dataset.py:107-145) is an iterator over
+        ``(images f32 [B,H,W,3] BGR-mean, labels f32 [B,H,W,1], ids)`` device tensors: shuffled every epoch, ``epoches``
+        passes (-1 = endless), "train" samples get the random scale U[0.75,1.25) and the coin-toss flip
+        (dataset.py:125-126), other categories neither; a short final batch is yielded as is (tf.data ``batch``);
+      * JPEG/PNG decoding runs in a small host thread pool one batch ahead of the consumer; scaling, resizing, channel
+        swap, mean subtraction and flip are the HIP kernels behind ``image_preprocess``.
+    ``ADAPT.train`` accepts it as ``config["data"]`` (it ignores the third element)."""
+
+    def __init__(self, config={}):
+        import os
+        self.config = config
+        self.w, self.h = self.config.get("input_size", (240, 240))   # (w, h) naming as in dataset.py:9; square inputs
+        self.categorys = self.config.get("categorys", ["train", "val"])
+        assert len(self.categorys) > 0, "no enough categorys in dataset"
+        self.main_path = self.config.get("main_path", os.path.join("pascal", "VOCdevkit", "VOC2012"))
+        self.list_path = self.config.get("list_path", os.path.join("pascal", "txt"))
+        self.ignore_label = self.config.get("ignore_label", 255)
+        self.default_category = self.config.get("default_category", self.categorys[0])
+        self.device = self.config.get("device", "cuda")
+        self.workers = int(self.config.get("decode_workers", 4))
+        self.rng = np.random.default_rng(self.config.get("seed", None))
+        self.img_mean = np.ones((self.w, self.h, 3))
+        self.img_mean[:, :, 0] *= 104.00698793
+        self.img_mean[:, :, 1] *= 116.66876762
+        self.img_mean[:, :, 2] *= 122.67891434
+        self.init()
+
+    def init(self):
+        self.data_f, self.data_len = self.get_data_f()
+        self.reset_info()
+
+    def get_data_f(self):
+        import os
+        data_f, data_len = {}, {}
+        for one in self.categorys:
+            data_f[one] = {"img": [], "label": [], "id": []}
+            with open(os.path.join(self.list_path, "%s.txt" % one), "r") as f:
+                for line in f.readlines():
+                    line = line.strip("\n")
+                    if not line:
+                        continue
+                    data_f[one]["id"].append(line)
+                    data_f[one]["img"].append(os.path.join(self.main_path, "JPEGImages", "%s.jpg" % line))
+                    data_f[one]["label"].append(os.path.join(self.main_path, "SegmentationClassAug", "%s.png" % line))
+            if "length" in self.config:
+                n = self.config["length"]
+                for k in ("id", "img", "label"):
+                    data_f[one][k] = data_f[one][k][:n]
+            data_len[one] = len(data_f[one]["label"])
+        print("len:%s" % str(data_len))
+        return data_f, data_len
+
+    def reset_info(self):
+        self.info = {"epoch": {}, "index": {}, "perm": {}}
+        for category in self.categorys:
+            self.info["epoch"][category] = 0
+            self.info["index"][category] = 0
+            self.info["perm"][category] = self.rng.permutation(self.data_len[category])
+        return self.info
+
+    def get_info(self, key="epoch", category=None):
+        return self.info[key][category or self.default_category]
+
+    def get_data_len(self, category=None):
+        return self.data_len[category or self.default_category]
+
+    def get_cur_epoch(self, category=None):
+        return self.info["epoch"][category or self.default_category]
+
+    @staticmethod
+    def label2rgb(label, colors=(), ignore_label=255, ignore_color=(255, 255, 255)):
+        colors = list(colors) or VOC_COLORS
+        label = np.asarray(label)
+        out = np.empty(label.shape[:2] + (3,), np.uint8)
+        out[...] = ignore_color
+        for i, c in enumerate(colors):
+            out[label[..., 0] == i if label.ndim == 3 else label == i] = c
+        return out
+
+    @staticmethod
+    def rgb2label(label, colors=(), ignore_color=255):
+        colors = list(colors) or VOC_COLORS
+        label = np.asarray(label)
+        out = ignore_color * np.ones(label.shape[0:2], dtype=np.uint8)
+        for i, c in enumerate(colors):
+            out[np.all(label[:, :, 0:3] == np.asarray(c, label.dtype), axis=2)] = i
+        return out
+
+    # -- decoding (host) and preprocessing (device) ----------------------------------------------------------------
+    @staticmethod
+    def _decode(img_f, label_f):
+        from PIL import Image
+        img = np.asarray(Image.open(img_f).convert("RGB"), dtype=np.uint8)
+        lab = Image.open(label_f)
+        lab = np.asarray(lab if lab.mode in ("L", "P") else lab.convert("L"), dtype=np.uint8)  # palette index = class id
+        return img, lab
+
+    def image_preprocess(self, img, label, random_scale=False, flip=False):
+        """dataset.image_preprocess (dataset.py:147-185) for one decoded sample, on the device."""
+        scale = float(self.rng.uniform(0.75, 1.25)) if random_scale else None
+        do_flip = bool(flip) and bool(self.rng.uniform() < 0.5)
+        return image_preprocess(img, label, (self.h, self.w), scale=scale, flip=do_flip, device=self.device)
+
+    def next_batch(self, category=None, batch_size=None, epoches=-1):
+        import concurrent.futures
+        category = category or self.default_category
+        batch_size = batch_size or self.config.get("batch_size", 1)
+        files = self.data_f[category]
+        n = self.data_len[category]
+        train = category == "train"
+
+        def order():
+            ep = 0
+            while epoches < 0 or ep < epoches:
+                perm = self.rng.permutation(n)
+                self.info["perm"][category] = perm
+                for s in range(0, n, batch_size):
+                    yield ep, s, perm[s:s + batch_size]
+                ep += 1
+
+        with concurrent.futures.ThreadPoolExecutor(max(self.workers, 1)) as pool:
+            def submit(idx):
+                return [pool.submit(self._decode, files["img"][i], files["label"][i]) for i in idx]
+
+            it = order()
+            nxt = next(it, None)
+            pending = submit(nxt[2]) if nxt else None
+            while nxt is not None:
+                ep, s, idx = nxt
+                futs = pending
+                nxt = next(it, None)
+                pending = submit(nxt[2]) if nxt else None   # decode the next batch while this one is consumed
+                imgs, labs = [], []
+                for f in futs:
+                    img, lab = f.result()
+                    x, y = self.image_preprocess(img, lab, random_scale=train, flip=train)
+                    imgs.append(x)
+                    labs.append(y)
+                self.info["epoch"][category] = ep
+                self.info["index"][category] = s + len(idx)
+                yield torch.stack(imgs), torch.stack(labs), [files["id"][i] for i in idx]

@@ -647,7 +647,8 @@ class ADAPT(Network):
                     self.saver["lr"].save(None, os.path.join(saver_dir, "lr-%f" % base_lr), global_step=i)
                     self.net["lr"] = new_lr
                     base_lr = new_lr
-            data_x, data_y = next(train_iter)
+            batch = next(train_iter)   # (images, labels) or the dataset class's (images, labels, ids)
+            data_x, data_y = batch[0], batch[1]
             self.net["accum_gradient_accum"](data_x, data_y, 0.5)
             if i % self.accum_num == self.accum_num - 1:
                 self.net["accum_gradient_update"]()
