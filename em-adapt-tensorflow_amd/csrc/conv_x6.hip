@@ -87,18 +87,23 @@ __global__ void __launch_bounds__(256) filter_kmajor_kernel(const float *__restr
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kPitchX = 48;  // bytes per LDS row of 16 bf16 (+8 pad)
 
-__global__ void __launch_bounds__(512, 4) igemm_x6_kernel(IgemmArgs a) {
-    constexpr int BM = 128, BN = 128, BK = 16, WM = 64, WN = 64;
+// Tile BM x 128: BM = 128 (4 MFMA + 4 loader waves, two workgroups per CU) or BM = 256 (8 + 4 waves, one per CU).  The
+// loaders' split arithmetic is per loaded element while the MFMA count grows with the tile area: 7 VALU instructions
+// per MFMA at 128x128 (measured; enough to fill the SIMD issue ports) against ~3.8 at 256x128.
+template <int BM>
+__global__ void __launch_bounds__((BM / 64 * 2 + 4) * 64, BM == 128 ? 4 : 3) igemm_x6_kernel(IgemmArgs a) {
+    constexpr int BN = 128, BK = 16, WM = 64, WN = 64;
     constexpr int TM = 2, TN = 2;
+    constexpr int CTHREADS = (BM / WM) * 2 * 64;  // MFMA threads; the 256 loader threads follow
     constexpr int KQ = BK / 4;            // 4 fp32 quads per row
     constexpr int RSTEP = 256 / KQ;       // 64 rows per pass of the loaders
-    constexpr int A_N = BM / RSTEP, B_N = BN / RSTEP;   // 2 + 2 loads per thread and K step
-    constexpr int PLANE = BM * kPitchX;   // bytes per plane of a tile (BM == BN)
-    constexpr int TILE = 3 * PLANE;       // bytes per operand tile
+    constexpr int A_N = BM / RSTEP, B_N = BN / RSTEP;   // fp32 quads per thread and K step
+    constexpr int PLANE_A = BM * kPitchX, PLANE_B = BN * kPitchX;   // bytes per plane
+    constexpr int TILE_A = 3 * PLANE_A, TILE_B = 3 * PLANE_B;       // bytes per operand tile
 
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
-    char *As = ldsb;               // [2][3][BM][kPitchX]
-    char *Bs = ldsb + 2 * TILE;    // [2][3][BN][kPitchX]
+    char *As = ldsb;                 // [2][3][BM][kPitchX]
+    char *Bs = ldsb + 2 * TILE_A;    // [2][3][BN][kPitchX]
 
     int tile_m, tile_n, split;
     {
@@ -109,7 +114,7 @@ __global__ void __launch_bounds__(512, 4) igemm_x6_kernel(IgemmArgs a) {
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         split = t / ntile;
         t -= split * ntile;
-        constexpr int GM = 8;
+        constexpr int GM = BM == 128 ? 8 : 4;
         const int per_group = GM * a.tiles_n;
         const int g = t / per_group;
         const int first_m = g * GM;
@@ -123,9 +128,9 @@ __global__ void __launch_bounds__(512, 4) igemm_x6_kernel(IgemmArgs a) {
     const int kt0 = (int)((long long)nk_all * split / a.splits);
     const int nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
 
-    if (threadIdx.x >= 256) {
+    if (threadIdx.x >= CTHREADS) {
         // ================================ LOADER wavefronts ================================
-        const int tid = threadIdx.x - 256;
+        const int tid = threadIdx.x - CTHREADS;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
         constexpr unsigned kOOB = 0x80000000u;
@@ -175,13 +180,13 @@ __global__ void __launch_bounds__(512, 4) igemm_x6_kernel(IgemmArgs a) {
             const int n = n0 + r0 + j * RSTEP;
             rb[j] = buf_ld4(wr, ((unsigned)(boff + j * RSTEP * a.Cx) * 4u) | ((kvalid && n < a.N) ? 0u : kOOB));
         };
-        auto store3 = [&](char *base, int row, const float4 &v) {
+        auto store3 = [&](char *base, int plane, int row, const float4 &v) {
             uint2 p0, p1, p2;
             split3(v, p0, p1, p2);
             char *d = base + row * kPitchX + kq * 8;
             *reinterpret_cast<uint2 *>(d) = p0;
-            *reinterpret_cast<uint2 *>(d + PLANE) = p1;
-            *reinterpret_cast<uint2 *>(d + 2 * PLANE) = p2;
+            *reinterpret_cast<uint2 *>(d + plane) = p1;
+            *reinterpret_cast<uint2 *>(d + 2 * plane) = p2;
         };
         step_setup(kt0);
 #pragma unroll
@@ -190,18 +195,18 @@ __global__ void __launch_bounds__(512, 4) igemm_x6_kernel(IgemmArgs a) {
         for (int j = 0; j < B_N; j++) load_b(j);
         step_setup(kt0 + 1);  // K steps past the end are zero-filled by the range check
 #pragma unroll
-        for (int j = 0; j < A_N; j++) { store3(As, r0 + j * RSTEP, ra[j]); load_a(j); }
+        for (int j = 0; j < A_N; j++) { store3(As, PLANE_A, r0 + j * RSTEP, ra[j]); load_a(j); }
 #pragma unroll
-        for (int j = 0; j < B_N; j++) { store3(Bs, r0 + j * RSTEP, rb[j]); load_b(j); }
+        for (int j = 0; j < B_N; j++) { store3(Bs, PLANE_B, r0 + j * RSTEP, rb[j]); load_b(j); }
         __syncthreads();
         // steady state: park register j (split into its planes) and re-arm it with the load of the step after next
         for (int kt = 0; kt < nk; kt++) {
             const int buf = (kt + 1) & 1;
             step_setup(kt0 + kt + 2);
 #pragma unroll
-            for (int j = 0; j < A_N; j++) { store3(As + buf * TILE, r0 + j * RSTEP, ra[j]); load_a(j); }
+            for (int j = 0; j < A_N; j++) { store3(As + buf * TILE_A, PLANE_A, r0 + j * RSTEP, ra[j]); load_a(j); }
 #pragma unroll
-            for (int j = 0; j < B_N; j++) { store3(Bs + buf * TILE, r0 + j * RSTEP, rb[j]); load_b(j); }
+            for (int j = 0; j < B_N; j++) { store3(Bs + buf * TILE_B, PLANE_B, r0 + j * RSTEP, rb[j]); load_b(j); }
             __syncthreads();
         }
         return;
@@ -222,15 +227,15 @@ __global__ void __launch_bounds__(512, 4) igemm_x6_kernel(IgemmArgs a) {
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
-        const char *as = As + cur * TILE + (wm * WM + l31) * kPitchX + lh * 16;
-        const char *bs = Bs + cur * TILE + (wn * WN + l31) * kPitchX + lh * 16;
+        const char *as = As + cur * TILE_A + (wm * WM + l31) * kPitchX + lh * 16;
+        const char *bs = Bs + cur * TILE_B + (wn * WN + l31) * kPitchX + lh * 16;
         bf16x8 av[3][TM], bv[3][TN];
 #pragma unroll
         for (int p = 0; p < 3; p++) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) av[p][i] = *reinterpret_cast<const bf16x8 *>(as + p * PLANE + i * 32 * kPitchX);
+            for (int i = 0; i < TM; i++) av[p][i] = *reinterpret_cast<const bf16x8 *>(as + p * PLANE_A + i * 32 * kPitchX);
 #pragma unroll
-            for (int j = 0; j < TN; j++) bv[p][j] = *reinterpret_cast<const bf16x8 *>(bs + p * PLANE + j * 32 * kPitchX);
+            for (int j = 0; j < TN; j++) bv[p][j] = *reinterpret_cast<const bf16x8 *>(bs + p * PLANE_B + j * 32 * kPitchX);
         }
 #define X6_MFMA(P, Q)                                                                                              \
     _Pragma("unroll") for (int i = 0; i < TM; i++) _Pragma("unroll") for (int j = 0; j < TN; j++) acc[i][j] =      \
@@ -240,21 +245,45 @@ __global__ void __launch_bounds__(512, 4) igemm_x6_kernel(IgemmArgs a) {
         __syncthreads();
     }
     constexpr int SLAB = 32 * (WN + 4);
-    static_assert(SLAB * 4 * 4 <= 4 * TILE, "epilogue slabs must fit in the tile LDS");
+    static_assert(SLAB * 4 * (CTHREADS / 64) <= 2 * (TILE_A + TILE_B), "epilogue slabs must fit in the tile LDS");
     float *slab = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
     store_acc_tile<TM, TN, 32, false>(a, acc, reinterpret_cast<float *>(ldsb) + wave * SLAB, lane, m0 + wm * WM, n0 + wn * WN, slab);
 }
 
-int x6_splits(const IgemmArgs &a) { return choose_splits(a.M, a.N, a.K, 128, 128, 16, 512.0, 250e12); }
+// 128x128 tiles by default.  The 256x128 configuration (one workgroup per CU) is kept selectable and parity-tested, but
+// does not pay for the forward / data-gradient kernels: with three planes per operand these kernels are bound by LDS
+// traffic (SQ_LDS_IDX_ACTIVE ~ the kernel's cycles), which the taller tile reduces by only a quarter while halving the
+// number of resident MFMA waves that can cover each other's LDS round trips.
+bool x6_big(const IgemmArgs &a) {
+    (void)a;
+    const char *force = getenv("EMADAPT_X6_TILE");  // 128|256, read per call (the parity tests run both)
+    return force && atoi(force) == 256;
+}
 
-int dispatch_igemm_x6(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    constexpr size_t lds = 4 * 3 * 128 * kPitchX;
+int x6_splits(const IgemmArgs &a) {
+    return x6_big(a) ? choose_splits(a.M, a.N, a.K, 256, 128, 16, 256.0, 250e12)
+                     : choose_splits(a.M, a.N, a.K, 128, 128, 16, 512.0, 200e12);
+}
+
+template <int BM>
+int launch_igemm_x6(IgemmArgs &a, hipStream_t stream) {
+    constexpr size_t lds = 2 * 3 * (BM + 128) * kPitchX;
+    constexpr int threads = (BM / 64 * 2 + 4) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_x6_kernel),
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_x6_kernel<BM>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    a.tiles_m = (int)ceil_div(a.M, BM);
+    a.tiles_n = (int)ceil_div(a.N, 128);
+    const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
+    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((igemm_x6_kernel<BM>), dim3((unsigned)nblk), dim3(threads), lds, stream, a);
+    return launch_status();
+}
+
+int dispatch_igemm_x6(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     int splits = x6_splits(a);
     if (splits > 1 && (!workspace || workspace_bytes < (size_t)splits * a.M * a.N * sizeof(float))) splits = 1;
     a.ablate = 0;
@@ -263,12 +292,7 @@ int dispatch_igemm_x6(IgemmArgs &a, void *workspace, size_t workspace_bytes, hip
     a.m_end = a.M;
     a.splits = splits;
     a.slab = splits > 1 ? static_cast<float *>(workspace) : nullptr;
-    a.tiles_m = (int)ceil_div(a.M, 128);
-    a.tiles_n = (int)ceil_div(a.N, 128);
-    const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
-    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(igemm_x6_kernel, dim3((unsigned)nblk), dim3(512), lds, stream, a);
-    int rc = launch_status();
+    int rc = x6_big(a) ? launch_igemm_x6<256>(a, stream) : launch_igemm_x6<128>(a, stream);
     if (rc || a.splits <= 1) return rc;
     long long g = ((long long)a.M * a.N / 4 + 255) / 256;
     if (g > 8192) g = 8192;
@@ -297,12 +321,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const char *p0, const char *p1) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int BN>
-__global__ void __launch_bounds__(512, 4) wgrad_x6_kernel(WgradX6Args a) {
-    constexpr int BKO = 128, BMR = 16;
+template <int BKO, int BN>
+__global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) wgrad_x6_kernel(WgradX6Args a) {
+    constexpr int BMR = 16;
     constexpr int WK = 64, WN = BN / 2;
     constexpr int TK = WK / 32, TN = WN / 32;
-    constexpr int XQ = BKO / 4, X_RSTEP = 256 / XQ, X_N = BMR / X_RSTEP;  // 32, 8, 2
+    constexpr int CTHREADS = (BKO / WK) * 2 * 64;
+    constexpr int XQ = BKO / 4, X_RSTEP = 256 / XQ, X_N = BMR / X_RSTEP;  // BKO 128: 32, 8, 2; BKO 256: 64, 4, 4
     constexpr int YQ = BN / 4, Y_RSTEP = 256 / YQ, Y_N = BMR / Y_RSTEP;   // BN 128: 32, 8, 2; BN 64: 16, 16, 1
     constexpr int PX = BKO * 2 + 64, PY = BN * 2 + 64;                    // LDS row pitches in bytes
     constexpr int PLANE_X = BMR * PX, PLANE_Y = BMR * PY;
@@ -321,7 +346,7 @@ __global__ void __launch_bounds__(512, 4) wgrad_x6_kernel(WgradX6Args a) {
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         split = t / ntile;
         t -= split * ntile;
-        constexpr int GK = 8;
+        constexpr int GK = BKO == 128 ? 8 : 4;
         const int per_group = GK * a.tiles_n;
         const int g = t / per_group;
         const int first_k = g * GK;
@@ -336,9 +361,9 @@ __global__ void __launch_bounds__(512, 4) wgrad_x6_kernel(WgradX6Args a) {
     if (m_end > a.M) m_end = a.M;
     const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BMR - 1) / BMR : 0;
 
-    if (threadIdx.x >= 256) {
+    if (threadIdx.x >= CTHREADS) {
         // ================================ LOADER wavefronts ================================
-        const int tid = threadIdx.x - 256;
+        const int tid = threadIdx.x - CTHREADS;
         const int x_kq = tid % XQ, x_r0 = tid / XQ;
         const int k = k0 + x_kq * 4;
         const bool kvalid = k < a.K;
@@ -447,24 +472,29 @@ __global__ void __launch_bounds__(512, 4) wgrad_x6_kernel(WgradX6Args a) {
 }
 
 struct PlanX6 {
-    int bn, tiles_k, tiles_n, splits, rows_per_split;
+    int bko, bn, tiles_k, tiles_n, splits, rows_per_split;
 };
 
 PlanX6 make_plan_x6(const emadapt_conv_desc *d) {
     PlanX6 p;
     const long long M = (long long)d->B * d->H * d->W;
     const int K = d->KH * d->KW * d->Cin;
-    p.bn = d->Cout <= 64 ? 64 : 128;
-    p.tiles_k = (int)ceil_div(K, 128);
+    const char *force = getenv("EMADAPT_X6_TILE");  // 128|256, read per call (the parity tests run both)
+    bool big = K >= 256 && d->Cout >= 128;
+    if (force) big = atoi(force) == 256;
+    p.bko = big ? 256 : 128;
+    p.bn = big ? 128 : (d->Cout <= 64 ? 64 : 128);
+    p.tiles_k = (int)ceil_div(K, p.bko);
     p.tiles_n = (int)ceil_div(d->Cout, p.bn);
     const long long tiles = (long long)p.tiles_k * p.tiles_n;
-    const double t_kernel = 2.0 * (double)M * (p.tiles_k * 128.0) * (p.tiles_n * (double)p.bn) / 250e12;
+    const double slots = big ? 256.0 : 512.0;
+    const double t_kernel = 2.0 * (double)M * (p.tiles_k * (double)p.bko) * (p.tiles_n * (double)p.bn) / (big ? 250e12 : 200e12);
     const double kn_bytes = (double)K * d->Cout * 4.0;
     long long best = 1;
     double best_t = 1e30;
     const long long max_s = ceil_div(M, 256) < 2048 ? ceil_div(M, 256) : 2048;
     for (long long s = 1; s <= max_s; s++) {
-        const double rounds = (double)tiles * s / 512.0;
+        const double rounds = (double)tiles * s / slots;
         const double eff = rounds / (double)(long long)(rounds + 0.999999);
         double t = t_kernel / eff + 2e-6 * (double)(long long)(rounds + 0.999999);
         if (s > 1) t += (double)(s + 1) * kn_bytes / 3e12 + 3e-6;
@@ -486,18 +516,19 @@ int check_desc_wgrad_x6(const emadapt_conv_desc *d) {
     return EMADAPT_OK;
 }
 
-template <int BN>
+template <int BKO, int BN>
 int launch_wgrad_x6(const WgradX6Args &a, hipStream_t stream) {
-    constexpr size_t lds = 2 * 3 * 16 * (128 * 2 + 64 + BN * 2 + 64);
+    constexpr size_t lds = 2 * 3 * 16 * (BKO * 2 + 64 + BN * 2 + 64);
+    constexpr int threads = (BKO / 64 * 2 + 4) * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_x6_kernel<BN>),
+        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_x6_kernel<BKO, BN>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((wgrad_x6_kernel<BN>), dim3((unsigned)nblk), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((wgrad_x6_kernel<BKO, BN>), dim3((unsigned)nblk), dim3(threads), lds, stream, a);
     return launch_status();
 }
 
@@ -600,7 +631,9 @@ int emadapt_conv_wgrad_x6(const emadapt_conv_desc *d, const float *x, const floa
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    rc = (p.bn == 64) ? launch_wgrad_x6<64>(a, stream) : launch_wgrad_x6<128>(a, stream);
+    rc = p.bko == 256 ? launch_wgrad_x6<256, 128>(a, stream)
+       : p.bn == 64  ? launch_wgrad_x6<128, 64>(a, stream)
+                     : launch_wgrad_x6<128, 128>(a, stream);
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
     return rc;

@@ -46,8 +46,16 @@ SHAPES = [
 ]
 
 
+@pytest.fixture(params=["auto", "128", "256"])
+def tile(request, monkeypatch):
+    """Run the kernels in their automatic plan and with each tile configuration forced."""
+    if request.param != "auto":
+        monkeypatch.setenv("EMADAPT_X6_TILE", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("shape", SHAPES)
-def test_x6_conv_fwd_dgrad_wgrad(env, shape):
+def test_x6_conv_fwd_dgrad_wgrad(env, shape, tile):
     ops, do, torch = env
     B, H, W, Cin, Cout, k, dil = shape
     rng = np.random.default_rng(hash(shape) % (1 << 31))
