@@ -14,8 +14,8 @@
 // Structure (see conv_bf16.hip for the bf16 building blocks): wave-specialised 128x128 tiles, K steps of 16 (one MFMA k
 // group x 6 plane pairs x 4 accumulator tiles = 24 MFMAs per wave and step), 4 MFMA + 4 loader waves, two workgroups per
 // CU.  Both operands are gathered along k as fp32 float4s and split into their three planes by the loader waves
-// (v_cvt_pk_bf16_f32 + two exact subtractions) on the way into LDS: tiles are [plane][row][k] bf16, 48-byte rows
-// (3r mod 16 is a bijection: conflict-free ds_read_b128).  The forward pass reads the filter from a k-contiguous fp32
+// (v_cvt_pk_bf16_f32 + two exact subtractions) on the way into LDS: tiles are [plane][row][k] bf16, 32-byte rows
+// with a chunk swizzle (conflict-free ds_write_b64 and ds_read_b128).  The forward pass reads the filter from a k-contiguous fp32
 // image [tap][co][ci] (emadapt_filter_kmajor, refreshed once per optimizer step); the data gradient reads the HWIO master
 // copy directly (k = co is contiguous).  The filter gradient stores [plane][pixel][k|n] and gathers its fragments with
 // ds_read_b64_tr_b16, 16 pixels per step.
@@ -85,7 +85,11 @@ __global__ void __launch_bounds__(256) filter_kmajor_kernel(const float *__restr
 // ------------------------------------------------------------------------------------------------------------------
 // Forward / data gradient: out[m][n] = sum_k A[m][k] B[n][k]; B = a.w is [tap][N][Cx] fp32 with k contiguous.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kPitchX = 48;  // bytes per LDS row of 16 bf16 (+8 pad)
+// LDS rows of 16 bf16 = 32 bytes, unpadded; the two 16-byte chunks of a row are swapped when bit 3 of the row is set.
+// Loaders: 16 consecutive lanes store 4 rows x 4 quads = 128 contiguous bytes (conflict-free ds_write_b64; rows of a
+// group share bit 3).  MFMA waves: the 16-lane groups of ds_read_b128 cover each row residue mod 8 twice, with opposite
+// bit 3 -> 16 distinct 16-byte slots.  (A padded 48-byte pitch cost a third of the LDS cycles in store conflicts.)
+constexpr int kPitchX = 32;
 
 // Tile BM x 128: BM = 128 (4 MFMA + 4 loader waves, two workgroups per CU) or BM = 256 (8 + 4 waves, one per CU).  The
 // loaders' split arithmetic is per loaded element while the MFMA count grows with the tile area: 7 VALU instructions
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__((BM / 64 * 2 + 4) * 64, BM == 128 ? 4 : 3) ige
         auto store3 = [&](char *base, int plane, int row, const float4 &v) {
             uint2 p0, p1, p2;
             split3(v, p0, p1, p2);
-            char *d = base + row * kPitchX + kq * 8;
+            char *d = base + row * kPitchX + (((kq >> 1) ^ ((row >> 3) & 1)) * 16) + (kq & 1) * 8;
             *reinterpret_cast<uint2 *>(d) = p0;
             *reinterpret_cast<uint2 *>(d + plane) = p1;
             *reinterpret_cast<uint2 *>(d + 2 * plane) = p2;
@@ -227,8 +231,9 @@ __global__ void __launch_bounds__((BM / 64 * 2 + 4) * 64, BM == 128 ? 4 : 3) ige
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
-        const char *as = As + cur * TILE_A + (wm * WM + l31) * kPitchX + lh * 16;
-        const char *bs = Bs + cur * TILE_B + (wn * WN + l31) * kPitchX + lh * 16;
+        const int chunk = (lh ^ ((l31 >> 3) & 1)) * 16;   // swizzled chunk (tile bases are multiples of 16 rows)
+        const char *as = As + cur * TILE_A + (wm * WM + l31) * kPitchX + chunk;
+        const char *bs = Bs + cur * TILE_B + (wn * WN + l31) * kPitchX + chunk;
         bf16x8 av[3][TM], bv[3][TN];
 #pragma unroll
         for (int p = 0; p < 3; p++) {
