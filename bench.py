@@ -178,7 +178,7 @@ def main():
     cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
            "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist)}
-    data = SyntheticData(dict(cfg, seed=rank, unique_batches=2))
+    data = SyntheticData(dict(cfg, seed=0, unique_batches=2))   # SyntheticData mixes the rank into its seed
     adapt = ADAPT(dict(cfg, data=data))
     adapt.build()
     adapt.pre_train(base_lr=1e-3, weight_decay=1e-5, momentum=0.9, batch_size=args.batch)

@@ -4,6 +4,7 @@ hipcc cross-compiles without a GPU.  The .so stays next to this file so that it 
 repository snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
 """
 import concurrent.futures
+import fcntl
 import glob
 import os
 import shutil
@@ -13,6 +14,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
 LIB_PATH = os.path.join(PKG_DIR, "libemadapt_hip.so")
+# diagnostic build (-DEMADAPT_ABLATE_BUILD: E-step phase exits, igemm ablation bits); never loaded by the product path,
+# only by scripts/ (they bind it explicitly with _lib._bind before using any operator)
+ABLATE_LIB_PATH = os.path.join(PKG_DIR, "libemadapt_hip_ablate.so")
 ARCH = "gfx950"
 # No -ffast-math: the E-step must keep IEEE fp32 semantics (bit-exact label maps), and the conv
 # accumulation order is part of the documented numerics.
@@ -42,35 +46,47 @@ def is_stale():
     return any(os.path.getmtime(s) > t for s in sources()) or _deps_mtime() > t
 
 
-def _compile(src):
-    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+def _compile(src, obj_dir=OBJ_DIR, extra=()):
+    obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _deps_mtime()):
         return obj
-    subprocess.check_call([_hipcc()] + CXXFLAGS + ["-c", src, "-o", obj])
+    subprocess.check_call([_hipcc()] + CXXFLAGS + list(extra) + ["-c", src, "-o", obj])
     return obj
 
 
-def build(force=False, jobs=None, verbose=True):
-    """Compile every csrc/*.hip for gfx950 and link libemadapt_hip.so.  Returns the .so path."""
-    if not force and not is_stale():
-        return LIB_PATH
-    os.makedirs(OBJ_DIR, exist_ok=True)
-    if force:
-        for o in glob.glob(os.path.join(OBJ_DIR, "*.o")):
-            os.remove(o)
-    srcs = sources()
-    jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) // 2))
-    with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
-        objs = list(ex.map(_compile, srcs))
-    tmp = LIB_PATH + ".tmp"
-    subprocess.check_call([_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs)
-    os.replace(tmp, LIB_PATH)
+def build(force=False, jobs=None, verbose=True, ablate=False):
+    """Compile every csrc/*.hip for gfx950 and link libemadapt_hip.so.  Returns the .so path.
+    Serialised across processes by a file lock (ranks of a data-parallel job may all find the library stale)."""
+    lib_path = ABLATE_LIB_PATH if ablate else LIB_PATH
+    obj_dir = OBJ_DIR + ("_ablate" if ablate else "")
+    os.makedirs(obj_dir, exist_ok=True)
+    with open(os.path.join(obj_dir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            stale = is_stale() if not ablate else (
+                not os.path.exists(lib_path) or os.path.getmtime(lib_path) < max(
+                    [os.path.getmtime(s) for s in sources()] + [_deps_mtime()]))
+            if not force and not stale:
+                return lib_path
+            if force:
+                for o in glob.glob(os.path.join(obj_dir, "*.o")):
+                    os.remove(o)
+            srcs = sources()
+            jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) // 2))
+            extra = ("-DEMADAPT_ABLATE_BUILD",) if ablate else ()
+            with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
+                objs = list(ex.map(lambda src: _compile(src, obj_dir, extra), srcs))
+            tmp = "%s.tmp.%d" % (lib_path, os.getpid())
+            subprocess.check_call([_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", tmp] + objs)
+            os.replace(tmp, lib_path)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     if verbose:
-        print("built %s (%d sources)" % (LIB_PATH, len(srcs)))
-    return LIB_PATH
+        print("built %s (%d sources)" % (lib_path, len(srcs)))
+    return lib_path
 
 
 if __name__ == "__main__":
     import sys
 
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, ablate="--ablate" in sys.argv)

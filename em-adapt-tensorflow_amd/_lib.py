@@ -97,6 +97,9 @@ PROTOTYPES = {
     "emadapt_l2_loss": (c_int, [_vp, c_int64, _vp, _vp, c_size_t, _vp]),
     "emadapt_sgd_accumulate": (c_int, [_vp, _vp, _vp, c_int64, c_int64, c_float, c_float, _vp]),
     "emadapt_sgd_momentum": (c_int, [_vp, _vp, _vp, c_int64, c_float, c_float, c_float, _vp]),
+    "emadapt_conv_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
+    "emadapt_tune_set": (c_int, [ctypes.c_char_p, c_int]),
+    "emadapt_tune_get": (c_int, [ctypes.c_char_p, POINTER(c_int)]),
     "emadapt_prof_enable": (None, [c_int]),
     "emadapt_prof_reset": (None, []),
     "emadapt_prof_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
@@ -124,10 +127,17 @@ def load(build_if_missing=True):
                     "there is no CPU fallback." % e) from e
     if not os.path.exists(LIB_PATH):
         raise EmadaptLibraryError("libemadapt_hip.so not found at %s; run `python __graft_entry__.py` / build()" % LIB_PATH)
+    return _bind(LIB_PATH)
+
+
+def _bind(path):
+    """dlopen `path` and bind the prototypes.  (scripts/ bind the -DEMADAPT_ABLATE_BUILD library this way, before any
+    operator is used; the product path only ever binds LIB_PATH.)"""
+    global _LIB
     try:
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
     except OSError as e:
-        raise EmadaptLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+        raise EmadaptLibraryError("cannot load %s: %s" % (path, e)) from e
     for name, (res, args) in PROTOTYPES.items():
         try:
             fn = getattr(lib, name)

@@ -41,6 +41,32 @@ struct ProfScope {
 
 constexpr int kWave = 64;
 
+// Division by a launch-time constant d as one v_mul_hi_u32: magic = ceil(2^32 / d) gives n / d exactly while
+// n * d < 2^32 (checked on the host for every quantity divided this way); d == 1 is encoded as magic 0 (identity).
+inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
+__device__ __forceinline__ unsigned div_magic(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
+
+// ---- launch-plan overrides (emadapt_tune_set in emadapt.h): 0 = automatic.  They select among kernel variants that
+// all compute the same result (the parity tests run every variant on small awkward shapes through them).
+enum TuneKey {
+    TUNE_FP32_TILE,    // 1: 256x64x16 tiles, 2: 256x256x32 main launch (+128x128 split-K tail), 3: 128x128x32 wave-specialised
+    TUNE_SPLITK,       // force the split-K factor of the forward / data-gradient launches (when K allows it)
+    TUNE_BF16_TILE,    // 128 | 256
+    TUNE_X6_TILE,      // 128 | 256
+    TUNE_PLAN_CUS,     // CU count the launch plans are laid out for (default 256)
+    TUNE_ESTEP_STOP,   // diagnostic builds only (-DEMADAPT_ABLATE_BUILD): leave the E-step kernel after phase n
+    TUNE_ABLATE,       // diagnostic builds only: ablation bit mask of the fp32 igemm kernel
+    TUNE_COUNT
+};
+int tune(TuneKey key);
+inline int plan_cus() { const int c = tune(TUNE_PLAN_CUS); return c > 0 ? c : 256; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device).
+struct DynLdsAttr {
+    unsigned done_mask = 0;  // bit d: set on device d (devices >= 32 are set on every launch)
+    int ensure(const void *kernel, size_t bytes);
+};
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

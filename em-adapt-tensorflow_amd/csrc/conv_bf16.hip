@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
                 tapb = __umulhi(kb, a.magic_cx);
                 cb = (int)(kb - tapb * (unsigned)Cxp);
             }
-            const unsigned kh = __umulhi(tap, a.magic_kw);
+            const unsigned kh = div_magic(tap, a.magic_kw);
             const int kw = (int)(tap - kh * (unsigned)a.KW);
             kvalid = (int)tap < a.ntaps && c < a.Cx;
             dh = a.sign * ((int)kh * a.dil - a.pad_h);
@@ -375,12 +375,11 @@ struct PlanG {
 };
 
 PlanG plan_bf16(const IgemmArgs &a) {
-    // EMADAPT_BF16_TILE=128|256 forces a configuration (read per call: the parity tests run both on small shapes)
-    const char *force = getenv("EMADAPT_BF16_TILE");
+    const int force = tune(TUNE_BF16_TILE);  // 128|256 forces a configuration (the parity tests run both on small shapes)
     PlanG p;
     const long long t256 = ceil_div(a.M, 256) * ceil_div(a.N, 256);
     p.big = (a.N >= 256 && t256 >= 192) ? 1 : 0;
-    if (force) p.big = atoi(force) == 256 ? 1 : 0;
+    if (force) p.big = force == 256 ? 1 : 0;
     p.splits = p.big ? choose_splits(a.M, a.N, a.K, 256, 256, 64, 256.0, 1000e12)
                      : choose_splits(a.M, a.N, a.K, 128, 128, 64, 512.0, 450e12);
     return p;
@@ -395,11 +394,10 @@ template <int BM, int BN, int WN, bool XBF, bool YBF>
 int launch_igemm_bf16(IgemmArgs &a, int Cxp, hipStream_t stream) {
     constexpr size_t lds = 2 * (BM + BN) * kPitchG;
     constexpr int threads = ((BM / 64) * (BN / WN) + 4) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_bf16_kernel<BM, BN, WN, XBF, YBF>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    static DynLdsAttr attr;
+    {
+        const int arc = attr.ensure(reinterpret_cast<const void *>(&igemm_bf16_kernel<BM, BN, WN, XBF, YBF>), lds);
+        if (arc) return arc;
     }
     a.tiles_m = (int)ceil_div(a.M, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
@@ -538,9 +536,9 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
         };
         auto load_x = [&](int mb, int j) {
             const int m = mb + x_r0 + j * X_RSTEP;
-            const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
+            const unsigned t2 = div_magic((unsigned)m, a.magic_w);
             const int ow = m - (int)t2 * a.W;
-            const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
+            const int oh = (int)(t2 - div_magic(t2, a.magic_h) * (unsigned)a.H);
             const int ih = oh + dh, iw = ow + dw;
             const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
             rx[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(((unsigned)(m * a.Cin + x_off) * (XBF ? 2u : 4u)) | (ok ? 0u : kOOB)), 0, 0);
@@ -648,9 +646,9 @@ PlanW make_plan_bf16(const emadapt_conv_desc *d) {
     PlanW p;
     const long long M = (long long)d->B * d->H * d->W;
     const int K = d->KH * d->KW * d->Cin;
-    const char *force = getenv("EMADAPT_BF16_TILE");  // 128|256, read per call (parity tests run both)
+    const int force = tune(TUNE_BF16_TILE);  // 128|256 (the parity tests run both)
     bool big = K >= 256 && d->Cout >= 256;
-    if (force) big = atoi(force) == 256;
+    if (force) big = force == 256;
     p.bko = big ? 256 : 128;
     p.bn = big ? 256 : (d->Cout <= 64 ? 64 : 128);
     p.tiles_k = (int)ceil_div(K, p.bko);
@@ -690,11 +688,10 @@ template <int BKO, int BN, int BMR, bool XBF, bool DBF>
 int launch_wgrad_bf16(const WgradBf16Args &a, hipStream_t stream) {
     constexpr size_t lds = 2 * BMR * (BKO * 2 + 64 + BN * 2 + 64);
     constexpr int threads = (BKO / 64 * 2 + 4) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_bf16_kernel<BKO, BN, BMR, XBF, DBF>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    static DynLdsAttr attr;
+    {
+        const int arc = attr.ensure(reinterpret_cast<const void *>(&wgrad_bf16_kernel<BKO, BN, BMR, XBF, DBF>), lds);
+        if (arc) return arc;
     }
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;

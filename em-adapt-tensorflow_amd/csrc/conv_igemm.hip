@@ -19,8 +19,6 @@
 // buffers, one barrier per K step; two workgroups per CU.  blockIdx is remapped so that the eight
 // workgroups that share an XCD (and its L2) work on neighbouring tiles (8 M-tiles x all N-tiles).
 // Epilogue (bias / ReLU / dropout, or the ReLU-gradient gate for dgrad) is fused.
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "igemm_common.h"
@@ -130,7 +128,7 @@ __global__ void __launch_bounds__((BM / 64) * (BN / WN) * 64, 2) igemm_kernel(Ig
             t.tap = __umulhi(k, a.magic_cx);
             t.c = (int)(k - t.tap * (unsigned)a.Cx);
         }
-        const unsigned kh = __umulhi(t.tap, a.magic_kw);
+        const unsigned kh = div_magic(t.tap, a.magic_kw);
         const int kw = (int)(t.tap - kh * (unsigned)a.KW);
         t.valid = (int)t.tap < a.ntaps;
         t.dh = a.sign * ((int)kh * a.dil - a.pad_h);
@@ -388,7 +386,7 @@ __global__ void __launch_bounds__(512, 4) igemm_ws_kernel(IgemmArgs a) {
                 tap = __umulhi(k, a.magic_cx);
                 c = (int)(k - tap * (unsigned)a.Cx);
             }
-            const unsigned kh = __umulhi(tap, a.magic_kw);
+            const unsigned kh = div_magic(tap, a.magic_kw);
             const int kw = (int)(tap - kh * (unsigned)a.KW);
             const bool kvalid = (int)tap < a.ntaps;
             const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
@@ -500,23 +498,17 @@ int launch_igemm_ws(IgemmArgs &a, hipStream_t stream) {
     constexpr int BM = 128, BN = 128, BK = 32;
     constexpr int AS = BM + 1, BS = BT ? BN + 1 : BN;
     constexpr size_t lds = sizeof(float) * 2 * BK * (AS + BS);
-    static bool attr_set = false;
-    if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_ws_kernel<BT>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static DynLdsAttr attr;
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_ws_kernel<BT>), lds);
+    if (rc) return rc;
     a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
     const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((igemm_ws_kernel<BT>), dim3((unsigned)nblk), dim3(512), lds, stream, a);
-    int rc = launch_status();
+    rc = launch_status();
     if (rc || a.splits <= 1) return rc;
-    long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
-    return launch_status();
+    return launch_splitk_epilogue(a, stream);
 }
 
 template <int BM, int BN, int BK, int WN, bool BT>
@@ -525,23 +517,17 @@ int launch_igemm(IgemmArgs &a, hipStream_t stream) {
     constexpr int AS = BM + 1, BS = BT ? BN + 1 : BN;
     constexpr size_t lds = sizeof(float) * 2 * BK * (AS + BS);
     static_assert((2 * BK * AS * 4) % 16 == 0, "B tile must stay 16-byte aligned");
-    static bool attr_set = false;
-    if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_kernel<BM, BN, BK, WN, BT>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static DynLdsAttr attr;
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_kernel<BM, BN, BK, WN, BT>), lds);
+    if (rc) return rc;
     a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
     const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((igemm_kernel<BM, BN, BK, WN, BT>), dim3((unsigned)nblk), dim3(THREADS), lds, stream, a);
-    int rc = launch_status();
+    rc = launch_status();
     if (rc || a.splits <= 1) return rc;
-    long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
-    return launch_status();
+    return launch_splitk_epilogue(a, stream);
 }
 
 // How one convolution is launched.
@@ -557,28 +543,26 @@ struct LaunchPlan {
 };
 
 LaunchPlan plan_launches(const IgemmArgs &a) {
-    static const int no_big = getenv("EMADAPT_NO_BIG_TILES") ? 1 : 0;
-    static const int no_tail = getenv("EMADAPT_NO_TAIL") ? 1 : 0;
+    const int force = tune(TUNE_FP32_TILE);  // 0 = by shape; 1 / 2 / 3 = cfg 1 / cfg 2 / cfg 0 (tests run each on small shapes)
+    const int cus = plan_cus();
     LaunchPlan p;
     p.main_rows = a.M;
     p.tail_splits = 0;
     p.main_splits = 1;
-    if (a.N <= 64) {
-        p.cfg = 1;
+    p.cfg = force ? (force == 3 ? 0 : force) : (a.N <= 64 ? 1 : (a.N >= 1024 && a.M >= 8192) ? 2 : 0);
+    if (p.cfg == 1) {
         p.main_splits = choose_splits(a.M, a.N, a.K, 256, 64, 16);
-    } else if (!no_big && a.N >= 1024 && a.M >= 8192) {
-        p.cfg = 2;
+    } else if (p.cfg == 2) {
         const long long tn = ceil_div(a.N, 256), tm = ceil_div(a.M, 256);
-        const long long full = (tm * tn) / 256;  // whole rounds of one 256x256 workgroup per CU
-        if (!no_tail && full >= 1 && (tm * tn) % 256 != 0) {
-            const long long tm_full = full * 256 / tn;
+        const long long full = (tm * tn) / cus;  // whole rounds of one 256x256 workgroup per CU
+        if (full >= 1 && (tm * tn) % cus != 0) {
+            const long long tm_full = full * cus / tn;
             if (tm_full >= 1 && tm_full < tm) {
                 p.main_rows = (int)(tm_full * 256);
                 p.tail_splits = choose_splits(a.M - p.main_rows, a.N, a.K, 128, 128, 32);
             }
         }
     } else {
-        p.cfg = 0;
         p.main_splits = choose_splits(a.M, a.N, a.K, 128, 128, 32);
     }
     return p;
@@ -593,16 +577,17 @@ size_t igemm_workspace_bytes(const IgemmArgs &a) {
 
 template <bool BT>
 int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    static const int ablate = getenv("EMADAPT_ABLATE") ? atoi(getenv("EMADAPT_ABLATE")) : 0;
-    static const int no_tap_inner = getenv("EMADAPT_NO_TAP_INNER") ? 1 : 0;
-    static const int no_ws = getenv("EMADAPT_NO_WS") ? 1 : 0;
-    a.ablate = ablate;
+#ifdef EMADAPT_ABLATE_BUILD
+    a.ablate = tune(TUNE_ABLATE);
+#else
+    a.ablate = 0;
+#endif
     LaunchPlan p = plan_launches(a);
     if (!workspace || workspace_bytes < igemm_workspace_bytes(a)) {  // no room for slabs: unsplit, same result
         p.main_splits = 1;
         if (p.tail_splits > 1) p.tail_splits = 1;
     }
-    a.tap_inner = (!no_tap_inner && a.ntaps > 1 && a.Cx % (p.cfg == 1 ? 16 : 32) == 0) ? 1 : 0;
+    a.tap_inner = (a.ntaps > 1 && a.Cx % (p.cfg == 1 ? 16 : 32) == 0) ? 1 : 0;
     a.m_begin = 0;
     a.m_end = p.main_rows;
     a.splits = p.main_splits;
@@ -611,15 +596,15 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
     switch (p.cfg) {
         case 1: rc = launch_igemm<256, 64, 16, 64, BT>(a, stream); break;
         case 2: rc = launch_igemm<256, 256, 32, 128, BT>(a, stream); break;
-        default: rc = no_ws ? launch_igemm<128, 128, 32, 64, BT>(a, stream) : launch_igemm_ws<BT>(a, stream); break;
+        default: rc = launch_igemm_ws<BT>(a, stream); break;
     }
     if (rc || p.tail_splits == 0) return rc;
-    a.tap_inner = (!no_tap_inner && a.ntaps > 1 && a.Cx % 32 == 0) ? 1 : 0;
+    a.tap_inner = (a.ntaps > 1 && a.Cx % 32 == 0) ? 1 : 0;
     a.m_begin = p.main_rows;
     a.m_end = a.M;
     a.splits = p.tail_splits;
     a.slab = p.tail_splits > 1 ? static_cast<float *>(workspace) : nullptr;  // the cfg-2 main launch uses no slab
-    return no_ws ? launch_igemm<128, 128, 32, 64, BT>(a, stream) : launch_igemm_ws<BT>(a, stream);
+    return launch_igemm_ws<BT>(a, stream);
 }
 
 }  // namespace
@@ -645,6 +630,20 @@ size_t emadapt_conv_dgrad_workspace_bytes(const emadapt_conv_desc *d) {
     IgemmArgs a;
     fill_geometry(a, d, true);
     return igemm_workspace_bytes(a);
+}
+
+int emadapt_conv_plan(const emadapt_conv_desc *d, int dgrad, int plan[4]) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!plan) return EMADAPT_ERR_INVALID;
+    IgemmArgs a;
+    fill_geometry(a, d, dgrad != 0);
+    const LaunchPlan p = plan_launches(a);
+    plan[0] = p.cfg == 0 ? 3 : p.cfg;
+    plan[1] = p.main_rows;
+    plan[2] = p.main_splits;
+    plan[3] = p.tail_splits;
+    return EMADAPT_OK;
 }
 
 int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w, const float *bias, float *y,

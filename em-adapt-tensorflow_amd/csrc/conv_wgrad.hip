@@ -13,10 +13,6 @@
 // Layers whose [K x N] filter has few 128x128 tiles (conv1_x .. conv5_x) would leave most of the 256
 // CUs idle, so the pixel range is split across workgroups ("split-M"); each split writes an fp32
 // partial slab and a second kernel adds the slabs in a fixed order -- deterministic, no atomics.
-#include <stdlib.h>
-
-#include <type_traits>
-
 #include "common.h"
 
 namespace emadapt {
@@ -51,191 +47,8 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
 
 constexpr int BMR = 32;  // pixels per reduction step
 
-template <int BKO, int BN>
-__global__ void __launch_bounds__(256, 2) wgrad_kernel(WgradArgs a) {
-    // 4 waves: 2 along k (64 rows each) x 2 along n
-    constexpr int WK = BKO / 2, WN = BN / 2;
-    constexpr int TK = WK / 32, TN = WN / 32;
-    static_assert(BKO == 128, "k tile is 128");
-    constexpr int XQ = BKO / 4;            // 32 float4 quads along k
-    constexpr int X_RSTEP = 256 / XQ;      // 8 pixel rows per pass
-    constexpr int X_N = BMR / X_RSTEP;     // 4 loads per thread
-    constexpr int YQ = BN / 4;
-    constexpr int Y_RSTEP = 256 / YQ;
-    constexpr int Y_N = BMR / Y_RSTEP;
-
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *Xs = lds;                    // [2][BMR][BKO]
-    float *Ys = lds + 2 * BMR * BKO;    // [2][BMR][BN]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wk = wave >> 1, wn = wave & 1;
-
-    // XCD-aware block order (blocks b, b+8, .. share an XCD and its L2): each XCD takes a contiguous run of logical
-    // blocks in split-major order -- so the workgroups of one XCD stream the SAME pixel range -- and inside a split
-    // the filter tiles go in groups of 8 k-tiles x all n-tiles (k fastest): 64 co-resident workgroups then share
-    // 8 x-panels and 8 dy-panels instead of 2 and 32.
-    int tile_k, tile_n, split;
-    {
-        const int ntile = a.tiles_k * a.tiles_n;
-        const int nblk = ntile * a.splits;
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        split = t / ntile;
-        t -= split * ntile;
-        constexpr int GK = 8;
-        const int per_group = GK * a.tiles_n;
-        const int g = t / per_group;
-        const int first_k = g * GK;
-        const int gsz = (a.tiles_k - first_k < GK) ? (a.tiles_k - first_k) : GK;
-        const int in_g = t - g * per_group;
-        tile_k = first_k + in_g % gsz;
-        tile_n = in_g / gsz;
-    }
-    const int k0 = tile_k * BKO, n0 = tile_n * BN;
-    const int m_begin = split * a.rows_per_split;
-    int m_end = m_begin + a.rows_per_split;
-    if (m_end > a.M) m_end = a.M;
-
-    // fixed k quad of this thread
-    const int x_kq = tid % XQ, x_r0 = tid / XQ;
-    const int k = k0 + x_kq * 4;
-    const bool kvalid = k < a.K;
-    const int tap = kvalid ? k / a.Cin : 0;
-    const int c = kvalid ? k % a.Cin : 0;
-    const int dh = (tap / a.KW) * a.dil - a.pad_h;
-    const int dw = (tap % a.KW) * a.dil - a.pad_w;
-    const int x_off = (dh * a.W + dw) * a.Cin + c;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dy), 0, (int)a.y_bytes, 0x00020000);
-    constexpr unsigned kOOB = 0x80000000u;
-
-    const int y_nq = tid % YQ, y_r0 = tid / YQ;
-    const int y_n = n0 + y_nq * 4;
-    const bool nvalid = y_n < a.N;
-
-    // two register sets, as in the forward kernel: set P receives the loads of step s+2 while set P^1 (step s+1)
-    // is parked in LDS.
-    float4 rx[2][X_N], ry[2][Y_N];
-
-    auto load_x = [&](float4 &dst, int j, int mb) {
-        const int m = mb + x_r0 + j * X_RSTEP;
-        // pixel -> (oh, ow), exact while M * max(W, H) < 2^32 (checked on the host)
-        const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
-        const int ow = m - (int)t2 * a.W;
-        const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
-        const int ih = oh + dh, iw = ow + dw;
-        const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-        const unsigned off = (unsigned)(m * a.Cin + x_off) * 4u;
-        dst = buf_ld4(xr, off | (ok ? 0u : kOOB));
-    };
-    auto load_y = [&](float4 &dst, int j, int mb) {
-        const int m = mb + y_r0 + j * Y_RSTEP;
-        const unsigned off = (unsigned)(m * a.N + y_n) * 4u;
-        dst = buf_ld4(yr, off | ((nvalid && m < m_end) ? 0u : kOOB));
-    };
-    auto store_x = [&](int buf, int j, const float4 &v) {
-        *reinterpret_cast<float4 *>(&Xs[buf * BMR * BKO + (x_r0 + j * X_RSTEP) * BKO + x_kq * 4]) = v;
-    };
-    auto store_y = [&](int buf, int j, const float4 &v) {
-        *reinterpret_cast<float4 *>(&Ys[buf * BMR * BN + (y_r0 + j * Y_RSTEP) * BN + y_nq * 4]) = v;
-    };
-
-    f32x16 acc[TK][TN];
-#pragma unroll
-    for (int i = 0; i < TK; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BMR - 1) / BMR : 0;
-    const int l31 = lane & 31, lh = lane >> 5;
-    // software pipeline (see conv_igemm.hip): loads of step s+2 early in the MFMA stream, LDS stores of step s+1 late
-    constexpr int NKK = BMR / 2;
-    constexpr int NST = X_N + Y_N;
-    constexpr int ST0 = NKK - NST;
-    static_assert(ST0 >= 2, "reduction step too short for the software pipeline");
-    constexpr int LPK = (NST + (ST0 - 1) - 1) / (ST0 - 1);
-    if (nsteps > 0) {
-#pragma unroll
-        for (int j = 0; j < X_N; j++) load_x(rx[0][j], j, m_begin);
-#pragma unroll
-        for (int j = 0; j < Y_N; j++) load_y(ry[0][j], j, m_begin);
-#pragma unroll
-        for (int j = 0; j < X_N; j++) load_x(rx[1][j], j, m_begin + BMR);
-#pragma unroll
-        for (int j = 0; j < Y_N; j++) load_y(ry[1][j], j, m_begin + BMR);
-#pragma unroll
-        for (int j = 0; j < X_N; j++) store_x(0, j, rx[0][j]);
-#pragma unroll
-        for (int j = 0; j < Y_N; j++) store_y(0, j, ry[0][j]);
-    }
-    __syncthreads();
-    auto m_step = [&](auto parity, int st) {
-        constexpr int P = decltype(parity)::value;
-        const float *xs = Xs + P * BMR * BKO + wk * WK + l31;
-        const float *ys = Ys + P * BMR * BN + wn * WN + l31;
-        const int mb2 = m_begin + (st + 2) * BMR;  // rows >= m_end are zero-filled by the range check
-        float av[2][TK], bv[2][TN];
-#pragma unroll
-        for (int i = 0; i < TK; i++) av[0][i] = xs[lh * BKO + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; j++) bv[0][j] = ys[lh * BN + j * 32];
-#pragma unroll
-        for (int kk = 0; kk < NKK; kk++) {
-            if (kk + 1 < NKK) {
-#pragma unroll
-                for (int i = 0; i < TK; i++) av[(kk + 1) & 1][i] = xs[((kk + 1) * 2 + lh) * BKO + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = ys[((kk + 1) * 2 + lh) * BN + j * 32];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TK; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk & 1][i], bv[kk & 1][j], acc[i][j], 0, 0, 0);
-            if (kk >= 1 && kk < ST0) {
-#pragma unroll
-                for (int q = 0; q < LPK; q++) {
-                    const int lidx = (kk - 1) * LPK + q;
-                    if (lidx < X_N) load_x(rx[P][lidx < X_N ? lidx : 0], lidx, mb2);
-                    else if (lidx < NST) load_y(ry[P][lidx >= X_N && lidx - X_N < Y_N ? lidx - X_N : 0], lidx - X_N, mb2);
-                }
-            }
-            if (kk >= ST0) {
-                const int sidx = kk - ST0;
-                if (sidx < X_N) store_x(P ^ 1, sidx, rx[P ^ 1][sidx < X_N ? sidx : 0]);
-                else store_y(P ^ 1, sidx - X_N, ry[P ^ 1][sidx >= X_N ? sidx - X_N : 0]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-    };
-    for (int st = 0; st < nsteps; st += 2) {
-        m_step(std::integral_constant<int, 0>{}, st);
-        if (st + 1 < nsteps) m_step(std::integral_constant<int, 1>{}, st + 1);
-    }
-
-    float *out = a.out + (long long)split * a.K * a.N;
-#pragma unroll
-    for (int i = 0; i < TK; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int col = n0 + wn * WN + j * 32 + l31;
-            if (col >= a.N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = k0 + wk * WK + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < a.K) out[(long long)row * a.N + col] = acc[i][j][r];
-            }
-        }
-}
-
-// Wave-specialised variant (see igemm_ws_kernel in conv_igemm.hip): 512 threads = 4 consumer wavefronts (LDS fragment
-// reads + MFMA only) + 4 producer wavefronts (gather of x, rows of dy, LDS stores); one barrier per reduction step.
+// Wave-specialised (see igemm_ws_kernel in conv_igemm.hip): 512 threads = 4 consumer wavefronts (LDS fragment reads +
+// MFMA only) + 4 producer wavefronts (gather of x, rows of dy, LDS stores); one barrier per reduction step.
 template <int BN>
 __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
     constexpr int BKO = 128;
@@ -299,9 +112,9 @@ __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
 #pragma unroll
             for (int j = 0; j < X_N; j++) {
                 const int m = mb + x_r0 + j * X_RSTEP;
-                const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
+                const unsigned t2 = div_magic((unsigned)m, a.magic_w);
                 const int ow = m - (int)t2 * a.W;
-                const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
+                const int oh = (int)(t2 - div_magic(t2, a.magic_h) * (unsigned)a.H);
                 const int ih = oh + dh, iw = ow + dw;
                 const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
                 rx[j] = buf_ld4(xr, ((unsigned)(m * a.Cin + x_off) * 4u) | (ok ? 0u : kOOB));
@@ -406,8 +219,9 @@ Plan make_plan(const emadapt_conv_desc *d) {
     long long best = 1;
     double best_t = 1e30;
     const long long max_s = ceil_div(M, 256) < 2048 ? ceil_div(M, 256) : 2048;  // >= 256 pixels per split
+    const double slots = 2.0 * plan_cus();
     for (long long s = 1; s <= max_s; s++) {
-        const double rounds = (double)tiles * s / 512.0;
+        const double rounds = (double)tiles * s / slots;
         const double eff = rounds / (double)(long long)(rounds + 0.999999);
         double t = t_kernel / eff + 2e-6 * (double)(long long)(rounds + 0.999999);  // + per-round turnover
         if (s > 1) t += (double)(s + 1) * kn_bytes / 3e12 + 3e-6;
@@ -433,31 +247,15 @@ int check_desc(const emadapt_conv_desc *d) {
     return EMADAPT_OK;
 }
 
-inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
-
 template <int BN>
 int launch_wgrad(const WgradArgs &a, hipStream_t stream) {
     constexpr size_t lds = sizeof(float) * 2 * BMR * (128 + BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_kernel<128, BN>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static DynLdsAttr attr;
+    int rc = attr.ensure(reinterpret_cast<const void *>(&wgrad_ws_kernel<BN>), lds);
+    if (rc) return rc;
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    static const int no_ws = getenv("EMADAPT_NO_WS") ? 1 : 0;
-    if (no_ws) {
-        hipLaunchKernelGGL((wgrad_kernel<128, BN>), dim3((unsigned)nblk), dim3(256), lds, stream, a);
-    } else {
-        static bool ws_attr_set = false;
-        if (!ws_attr_set) {
-            EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_ws_kernel<BN>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ws_attr_set = true;
-        }
-        hipLaunchKernelGGL((wgrad_ws_kernel<BN>), dim3((unsigned)nblk), dim3(512), lds, stream, a);
-    }
+    hipLaunchKernelGGL((wgrad_ws_kernel<BN>), dim3((unsigned)nblk), dim3(512), lds, stream, a);
     return launch_status();
 }
 

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__((BM / 64 * 2 + 4) * 64, BM == 128 ? 4 : 3) ige
                 tap = __umulhi(k, a.magic_cx);
                 c = (int)(k - tap * (unsigned)a.Cx);
             }
-            const unsigned kh = __umulhi(tap, a.magic_kw);
+            const unsigned kh = div_magic(tap, a.magic_kw);
             const int kw = (int)(tap - kh * (unsigned)a.KW);
             kvalid = (int)tap < a.ntaps;
             dh = a.sign * ((int)kh * a.dil - a.pad_h);
@@ -261,8 +261,7 @@ __global__ void __launch_bounds__((BM / 64 * 2 + 4) * 64, BM == 128 ? 4 : 3) ige
 // number of resident MFMA waves that can cover each other's LDS round trips.
 bool x6_big(const IgemmArgs &a) {
     (void)a;
-    const char *force = getenv("EMADAPT_X6_TILE");  // 128|256, read per call (the parity tests run both)
-    return force && atoi(force) == 256;
+    return tune(TUNE_X6_TILE) == 256;  // 128|256 (the parity tests run both)
 }
 
 int x6_splits(const IgemmArgs &a) {
@@ -274,11 +273,10 @@ template <int BM>
 int launch_igemm_x6(IgemmArgs &a, hipStream_t stream) {
     constexpr size_t lds = 2 * 3 * (BM + 128) * kPitchX;
     constexpr int threads = (BM / 64 * 2 + 4) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&igemm_x6_kernel<BM>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    static DynLdsAttr attr;
+    {
+        const int arc = attr.ensure(reinterpret_cast<const void *>(&igemm_x6_kernel<BM>), lds);
+        if (arc) return arc;
     }
     a.tiles_m = (int)ceil_div(a.M, BM);
     a.tiles_n = (int)ceil_div(a.N, 128);
@@ -386,9 +384,9 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
         float4 rx[X_N], ry[Y_N];
         auto load_x = [&](int mb, int j) {
             const int m = mb + x_r0 + j * X_RSTEP;
-            const unsigned t2 = __umulhi((unsigned)m, a.magic_w);
+            const unsigned t2 = div_magic((unsigned)m, a.magic_w);
             const int ow = m - (int)t2 * a.W;
-            const int oh = (int)(t2 - __umulhi(t2, a.magic_h) * (unsigned)a.H);
+            const int oh = (int)(t2 - div_magic(t2, a.magic_h) * (unsigned)a.H);
             const int ih = oh + dh, iw = ow + dw;
             const bool ok = kvalid && m < m_end && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
             rx[j] = buf_ld4(xr, ((unsigned)(m * a.Cin + x_off) * 4u) | (ok ? 0u : kOOB));
@@ -484,9 +482,9 @@ PlanX6 make_plan_x6(const emadapt_conv_desc *d) {
     PlanX6 p;
     const long long M = (long long)d->B * d->H * d->W;
     const int K = d->KH * d->KW * d->Cin;
-    const char *force = getenv("EMADAPT_X6_TILE");  // 128|256, read per call (the parity tests run both)
+    const int force = tune(TUNE_X6_TILE);  // 128|256 (the parity tests run both)
     bool big = K >= 256 && d->Cout >= 128;
-    if (force) big = atoi(force) == 256;
+    if (force) big = force == 256;
     p.bko = big ? 256 : 128;
     p.bn = big ? 128 : (d->Cout <= 64 ? 64 : 128);
     p.tiles_k = (int)ceil_div(K, p.bko);
@@ -525,11 +523,10 @@ template <int BKO, int BN>
 int launch_wgrad_x6(const WgradX6Args &a, hipStream_t stream) {
     constexpr size_t lds = 2 * 3 * 16 * (BKO * 2 + 64 + BN * 2 + 64);
     constexpr int threads = (BKO / 64 * 2 + 4) * 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_x6_kernel<BKO, BN>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+    static DynLdsAttr attr;
+    {
+        const int arc = attr.ensure(reinterpret_cast<const void *>(&wgrad_x6_kernel<BKO, BN>), lds);
+        if (arc) return arc;
     }
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;

@@ -32,7 +32,7 @@ namespace {
 
 using namespace emadapt;
 
-// Phase-timing exits (EMADAPT_ESTEP_STOP) exist only in diagnostic builds (-DEMADAPT_ABLATE_BUILD).
+// Phase-timing exits (emadapt_tune_set("estep_stop", n)) exist only in diagnostic builds (-DEMADAPT_ABLATE_BUILD).
 #ifdef EMADAPT_ABLATE_BUILD
 #define ESTEP_STOP(n) if (a.stop_after == (n)) return
 #else
@@ -92,7 +92,7 @@ struct EstepArgs {
     int p_res;  // present-channel slots resident in LDS
     int hwp;    // HW rounded up to a multiple of 4 (LDS row pitch)
     int full;   // 1: all C channels are staged into LDS, indexed by class (p_res == C)
-    int stop_after;  // diagnostics (EMADAPT_ESTEP_STOP): leave the kernel after phase n (0 = run everything)
+    int stop_after;  // diagnostic builds (tune "estep_stop"): leave the kernel after phase n (0 = run everything)
 };
 
 // One leaf (n <= 128) of NumPy's float32 pairwise summation.
@@ -516,11 +516,10 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
 
 template <int EPT>
 int launch_estep(const EstepArgs &a, int B, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        EMADAPT_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&estep_kernel<EPT>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
+    static DynLdsAttr attr;
+    {
+        const int arc = attr.ensure(reinterpret_cast<const void *>(&estep_kernel<EPT>), kLdsBudget);
+        if (arc) return arc;
     }
     hipLaunchKernelGGL(estep_kernel<EPT>, dim3(B), dim3(kThreads), lds, stream, a);
     return launch_status();
@@ -677,8 +676,11 @@ int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label
     a.margin = margin_others; a.k_bg = k_bg; a.k_fg = k_fg; a.gmax_key = gkey; a.map_out = map_out;
     a.labels_out = reinterpret_cast<long long *>(labels_out); a.p_res = p_res; a.hwp = hwp;
     a.full = (p_res >= C) ? 1 : 0;
-    static const int stop_after = getenv("EMADAPT_ESTEP_STOP") ? atoi(getenv("EMADAPT_ESTEP_STOP")) : 0;
-    a.stop_after = stop_after;
+#ifdef EMADAPT_ABLATE_BUILD
+    a.stop_after = tune(TUNE_ESTEP_STOP);
+#else
+    a.stop_after = 0;
+#endif
     const size_t lds = align_up(lds_bytes(hwp, p_res), 16);
     const int ept = (int)ceil_div(HW, kThreads);
     if (ept <= 1) return launch_estep<1>(a, B, lds, stream);

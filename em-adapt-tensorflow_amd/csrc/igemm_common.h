@@ -1,8 +1,6 @@
 // Shared pieces of the implicit-GEMM convolution kernels (fp32: conv_igemm.hip, bf16: conv_bf16.hip):
 // launch arguments, bounds-checked loads, the fused epilogue, the split-K second stage and its cost model.
 #pragma once
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace emadapt {
@@ -15,8 +13,9 @@ using namespace emadapt;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Ablation switches (EMADAPT_ABLATE env var) exist only in diagnostic builds (-DEMADAPT_ABLATE_BUILD): in the
-// shipped kernel they would put scalar branches into every k-pair of the MFMA stream.
+// Ablation switches (emadapt_tune_set("ablate", bits)) exist only in diagnostic builds (-DEMADAPT_ABLATE_BUILD,
+// `python -m em_adapt_tensorflow_amd._build --ablate`): in the shipped kernel they would put scalar branches into
+// every k-pair of the MFMA stream.
 #ifdef EMADAPT_ABLATE_BUILD
 #define ABL(bit) (a.ablate & (bit))
 #else
@@ -44,7 +43,7 @@ struct IgemmArgs {
     float *slab;         // [splits][M][N] fp32 partials when splits > 1
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
     unsigned magic_nt;   // ceil(2^32/ntaps)
-    int ablate;  // diagnostics only (EMADAPT_ABLATE): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
+    int ablate;  // diagnostic builds only (tune "ablate"): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
 };
 
 // 16-byte buffer load with hardware range checking: an offset at/after the end of the buffer returns 0,
@@ -201,12 +200,20 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(IgemmArgs a) {
     }
 }
 
+inline int launch_splitk_epilogue(const IgemmArgs &a, hipStream_t stream) {
+    long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
+    return launch_status();
+}
+
 // Split-K factor: with T tiles on `slots` resident workgroup slots (256 CUs x 2) a launch runs ceil(T/slots) rounds;
 // when T is a few hundred (the M = 26 896, N = 512 layers: 844 tiles -> 2 rounds at 82 %) splitting K by S makes T*S
 // workgroups fill whole rounds (S = 3 -> 4.95 of 5).  The price is one extra pass over S+1 output-sized slabs,
 // charged at ~3 TB/s against the kernel's time at ~110 TFLOP/s.
 int choose_splits(long long M, int N, int K, int bm, int bn, int bk, double slots = 512.0, double rate = 110e12) {
-    static const int force = getenv("EMADAPT_SPLITK") ? atoi(getenv("EMADAPT_SPLITK")) : 0;
+    const int force = tune(TUNE_SPLITK);
+    slots *= plan_cus() / 256.0;
     const long long tiles = ceil_div(M, bm) * ceil_div(N, bn);
     const int nk = (K + bk - 1) / bk;
     if (force > 0) return force <= nk ? force : 1;
@@ -234,15 +241,13 @@ int check_desc(const emadapt_conv_desc *d) {
     // activations and filters are addressed with 32-bit byte offsets (bounds-checked buffer loads)
     if ((long long)d->B * d->H * d->W * (d->Cin > d->Cout ? d->Cin : d->Cout) * 4 >= (1LL << 31)) return EMADAPT_ERR_UNSUPPORTED;
     if ((long long)d->KH * d->KW * d->Cin * d->Cout * 4 >= (1LL << 31)) return EMADAPT_ERR_UNSUPPORTED;
+    // k -> (tap, channel) by magic division: exact while K * C < 2^32 (common.h: div_magic)
+    const long long cmax = (d->Cin > d->Cout ? d->Cin : d->Cout) + 7;
+    if ((long long)d->KH * d->KW * cmax * cmax >= (1LL << 32)) return EMADAPT_ERR_UNSUPPORTED;
     return EMADAPT_OK;
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-// ceil(2^32 / d) for d >= 2: __umulhi(n, magic) == n / d exactly for n < 2^20, d <= 4096 (d == 1 -> identity
-// is handled by the 0 encoding below: __umulhi(n, 0xFFFFFFFF) = n - 1 for n >= 1, so d == 1 uses its own path).
-inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
-
 
 // geometry shared by the launch and the workspace query
 void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {

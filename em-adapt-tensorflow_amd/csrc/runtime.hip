@@ -1,4 +1,7 @@
 // Library-level entry points: version, error strings, event-based per-kernel timing.
+#include <string.h>
+
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -19,6 +22,26 @@ bool g_prof_on = false;
 std::vector<ProfRec *> g_prof_recs;
 std::vector<ProfRec *> g_prof_free;
 }  // namespace
+
+namespace {
+std::atomic<int> g_tune[TUNE_COUNT];
+const char *const kTuneNames[TUNE_COUNT] = {"fp32_tile", "splitk", "bf16_tile", "x6_tile", "plan_cus",
+                                            "estep_stop", "ablate"};
+std::mutex g_attr_mu;
+}  // namespace
+
+int tune(TuneKey key) { return g_tune[key].load(std::memory_order_relaxed); }
+
+int DynLdsAttr::ensure(const void *kernel, size_t bytes) {
+    int dev = 0;
+    EMADAPT_HIP_TRY(hipGetDevice(&dev));
+    const unsigned bit = (dev >= 0 && dev < 32) ? 1u << dev : 0u;
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (bit && (done_mask & bit)) return EMADAPT_OK;
+    EMADAPT_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done_mask |= bit;
+    return EMADAPT_OK;
+}
 
 ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t stream)
     : kind_(kind), stream_(stream), rec_(nullptr) {
@@ -76,6 +99,26 @@ int emadapt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int emadapt_tune_set(const char *key, int value) {
+    if (!key) return EMADAPT_ERR_INVALID;
+    for (int k = 0; k < TUNE_COUNT; k++)
+        if (strcmp(key, kTuneNames[k]) == 0) {
+            g_tune[k].store(value, std::memory_order_relaxed);
+            return EMADAPT_OK;
+        }
+    return EMADAPT_ERR_INVALID;
+}
+
+int emadapt_tune_get(const char *key, int *value) {
+    if (!key || !value) return EMADAPT_ERR_INVALID;
+    for (int k = 0; k < TUNE_COUNT; k++)
+        if (strcmp(key, kTuneNames[k]) == 0) {
+            *value = g_tune[k].load(std::memory_order_relaxed);
+            return EMADAPT_OK;
+        }
+    return EMADAPT_ERR_INVALID;
 }
 
 void emadapt_prof_enable(int on) {

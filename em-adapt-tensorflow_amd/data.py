@@ -11,6 +11,19 @@ import numpy as np
 import torch
 
 
+def dist_rank_world(config=None):
+    """(rank, world_size) of this process: config["rank"] / config["world_size"] when given, else torch.distributed's
+    (0, 1 for a single process).  Data parallelism maps micro-batches to ranks (dist.py), so every source below hands
+    rank r the r-th slice of each global batch and seeds its augmentation / synthetic draws per rank."""
+    config = config or {}
+    if "rank" in config or "world_size" in config:
+        return int(config.get("rank", 0)), int(config.get("world_size", 1))
+    d = torch.distributed
+    if d.is_available() and d.is_initialized():
+        return d.get_rank(), d.get_world_size()
+    return 0, 1
+
+
 def synthetic_labels(rng, B, h, w, category_num, max_objects=3):
     labels = np.zeros((B, h, w, 1), np.float32)
     lo_h, lo_w = max(h // 5, 2), max(w // 5, 2)
@@ -37,7 +50,8 @@ class SyntheticData:
         self.h, self.w = config.get("input_size", (321, 321))
         self.category_num = config.get("category_num", 21)
         self.length = int(config.get("length", 10582))  # size of VOC12 train_aug
-        self.seed = int(config.get("seed", 0))
+        self.rank, self.world = dist_rank_world(config)
+        self.seed = int(config.get("seed", 0)) * self.world + self.rank   # every rank draws its own batches
         self.device = torch.device(config.get("device", "cuda"))
         self.unique_batches = int(config.get("unique_batches", 2))
 
@@ -119,7 +133,16 @@ class dataset:
         self.default_category = self.config.get("default_category", self.categorys[0])
         self.device = self.config.get("device", "cuda")
         self.workers = int(self.config.get("decode_workers", 4))
-        self.rng = np.random.default_rng(self.config.get("seed", None))
+        # two generators: the epoch permutations must be the SAME on every rank of a data-parallel job (each rank then
+        # takes its own slice of every global batch), the augmentation draws must differ
+        self.rank, self.world = dist_rank_world(self.config)
+        seed = self.config.get("seed", None)
+        if seed is None and self.world > 1:
+            box = [int(np.random.SeedSequence().entropy % (1 << 31))]
+            torch.distributed.broadcast_object_list(box, src=0)
+            seed = box[0]
+        self.perm_rng = np.random.default_rng(seed)
+        self.rng = np.random.default_rng(None if seed is None else [int(seed), self.rank])
         self.img_mean = np.ones((self.w, self.h, 3))
         self.img_mean[:, :, 0] *= 104.00698793
         self.img_mean[:, :, 1] *= 116.66876762
@@ -156,7 +179,7 @@ class dataset:
         for category in self.categorys:
             self.info["epoch"][category] = 0
             self.info["index"][category] = 0
-            self.info["perm"][category] = self.rng.permutation(self.data_len[category])
+            self.info["perm"][category] = self.perm_rng.permutation(self.data_len[category])
         return self.info
 
     def get_info(self, key="epoch", category=None):
@@ -202,28 +225,40 @@ class dataset:
         do_flip = bool(flip) and bool(self.rng.uniform() < 0.5)
         return image_preprocess(img, label, (self.h, self.w), scale=scale, flip=do_flip, device=self.device)
 
+    def sample_order(self, category=None, batch_size=None, epoches=-1):
+        """Iterator over (epoch, position, sample indices) of this rank's batches.  One permutation per epoch, shared
+        by all ranks (common ``perm_rng``); a global batch is ``batch_size * world`` consecutive entries of it and rank r
+        takes entries [r*batch_size, (r+1)*batch_size) -- ranks never see the same sample within an epoch.  With one
+        rank a short final batch is yielded as is (tf.data ``batch``); with several ranks the ragged remainder of an
+        epoch is dropped so that every rank always holds the same number of samples (the gradient all-reduce averages
+        equal-sized shards, dist.py)."""
+        category = category or self.default_category
+        batch_size = batch_size or self.config.get("batch_size", 1)
+        n = self.data_len[category]
+        gb = batch_size * self.world
+        ep = 0
+        while epoches < 0 or ep < epoches:
+            perm = self.perm_rng.permutation(n)
+            self.info["perm"][category] = perm
+            stop = n if self.world == 1 else (n // gb) * gb
+            for s in range(0, stop, gb):
+                yield ep, s, perm[s + self.rank * batch_size:s + (self.rank + 1) * batch_size]
+            ep += 1
+            if stop == 0:
+                return
+
     def next_batch(self, category=None, batch_size=None, epoches=-1):
         import concurrent.futures
         category = category or self.default_category
         batch_size = batch_size or self.config.get("batch_size", 1)
         files = self.data_f[category]
-        n = self.data_len[category]
         train = category == "train"
-
-        def order():
-            ep = 0
-            while epoches < 0 or ep < epoches:
-                perm = self.rng.permutation(n)
-                self.info["perm"][category] = perm
-                for s in range(0, n, batch_size):
-                    yield ep, s, perm[s:s + batch_size]
-                ep += 1
 
         with concurrent.futures.ThreadPoolExecutor(max(self.workers, 1)) as pool:
             def submit(idx):
                 return [pool.submit(self._decode, files["img"][i], files["label"][i]) for i in idx]
 
-            it = order()
+            it = self.sample_order(category, batch_size, epoches)
             nxt = next(it, None)
             pending = submit(nxt[2]) if nxt else None
             while nxt is not None:
@@ -238,5 +273,5 @@ class dataset:
                     imgs.append(x)
                     labs.append(y)
                 self.info["epoch"][category] = ep
-                self.info["index"][category] = s + len(idx)
+                self.info["index"][category] = s + len(idx) * self.world
                 yield torch.stack(imgs), torch.stack(labs), [files["id"][i] for i in idx]

@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .data import dist_rank_world
 from .estep import draw_perms
 from .network import Network, round_up
 
@@ -432,7 +433,7 @@ class ADAPT(Network):
                 mask = None
                 if op.drop and kp < 1.0 and drop_masks is not None:
                     mask = self._pad_mask(drop_masks[op.name], op)
-                seed = (self.seed << 32) + self._micro * 64 + op.index
+                seed = self._drop_seed(op)
                 if bf16:
                     ops.conv_fwd_bf16(x, op.seg["wf16"], (op.k, op.k), op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
                                       drop_mask=mask, drop_seed=seed, out=out)
@@ -447,6 +448,12 @@ class ADAPT(Network):
             x = out
         bufs["keep_prob"] = keep_prob
         return self.net["output"]
+
+    def _drop_seed(self, op):
+        """Seed of the built-in dropout generator for this op and micro-step; ranks of a data-parallel job draw
+        different masks (tf.nn.dropout on every tower draws independently)."""
+        rank, world = dist_rank_world(self.config)
+        return ((self.seed * world + rank) << 32) + self._micro * 64 + op.index
 
     def _pad_mask(self, m, op):
         m = self._to_dev(m, torch.uint8)
@@ -621,7 +628,14 @@ class ADAPT(Network):
     # training loop (deeplab.py:210-285)
     # ------------------------------------------------------------------------------------------
     def train(self, base_lr, weight_decay, momentum, batch_size, epoches, max_iterations=None, log=print):
+        """deeplab.py:210-285.  In a data-parallel job (torch.distributed initialised, one process per GPU) every rank
+        runs this loop on its own shard: `batch_size` is per rank, an epoch is data_len // (batch_size * world)
+        iterations, the data source hands each rank its slice of every global batch (data.py), rank 0 alone writes
+        checkpoints and logs, and all ranks meet at a barrier after each save."""
         assert self.data is not None, "data is None"
+        rank, world = dist_rank_world(self.config)
+        if rank != 0:
+            log = lambda *a, **k: None  # noqa: E731
         train_iter = self.data.next_batch(category="train", batch_size=batch_size, epoches=-1)
         self.config.setdefault("batch_size", batch_size)
         self.build()
@@ -636,15 +650,22 @@ class ADAPT(Network):
         log("config -- lr:%f weight_decay:%f momentum:%f batch_size:%f epoches:%f" % (
             base_lr, weight_decay, momentum, batch_size, epoches))
         epoch, i = 0.0, 0
-        iterations_per_epoch_train = max(self.data.get_data_len() // batch_size, 1)
+        iterations_per_epoch_train = max(self.data.get_data_len() // (batch_size * world), 1)
         saver_dir = self.config.get("saver_path", "saver")
+
+        def save(which, name, step):
+            path = self.saver[which].save(None, os.path.join(saver_dir, name), global_step=step)
+            if world > 1:
+                torch.distributed.barrier()
+            return path
+
         while epoch < epoches and (max_iterations is None or i < max_iterations):
             if i == 0:
                 self.net["lr"] = base_lr
             for mult, new_lr in ((10, 1e-4), (20, 1e-5), (30, 1e-6)):  # deeplab.py:245-262
                 if i == mult * iterations_per_epoch_train:
                     log("save model before new_lr:%f" % new_lr)
-                    self.saver["lr"].save(None, os.path.join(saver_dir, "lr-%f" % base_lr), global_step=i)
+                    save("lr", "lr-%f" % base_lr, i)
                     self.net["lr"] = new_lr
                     base_lr = new_lr
             batch = next(train_iter)   # (images, labels) or the dataset class's (images, labels, ids)
@@ -657,12 +678,12 @@ class ADAPT(Network):
                 loss = self.eval_loss(data_x, data_y, 0.5)
                 log("epoch:%f, iteration:%f, lr:%f, loss:%f" % (epoch, i, self.net["lr"], loss))
             if i % 6000 == 5999:
-                self.saver["norm"].save(None, os.path.join(saver_dir, "norm"), global_step=i)
+                save("norm", "norm", i)
             i += 1
             epoch = i / iterations_per_epoch_train
         torch.cuda.synchronize(self.device)
         if self.config.get("save_final", True):
-            self.saver["norm"].save(None, os.path.join(saver_dir, "norm"), global_step=i)
+            save("norm", "norm", i)
         end_time = time.time()
         log("end_time:%f" % end_time)
         log("duration time:%f" % (end_time - start_time))

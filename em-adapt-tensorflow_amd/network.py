@@ -9,7 +9,9 @@ buffers per batch size) and the "session runs" of the training loop become metho
 
 State dicts keep the reference's names: ``net``, ``weights``, ``loss``, ``saver``, ``trainable_list``.
 """
+import json
 import os
+import re
 
 import numpy as np
 import torch
@@ -89,39 +91,103 @@ class Network:
         # accumulators = zeros_like(trainable_list) (network.py:92) live in the flat `accum` buffer
         self.getloss(weight_decay)
         self.optimize(base_lr, momentum)
-        for name in ("norm", "lr", "best"):
-            self.saver[name] = _Saver(self)
+        # network.py:100-102: Saver(max_to_keep=2) for "norm" and "best", the TF default (5) for "lr"
+        for name, keep in (("norm", 2), ("lr", 5), ("best", 2)):
+            self.saver[name] = _Saver(self, max_to_keep=keep)
 
     def restore_from_model(self, saver, model_path, checkpoint=False):
-        """network.py:104-110."""
+        """network.py:104-110.  checkpoint=True: `model_path` is a directory and the checkpoint to load is the one its
+        ``checkpoint`` index file names (tf.train.get_checkpoint_state: the LAST one written there)."""
         if checkpoint:
-            cands = sorted(p for p in os.listdir(model_path) if p.endswith(".npz"))
-            if not cands:
-                raise FileNotFoundError("no checkpoint in %s" % model_path)
-            model_path = os.path.join(model_path, cands[-1])
+            model_path = latest_checkpoint(model_path)
         saver.restore(None, model_path)
 
 
-class _Saver:
-    """Stand-in for tf.train.Saver over trainable_list (network.py:100-102).  Unlike the reference it also
-    stores the momentum slots, so a resumed run continues exactly (checkpoint row)."""
+_INDEX = "checkpoint"   # the index file tf.train.Saver keeps next to its checkpoints
 
-    def __init__(self, net):
+
+def _step_of(path):
+    m = re.search(r"-(\d+)\.npz$", path)
+    return int(m.group(1)) if m else -1
+
+
+def latest_checkpoint(model_dir):
+    """tf.train.get_checkpoint_state(dir).model_checkpoint_path: the checkpoint written last into `model_dir`, from
+    the ``checkpoint`` index file; directories without one (hand-copied files) fall back to the highest global step,
+    compared as a NUMBER ("norm-11999" is newer than "norm-5999")."""
+    index = os.path.join(model_dir, _INDEX)
+    if os.path.exists(index):
+        with open(index) as f:
+            state = json.load(f)
+        path = state["model_checkpoint_path"]
+        path = path if os.path.isabs(path) else os.path.join(model_dir, path)
+        if os.path.exists(path):
+            return path
+    cands = [p for p in os.listdir(model_dir) if p.endswith(".npz")]
+    if not cands:
+        raise FileNotFoundError("no checkpoint in %s" % model_dir)
+    cands.sort(key=lambda p: (_step_of(p), os.path.getmtime(os.path.join(model_dir, p))))
+    return os.path.join(model_dir, cands[-1])
+
+
+class _Saver:
+    """Stand-in for tf.train.Saver over trainable_list (network.py:100-102): ``save(sess, path, global_step)`` writes
+    ``<path>-<step>.npz`` and keeps the last `max_to_keep` files THIS saver wrote (TF semantics: "norm" and "best"
+    keep 2, "lr" the default 5).  Writes are atomic (temp file + rename) and recorded in a ``checkpoint`` index file
+    like TF's, which ``restore_from_model(checkpoint=True)`` follows.  Unlike the reference it also stores the
+    momentum slots, per layer in the layer's own (unpadded) shape like the weights, so a resumed run continues exactly
+    and a checkpoint does not depend on the buffer padding of the run that wrote it."""
+
+    def __init__(self, net, max_to_keep=5):
         self.netobj = net
+        self.max_to_keep = max_to_keep
+        self._kept = []
+
+    def _momentum_views(self, layer):
+        n = self.netobj
+        seg = n._segments[layer]
+        s, nw, nb = seg["start"], seg["nw"], seg["nb"]
+        kh, kw, cin, cout = seg["shape"]
+        v = n._flat["momentum"]
+        return v[s:s + nw].view(seg["pshape"])[:, :, :cin, :cout], v[s + nw:s + nw + nb][:cout]
 
     def save(self, sess, path, global_step=None):
         n = self.netobj
         if global_step is not None:
             path = "%s-%d" % (path, int(global_step))
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        final = os.path.abspath(path + ".npz")
+        if _rank() != 0:          # data-parallel runs: the replicas are identical, rank 0 writes
+            return final
+        os.makedirs(os.path.dirname(final), exist_ok=True)
         blob = {}
         for layer, (w, b) in n.weights.items():
             blob[layer + "_weights"] = w.detach().cpu().numpy()
             blob[layer + "_bias"] = b.detach().cpu().numpy()
-        if getattr(n, "_flat", None) is not None:
-            blob["__momentum__"] = n._flat["momentum"].detach().cpu().numpy()
-        np.savez(path + ".npz", **blob)
-        return path + ".npz"
+            if getattr(n, "_flat", None) is not None:
+                vw, vb = self._momentum_views(layer)
+                blob[layer + "_weights/Momentum"] = vw.detach().cpu().numpy()
+                blob[layer + "_bias/Momentum"] = vb.detach().cpu().numpy()
+        tmp = "%s.tmp.%d" % (final, os.getpid())
+        with open(tmp, "wb") as f:
+            np.savez(f, **blob)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, final)
+        if final in self._kept:
+            self._kept.remove(final)
+        self._kept.append(final)
+        while self.max_to_keep and len(self._kept) > self.max_to_keep:
+            old = self._kept.pop(0)
+            if os.path.exists(old):
+                os.remove(old)
+        d = os.path.dirname(final)
+        index_tmp = os.path.join(d, "%s.tmp.%d" % (_INDEX, os.getpid()))
+        with open(index_tmp, "w") as f:
+            json.dump({"model_checkpoint_path": os.path.basename(final),
+                       "all_model_checkpoint_paths": [os.path.basename(p) for p in self._kept
+                                                      if os.path.dirname(p) == d]}, f)
+        os.replace(index_tmp, os.path.join(d, _INDEX))
+        return final
 
     def restore(self, sess, path):
         n = self.netobj
@@ -131,8 +197,17 @@ class _Saver:
             for layer, (w, b) in n.weights.items():
                 w.copy_(torch.from_numpy(z[layer + "_weights"]).to(w.device))
                 b.copy_(torch.from_numpy(z[layer + "_bias"]).to(b.device))
-            if "__momentum__" in z.files and getattr(n, "_flat", None) is not None:
-                n._flat["momentum"].copy_(torch.from_numpy(z["__momentum__"]).to(n._flat["momentum"].device))
+                if getattr(n, "_flat", None) is not None and layer + "_weights/Momentum" in z.files:
+                    vw, vb = self._momentum_views(layer)
+                    vw.copy_(torch.from_numpy(z[layer + "_weights/Momentum"]).to(vw.device))
+                    vb.copy_(torch.from_numpy(z[layer + "_bias/Momentum"]).to(vb.device))
+        if getattr(n, "_flat", None) is not None:
+            n._flat["params"].add_(0)   # bump torch's version counter: derived filter images are refreshed
 
 
-__all__ = ["Network", "ops", "round_up"]
+def _rank():
+    d = torch.distributed
+    return d.get_rank() if d.is_available() and d.is_initialized() else 0
+
+
+__all__ = ["Network", "ops", "round_up", "latest_checkpoint"]

@@ -451,6 +451,44 @@ def sgd_momentum(w, v, accum, lr, momentum, accum_scale=1.0):
               float(accum_scale), _stream())
 
 
+def conv_plan(B, H, W, Cin, Cout, k, dil=1, dgrad=False):
+    """(tile variant, main rows, main split-K, tail split-K) of the fp32 forward / data-gradient launch plan."""
+    d = conv_desc(B, H, W, Cin, Cout, k, k, dil)
+    out = (ctypes.c_int * 4)()
+    _lib.call("emadapt_conv_plan", ctypes.byref(d), 1 if dgrad else 0, out)
+    return tuple(out)
+
+
+def tune_set(key, value):
+    """Force a launch-plan choice (include/emadapt.h "Launch-plan overrides"); 0 restores the automatic plan."""
+    _lib.call("emadapt_tune_set", key.encode(), int(value))
+
+
+def tune_get(key):
+    v = ctypes.c_int(0)
+    _lib.call("emadapt_tune_get", key.encode(), ctypes.byref(v))
+    return v.value
+
+
+class tuned:
+    """Context manager: ``with ops.tuned(fp32_tile=2, plan_cus=4): ...`` -- restores the previous values on exit."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+        self.old = {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = tune_get(k)
+            tune_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tune_set(k, v)
+        return False
+
+
 def prof_enable(on=True):
     _lib.load().emadapt_prof_enable(1 if on else 0)
 

@@ -279,6 +279,25 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
                          float accum_scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Launch-plan overrides.  Every convolution picks a kernel variant and a split factor from its shape; these
+ * integer knobs force the choice (0 = automatic, the default).  All variants compute the same function -- the
+ * parity tests use the knobs to run each variant on small awkward shapes -- so they are a tuning / test aid, not
+ * part of the numerics.  Process-wide; returns EMADAPT_ERR_INVALID for an unknown key.
+ *   "fp32_tile"  1: 256x64x16 tiles | 2: 256x256x32 tiles for the rows that fill whole rounds of the CUs + a
+ *                128x128 split-K launch for the rest | 3: 128x128x32 wave-specialised tiles
+ *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
+ *   "bf16_tile"  128 | 256          "x6_tile"  128 | 256
+ *   "plan_cus"   number of CUs the launch plans are laid out for (default 256: MI355X)
+ *   "estep_stop", "ablate": honoured by diagnostic builds only (-DEMADAPT_ABLATE_BUILD), ignored otherwise
+ * ---------------------------------------------------------------------------------------- */
+int emadapt_tune_set(const char *key, int value);
+/* The plan emadapt_conv_fwd (dgrad = 0) / emadapt_conv_dgrad (dgrad = 1) will use for this shape, given enough workspace:
+ * plan[0] = tile variant ("fp32_tile" numbering), plan[1] = rows of the main launch, plan[2] = its split-K factor,
+ * plan[3] = split-K factor of the 128x128 launch over the remaining rows (0 = there is none). */
+int emadapt_conv_plan(const emadapt_conv_desc *d, int dgrad, int plan[4]);
+int emadapt_tune_get(const char *key, int *value);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement support (bench.py): per-kernel HIP-event timing on the launch stream.
  * ---------------------------------------------------------------------------------------- */
 #define EMADAPT_K_IGEMM_FWD 0   /* conv forward implicit GEMM           */

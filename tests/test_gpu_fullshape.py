@@ -1,0 +1,196 @@
+"""GPU parity of the fp32 conv kernels AT THE BENCHMARK SHAPES (BASELINE configs[1]: batch 16, 41x41 maps) and of every
+launch-plan variant on small awkward shapes.
+
+Why a file of its own: the launch plan depends on the shape (csrc/conv_igemm.hip plan_launches).  At batch 16 the wide
+layers -- fc6 / fc7 forward, fc7 / fc8 data gradient: deeplab.py:86-96, shapes deeplab.py:143-149, a quarter of the step
+-- run `igemm_kernel<256,256,32,128>` on the rows that fill whole rounds of the 256 CUs plus a 128x128 split-K launch on
+the remaining rows, and conv3..conv5 run split-K by 3; none of the small shapes in test_gpu_kernels.py selects those
+plans by itself.  Here:
+
+  * the true shapes run against the fp32 PyTorch-CPU oracle (oracle/deeplab_oracle.conv_same and its autograd; each
+    layer is a few seconds on the GPU box's host cores) with a bar of 1e-4 of the tensor's max magnitude, with the
+    epilogues the model uses (bias + ReLU + dropout mask forward; ReLU-gradient gate with the dropout scale backward),
+    a bitwise repeatability check, and an assertion (emadapt_conv_plan) that the plan under test IS the big-tile one;
+  * every tile variant is forced (emadapt_tune_set) onto small shapes with M / N / K tails, against the fp64 oracle at
+    2e-5, with `plan_cus` shrunk so that the row split (m_begin / m_end), the partial last tile and the slab reuse of
+    the tail launch are hit at awkward sizes.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import em_adapt_tensorflow_amd.ops as ops
+    from oracle import deeplab_oracle as do
+    torch.set_num_threads(max(1, min(64, len(__import__("os").sched_getaffinity(0)))))
+    return ops, do, torch
+
+
+def _rel(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def _t(torch, a, dtype=None):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype or torch.float32, device="cuda:0")
+
+
+# name, (B, H, W, Cin, Cout, k, dil), expected forward plan variant, expected dgrad plan variant
+FULL_SHAPES = [
+    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 2, 3),      # deeplab.py:92,145: 44.8 % of the MACs
+    ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 2, 2),     # deeplab.py:95,147
+    ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 2),       # deeplab.py:95,149 (21 classes padded to 24)
+    ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 3, 3),   # split-K by 3 on 844 tiles
+    ("conv5_2", (16, 41, 41, 512, 512, 3, 2), 3, 3),   # atrous rate 2 (deeplab.py:65)
+]
+
+
+@pytest.mark.parametrize("name,shape,fwd_variant,dgrad_variant", FULL_SHAPES, ids=[s[0] for s in FULL_SHAPES])
+def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgrad_variant):
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    pf = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=False)
+    pd = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=True)
+    assert pf[0] == fwd_variant and pd[0] == dgrad_variant, (pf, pd)
+    if fwd_variant == 2:  # rows of whole rounds on 256x256 tiles + a split 128x128 launch over the rest
+        assert 0 < pf[1] < B * H * W and pf[1] % 256 == 0 and pf[3] >= 1, pf
+    if name.startswith("conv"):
+        assert pf[2] == 3 and pd[2] == 3, (pf, pd)
+
+    rng = np.random.default_rng(__import__("zlib").crc32(name.encode()))
+    fan_in = k * k * Cin
+    x = np.maximum(rng.normal(0, 1, (B, H, W, Cin)), 0).astype(np.float32)     # post-ReLU-like input (the dgrad gate)
+    w = rng.normal(0, np.sqrt(2.0 / fan_in), (k, k, Cin, Cout)).astype(np.float32)
+    b = rng.normal(0, 0.1, (Cout,)).astype(np.float32)
+    dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
+    mask = (rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8)
+    relu = name != "fc8"
+    drop = name in ("fc6", "fc7")
+
+    xt = torch.tensor(x, requires_grad=True)
+    wt = torch.tensor(w, requires_grad=True)
+    bt = torch.tensor(b)
+    y_lin = do.conv_same(xt, wt, bt, dil)
+    y_lin.backward(torch.tensor(dy))
+    want_y = y_lin.detach().numpy()
+    if relu:
+        want_y = np.maximum(want_y, 0)
+    if drop:
+        want_y = want_y / np.float32(0.5) * mask
+    want_dx = np.where(x > 0, xt.grad.numpy() * np.float32(2.0 if drop else 1.0), 0)
+
+    xg, wg, bg, dyg = _t(torch, x), _t(torch, w), _t(torch, b), _t(torch, dy)
+    mg = _t(torch, mask, torch.uint8) if drop else None
+    kw = dict(relu=relu, keep_prob=0.5 if drop else 1.0, drop_mask=mg)
+    y1 = ops.conv_fwd(xg, wg, bg, dil, **kw).cpu().numpy()
+    assert _rel(y1, want_y) < 1e-4
+    assert np.array_equal(y1, ops.conv_fwd(xg, wg, bg, dil, **kw).cpu().numpy()), "forward must repeat bitwise"
+    dx1 = ops.conv_dgrad(dyg, wg, dil, gate=xg, gate_scale=2.0 if drop else 1.0).cpu().numpy()
+    assert _rel(dx1, want_dx) < 1e-4
+    assert np.array_equal(dx1, ops.conv_dgrad(dyg, wg, dil, gate=xg, gate_scale=2.0 if drop else 1.0).cpu().numpy())
+    dw1 = ops.conv_wgrad(xg, dyg, k, k, dil).cpu().numpy()
+    assert _rel(dw1, wt.grad.numpy()) < 1e-4
+    assert np.array_equal(dw1, ops.conv_wgrad(xg, dyg, k, k, dil).cpu().numpy()), "filter gradient must repeat bitwise"
+    assert _rel(ops.bias_grad(dyg).cpu(), dy.astype(np.float64).sum((0, 1, 2))) < 1e-5
+
+
+def test_builtin_dropout_on_the_big_tile_path(env):
+    """fc7 at batch 16 with the counter-hash generator: the element index fed to the hash must be the global one in
+    both launches of the plan (rows below and above main_rows): kept values equal relu(y)/keep exactly, the keep rate
+    is right in both row ranges and the same seed repeats."""
+    ops, do, torch = env
+    B, H, W, C = 16, 41, 41, 4096
+    plan = ops.conv_plan(B, H, W, C, C, 1, 1)
+    assert plan[0] == 2 and plan[3] >= 1
+    rng = np.random.default_rng(1)
+    xg = _t(torch, np.abs(rng.normal(0, 1, (B, H, W, C))).astype(np.float32))
+    wg = _t(torch, np.abs(rng.normal(0, 0.01, (1, 1, C, C))).astype(np.float32))
+    bg = _t(torch, np.full((C,), 0.1, np.float32))
+    base = ops.conv_fwd(xg, wg, bg, 1, relu=True)
+    d1 = ops.conv_fwd(xg, wg, bg, 1, relu=True, keep_prob=0.5, drop_seed=77)
+    d2 = ops.conv_fwd(xg, wg, bg, 1, relu=True, keep_prob=0.5, drop_seed=77)
+    assert torch.equal(d1, d2)
+    kept = d1 != 0
+    assert torch.equal(d1[kept], (base / 0.5)[kept])
+    rows = kept.reshape(-1, C)
+    main = plan[1]
+    assert abs(float(rows[:main].float().mean()) - 0.5) < 2e-3 and abs(float(rows[main:].float().mean()) - 0.5) < 2e-3
+    # the two row ranges draw from one stream: no duplicated pattern between the first main and the first tail row
+    assert not torch.equal(rows[0], rows[main])
+
+
+# (B, H, W, Cin, Cout, k, dil): M tails (M % 256, M % 128 != 0), N tails, K % 32 != 0, N below / above the tile width
+SMALL = [
+    (2, 23, 29, 40, 72, 3, 1),
+    (1, 37, 35, 64, 264, 3, 2),
+    (3, 17, 19, 24, 520, 1, 1),
+    (2, 21, 21, 32, 40, 4, 4),
+    (1, 45, 43, 160, 24, 1, 1),
+]
+
+
+@pytest.mark.parametrize("shape", SMALL)
+def test_every_plan_variant_on_small_awkward_shapes(env, shape):
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    w = rng.normal(0, 0.2, (k, k, Cin, Cout)).astype(np.float32)
+    b = rng.normal(0, 0.5, (Cout,)).astype(np.float32)
+    dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
+    gate = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    mask = (rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64)
+    y = do.conv_same(xt, wt, torch.tensor(b, dtype=torch.float64), dil)
+    y.backward(torch.tensor(dy, dtype=torch.float64))
+    want_y = torch.relu(y).detach().numpy() / 0.5 * mask
+    want_dx = np.where(gate > 0, xt.grad.numpy() * 2.0, 0.0)
+    xg, wg, bg, dyg, gg, mg = (_t(torch, x), _t(torch, w), _t(torch, b), _t(torch, dy), _t(torch, gate),
+                               _t(torch, mask, torch.uint8))
+    M = B * H * W
+    seen = set()
+    # variant x CU count the plan is laid out for x forced split-K: reaches row splits at m_begin > 0, partial last
+    # tiles in both launches, and the tail launch's slab at workspace offset 0
+    for variant, cus, splitk in [(1, 0, 0), (1, 2, 2), (3, 0, 0), (3, 2, 3), (2, 0, 0), (2, 2, 0), (2, 3, 0), (2, 4, 2),
+                                 (2, 5, 3)]:
+        with ops.tuned(fp32_tile=variant, plan_cus=cus, splitk=splitk):
+            for dgrad in (False, True):
+                plan = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=dgrad)
+                assert plan[0] == variant
+                seen.add((variant, plan[1] < M, plan[2] > 1, plan[3] > 1))
+            got_y = ops.conv_fwd(xg, wg, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg).cpu().numpy()
+            got_dx = ops.conv_dgrad(dyg, wg, dil, gate=gg, gate_scale=2.0).cpu().numpy()
+        assert _rel(got_y, want_y) < 2e-5, (variant, cus, splitk)
+        assert _rel(got_dx, want_dx) < 2e-5, (variant, cus, splitk)
+    assert ops.tune_get("fp32_tile") == 0 and ops.tune_get("plan_cus") == 0
+    if M > 1024 and max(Cin, Cout) >= 40:
+        assert any(v == 2 and rows_split for v, rows_split, _, _ in seen), "no forced plan split the rows: %s" % seen
+
+
+def test_one_wide_filters_and_one_pixel_wide_maps(env):
+    """KW == 1 with KH > 1 (and the reverse), W == 1 / H == 1 inputs: the magic-number divisions by 1 (common.h:
+    div_magic) in the tap decomposition of the forward / data-gradient kernels and the pixel decomposition of wgrad."""
+    ops, do, torch = env
+    rng = np.random.default_rng(8)
+    for (B, H, W, Cin, Cout, kh, kw, dil) in [(2, 9, 11, 16, 72, 3, 1, 1), (2, 9, 11, 16, 72, 1, 3, 2),
+                                              (2, 1, 37, 16, 72, 3, 3, 1), (2, 37, 1, 16, 72, 3, 3, 2),
+                                              (1, 1, 1, 8, 8, 3, 3, 1)]:
+        x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+        w = rng.normal(0, 0.2, (kh, kw, Cin, Cout)).astype(np.float32)
+        dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        y = do.conv_same(xt, wt, None, dil)
+        y.backward(torch.tensor(dy, dtype=torch.float64))
+        xg, wg, dyg = _t(torch, x), _t(torch, w), _t(torch, dy)
+        case = (B, H, W, Cin, Cout, kh, kw, dil)
+        assert _rel(ops.conv_fwd(xg, wg, None, dil).cpu(), y.detach()) < 2e-5, case
+        assert _rel(ops.conv_dgrad(dyg, wg, dil).cpu(), xt.grad) < 2e-5, case
+        assert _rel(ops.conv_wgrad(xg, dyg, kh, kw, dil).cpu(), wt.grad) < 2e-5, case

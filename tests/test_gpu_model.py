@@ -155,3 +155,29 @@ def test_full_size_single_image_config1(env):
     torch.cuda.synchronize()
     want_labels, _ = oracle.estep_labels(logits, labels, perms)
     assert np.array_equal(adapt.net["e_argmax"].cpu().numpy(), want_labels)
+
+
+@pytest.mark.parametrize("preset", ["largefov", "ref"])
+def test_full_size_config5(env, preset):
+    """BASELINE config 5: one 513x513 image, 41 classes -- fc6 3x3 atrous rate 12 -> 1024 ("largefov") and the network
+    as written (fc6 4x4 rate 4 -> 4096, "ref").  65x65 output maps: the E-step runs its LDS-overflow path (only the
+    present classes stay resident), the rate-12 gather reaches 12 pixels into the zero padding on every side."""
+    ADAPT, do, eo, torch = env
+    C, size = 41, 513
+    adapt, oracle, params = _build(ADAPT, do, torch, size, C, 64, preset, B=1, dtype=torch.float32)
+    assert tuple(adapt.weights["fc6"][0].shape) == ((3, 3, 512, 1024) if preset == "largefov" else (4, 4, 512, 4096))
+    images, labels = do.synthetic_batch(1, size, C, seed=4)
+    images = (images / 50.0).astype(np.float32)
+    logits = adapt.forward(images, 1.0).cpu().numpy()
+    want = oracle.forward(oracle.tensors(params, requires_grad=False), images)["output"].numpy()
+    assert logits.shape == (1, 65, 65, C)
+    assert _rel(logits, want) < 1e-3                      # north_star: fp32 logits within 1e-3 relative
+    perms = eo.draw_perms(5, C, seed=6)
+    adapt.pre_train(1e-3, 1e-5, 0.9, 1)
+    adapt.micro_step(images, labels, keep_prob=1.0, perms=perms)
+    adapt.apply_update()
+    torch.cuda.synchronize()
+    want_labels, _ = oracle.estep_labels(logits, labels, perms)
+    got = adapt.net["e_argmax"].cpu().numpy()
+    assert np.array_equal(got, want_labels)               # bit-identical label map
+    assert len(np.unique(got)) >= 2 and np.isfinite(float(adapt.loss["norm"].cpu()))

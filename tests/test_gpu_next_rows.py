@@ -161,3 +161,78 @@ def test_train_loop_runs_on_the_dataset_class(tmp_path):
                    "save_final": False, "saver_path": str(tmp_path / "saver")})
     n = adapt.train(base_lr=1e-3, weight_decay=1e-5, momentum=0.9, batch_size=2, epoches=2, log=lambda *a: None)
     assert n == 4 and np.isfinite(float(adapt.loss["norm"].cpu()))
+
+
+def test_step_lr_schedule_and_save_cadence(env, tmp_path):
+    """f2: the loop bookkeeping of deeplab.py:240-285 across its boundaries.  One iteration per epoch, 31 epochs:
+    lr = base for i < 10, 1e-4 for 10 <= i < 20, 1e-5 for 20 <= i < 30, 1e-6 from i = 30 (deeplab.py:245-262); a "lr"
+    checkpoint named after the OLD rate is written right before each drop and the final "norm" checkpoint at the end
+    (deeplab.py:248,254,260,282); the update runs every accum_num-th iteration (deeplab.py:268-270)."""
+    ops, ADAPT, do, torch = env
+    from em_adapt_tensorflow_amd.data import SyntheticData
+    from em_adapt_tensorflow_amd.network import latest_checkpoint
+    seen = []
+
+    class Probe(ADAPT):
+        def micro_step(self, images, labels, keep_prob=0.5, perms=None, drop_masks=None):
+            seen.append((self._micro, self.net["lr"], keep_prob, self._step))
+            return ADAPT.micro_step(self, images, labels, keep_prob, perms, drop_masks)
+
+    cfg = {"input_size": (33, 33), "category_num": 5, "width": 8, "accum_num": 2, "batch_size": 2,
+           "saver_path": str(tmp_path / "saver")}
+    data = SyntheticData(dict(cfg, length=2))       # data_len // batch_size = 1 iteration per epoch
+    lines = []
+    adapt = Probe(dict(cfg, data=data))
+    n = adapt.train(base_lr=1e-3, weight_decay=1e-5, momentum=0.9, batch_size=2, epoches=31, log=lines.append)
+    assert n == 31 and len(seen) == 31
+    for i, (micro, lr, keep, step) in enumerate(seen):
+        want = 1e-3 if i < 10 else 1e-4 if i < 20 else 1e-5 if i < 30 else 1e-6
+        assert micro == i and lr == want and keep == 0.5, (i, lr)
+        assert step == i // 2                                       # one Momentum update per accum_num micro-steps
+    saver = tmp_path / "saver"
+    for name in ("lr-0.001000-10.npz", "lr-0.000100-20.npz", "lr-0.000010-30.npz", "norm-31.npz"):
+        assert (saver / name).exists(), sorted(p.name for p in saver.iterdir())
+    assert latest_checkpoint(str(saver)).endswith("norm-31.npz")
+    assert [l for l in lines if l.startswith("save model before new_lr")] == [
+        "save model before new_lr:%f" % v for v in (1e-4, 1e-5, 1e-6)]
+    assert any(l.startswith("epoch:10.000000, iteration:10.000000, lr:0.000100") for l in lines)   # i % 500 == 10
+    # the lr checkpoint holds the weights as they were BEFORE the drop: restoring it and the final one differ
+    a2 = ADAPT(dict(cfg))
+    a2.build()
+    a2.pre_train(1e-3, 1e-5, 0.9, 2)
+    a2.restore_from_model(a2.saver["norm"], str(saver), checkpoint=True)
+    assert torch.equal(a2._flat["params"], adapt._flat["params"]) and torch.equal(a2._flat["momentum"], adapt._flat["momentum"])
+    a2.restore_from_model(a2.saver["lr"], str(saver / "lr-0.001000-10"))
+    assert not torch.equal(a2._flat["params"], adapt._flat["params"])
+
+
+def test_saver_keeps_the_last_two_and_resumes_from_the_newest(env, tmp_path):
+    """network.py:100-110: Saver(max_to_keep=2) for "norm"; get_checkpoint_state picks the last written file even when
+    its name sorts first ("norm-11999" < "norm-5999" as strings); a bf16 run restores an fp32 run's checkpoint."""
+    ops, ADAPT, do, torch = env
+    from em_adapt_tensorflow_amd.network import latest_checkpoint
+    cfg = {"input_size": (33, 33), "category_num": 5, "width": 8, "batch_size": 2, "accum_num": 1}
+    a = ADAPT(dict(cfg))
+    a.build()
+    a.pre_train(1e-2, 1e-5, 0.9, 2)
+    images, labels = do.synthetic_batch(2, 33, 5, seed=1)
+    d = tmp_path / "ck"
+    states = {}
+    for step in (5999, 11999, 17999):
+        a.micro_step(images / 50, labels, keep_prob=1.0)
+        a.apply_update()
+        a.saver["norm"].save(None, str(d / "norm"), global_step=step)
+        states[step] = (a._flat["params"].clone(), a._flat["momentum"].clone())
+    names = sorted(p.name for p in d.iterdir())
+    assert names == ["checkpoint", "norm-11999.npz", "norm-17999.npz"], names    # the oldest was pruned, no temp files
+    assert latest_checkpoint(str(d)).endswith("norm-17999.npz")
+    (d / "checkpoint").unlink()
+    assert latest_checkpoint(str(d)).endswith("norm-17999.npz")                  # by step NUMBER, not by string order
+    b = ADAPT(dict(cfg, compute_dtype="bf16"))      # other channel padding (8 instead of 4) in the flat buffers
+    b.build()
+    b.pre_train(1e-2, 1e-5, 0.9, 2)
+    b.restore_from_model(b.saver["norm"], str(d), checkpoint=True)
+    for layer, (w, bias) in a.weights.items():
+        assert torch.equal(b.weights[layer][0], w) and torch.equal(b.weights[layer][1], bias)
+        va, vb = a.saver["norm"]._momentum_views(layer), b.saver["norm"]._momentum_views(layer)
+        assert torch.equal(va[0], vb[0]) and torch.equal(va[1], vb[1]) and float(va[0].abs().max()) > 0

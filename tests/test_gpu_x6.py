@@ -47,11 +47,12 @@ SHAPES = [
 
 
 @pytest.fixture(params=["auto", "128", "256"])
-def tile(request, monkeypatch):
+def tile(request):
     """Run the kernels in their automatic plan and with each tile configuration forced."""
-    if request.param != "auto":
-        monkeypatch.setenv("EMADAPT_X6_TILE", request.param)
-    return request.param
+    import em_adapt_tensorflow_amd.ops as ops
+    ops.tune_set("x6_tile", 0 if request.param == "auto" else int(request.param))
+    yield request.param
+    ops.tune_set("x6_tile", 0)
 
 
 @pytest.mark.parametrize("shape", SHAPES)

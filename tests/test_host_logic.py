@@ -93,3 +93,81 @@ def test_synthetic_data_shapes():
     vals = set(np.unique(y.numpy()).tolist())
     assert 0.0 in vals and vals <= set(float(v) for v in range(21)) | {255.0}
     assert d.get_data_len() == 10
+
+
+def test_launch_plans_at_the_benchmark_shapes():
+    """The plans the batch-16 layers get (csrc/conv_igemm.hip plan_launches; no device needed): fc6 / fc7 forward run
+    256x256 tiles on the rows that fill whole rounds of the 256 CUs and a split 128x128 launch on the rest."""
+    from em_adapt_tensorflow_amd import ops
+    M = 16 * 41 * 41
+    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4) == (2, 24576, 1, 5)          # fc6 fwd: 96 x 16 tiles = 6 rounds
+    assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1)[:2] == (2, 24576)           # fc7 fwd
+    assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1, dgrad=True)[:2] == (2, 24576)
+    assert ops.conv_plan(16, 41, 41, 4096, 24, 1, 1, dgrad=True)[0] == 2           # fc8 dgrad (N = 4096)
+    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4, dgrad=True)[0] == 3          # fc6 dgrad (N = 512)
+    assert ops.conv_plan(16, 41, 41, 512, 512, 3, 1) == (3, M, 3, 0)               # conv4_x / conv5_x: split-K by 3
+    assert ops.conv_plan(16, 321, 321, 64, 64, 3, 1)[0] == 1                       # conv1_2: N <= 64
+    with ops.tuned(fp32_tile=2, plan_cus=4):
+        assert ops.conv_plan(2, 23, 29, 40, 72, 3, 1)[:2] == (2, 1024)             # forced: 4 of 6 row tiles + a tail
+    assert ops.tune_get("fp32_tile") == 0
+    from em_adapt_tensorflow_amd import _lib
+    with pytest.raises(_lib.EmadaptError):
+        ops.tune_set("no_such_knob", 1)
+
+
+def _list_only_dataset(tmp_path, n, **cfg):
+    from em_adapt_tensorflow_amd.data import dataset
+    (tmp_path / "txt").mkdir(exist_ok=True)
+    ids = ["img%03d" % i for i in range(n)]
+    for cat in ("train", "val"):
+        (tmp_path / "txt" / (cat + ".txt")).write_text("\n".join(ids) + "\n")
+    base = {"input_size": (33, 33), "main_path": str(tmp_path), "list_path": str(tmp_path / "txt"), "device": "cpu"}
+    base.update(cfg)
+    return dataset(base)
+
+
+def test_dataset_shards_every_global_batch_across_ranks(tmp_path):
+    """Data-parallel input: with a common seed all ranks draw the same permutation and take disjoint slices of every
+    global batch; the ragged remainder of an epoch is dropped so shards stay equal-sized."""
+    world, bs, n = 2, 3, 20
+    orders = []
+    for rank in range(world):
+        ds = _list_only_dataset(tmp_path, n, seed=11, rank=rank, world_size=world)
+        assert (ds.rank, ds.world) == (rank, world)
+        orders.append(list(ds.sample_order("train", bs, epoches=2)))
+    assert len(orders[0]) == len(orders[1]) == 2 * (n // (bs * world))
+    for (e0, s0, i0), (e1, s1, i1) in zip(*orders):
+        assert (e0, s0) == (e1, s1) and len(i0) == len(i1) == bs
+        assert not set(i0.tolist()) & set(i1.tolist()), "ranks must not see the same sample in one step"
+    for ep in range(2):
+        seen = [i for o in orders for e, s, idx in o if e == ep for i in idx.tolist()]
+        assert len(seen) == len(set(seen)) == (n // (bs * world)) * bs * world    # each sample at most once per epoch
+    # augmentation draws differ per rank, single-process behaviour is unchanged (short last batch kept)
+    a = _list_only_dataset(tmp_path, n, seed=11, rank=0, world_size=2).rng.uniform()
+    b = _list_only_dataset(tmp_path, n, seed=11, rank=1, world_size=2).rng.uniform()
+    assert a != b
+    single = list(_list_only_dataset(tmp_path, 5, seed=1).sample_order("train", 3, epoches=1))
+    assert [len(i) for _, _, i in single] == [3, 2]
+
+
+def test_synthetic_data_differs_per_rank():
+    from em_adapt_tensorflow_amd.data import SyntheticData
+    cfg = {"input_size": (33, 33), "category_num": 21, "device": "cpu", "seed": 0}
+    y0 = next(SyntheticData(dict(cfg, rank=0, world_size=2)).next_batch("train", 2))[0]
+    y1 = next(SyntheticData(dict(cfg, rank=1, world_size=2)).next_batch("train", 2))[0]
+    assert not torch.equal(y0, y1)
+
+
+def test_latest_checkpoint_is_chosen_by_step_number_or_index(tmp_path):
+    """network.py:104-110 with checkpoint=True resumes from the LAST checkpoint written (tf.train.get_checkpoint_state),
+    not the lexicographically largest file name ("norm-5999" sorts after "norm-11999")."""
+    import json
+    from em_adapt_tensorflow_amd.network import latest_checkpoint
+    for name in ("norm-5999.npz", "norm-11999.npz", "lr-0.001000-100.npz"):
+        (tmp_path / name).write_bytes(b"x")
+    assert latest_checkpoint(str(tmp_path)).endswith("norm-11999.npz")
+    (tmp_path / "checkpoint").write_text(json.dumps({"model_checkpoint_path": "norm-5999.npz"}))
+    assert latest_checkpoint(str(tmp_path)).endswith("norm-5999.npz")      # the index file wins: it records what was written last
+    (tmp_path / "empty").mkdir()
+    with pytest.raises(FileNotFoundError):
+        latest_checkpoint(str(tmp_path / "empty"))
