@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "igemm_common.h"
+#include "igemm_v2.h"
 
 namespace {
 
@@ -530,40 +531,59 @@ int launch_igemm(IgemmArgs &a, hipStream_t stream) {
     return launch_splitk_epilogue(a, stream);
 }
 
-// How one convolution is launched.
-//   cfg 1: 256x64x16 tiles (N <= 64);  cfg 0: 128x128x32 tiles, wave-specialised (4 MFMA + 4 loader waves), split-K when
-//   the tile count is small;  cfg 2 (N >= 1024, many rows): 256x256x32 tiles for the rows that fill WHOLE rounds of the
-//   256 CUs, and the remaining rows (the partial last round: 160 of fc6's 1696 tiles) as a second launch of 128x128
-//   tiles with split-K, so that no CU idles while a handful of big tiles finish.
+// How one convolution is launched.  Tile variants ("fp32_tile" numbering of emadapt_tune_set / emadapt_conv_plan):
+//   1: 256x64x16 unified kernel (N <= 64)
+//   2: 256x256x32 unified kernel                      -- round-1 kernels, still used where the second-generation
+//   3: 128x128x32 wave-specialised kernel                kernels do not apply (Cx % 16 != 0, more than 32 taps, N < 256)
+//   4: 256x256x32 second generation (igemm_v2.h), one workgroup per CU: N >= 1024 and many rows (fc6 / fc7)
+//   5: 128x256x16 second generation, two workgroups per CU: 256 <= N (conv3 .. conv5, and the tail of variant 4)
+// Variants 2 and 4 take the rows that fill WHOLE rounds of the CUs; the remaining rows (the partial last round: 160 of
+// fc6's 1696 tiles) go to a second launch of the smaller tile with split-K, so that no CU idles while a handful of big
+// tiles finish.  Split-K (fp32 partial slabs + a fixed-order reduce) fills whole rounds when the tile count is small.
 struct LaunchPlan {
-    int cfg;         // configuration of the main launch
+    int cfg;         // tile variant of the main launch
     int main_rows;   // rows [0, main_rows) go to the main launch
     int main_splits;
-    int tail_splits; // rows [main_rows, M) go to a cfg-0 launch with this split factor (0 = no tail)
+    int tail_cfg;    // tile variant of the launch over rows [main_rows, M)
+    int tail_splits; // its split-K factor (0 = no tail)
 };
 
+inline bool v2_ok(const IgemmArgs &a, int bk) { return a.Cx % bk == 0 && a.ntaps <= 32 && a.K >= 2 * bk; }
+
+int splits_for(const IgemmArgs &a, int cfg, long long rows) {
+    switch (cfg) {
+        case 1: return choose_splits(rows, a.N, a.K, 256, 64, 16);
+        case 3: return choose_splits(rows, a.N, a.K, 128, 128, 32);
+        case 5: return choose_splits(rows, a.N, a.K, 128, 256, 16);
+        default: return 1;
+    }
+}
+
 LaunchPlan plan_launches(const IgemmArgs &a) {
-    const int force = tune(TUNE_FP32_TILE);  // 0 = by shape; 1 / 2 / 3 = cfg 1 / cfg 2 / cfg 0 (tests run each on small shapes)
+    const int force = tune(TUNE_FP32_TILE);  // 0 = by shape; the tests force every variant onto small shapes
     const int cus = plan_cus();
     LaunchPlan p;
     p.main_rows = a.M;
+    p.tail_cfg = 0;
     p.tail_splits = 0;
     p.main_splits = 1;
-    p.cfg = force ? (force == 3 ? 0 : force) : (a.N <= 64 ? 1 : (a.N >= 1024 && a.M >= 8192) ? 2 : 0);
-    if (p.cfg == 1) {
-        p.main_splits = choose_splits(a.M, a.N, a.K, 256, 64, 16);
-    } else if (p.cfg == 2) {
+    const bool wide = a.N >= 1024 && a.M >= 8192;
+    int cfg = a.N <= 64 ? 1 : wide ? (v2_ok(a, 32) ? 4 : 2) : (a.N >= 256 && v2_ok(a, 16)) ? 5 : 3;
+    if (force >= 1 && force <= 5 && !((force == 4 && !v2_ok(a, 32)) || (force == 5 && !v2_ok(a, 16)))) cfg = force;
+    p.cfg = cfg;
+    if (cfg == 2 || cfg == 4) {
         const long long tn = ceil_div(a.N, 256), tm = ceil_div(a.M, 256);
         const long long full = (tm * tn) / cus;  // whole rounds of one 256x256 workgroup per CU
         if (full >= 1 && (tm * tn) % cus != 0) {
             const long long tm_full = full * cus / tn;
             if (tm_full >= 1 && tm_full < tm) {
                 p.main_rows = (int)(tm_full * 256);
-                p.tail_splits = choose_splits(a.M - p.main_rows, a.N, a.K, 128, 128, 32);
+                p.tail_cfg = (cfg == 4 && v2_ok(a, 16)) ? 5 : 3;
+                p.tail_splits = splits_for(a, p.tail_cfg, a.M - p.main_rows);
             }
         }
     } else {
-        p.main_splits = choose_splits(a.M, a.N, a.K, 128, 128, 32);
+        p.main_splits = splits_for(a, cfg, a.M);
     }
     return p;
 }
@@ -573,6 +593,18 @@ size_t igemm_workspace_bytes(const IgemmArgs &a) {
     size_t b = p.main_splits > 1 ? (size_t)p.main_splits * p.main_rows * a.N * sizeof(float) : 0;
     if (p.tail_splits > 1) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
     return b;
+}
+
+template <bool BT>
+int launch_variant(int cfg, IgemmArgs &a, hipStream_t stream) {
+    a.tap_inner = (a.ntaps > 1 && a.Cx % (cfg == 1 ? 16 : 32) == 0) ? 1 : 0;   // (variants 4 / 5 always use that order)
+    switch (cfg) {
+        case 1: return launch_igemm<256, 64, 16, 64, BT>(a, stream);
+        case 2: return launch_igemm<256, 256, 32, 128, BT>(a, stream);
+        case 4: return launch_igemm2<4, 2, 32, 4, BT>(a, stream);
+        case 5: return launch_igemm2<2, 2, 16, 2, BT>(a, stream);
+        default: return launch_igemm_ws<BT>(a, stream);
+    }
 }
 
 template <bool BT>
@@ -587,24 +619,17 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
         p.main_splits = 1;
         if (p.tail_splits > 1) p.tail_splits = 1;
     }
-    a.tap_inner = (a.ntaps > 1 && a.Cx % (p.cfg == 1 ? 16 : 32) == 0) ? 1 : 0;
     a.m_begin = 0;
     a.m_end = p.main_rows;
     a.splits = p.main_splits;
     a.slab = p.main_splits > 1 ? static_cast<float *>(workspace) : nullptr;
-    int rc;
-    switch (p.cfg) {
-        case 1: rc = launch_igemm<256, 64, 16, 64, BT>(a, stream); break;
-        case 2: rc = launch_igemm<256, 256, 32, 128, BT>(a, stream); break;
-        default: rc = launch_igemm_ws<BT>(a, stream); break;
-    }
+    int rc = launch_variant<BT>(p.cfg, a, stream);
     if (rc || p.tail_splits == 0) return rc;
-    a.tap_inner = (a.ntaps > 1 && a.Cx % 32 == 0) ? 1 : 0;
     a.m_begin = p.main_rows;
     a.m_end = a.M;
     a.splits = p.tail_splits;
-    a.slab = p.tail_splits > 1 ? static_cast<float *>(workspace) : nullptr;  // the cfg-2 main launch uses no slab
-    return launch_igemm_ws<BT>(a, stream);
+    a.slab = p.tail_splits > 1 ? static_cast<float *>(workspace) : nullptr;  // the main launch of a split plan uses no slab
+    return launch_variant<BT>(p.tail_cfg, a, stream);
 }
 
 }  // namespace
@@ -639,7 +664,7 @@ int emadapt_conv_plan(const emadapt_conv_desc *d, int dgrad, int plan[4]) {
     IgemmArgs a;
     fill_geometry(a, d, dgrad != 0);
     const LaunchPlan p = plan_launches(a);
-    plan[0] = p.cfg == 0 ? 3 : p.cfg;
+    plan[0] = p.cfg;
     plan[1] = p.main_rows;
     plan[2] = p.main_splits;
     plan[3] = p.tail_splits;

@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
-"""Time single conv kernels (fwd / dgrad / wgrad) at DeepLab layer shapes.  usage: conv_bench.py [--bf16|--x6] [layer ...]"""
+"""Time single conv kernels (fwd / dgrad / wgrad) at DeepLab layer shapes.
+usage: conv_bench.py [--bf16|--x6] [--tile=N] [--splitk=S] [layer ...]   (--tile / --splitk: emadapt_tune_set overrides)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if any(a.startswith("--ablate=") for a in sys.argv):   # diagnostic library (-DEMADAPT_ABLATE_BUILD), bound before first use
+    from em_adapt_tensorflow_amd import _build, _lib
+    _lib._bind(_build.ABLATE_LIB_PATH)
 from em_adapt_tensorflow_amd import ops
 
 SHAPES = {  # name: (B, H, W, Cin, Cout, k, dil)
     "fc6": (16, 41, 41, 512, 4096, 4, 4), "fc7": (16, 41, 41, 4096, 4096, 1, 1), "conv4_2": (16, 41, 41, 512, 512, 3, 1),
     "conv5_2": (16, 41, 41, 512, 512, 3, 2), "conv3_2": (16, 81, 81, 256, 256, 3, 1), "conv2_2": (16, 161, 161, 128, 128, 3, 1),
-    "conv1_2": (16, 321, 321, 64, 64, 3, 1), "conv4_2x8": (128, 41, 41, 512, 512, 3, 1),
+    "conv1_2": (16, 321, 321, 64, 64, 3, 1), "conv4_2x8": (128, 41, 41, 512, 512, 3, 1), "conv4_1": (16, 41, 41, 256, 512, 3, 1),
+    "conv3_1": (16, 81, 81, 128, 256, 3, 1), "conv2_1": (16, 161, 161, 64, 128, 3, 1), "conv1_1": (16, 321, 321, 4, 64, 3, 1),
+    "fc8": (16, 41, 41, 4096, 24, 1, 1),
     "fc7p": (16, 41, 41, 4096 + 64, 4096 + 64, 1, 1), "fc7h": (16, 41, 41, 2048, 2048, 1, 1), "fc7hp": (16, 41, 41, 2048 + 32, 2048 + 32, 1, 1),
 }
 
@@ -23,6 +29,11 @@ def timeit(fn, reps=5):
 BF16 = "--bf16" in sys.argv
 X6 = "--x6" in sys.argv
 names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fc6", "conv4_2", "conv2_2"]
+for a in sys.argv[1:]:
+    if a.startswith("--tile="): ops.tune_set("fp32_tile", int(a.split("=")[1]))
+    if a.startswith("--splitk="): ops.tune_set("splitk", int(a.split("=")[1]))
+    if a.startswith("--pace="): ops.tune_set("pace", int(a.split("=")[1]))
+    if a.startswith("--ablate="): ops.tune_set("ablate", int(a.split("=")[1]))
 for n in names:
     B, H, W, Cin, Cout, k, dil = SHAPES[n]
     x = torch.randn(B, H, W, Cin, device="cuda"); w = torch.randn(k, k, Cin, Cout, device="cuda") * 0.05
@@ -49,5 +60,8 @@ for n in names:
         peak = 157.3
     for kind, fn in kinds:
         ms = timeit(fn)
-        print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  %s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / peak * 100,
-                                                           "bf16" if BF16 else "bf16x6" if X6 else "fp32"), flush=True)
+        plan = ""
+        if not BF16 and not X6 and kind in ("fwd", "dgrad"):
+            plan = " plan %s" % (ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=kind == "dgrad"),)
+        print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  %s%s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / peak * 100,
+                                                             "bf16" if BF16 else "bf16x6" if X6 else "fp32", plan), flush=True)

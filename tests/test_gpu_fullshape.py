@@ -43,11 +43,12 @@ def _t(torch, a, dtype=None):
 
 # name, (B, H, W, Cin, Cout, k, dil), expected forward plan variant, expected dgrad plan variant
 FULL_SHAPES = [
-    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 2, 3),      # deeplab.py:92,145: 44.8 % of the MACs
-    ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 2, 2),     # deeplab.py:95,147
-    ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 2),       # deeplab.py:95,149 (21 classes padded to 24)
-    ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 3, 3),   # split-K by 3 on 844 tiles
-    ("conv5_2", (16, 41, 41, 512, 512, 3, 2), 3, 3),   # atrous rate 2 (deeplab.py:65)
+    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 4, 5),      # deeplab.py:92,145: 44.8 % of the MACs
+    ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 4, 4),     # deeplab.py:95,147
+    ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 2),       # deeplab.py:95,149 (21 classes padded to 24: dgrad K = 24)
+    ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 5, 5),   # few tiles: split-K
+    ("conv5_2", (16, 41, 41, 512, 512, 3, 2), 5, 5),   # atrous rate 2 (deeplab.py:65)
+    ("conv3_1", (16, 81, 81, 128, 256, 3, 1), 5, 3),   # dgrad has N = 128: round-1 wave-specialised kernel
 ]
 
 
@@ -58,10 +59,10 @@ def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgra
     pf = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=False)
     pd = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=True)
     assert pf[0] == fwd_variant and pd[0] == dgrad_variant, (pf, pd)
-    if fwd_variant == 2:  # rows of whole rounds on 256x256 tiles + a split 128x128 launch over the rest
+    if fwd_variant in (2, 4):  # rows of whole rounds on 256x256 tiles + a split launch of smaller tiles over the rest
         assert 0 < pf[1] < B * H * W and pf[1] % 256 == 0 and pf[3] >= 1, pf
-    if name.startswith("conv"):
-        assert pf[2] == 3 and pd[2] == 3, (pf, pd)
+    if name.startswith("conv4") or name.startswith("conv5"):
+        assert pf[2] > 1 and pd[2] > 1, (pf, pd)     # split-K plans
 
     rng = np.random.default_rng(__import__("zlib").crc32(name.encode()))
     fan_in = k * k * Cin
@@ -107,7 +108,7 @@ def test_builtin_dropout_on_the_big_tile_path(env):
     ops, do, torch = env
     B, H, W, C = 16, 41, 41, 4096
     plan = ops.conv_plan(B, H, W, C, C, 1, 1)
-    assert plan[0] == 2 and plan[3] >= 1
+    assert plan[0] == 4 and plan[3] >= 1
     rng = np.random.default_rng(1)
     xg = _t(torch, np.abs(rng.normal(0, 1, (B, H, W, C))).astype(np.float32))
     wg = _t(torch, np.abs(rng.normal(0, 0.01, (1, 1, C, C))).astype(np.float32))
@@ -132,7 +133,17 @@ SMALL = [
     (3, 17, 19, 24, 520, 1, 1),
     (2, 21, 21, 32, 40, 4, 4),
     (1, 45, 43, 160, 24, 1, 1),
+    (2, 23, 29, 64, 288, 3, 1),     # both directions eligible for the second-generation tiles (channels % 32 == 0)
+    (1, 37, 35, 272, 48, 3, 2),     # % 16 only: variant 5 but not 4
+    (3, 17, 19, 96, 544, 1, 1),     # 1x1 (one tap), N tail of the 256-wide tile
+    (2, 21, 21, 32, 160, 4, 4),     # 16 taps, dilation 4
 ]
+
+
+def _eligible(variant, Cx, k):
+    """csrc/conv_igemm.hip v2_ok: what a forced second-generation variant needs (otherwise the automatic plan is used)."""
+    bk = {4: 32, 5: 16}.get(variant)
+    return bk is None or (Cx % bk == 0 and k * k <= 32 and k * k * Cx >= 2 * bk)
 
 
 @pytest.mark.parametrize("shape", SMALL)
@@ -159,12 +170,13 @@ def test_every_plan_variant_on_small_awkward_shapes(env, shape):
     # variant x CU count the plan is laid out for x forced split-K: reaches row splits at m_begin > 0, partial last
     # tiles in both launches, and the tail launch's slab at workspace offset 0
     for variant, cus, splitk in [(1, 0, 0), (1, 2, 2), (3, 0, 0), (3, 2, 3), (2, 0, 0), (2, 2, 0), (2, 3, 0), (2, 4, 2),
-                                 (2, 5, 3)]:
+                                 (2, 5, 3), (4, 0, 0), (4, 2, 0), (4, 3, 2), (4, 5, 3), (5, 0, 0), (5, 2, 2), (5, 2, 3)]:
         with ops.tuned(fp32_tile=variant, plan_cus=cus, splitk=splitk):
             for dgrad in (False, True):
                 plan = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=dgrad)
-                assert plan[0] == variant
-                seen.add((variant, plan[1] < M, plan[2] > 1, plan[3] > 1))
+                if _eligible(variant, Cout if dgrad else Cin, k):
+                    assert plan[0] == variant, (plan, variant, dgrad)
+                seen.add((plan[0], plan[1] < M, plan[2] > 1, plan[3] > 1))
             got_y = ops.conv_fwd(xg, wg, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg).cpu().numpy()
             got_dx = ops.conv_dgrad(dyg, wg, dil, gate=gg, gate_scale=2.0).cpu().numpy()
         assert _rel(got_y, want_y) < 2e-5, (variant, cus, splitk)
@@ -172,6 +184,9 @@ def test_every_plan_variant_on_small_awkward_shapes(env, shape):
     assert ops.tune_get("fp32_tile") == 0 and ops.tune_get("plan_cus") == 0
     if M > 1024 and max(Cin, Cout) >= 40:
         assert any(v == 2 and rows_split for v, rows_split, _, _ in seen), "no forced plan split the rows: %s" % seen
+    if M > 1024 and Cin % 32 == 0 and Cout % 32 == 0 and k * k <= 32:
+        assert any(v == 4 and rows_split for v, rows_split, _, _ in seen), "variant 4 never split the rows: %s" % seen
+        assert any(v == 5 and split for v, _, split, _ in seen), "variant 5 never ran split-K: %s" % seen
 
 
 def test_one_wide_filters_and_one_pixel_wide_maps(env):

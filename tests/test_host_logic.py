@@ -100,12 +100,15 @@ def test_launch_plans_at_the_benchmark_shapes():
     256x256 tiles on the rows that fill whole rounds of the 256 CUs and a split 128x128 launch on the rest."""
     from em_adapt_tensorflow_amd import ops
     M = 16 * 41 * 41
-    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4) == (2, 24576, 1, 5)          # fc6 fwd: 96 x 16 tiles = 6 rounds
-    assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1)[:2] == (2, 24576)           # fc7 fwd
-    assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1, dgrad=True)[:2] == (2, 24576)
-    assert ops.conv_plan(16, 41, 41, 4096, 24, 1, 1, dgrad=True)[0] == 2           # fc8 dgrad (N = 4096)
-    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4, dgrad=True)[0] == 3          # fc6 dgrad (N = 512)
-    assert ops.conv_plan(16, 41, 41, 512, 512, 3, 1) == (3, M, 3, 0)               # conv4_x / conv5_x: split-K by 3
+    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4)[:3] == (4, 24576, 1)         # fc6 fwd: 96 x 16 tiles = 6 rounds
+    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4)[3] > 1                       #   + the other 2320 rows split-K
+    assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1)[:2] == (4, 24576)           # fc7 fwd
+    assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1, dgrad=True)[:2] == (4, 24576)
+    assert ops.conv_plan(16, 41, 41, 4096, 24, 1, 1, dgrad=True)[0] == 2           # fc8 dgrad (N = 4096, K = 24: round-1 kernel)
+    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4, dgrad=True)[0] == 5          # fc6 dgrad (N = 512)
+    p = ops.conv_plan(16, 41, 41, 512, 512, 3, 1)                                  # conv4_x / conv5_x: split-K
+    assert p[0] in (3, 5) and p[1] == M and p[2] > 1 and p[3] == 0
+    assert ops.conv_plan(16, 161, 161, 128, 128, 3, 1)[0] == 3                     # conv2_2: N = 128
     assert ops.conv_plan(16, 321, 321, 64, 64, 3, 1)[0] == 1                       # conv1_2: N <= 64
     with ops.tuned(fp32_tile=2, plan_cus=4):
         assert ops.conv_plan(2, 23, 29, 40, 72, 3, 1)[:2] == (2, 1024)             # forced: 4 of 6 row tiles + a tail
