@@ -49,11 +49,10 @@ __device__ __forceinline__ unsigned div_magic(unsigned n, unsigned magic) { retu
 // ---- launch-plan overrides (emadapt_tune_set in emadapt.h): 0 = automatic.  They select among kernel variants that
 // all compute the same result (the parity tests run every variant on small awkward shapes through them).
 enum TuneKey {
-    TUNE_FP32_TILE,    // 1..5: tile variant of the fp32 forward / data-gradient launch (conv_igemm.hip: LaunchPlan)
+    TUNE_FP32_TILE,    // 1..4: tile variant of the fp32 forward / data-gradient launch (conv_igemm.hip: LaunchPlan)
     TUNE_SPLITK,       // force the split-K factor of the forward / data-gradient launches (when K allows it)
     TUNE_BF16_TILE,    // 128 | 256
     TUNE_X6_TILE,      // 128 | 256
-    TUNE_PACE,         // second-generation fp32 kernels: producer sleep per chunk in 64-cycle units (-1 = none)
     TUNE_PLAN_CUS,     // CU count the launch plans are laid out for (default 256)
     TUNE_ESTEP_STOP,   // diagnostic builds only (-DEMADAPT_ABLATE_BUILD): leave the E-step kernel after phase n
     TUNE_ABLATE,       // diagnostic builds only: ablation bit mask of the fp32 igemm kernel

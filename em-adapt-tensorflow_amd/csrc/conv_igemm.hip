@@ -533,13 +533,14 @@ int launch_igemm(IgemmArgs &a, hipStream_t stream) {
 
 // How one convolution is launched.  Tile variants ("fp32_tile" numbering of emadapt_tune_set / emadapt_conv_plan):
 //   1: 256x64x16 unified kernel (N <= 64)
-//   2: 256x256x32 unified kernel                      -- round-1 kernels, still used where the second-generation
-//   3: 128x128x32 wave-specialised kernel                kernels do not apply (Cx % 16 != 0, more than 32 taps, N < 256)
-//   4: 256x256x32 second generation (igemm_v2.h), one workgroup per CU: N >= 1024 and many rows (fc6 / fc7)
-//   5: 128x256x16 second generation, two workgroups per CU: 256 <= N (conv3 .. conv5, and the tail of variant 4)
-// Variants 2 and 4 take the rows that fill WHOLE rounds of the CUs; the remaining rows (the partial last round: 160 of
-// fc6's 1696 tiles) go to a second launch of the smaller tile with split-K, so that no CU idles while a handful of big
-// tiles finish.  Split-K (fp32 partial slabs + a fixed-order reduce) fills whole rounds when the tile count is small.
+//   2: 256x256x32 unified kernel: what variant 4 falls back to (Cx % 16 != 0, more than 32 taps)
+//   3: 128x128x32 wave-specialised kernel, split-K when the tile count is small; also the "tail" of variants 2 / 4
+//   4: 256x256x16 second generation (igemm_v2.h: LDS-DMA loaders, 64x128 per MFMA wave), one workgroup per CU
+// Variants 2 / 4 are used when their tiles fill at least one whole round of the CUs (fc6 / fc7 forward, fc7 / fc8 data
+// gradient, conv3_x): they take the rows that fill WHOLE rounds, and the remaining rows (the partial last round: 160 of
+// fc6's 1696 tiles) go to a second launch of variant 3 with split-K, so that no CU idles while a handful of big tiles
+// finish.  Split-K (fp32 partial slabs + a fixed-order reduce) fills whole rounds when the tile count is small.
+// Measured in one process per layer (scripts/conv_bench.py --tiles=..., profiles/r02_fp32_tile_variants.txt).
 struct LaunchPlan {
     int cfg;         // tile variant of the main launch
     int main_rows;   // rows [0, main_rows) go to the main launch
@@ -554,7 +555,6 @@ int splits_for(const IgemmArgs &a, int cfg, long long rows) {
     switch (cfg) {
         case 1: return choose_splits(rows, a.N, a.K, 256, 64, 16);
         case 3: return choose_splits(rows, a.N, a.K, 128, 128, 32);
-        case 5: return choose_splits(rows, a.N, a.K, 128, 256, 16);
         default: return 1;
     }
 }
@@ -567,9 +567,10 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
     p.tail_cfg = 0;
     p.tail_splits = 0;
     p.main_splits = 1;
-    const bool wide = a.N >= 1024 && a.M >= 8192;
-    int cfg = a.N <= 64 ? 1 : wide ? (v2_ok(a, 32) ? 4 : 2) : (a.N >= 256 && v2_ok(a, 16)) ? 5 : 3;
-    if (force >= 1 && force <= 5 && !((force == 4 && !v2_ok(a, 32)) || (force == 5 && !v2_ok(a, 16)))) cfg = force;
+    // 256x256 tiles pay when they fill at least one whole round of the CUs and N uses the tile's width
+    const bool big = a.N >= 256 && ceil_div(a.M, 256) * ceil_div(a.N, 256) >= cus;
+    int cfg = a.N <= 64 ? 1 : big ? (v2_ok(a, 16) ? 4 : 2) : 3;
+    if (force >= 1 && force <= 4 && !(force == 4 && !v2_ok(a, 16))) cfg = force;
     p.cfg = cfg;
     if (cfg == 2 || cfg == 4) {
         const long long tn = ceil_div(a.N, 256), tm = ceil_div(a.M, 256);
@@ -578,7 +579,7 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
             const long long tm_full = full * cus / tn;
             if (tm_full >= 1 && tm_full < tm) {
                 p.main_rows = (int)(tm_full * 256);
-                p.tail_cfg = (cfg == 4 && v2_ok(a, 16)) ? 5 : 3;
+                p.tail_cfg = 3;
                 p.tail_splits = splits_for(a, p.tail_cfg, a.M - p.main_rows);
             }
         }
@@ -601,8 +602,7 @@ int launch_variant(int cfg, IgemmArgs &a, hipStream_t stream) {
     switch (cfg) {
         case 1: return launch_igemm<256, 64, 16, 64, BT>(a, stream);
         case 2: return launch_igemm<256, 256, 32, 128, BT>(a, stream);
-        case 4: return launch_igemm2<4, 2, 32, 4, BT>(a, stream);
-        case 5: return launch_igemm2<2, 2, 16, 2, BT>(a, stream);
+        case 4: return launch_igemm2<4, 2, 16, 4, 4, 3, BT>(a, stream);
         default: return launch_igemm_ws<BT>(a, stream);
     }
 }

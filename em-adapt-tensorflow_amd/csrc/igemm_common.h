@@ -43,7 +43,6 @@ struct IgemmArgs {
     float *slab;         // [splits][M][N] fp32 partials when splits > 1
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
     unsigned magic_nt;   // ceil(2^32/ntaps)
-    int pace;    // second-generation kernels: 64-cycle sleeps between the chunks of a K step's tile movement
     int ablate;  // diagnostic builds only (tune "ablate"): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
 };
 

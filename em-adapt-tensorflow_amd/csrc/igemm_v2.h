@@ -1,54 +1,77 @@
 // Second-generation fp32 implicit-GEMM kernel (forward and data gradient), included by conv_igemm.hip.
 //
-// Same arithmetic as igemm_kernel / igemm_ws_kernel (v_mfma_f32_32x32x2_f32, k-ordered fp32 FMA chains, K order =
-// (channel chunk, tap), bounds-checked gathers, fused epilogue, split-K slabs), re-laid-out around what the matrix pipe
-// of gfx950 actually tolerates (profiles/r02_mfma_loop_lab.txt):
+// Same arithmetic as igemm_kernel / igemm_ws_kernel (v_mfma_f32_32x32x2_f32, fp32 FMA chains, K order = (channel chunk,
+// tap), bounds-checked gathers, fused epilogue, split-K slabs), re-laid-out around what the matrix pipe of gfx950
+// tolerates (profiles/r02_mfma_loop_lab.txt):
 //
 //   * the fp32 MFMA runs on the vector ALU's datapath: every VALU / LDS instruction a MFMA wave issues costs ~10 cycles
-//     of matrix time, and VALU issued by ANY wave of the SIMD costs its issue cycles; LDS stores and global loads issued
-//     by other waves are free.  The round-1 loop (64x64 per wave, two ds_read2_b32 + two v_add per four MFMAs) tops out
-//     at 84-90 %; one ds_read_b64 + one ds_read_b128 per EIGHT MFMAs with immediate offsets reaches 97.5 %.
-//   * so every MFMA wave owns a 64 x 128 accumulator block (TM = 2, TN = 4 tiles of 32x32, 128 VGPRs) and the LDS tiles
-//     are interleaved so that ONE wide read returns all the values a lane needs for a k-pair:
-//         A tile  [wave-row block][k][l31][TM]   -> ds_read_b64  (rows l31 and l31 + 32 of the block, same k)
-//         B tile  [wave-col block][k][l31*TN..]  -> ds_read_b128 (four ADJACENT output columns: the lane's column
-//                                                   in the four 32x32 tiles is l31*4 + j, not l31 + 32*j)
-//     The consumers' instruction stream is LDS reads with 16-bit immediate offsets and MFMAs, nothing else.
-//   * the column interleave makes the accumulators of a lane four consecutive outputs of a row: the epilogue is direct
+//     of matrix time.  The round-1 loop (64x64 per wave, two ds_read2_b32 + two v_add per four MFMAs) tops out at 84-90 %;
+//     a few wide LDS reads with immediate offsets per SIXTEEN MFMAs reach 97.5 %.  So every MFMA wave owns a 64 x 128
+//     accumulator block (TM = 2, TN = 4 tiles of 32x32, 128 VGPRs) and its instruction stream is wide LDS reads and
+//     MFMAs, nothing else;
+//   * with two such dense MFMA waves per SIMD the LOADER waves become the critical path: ~116 vector instructions per
+//     K step (loads, transposing LDS stores, address arithmetic) took longer to issue than the consumers' 256 MFMAs.
+//     So the tiles are filled by LDS-DMA (buffer_load_dwordx4 ... lds): 16 instructions per K step and loader wave, no
+//     data registers, no ds_write -- which means the tiles lie in LDS exactly as they lie in memory:
+//         A  [row][k]     rows of BK floats (k contiguous), 16-byte chunks XOR-swizzled by the row
+//         Bw [k][n]       forward: rows of BN floats (n contiguous)           -> one ds_read_b128 per k-pair
+//            [n][k]       data gradient (filter read "transposed"): like A
+//     A k-contiguous operand is consumed without a transpose by letting the MFMA's k slot follow the memory order: a
+//     lane (l31, lh) reads the 8 bytes at columns 4q + 2*lh, 4q + 2*lh + 1 of its row and uses them as its operand of
+//     k-pairs 2q and 2q + 1, i.e. k-pair 2q multiplies columns {4q, 4q+2}, k-pair 2q+1 columns {4q+1, 4q+3} -- the same
+//     products, summed in a slightly different order than the round-1 kernels (both are valid fp32 sums; the parity
+//     tests hold both to the same bar).  The forward filter tile is read at rows 4q + 2*lh + (kk & 1) accordingly.
+//   * the lane's four B tiles are four ADJACENT output columns (l31*4 + j, not l31 + 32*j): the epilogue is direct
 //     16-byte stores (512 contiguous bytes per row and wave), no staging through LDS.
-//   * the producers (separate waves: gather, transpose into the interleaved tiles, plain ds_write) carry ~3 VALU per
-//     load: the tap-validity of each of a thread's rows is a bit mask computed once per tile, the per-step tap / channel
-//     offsets are wave-uniform (SALU).
 //
-// Configurations <WMW, WNW, BK, PW>: consumer waves WMW x WNW, producer waves PW
-//   <4, 2, 32, 4>  256 x 256 x 32, 12 waves, one workgroup per CU   (fc6 / fc7: N >= 1024)
-//   <2, 2, 16, 2>  128 x 256 x 16,  6 waves, two workgroups per CU  (conv3 .. conv5: 256 <= N < 1024)
-// Requirements (plan_launches falls back to the round-1 kernels otherwise): Cx % BK == 0, KH*KW <= 32.
+// Configuration <WMW, WNW, BK, PW, NBUF, DIST>: consumer waves WMW x WNW (64 x 128 each), loader waves PW, LDS ring
+//   <4, 2, 16, 4, 4, 3>  256 x 256 x 16, 12 waves, 128 KB LDS, one workgroup per CU
+// (a 128 x 256 x 16 two-workgroups-per-CU configuration, <2, 2, 16, 2, 3, 2>, was built and measured 3 points slower
+// than the round-1 wave-specialised kernel on conv4_x / conv5_x, and BK = 32 with two buffers ran at the mercy of the
+// DMA latency: profiles/r02_fp32_tile_variants.txt.)
+// Requirements (plan_launches falls back to the round-1 kernels otherwise): Cx % 16 == 0, KH*KW <= 32.
 #pragma once
 #include "igemm_common.h"
 
 namespace {
 
-template <int WMW, int WNW, int BK, int PW, bool BT>
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// LDS-DMA: 64 lanes x 16 bytes land at lds_base + 16 * lane (wave-uniform base), source = buffer + voffset per lane; an
+// out-of-range offset (bit 31 set) deposits zeros like the register form of the load.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float *lds_base, unsigned voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)lds_base, 16, (int)voffset, 0, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NBUF LDS buffers, tiles are fetched DIST K steps ahead of their use (NBUF >= DIST + 1): a DMA has DIST - 1 whole K steps
+// plus the rest of its own to land (with DIST = 1 the kernel ran at the mercy of the L2 / HBM latency: 66 % on conv4_x).
+template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT>
 __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmArgs a) {
     constexpr int CONS = WMW * WNW;          // consumer (MFMA) waves
     constexpr int BM = WMW * 64, BN = WNW * 128;
     constexpr int TM = 2, TN = 4;
-    constexpr int PA = 64 + 4, PB = 128 + 4;  // floats per k row of one wave block (16-byte aligned rows)
-    constexpr int A_BUF = WMW * BK * PA, B_BUF = WNW * BK * PB;
-    constexpr int NKK = BK / 2;
-    constexpr int NPT = PW * 64;              // producer threads
-    constexpr int KQ = BK / 4;                // float4 quads along k
-    constexpr int A_RSTEP = NPT / KQ;         // rows covered by one pass of the producers
-    constexpr int A_N = BM / A_RSTEP;
-    constexpr int QN = BN / 4;
-    constexpr int B_KSTEP = NPT / QN;
-    constexpr int B_N = BT ? (BN / A_RSTEP) : (BK / B_KSTEP);
-    static_assert(A_N >= 1 && B_N >= 1 && NPT % KQ == 0 && NPT % QN == 0, "tile / producer shape");
+    constexpr int CPR = BK / 4;               // 16-byte chunks per k-contiguous row (8 or 4)
+    constexpr int RPI = 64 / CPR;             // rows one DMA instruction fills (8 or 16)
+    constexpr int A_BUF = BM * BK;            // floats per A buffer   [row][BK]
+    constexpr int B_BUF = BN * BK;            // floats per B buffer   fwd [BK][BN], dgrad [col][BK]
+    constexpr int NQ = BK / 4;                // 4-column groups (two k-pairs each) per K step
+    constexpr int A_N = BM / RPI / PW;        // DMA instructions per loader wave and K step for A
+    constexpr int B_N = BT ? BN / RPI / PW : BK * (BN / 256) / PW;   // fwd: one instruction = 256 floats of one k row
+    static_assert(A_N >= 1 && B_N >= 1 && (BM / RPI) % PW == 0 && BN % 256 == 0, "tile / loader shape");
+    static_assert(NBUF >= DIST + 1 && DIST >= 1 && (DIST - 1) * (A_N + B_N) <= 63, "ring depth / vmcnt range");
+    // Swizzle of a k-contiguous row: chunk q of row r is stored at chunk position q ^ swz(r), swz in 0..3 (the low two
+    // bits of the position: the addresses of chunks q and q + 4 differ by an immediate).  A rows: swz from the row bits
+    // above those that share a 256-byte bank line; dgrad filter rows (read at rows 4*l31 + j): swz = l31 & 3.
+    constexpr int SWA_SHIFT = CPR == 8 ? 1 : 2;
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *As = lds;                  // [2][WMW][BK][PA]
-    float *Bs = lds + 2 * A_BUF;      // [2][WNW][BK][PB]
+    float *As = lds;                     // [NBUF][A_BUF]
+    float *Bs = lds + NBUF * A_BUF;      // [NBUF][B_BUF]
 
     // XCD-aware tile order (see igemm_kernel)
     int tile_m, tile_n, split;
@@ -75,25 +98,24 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     const int nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
 
     if (threadIdx.x >= CONS * 64) {
-        // ================================ PRODUCER wavefronts ================================
-        const int tid = threadIdx.x - CONS * 64;
-        if (a.pace != 99) __builtin_amdgcn_s_setprio(3);
+        // ================================ LOADER wavefronts ================================
+        const int lane = threadIdx.x & 63;
+        const int pw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) - CONS);   // loader wave index (uniform)
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
         constexpr unsigned kOOB = 0x80000000u;
-        const int a_kq = tid % KQ, a_r0 = tid / KQ;
-        // per row: byte offset of (pixel, channel quad a_kq) and the mask of taps that fall outside the image
+        // instruction j of this wave fills rows [(j*PW + pw)*RPI, +RPI) of the tile; lane -> (row in group, chunk position)
+        const int rl = lane / CPR, pos = lane % CPR;
         unsigned a_off[A_N], a_bad[A_N];
-        int a_dst[A_N];   // float index of (row, k = a_kq*4) inside one A buffer
 #pragma unroll
         for (int j = 0; j < A_N; j++) {
-            const int r = a_r0 + j * A_RSTEP;
+            const int r = (j * PW + pw) * RPI + rl;
             const int m = m0 + r;
-            a_dst[j] = ((r >> 6) * BK + a_kq * 4) * PA + (r & 31) * TM + ((r >> 5) & 1);
+            const int q = pos ^ ((r >> SWA_SHIFT) & 3);   // the channel chunk this lane fetches
             if (m < a.m_end) {
                 const int t2 = m / a.W;
                 const int oh = t2 % a.H, ow = m - t2 * a.W;
-                a_off[j] = (unsigned)(m * a.Cx + a_kq * 4) * 4u;
+                a_off[j] = (unsigned)(m * a.Cx + q * 4) * 4u;
                 unsigned rowbad = 0, colbad = 0;
                 const int KH = a.ntaps / a.KW;
                 for (int kh = 0; kh < KH; kh++) {
@@ -113,109 +135,70 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
                 a_bad[j] = 0xFFFFFFFFu;
             }
         }
-        // filter loads: per-thread constant part of the offset (bit 31 = column out of range), wave-uniform part per step
         unsigned b_off[B_N];
-        int b_dst[B_N];
         if constexpr (!BT) {
-            const int b_nq = tid % QN, b_kr = tid / QN;
-            const int n = n0 + b_nq * 4;
+            // instruction j: k row (j*PW + pw) / (BN/256), 256-float segment (j*PW + pw) % (BN/256); lane = 4 floats
 #pragma unroll
             for (int j = 0; j < B_N; j++) {
-                const int kr = b_kr + j * B_KSTEP;
+                const int idx = j * PW + pw;
+                const int kr = idx / (BN / 256), seg = idx % (BN / 256);
+                const int n = n0 + seg * 256 + lane * 4;
                 b_off[j] = ((unsigned)(kr * a.N + n) * 4u) | (n < a.N ? 0u : kOOB);
-                b_dst[j] = (((b_nq * 4) >> 7) * BK + kr) * PB + ((b_nq * 4) & 127);
             }
         } else {
-            const int b_nr = tid / KQ;
 #pragma unroll
             for (int j = 0; j < B_N; j++) {
-                const int nl = b_nr + j * A_RSTEP;
-                const int n = n0 + nl;
-                b_off[j] = ((unsigned)(n * a.Cx + a_kq * 4) * 4u) | (n < a.N ? 0u : kOOB);
-                b_dst[j] = ((nl >> 7) * BK + a_kq * 4) * PB + (nl & 127);
+                const int r = (j * PW + pw) * RPI + rl;
+                const int n = n0 + r;
+                const int q = pos ^ ((r >> 2) & 3);
+                b_off[j] = ((unsigned)(n * a.Cx + q * 4) * 4u) | (n < a.N ? 0u : kOOB);
             }
         }
-        float4 ra[A_N], rb[B_N];
-#ifdef EMADAPT_ABLATE_BUILD
-        for (int j = 0; j < A_N; j++) ra[j] = make_float4(1.f, 2.f, 3.f, 4.f);
-        for (int j = 0; j < B_N; j++) rb[j] = make_float4(1.f, 2.f, 3.f, 4.f);
-#endif
 
-        // One K step of tile movement: park tile kt+1 (registers) in LDS buffer `buf`, re-arm every register with its load
-        // of tile `kt_next`.  The parts are issued in CH chunks with the producers asleep in between (`pace` x 64 cycles):
-        // a burst of 40 LDS stores and 16 loads per wave right after the barrier sits in front of the consumers' first
-        // fragment reads and costs the matrix pipe 15 % (ablation, profiles/r02_igemm_v2_ablation.txt); spread over the
-        // K step it is hidden.
-        constexpr int CH = A_N > B_N ? A_N : B_N;
-        auto move_tile = [&](int buf, int kt, bool store, bool load) {
+        // Fill LDS buffer `buf` with the tile of K step kt (DMA; the caller awaits completion).
+        auto fill = [&](int buf, int kt) {
             const unsigned chunk = __umulhi((unsigned)kt, a.magic_nt);
             const unsigned tap_u = a.ntaps > 1 ? (unsigned)kt - chunk * (unsigned)a.ntaps : 0u;
             const unsigned chunk_u = a.ntaps > 1 ? chunk : (unsigned)kt;
-            const bool past = (int)chunk_u * BK >= a.Cx;   // K steps past the end are zero-filled
             const unsigned kh = div_magic(tap_u, a.magic_kw);
             const int kw = (int)(tap_u - kh * (unsigned)a.KW);
             const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
             const int dw = a.sign * (kw * a.dil - a.pad_w);
             const unsigned toff = (unsigned)(((dh * a.W + dw) * a.Cx + (int)chunk_u * BK) * 4);
-            const unsigned sh = past ? 0u : 31u - tap_u;   // moves this tap's "bad" bit to bit 31
+            const unsigned sh = 31u - tap_u;   // moves this tap's "bad" bit to bit 31
             unsigned woff;
             if constexpr (!BT) woff = (unsigned)(((int)tap_u * a.Cx + (int)chunk_u * BK) * a.N) * 4u;
             else woff = (unsigned)((int)tap_u * a.N * a.Cx + (int)chunk_u * BK) * 4u;
             float *as = As + buf * A_BUF;
             float *bs = Bs + buf * B_BUF;
 #pragma unroll
-            for (int j = 0; j < CH; j++) {
-                if (j < A_N) {
-                    if (store && !ABL(2)) {
-                        as[a_dst[j] + 0 * PA] = ra[j].x;
-                        as[a_dst[j] + 1 * PA] = ra[j].y;
-                        as[a_dst[j] + 2 * PA] = ra[j].z;
-                        as[a_dst[j] + 3 * PA] = ra[j].w;
-                    }
-                    if (load && !ABL(1)) {
-                        const unsigned bad = past ? kOOB : ((a_bad[j] << sh) & kOOB);
-                        ra[j] = buf_ld4(xr, (a_off[j] + toff) | bad);
-                    }
+            for (int j = 0; j < (A_N > B_N ? A_N : B_N); j++) {
+                if (j < A_N && !ABL(1)) dma16(xr, as + (j * PW + pw) * RPI * BK, (a_off[j] + toff) | ((a_bad[j] << sh) & kOOB));
+                if (j < B_N && !ABL(1)) {
+                    if constexpr (!BT) dma16(wr, bs + (j * PW + pw) * 256, b_off[j] + woff);
+                    else dma16(wr, bs + (j * PW + pw) * RPI * BK, b_off[j] + woff);
                 }
-                if (j < B_N) {
-                    if (store && !ABL(2)) {
-                        if constexpr (!BT) {
-                            *reinterpret_cast<float4 *>(bs + b_dst[j]) = rb[j];
-                        } else {
-                            bs[b_dst[j] + 0 * PB] = rb[j].x;
-                            bs[b_dst[j] + 1 * PB] = rb[j].y;
-                            bs[b_dst[j] + 2 * PB] = rb[j].z;
-                            bs[b_dst[j] + 3 * PB] = rb[j].w;
-                        }
-                    }
-                    if (load && !ABL(1)) rb[j] = buf_ld4(wr, past ? kOOB : b_off[j] + woff);
-                }
-                if (store && load)
-                    for (int z = 0; z < a.pace; z++) __builtin_amdgcn_s_sleep(1);
             }
         };
-        move_tile(0, kt0, false, true);
-        move_tile(0, kt0 + 1 < kt0 + nk ? kt0 + 1 : nk_all, true, true);   // K steps past this split's range load zeros
-        __syncthreads();
-#ifdef EMADAPT_ABLATE_BUILD
-        unsigned long long t_work = 0, t_wait = 0, t0 = __builtin_amdgcn_s_memtime();
-#endif
+#pragma unroll
+        for (int d = 0; d < DIST; d++)
+            if (d < nk) fill(d, kt0 + d);
+        if (nk >= DIST) wait_vmcnt<(DIST - 1) * (A_N + B_N)>();   // tile 0 has landed (all but the DIST - 1 youngest fills)
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; kt++) {
-            move_tile((kt + 1) & 1, kt + 2 < nk ? kt0 + kt + 2 : nk_all, true, true);
-#ifdef EMADAPT_ABLATE_BUILD
-            unsigned long long t1 = __builtin_amdgcn_s_memtime();
-            t_work += t1 - t0;
-#endif
-            __syncthreads();
-#ifdef EMADAPT_ABLATE_BUILD
-            t0 = __builtin_amdgcn_s_memtime();
-            t_wait += t0 - t1;
-#endif
+            // The consumers multiply buffer kt % NBUF during this step.  Buffer (kt + DIST) % NBUF was last read in step
+            // kt + DIST - NBUF <= kt - 1: free since the barrier that ended that step (every consumer drains its LDS reads
+            // before arriving there).  Before the barrier that ends this step, tile kt + 1 must have landed: all but the
+            // DIST - 1 youngest fills of this wave.
+            if (kt + DIST < nk) {
+                fill((kt + DIST) % NBUF, kt0 + kt + DIST);
+                wait_vmcnt<(DIST - 1) * (A_N + B_N)>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
         }
-#ifdef EMADAPT_ABLATE_BUILD
-        if (ABL(32) && blockIdx.x == 17 && tid == 0)
-            printf("producer: %d steps, work %llu cycles/step, barrier wait %llu cycles/step\n", nk, t_work / nk, t_wait / nk);
-#endif
         return;
     }
 
@@ -231,51 +214,67 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    __syncthreads();
-#ifdef EMADAPT_ABLATE_BUILD
-    unsigned long long t_work = 0, t_wait = 0, t0 = __builtin_amdgcn_s_memtime();
-#endif
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        const float *as = As + cur * A_BUF + (wm * BK + lh) * PA + l31 * TM;
-        const float *bs = Bs + cur * B_BUF + (wn * BK + lh) * PB + l31 * TN;
-        float2 av[2];
-        float4 bv[2];
-        av[0] = *reinterpret_cast<const float2 *>(as);
-        bv[0] = *reinterpret_cast<const float4 *>(bs);
+    // Fragment addresses (float indices inside a buffer) for the chunks q = 0..3; chunk q + 4 (BK = 32) is 16 floats on,
+    // the wave's second row block 32 rows on, the dgrad filter's columns j one row on: all immediates.
+    const int arow = wm * 64 + l31;
+    int a_idx[4], b_idx[BT ? 4 : 1];
 #pragma unroll
-        for (int kk = 0; kk < NKK; kk++) {
-            if (kk + 1 < NKK) {
-                av[(kk + 1) & 1] = *reinterpret_cast<const float2 *>(as + (kk + 1) * 2 * PA);
-                bv[(kk + 1) & 1] = *reinterpret_cast<const float4 *>(bs + (kk + 1) * 2 * PB);
+    for (int q = 0; q < 4; q++) a_idx[q] = arow * BK + ((q ^ ((arow >> SWA_SHIFT) & 3)) * 4) + lh * 2;
+    if constexpr (BT) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) b_idx[q] = (wn * 128 + l31 * TN) * BK + ((q ^ (l31 & 3)) * 4) + lh * 2;
+    } else {
+        b_idx[0] = (lh * 2) * BN + wn * 128 + l31 * TN;        // [k][n]: row 4q + 2*lh + (kk & 1)
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int cur = kt % NBUF;
+        const float *as = As + cur * A_BUF;
+        const float *bs = Bs + cur * B_BUF;
+        // the operands of k-pairs 2q and 2q+1 come from one 8-byte read per k-contiguous row, one 16-byte read per [k][n] row
+        float2 av[2][TM];
+        float2 bt[2][BT ? TN : 1];
+        float4 bf[2][BT ? 1 : 2];
+        auto read_q = [&](int q, int slot) {
+            const int hi = (q >> 2) * 16;   // chunks 4..7 of a 32-float row
+#pragma unroll
+            for (int i = 0; i < TM; i++) av[slot][i] = *reinterpret_cast<const float2 *>(as + a_idx[q & 3] + hi + i * 32 * BK);
+            if constexpr (BT) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) bt[slot][j] = *reinterpret_cast<const float2 *>(bs + b_idx[q & 3] + hi + j * BK);
+            } else {
+                bf[slot][0] = *reinterpret_cast<const float4 *>(bs + b_idx[0] + (4 * q + 0) * BN);
+                bf[slot][1] = *reinterpret_cast<const float4 *>(bs + b_idx[0] + (4 * q + 1) * BN);
+            }
+        };
+        read_q(0, 0);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if (q + 1 < NQ) read_q(q + 1, (q + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int s = q & 1;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {   // k-pair 2q + h
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const float av_ = h ? av[s][i].y : av[s][i].x;
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        float bv_;
+                        if constexpr (BT) {
+                            bv_ = h ? bt[s][j].y : bt[s][j].x;
+                        } else {
+                            const float4 b4 = bf[s][h];
+                            bv_ = j == 0 ? b4.x : j == 1 ? b4.y : j == 2 ? b4.z : b4.w;
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bv_, acc[i][j], 0, 0, 0);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            const float2 a2 = av[kk & 1];
-            const float4 b4 = bv[kk & 1];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b4.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b4.y, acc[0][1], 0, 0, 0);
-            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b4.z, acc[0][2], 0, 0, 0);
-            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b4.w, acc[0][3], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b4.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b4.y, acc[1][1], 0, 0, 0);
-            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b4.z, acc[1][2], 0, 0, 0);
-            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b4.w, acc[1][3], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
         }
-#ifdef EMADAPT_ABLATE_BUILD
-        unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        t_work += t1 - t0;
-#endif
         __syncthreads();
-#ifdef EMADAPT_ABLATE_BUILD
-        t0 = __builtin_amdgcn_s_memtime();
-        t_wait += t0 - t1;
-#endif
     }
-#ifdef EMADAPT_ABLATE_BUILD
-    if (ABL(32) && blockIdx.x == 17 && (tid == 0 || tid == 256))
-        printf("consumer wave %d: %d steps, work %llu cycles/step, barrier wait %llu cycles/step\n", wave, nk, t_work / nk, t_wait / nk);
-#endif
 
     // ---- epilogue: a lane holds, for each of its 2 x 16 rows, four consecutive output columns -> 16-byte stores.
     // C/D layout of the 32x32 MFMA: row in tile = (r&3) + 8*(r>>2) + 4*lh, column = l31 (here: column l31*4 + j).
@@ -323,26 +322,19 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     }
 }
 
-template <int WMW, int WNW, int BK, int PW, bool BT>
+template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT>
 int launch_igemm2(IgemmArgs &a, hipStream_t stream) {
     constexpr int BM = WMW * 64, BN = WNW * 128;
     constexpr int THREADS = (WMW * WNW + PW) * 64;
-    constexpr size_t lds = sizeof(float) * 2 * (WMW * BK * (64 + 4) + WNW * BK * (128 + 4));
+    constexpr size_t lds = sizeof(float) * NBUF * (BM + BN) * BK;
     static DynLdsAttr attr;
-    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm2_kernel<WMW, WNW, BK, PW, BT>), lds);
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT>), lds);
     if (rc) return rc;
     a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
     const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    // producers sleep between the chunks of a K step's tile movement: ~60 % of the step's MFMA time in all
-    // (a K step = BK/2 k-pairs x 8 MFMAs x 64 cycles per consumer wave, two consumer waves per SIMD)
-    {
-        constexpr int CH = (BM * (BK / 4) / (PW * 64)) > 8 ? (BM * (BK / 4) / (PW * 64)) : 8;
-        const int force = tune(TUNE_PACE);
-        a.pace = force ? (force < 0 ? 0 : force) : (BK / 2) * 8 * 64 * 2 * 6 / 10 / 64 / CH;
-    }
-    hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, BT>), dim3((unsigned)nblk), dim3(THREADS), lds, stream, a);
+    hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT>), dim3((unsigned)nblk), dim3(THREADS), lds, stream, a);
     rc = launch_status();
     if (rc || a.splits <= 1) return rc;
     return launch_splitk_epilogue(a, stream);

@@ -284,13 +284,11 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  * parity tests use the knobs to run each variant on small awkward shapes -- so they are a tuning / test aid, not
  * part of the numerics.  Process-wide; returns EMADAPT_ERR_INVALID for an unknown key.
  *   "fp32_tile"  1: 256x64x16 | 2: 256x256x32 for the rows that fill whole rounds of the CUs + a smaller-tile split-K
- *                launch for the rest | 3: 128x128x32 wave-specialised | 4: 256x256x32 second generation (wide
- *                fragment reads; needs Cin resp. Cout % 32 == 0, <= 32 taps), rows split like 2 | 5: 128x256x16 second
- *                generation (% 16).  A forced variant the shape is not eligible for is ignored.
+ *                launch for the rest | 3: 128x128x32 wave-specialised | 4: 256x256x16 second generation (LDS-DMA
+ *                loaders, wide fragment reads; needs Cin resp. Cout % 16 == 0, <= 32 taps), rows split like 2.
+ *                A forced variant the shape is not eligible for is ignored.
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
  *   "bf16_tile"  128 | 256          "x6_tile"  128 | 256
- *   "pace"       second-generation fp32 kernels: 64-cycle sleeps of the loader waves between the chunks of a K step's
- *                tile movement (-1 = none)
  *   "plan_cus"   number of CUs the launch plans are laid out for (default 256: MI355X)
  *   "estep_stop", "ablate": honoured by diagnostic builds only (-DEMADAPT_ABLATE_BUILD), ignored otherwise
  * ---------------------------------------------------------------------------------------- */

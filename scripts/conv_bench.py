@@ -29,10 +29,11 @@ def timeit(fn, reps=5):
 BF16 = "--bf16" in sys.argv
 X6 = "--x6" in sys.argv
 names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fc6", "conv4_2", "conv2_2"]
+tiles = [0]
 for a in sys.argv[1:]:
     if a.startswith("--tile="): ops.tune_set("fp32_tile", int(a.split("=")[1]))
+    if a.startswith("--tiles="): tiles = [int(t) for t in a.split("=")[1].split(",")]   # A/B in ONE process (devices differ)
     if a.startswith("--splitk="): ops.tune_set("splitk", int(a.split("=")[1]))
-    if a.startswith("--pace="): ops.tune_set("pace", int(a.split("=")[1]))
     if a.startswith("--ablate="): ops.tune_set("ablate", int(a.split("=")[1]))
 for n in names:
     B, H, W, Cin, Cout, k, dil = SHAPES[n]
@@ -59,9 +60,20 @@ for n in names:
                  ("wgrad", lambda: ops.conv_wgrad(x, dy, k, k, dil, out=dw)))
         peak = 157.3
     for kind, fn in kinds:
-        ms = timeit(fn)
-        plan = ""
-        if not BF16 and not X6 and kind in ("fwd", "dgrad"):
-            plan = " plan %s" % (ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=kind == "dgrad"),)
-        print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  %s%s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / peak * 100,
-                                                             "bf16" if BF16 else "bf16x6" if X6 else "fp32", plan), flush=True)
+        if len(tiles) > 1 and kind not in ("fwd", "dgrad"):
+            continue
+        best = {}
+        for rnd in range(3 if len(tiles) > 1 else 1):      # interleaved rounds, minimum per variant
+            for t in tiles:
+                if len(tiles) > 1: ops.tune_set("fp32_tile", t)
+                ms = timeit(fn)
+                best[t] = min(best.get(t, 1e9), ms)
+        for t in tiles:
+            if len(tiles) > 1: ops.tune_set("fp32_tile", t)
+            ms = best[t]
+            plan = ""
+            if not BF16 and not X6 and kind in ("fwd", "dgrad"):
+                plan = " plan %s" % (ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=kind == "dgrad"),)
+            print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  %s%s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / peak * 100,
+                                                                 "bf16" if BF16 else "bf16x6" if X6 else "fp32", plan), flush=True)
+        if len(tiles) > 1: ops.tune_set("fp32_tile", 0)

@@ -11,7 +11,7 @@ plans by itself.  Here:
     layer is a few seconds on the GPU box's host cores) with a bar of 1e-4 of the tensor's max magnitude, with the
     epilogues the model uses (bias + ReLU + dropout mask forward; ReLU-gradient gate with the dropout scale backward),
     a bitwise repeatability check, and an assertion (emadapt_conv_plan) that the plan under test IS the big-tile one;
-  * every tile variant is forced (emadapt_tune_set) onto small shapes with M / N / K tails, against the fp64 oracle at
+  * every tile variant (round-1 kernels 1-3, second-generation LDS-DMA kernel 4) is forced (emadapt_tune_set) onto small shapes with M / N / K tails, against the fp64 oracle at
     2e-5, with `plan_cus` shrunk so that the row split (m_begin / m_end), the partial last tile and the slab reuse of
     the tail launch are hit at awkward sizes.
 """
@@ -43,12 +43,13 @@ def _t(torch, a, dtype=None):
 
 # name, (B, H, W, Cin, Cout, k, dil), expected forward plan variant, expected dgrad plan variant
 FULL_SHAPES = [
-    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 4, 5),      # deeplab.py:92,145: 44.8 % of the MACs
+    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 4, 3),      # deeplab.py:92,145: 44.8 % of the MACs
     ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 4, 4),     # deeplab.py:95,147
     ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 2),       # deeplab.py:95,149 (21 classes padded to 24: dgrad K = 24)
-    ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 5, 5),   # few tiles: split-K
-    ("conv5_2", (16, 41, 41, 512, 512, 3, 2), 5, 5),   # atrous rate 2 (deeplab.py:65)
-    ("conv3_1", (16, 81, 81, 128, 256, 3, 1), 5, 3),   # dgrad has N = 128: round-1 wave-specialised kernel
+    ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 3, 3),   # few tiles: split-K by 3 on 844 tiles
+    ("conv5_2", (16, 41, 41, 512, 512, 3, 2), 3, 3),   # atrous rate 2 (deeplab.py:65)
+    ("conv3_2", (16, 81, 81, 256, 256, 3, 1), 4, 4),   # 411 tiles of 256x256: one whole round + a tail
+    ("conv3_1", (16, 81, 81, 128, 256, 3, 1), 4, 3),   # dgrad has N = 128
 ]
 
 
@@ -134,7 +135,7 @@ SMALL = [
     (2, 21, 21, 32, 40, 4, 4),
     (1, 45, 43, 160, 24, 1, 1),
     (2, 23, 29, 64, 288, 3, 1),     # both directions eligible for the second-generation tiles (channels % 32 == 0)
-    (1, 37, 35, 272, 48, 3, 2),     # % 16 only: variant 5 but not 4
+    (1, 37, 35, 272, 48, 3, 2),     # channels % 16 == 0 but not % 32
     (3, 17, 19, 96, 544, 1, 1),     # 1x1 (one tap), N tail of the 256-wide tile
     (2, 21, 21, 32, 160, 4, 4),     # 16 taps, dilation 4
 ]
@@ -142,7 +143,7 @@ SMALL = [
 
 def _eligible(variant, Cx, k):
     """csrc/conv_igemm.hip v2_ok: what a forced second-generation variant needs (otherwise the automatic plan is used)."""
-    bk = {4: 32, 5: 16}.get(variant)
+    bk = {4: 16}.get(variant)
     return bk is None or (Cx % bk == 0 and k * k <= 32 and k * k * Cx >= 2 * bk)
 
 
@@ -170,7 +171,7 @@ def test_every_plan_variant_on_small_awkward_shapes(env, shape):
     # variant x CU count the plan is laid out for x forced split-K: reaches row splits at m_begin > 0, partial last
     # tiles in both launches, and the tail launch's slab at workspace offset 0
     for variant, cus, splitk in [(1, 0, 0), (1, 2, 2), (3, 0, 0), (3, 2, 3), (2, 0, 0), (2, 2, 0), (2, 3, 0), (2, 4, 2),
-                                 (2, 5, 3), (4, 0, 0), (4, 2, 0), (4, 3, 2), (4, 5, 3), (5, 0, 0), (5, 2, 2), (5, 2, 3)]:
+                                 (2, 5, 3), (4, 0, 0), (4, 2, 0), (4, 3, 2), (4, 5, 3)]:
         with ops.tuned(fp32_tile=variant, plan_cus=cus, splitk=splitk):
             for dgrad in (False, True):
                 plan = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=dgrad)
@@ -184,9 +185,8 @@ def test_every_plan_variant_on_small_awkward_shapes(env, shape):
     assert ops.tune_get("fp32_tile") == 0 and ops.tune_get("plan_cus") == 0
     if M > 1024 and max(Cin, Cout) >= 40:
         assert any(v == 2 and rows_split for v, rows_split, _, _ in seen), "no forced plan split the rows: %s" % seen
-    if M > 1024 and Cin % 32 == 0 and Cout % 32 == 0 and k * k <= 32:
+    if M > 1024 and Cin % 16 == 0 and Cout % 16 == 0 and k * k <= 32:
         assert any(v == 4 and rows_split for v, rows_split, _, _ in seen), "variant 4 never split the rows: %s" % seen
-        assert any(v == 5 and split for v, _, split, _ in seen), "variant 5 never ran split-K: %s" % seen
 
 
 def test_one_wide_filters_and_one_pixel_wide_maps(env):
