@@ -50,6 +50,7 @@ __device__ __forceinline__ unsigned div_magic(unsigned n, unsigned magic) { retu
 // all compute the same result (the parity tests run every variant on small awkward shapes through them).
 enum TuneKey {
     TUNE_FP32_TILE,    // 1..4: tile variant of the fp32 forward / data-gradient launch (conv_igemm.hip: LaunchPlan)
+    TUNE_WGRAD_GEN,    // 1 / 2: kernel generation of the fp32 filter-gradient launch (conv_wgrad.hip)
     TUNE_SPLITK,       // force the split-K factor of the forward / data-gradient launches (when K allows it)
     TUNE_BF16_TILE,    // 128 | 256
     TUNE_X6_TILE,      // 128 | 256

@@ -567,12 +567,24 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
     p.tail_cfg = 0;
     p.tail_splits = 0;
     p.main_splits = 1;
-    // 256x256 tiles pay when they fill at least one whole round of the CUs and N uses the tile's width
-    const bool big = a.N >= 256 && ceil_div(a.M, 256) * ceil_div(a.N, 256) >= cus;
-    int cfg = a.N <= 64 ? 1 : big ? (v2_ok(a, 16) ? 4 : 2) : 3;
+    // 256x256 tiles pay when they fill at least one whole round of the CUs and N uses the tile's width; with fewer tiles
+    // (fc6's data gradient: 212 tiles, K = 65536) variant 4 runs split-K when the reduction is long enough to carry the
+    // slab traffic -- decided by the estimated times of the two plans (rates: sustained TFLOP/s of each main loop)
+    const long long t256 = ceil_div(a.M, 256) * ceil_div(a.N, 256);
+    const bool big = a.N >= 256 && t256 >= cus;
+    bool split4 = false;
+    if (!big && a.N >= 256 && v2_ok(a, 16)) {
+        double t3 = 0, t4 = 0;
+        (void)choose_splits(a.M, a.N, a.K, 128, 128, 32, 512.0, 132e12, &t3);
+        (void)choose_splits(a.M, a.N, a.K, 256, 256, 16, 256.0, 142e12, &t4);
+        split4 = t4 < t3 * 0.98;
+    }
+    int cfg = a.N <= 64 ? 1 : big ? (v2_ok(a, 16) ? 4 : 2) : split4 ? 4 : 3;
     if (force >= 1 && force <= 4 && !(force == 4 && !v2_ok(a, 16))) cfg = force;
     p.cfg = cfg;
-    if (cfg == 2 || cfg == 4) {
+    if (cfg == 4 && t256 < cus) {
+        p.main_splits = choose_splits(a.M, a.N, a.K, 256, 256, 16, 256.0, 142e12);
+    } else if (cfg == 2 || cfg == 4) {
         const long long tn = ceil_div(a.N, 256), tm = ceil_div(a.M, 256);
         const long long full = (tm * tn) / cus;  // whole rounds of one 256x256 workgroup per CU
         if (full >= 1 && (tm * tn) % cus != 0) {

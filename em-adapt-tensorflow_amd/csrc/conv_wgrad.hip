@@ -199,8 +199,174 @@ __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Second generation (see igemm_v2.h for the measurements behind it): 256(k) x 256(n) filter tiles, 8 MFMA waves with a
+// 64 x 128 accumulator block each + 4 loader waves, one workgroup per CU.  Both operand tiles lie in LDS as they lie
+// in memory, [pixel][k] and [pixel][n] -- the reduction index is the slow one, so ONE ds_read_b64 / ds_read_b128 with an
+// immediate offset brings a lane's operands of a k-pair (its tile rows are k = l31*2 + i, its tile columns n = l31*4 + j:
+// adjacent, not 32 apart) -- and are filled by LDS-DMA, 16 pixels per step, through a ring of 4 buffers fetched 3 steps
+// ahead.  A loader instruction is one pixel row of 256 k (resp. n): the pixel's (oh, ow) is wave-uniform (SALU), each
+// lane adds its own tap offset and bounds check (~7 VALU per instruction).
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int W2_BMR = 16, W2_NBUF = 4, W2_DIST = 3, W2_CONS = 8, W2_PW = 4;
+
+__global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(WgradArgs a) {
+    constexpr int BKO = 256, BN = 256, BMR = W2_BMR, NBUF = W2_NBUF, DIST = W2_DIST, CONS = W2_CONS, PW = W2_PW;
+    constexpr int TK = 2, TN = 4;
+    constexpr int X_BUF = BMR * BKO, Y_BUF = BMR * BN;
+    constexpr int IPW = BMR / PW;   // pixel rows (= DMA instructions) per loader wave, step and operand
+    static_assert(NBUF >= DIST + 1 && (DIST - 1) * 2 * IPW <= 63, "ring depth / vmcnt range");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Xs = lds;                  // [NBUF][BMR][BKO]
+    float *Ys = lds + NBUF * X_BUF;   // [NBUF][BMR][BN]
+
+    // XCD-aware block order, as wgrad_ws_kernel
+    int tile_k, tile_n, split;
+    {
+        const int ntile = a.tiles_k * a.tiles_n;
+        const int nblk = ntile * a.splits;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        split = t / ntile;
+        t -= split * ntile;
+        constexpr int GK = 8;
+        const int per_group = GK * a.tiles_n;
+        const int g = t / per_group;
+        const int first_k = g * GK;
+        const int gsz = (a.tiles_k - first_k < GK) ? (a.tiles_k - first_k) : GK;
+        const int in_g = t - g * per_group;
+        tile_k = first_k + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
+    const int k0 = tile_k * BKO, n0 = tile_n * BN;
+    const int m_begin = split * a.rows_per_split;
+    int m_end = m_begin + a.rows_per_split;
+    if (m_end > a.M) m_end = a.M;
+    const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BMR - 1) / BMR : 0;
+
+    if (threadIdx.x >= CONS * 64) {
+        // ================================ LOADER wavefronts ================================
+        const int lane = threadIdx.x & 63;
+        const int pw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) - CONS);
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.dy), 0, (int)a.y_bytes, 0x00020000);
+        constexpr unsigned kOOB = 0x80000000u;
+        // this lane's k quad: fixed (tap, channel) for the whole kernel
+        const int k = k0 + lane * 4;
+        const bool kvalid = k < a.K;
+        const int tap = kvalid ? k / a.Cin : 0;
+        const int c = kvalid ? k % a.Cin : 0;
+        const int dh = (tap / a.KW) * a.dil - a.pad_h;
+        const int dw = (tap % a.KW) * a.dil - a.pad_w;
+        const unsigned x_off = (unsigned)(((dh * a.W + dw) * a.Cin + c) * 4);
+        const int n = n0 + lane * 4;
+        const unsigned y_off = ((unsigned)n * 4u) | (n < a.N ? 0u : kOOB);
+        auto fill = [&](int buf, int st) {
+            float *xs = Xs + buf * X_BUF, *ys = Ys + buf * Y_BUF;
+#pragma unroll
+            for (int j = 0; j < IPW; j++) {
+                const int row = j * PW + pw;                       // pixel row of the step (wave-uniform)
+                const int m = m_begin + st * BMR + row;
+                const unsigned t2 = div_magic((unsigned)m, a.magic_w);   // pixel -> (oh, ow): scalar arithmetic
+                const int ow = m - (int)t2 * a.W;
+                const int oh = (int)(t2 - div_magic(t2, a.magic_h) * (unsigned)a.H);
+                const bool live = m < m_end;
+                const int ih = oh + dh, iw = ow + dw;
+                const bool ok = live && kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t *)(xs + row * BKO), 16,
+                                                         (int)(((unsigned)(m * a.Cin) * 4u + x_off) | (ok ? 0u : kOOB)), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lds_void_t *)(ys + row * BN), 16,
+                                                         (int)(live ? (unsigned)(m * a.N) * 4u + y_off : kOOB), 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DIST; d++)
+            if (d < nsteps) fill(d, d);
+        if (nsteps >= DIST) wait_vmcnt<(DIST - 1) * 2 * IPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        for (int st = 0; st < nsteps; st++) {
+            if (st + DIST < nsteps) {
+                fill((st + DIST) % NBUF, st + DIST);
+                wait_vmcnt<(DIST - 1) * 2 * IPW>();   // step st + 1 has landed: all but the DIST - 1 youngest fills
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+
+    // ================================ CONSUMER wavefronts ================================
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave & 3, wn = wave >> 2;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[TK][TN];
+#pragma unroll
+    for (int i = 0; i < TK; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int x_idx = lh * BKO + wk * 64 + l31 * TK;
+    const int y_idx = lh * BN + wn * 128 + l31 * TN;
+    __syncthreads();
+    for (int st = 0; st < nsteps; st++) {
+        const int cur = st % NBUF;
+        const float *xs = Xs + cur * X_BUF + x_idx;
+        const float *ys = Ys + cur * Y_BUF + y_idx;
+        float2 xv[2];
+        float4 yv[2];
+        xv[0] = *reinterpret_cast<const float2 *>(xs);
+        yv[0] = *reinterpret_cast<const float4 *>(ys);
+#pragma unroll
+        for (int kk = 0; kk < BMR / 2; kk++) {
+            if (kk + 1 < BMR / 2) {
+                xv[(kk + 1) & 1] = *reinterpret_cast<const float2 *>(xs + (kk + 1) * 2 * BKO);
+                yv[(kk + 1) & 1] = *reinterpret_cast<const float4 *>(ys + (kk + 1) * 2 * BN);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float2 x2 = xv[kk & 1];
+            const float4 y4 = yv[kk & 1];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.y, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.z, acc[0][2], 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.w, acc[0][3], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.y, acc[1][1], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.z, acc[1][2], 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.w, acc[1][3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    // tile row of the 32x32 MFMA = (r&3) + 8*(r>>2) + 4*lh -> filter row k0 + wk*64 + row*2 + i; the lane's four
+    // accumulator tiles j are four adjacent filter columns: 16-byte stores
+    float *out = a.out + (long long)split * a.K * a.N;
+    const int col = n0 + wn * 128 + l31 * TN;
+    if (col >= a.N) return;
+#pragma unroll
+    for (int i = 0; i < TK; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = k0 + wk * 64 + ((r & 3) + 8 * (r >> 2) + 4 * lh) * TK + i;
+            if (row < a.K)
+                *reinterpret_cast<float4 *>(out + (long long)row * a.N + col) =
+                    make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+        }
+}
+
 struct Plan {
-    int bn, tiles_k, tiles_n, splits, rows_per_split;
+    int gen, bn, tiles_k, tiles_n, splits, rows_per_split;   // gen 2: wgrad2_kernel (256x256 tiles, one workgroup per CU)
 };
 
 // Split-M plan.  T filter tiles x S pixel splits workgroups run in ceil(T*S/512) rounds on the 512 resident slots
@@ -210,16 +376,23 @@ Plan make_plan(const emadapt_conv_desc *d) {
     Plan p;
     const long long M = (long long)d->B * d->H * d->W;
     const int K = d->KH * d->KW * d->Cin;
-    p.bn = d->Cout <= 64 ? 64 : 128;
-    p.tiles_k = (int)ceil_div(K, 128);
+    const int force = tune(TUNE_WGRAD_GEN);   // 0 = by shape, 1 / 2 force a kernel generation (tests)
+    // the 256x256 tiles win ~3.3 points wherever they are not padded (conv3_1's K = 1152 = 4.5 tiles loses 3)
+    const bool fits = d->Cout >= 256 && K >= 256 && ceil_div(K, 256) * 256 * 100 <= (long long)K * 104 &&
+                      ceil_div(d->Cout, 256) * 256 * 100 <= (long long)d->Cout * 104;
+    p.gen = force ? force : fits ? 2 : 1;
+    const int bk = p.gen == 2 ? 256 : 128, bmr = p.gen == 2 ? W2_BMR : BMR;
+    p.bn = p.gen == 2 ? 256 : (d->Cout <= 64 ? 64 : 128);
+    p.tiles_k = (int)ceil_div(K, bk);
     p.tiles_n = (int)ceil_div(d->Cout, p.bn);
     const long long tiles = (long long)p.tiles_k * p.tiles_n;
-    const double t_kernel = 2.0 * (double)M * (p.tiles_k * 128.0) * (p.tiles_n * (double)p.bn) / 115e12;
+    const double rate = p.gen == 2 ? 135e12 : 115e12;
+    const double t_kernel = 2.0 * (double)M * (p.tiles_k * (double)bk) * (p.tiles_n * (double)p.bn) / rate;
     const double kn_bytes = (double)K * d->Cout * 4.0;
     long long best = 1;
     double best_t = 1e30;
     const long long max_s = ceil_div(M, 256) < 2048 ? ceil_div(M, 256) : 2048;  // >= 256 pixels per split
-    const double slots = 2.0 * plan_cus();
+    const double slots = (p.gen == 2 ? 1.0 : 2.0) * plan_cus();
     for (long long s = 1; s <= max_s; s++) {
         const double rounds = (double)tiles * s / slots;
         const double eff = rounds / (double)(long long)(rounds + 0.999999);
@@ -229,7 +402,7 @@ Plan make_plan(const emadapt_conv_desc *d) {
         if (rounds > 24.0) break;
     }
     long long rps = ceil_div(M, best);
-    rps = ceil_div(rps, BMR) * BMR;
+    rps = ceil_div(rps, bmr) * bmr;
     p.rows_per_split = (int)rps;
     p.splits = (int)ceil_div(M, rps);
     return p;
@@ -256,6 +429,17 @@ int launch_wgrad(const WgradArgs &a, hipStream_t stream) {
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((wgrad_ws_kernel<BN>), dim3((unsigned)nblk), dim3(512), lds, stream, a);
+    return launch_status();
+}
+
+int launch_wgrad2(const WgradArgs &a, hipStream_t stream) {
+    constexpr size_t lds = sizeof(float) * W2_NBUF * W2_BMR * (256 + 256);
+    static DynLdsAttr attr;
+    int rc = attr.ensure(reinterpret_cast<const void *>(&wgrad2_kernel), lds);
+    if (rc) return rc;
+    const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
+    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(wgrad2_kernel, dim3((unsigned)nblk), dim3((W2_CONS + W2_PW) * 64), lds, stream, a);
     return launch_status();
 }
 
@@ -296,7 +480,7 @@ int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    rc = (p.bn == 64) ? launch_wgrad<64>(a, stream) : launch_wgrad<128>(a, stream);
+    rc = p.gen == 2 ? launch_wgrad2(a, stream) : (p.bn == 64) ? launch_wgrad<64>(a, stream) : launch_wgrad<128>(a, stream);
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
     return rc;

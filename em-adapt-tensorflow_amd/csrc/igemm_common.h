@@ -211,24 +211,24 @@ inline int launch_splitk_epilogue(const IgemmArgs &a, hipStream_t stream) {
 // when T is a few hundred (the M = 26 896, N = 512 layers: 844 tiles -> 2 rounds at 82 %) splitting K by S makes T*S
 // workgroups fill whole rounds (S = 3 -> 4.95 of 5).  The price is one extra pass over S+1 output-sized slabs,
 // charged at ~3 TB/s against the kernel's time at ~110 TFLOP/s.
-int choose_splits(long long M, int N, int K, int bm, int bn, int bk, double slots = 512.0, double rate = 110e12) {
+int choose_splits(long long M, int N, int K, int bm, int bn, int bk, double slots = 512.0, double rate = 110e12,
+                  double *t_out = nullptr) {
     const int force = tune(TUNE_SPLITK);
     slots *= plan_cus() / 256.0;
     const long long tiles = ceil_div(M, bm) * ceil_div(N, bn);
     const int nk = (K + bk - 1) / bk;
-    if (force > 0) return force <= nk ? force : 1;
-    if (N % 4 != 0) return 1;
     const double t_kernel = 2.0 * M * (double)K * N / rate;
     int best = 1;
     double best_t = 1e30;
     for (int s = 1; s <= 8; s++) {
-        if (nk / s < 16) break;
+        if (s > 1 && (nk / s < 16 || N % 4 != 0)) break;
         const double rounds = (double)tiles * s / slots;
         const double eff = rounds / (double)(long long)(rounds + 0.999999);
         double t = t_kernel / eff;
         if (s > 1) t += (double)(s + 1) * M * N * 4.0 / 3e12 + 3e-6;
-        if (t < best_t * 0.97) { best_t = t; best = s; }
+        if (force > 0 ? (s == (force <= nk ? force : 1)) : (t < best_t * 0.97)) { best_t = t; best = s; }
     }
+    if (t_out) *t_out = best_t;   // estimated seconds of the launch with the chosen factor
     return best;
 }
 

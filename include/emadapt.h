@@ -287,6 +287,7 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  *                launch for the rest | 3: 128x128x32 wave-specialised | 4: 256x256x16 second generation (LDS-DMA
  *                loaders, wide fragment reads; needs Cin resp. Cout % 16 == 0, <= 32 taps), rows split like 2.
  *                A forced variant the shape is not eligible for is ignored.
+ *   "wgrad_gen"  1: 128x128 wave-specialised filter-gradient kernel | 2: 256x256 second generation (LDS-DMA loaders)
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
  *   "bf16_tile"  128 | 256          "x6_tile"  128 | 256
  *   "plan_cus"   number of CUs the launch plans are laid out for (default 256: MI355X)

@@ -30,7 +30,9 @@ BF16 = "--bf16" in sys.argv
 X6 = "--x6" in sys.argv
 names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fc6", "conv4_2", "conv2_2"]
 tiles = [0]
+wgens = [0]
 for a in sys.argv[1:]:
+    if a.startswith("--wgens="): wgens = [int(t) for t in a.split("=")[1].split(",")]
     if a.startswith("--tile="): ops.tune_set("fp32_tile", int(a.split("=")[1]))
     if a.startswith("--tiles="): tiles = [int(t) for t in a.split("=")[1].split(",")]   # A/B in ONE process (devices differ)
     if a.startswith("--splitk="): ops.tune_set("splitk", int(a.split("=")[1]))
@@ -61,6 +63,17 @@ for n in names:
         peak = 157.3
     for kind, fn in kinds:
         if len(tiles) > 1 and kind not in ("fwd", "dgrad"):
+            continue
+        if len(wgens) > 1:
+            if kind != "wgrad":
+                continue
+            best = {}
+            for rnd in range(3):
+                for g in wgens:
+                    ops.tune_set("wgrad_gen", g)
+                    best[g] = min(best.get(g, 1e9), timeit(fn))
+            ops.tune_set("wgrad_gen", 0)
+            print("%-10s wgrad  " % n + "   ".join("gen %d: %7.3f ms %5.1f%%" % (g, best[g], fl / best[g] / 1e9 / peak * 100) for g in wgens), flush=True)
             continue
         best = {}
         for rnd in range(3 if len(tiles) > 1 else 1):      # interleaved rounds, minimum per variant

@@ -43,7 +43,7 @@ def _t(torch, a, dtype=None):
 
 # name, (B, H, W, Cin, Cout, k, dil), expected forward plan variant, expected dgrad plan variant
 FULL_SHAPES = [
-    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 4, 3),      # deeplab.py:92,145: 44.8 % of the MACs
+    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 4, 4),      # deeplab.py:92,145: 44.8 % of the MACs (dgrad: variant 4 split-K)
     ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 4, 4),     # deeplab.py:95,147
     ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 2),       # deeplab.py:95,149 (21 classes padded to 24: dgrad K = 24)
     ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 3, 3),   # few tiles: split-K by 3 on 844 tiles
@@ -64,6 +64,8 @@ def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgra
         assert 0 < pf[1] < B * H * W and pf[1] % 256 == 0 and pf[3] >= 1, pf
     if name.startswith("conv4") or name.startswith("conv5"):
         assert pf[2] > 1 and pd[2] > 1, (pf, pd)     # split-K plans
+    if name == "fc6":
+        assert pd[1] == B * H * W and pd[2] > 1, pd  # 212 big tiles on 256 CUs: split-K over the 65536-long reduction
 
     rng = np.random.default_rng(__import__("zlib").crc32(name.encode()))
     fan_in = k * k * Cin
@@ -159,7 +161,7 @@ def test_every_plan_variant_on_small_awkward_shapes(env, shape):
     gate = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
     mask = (rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8)
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
-    wt = torch.tensor(w, dtype=torch.float64)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
     y = do.conv_same(xt, wt, torch.tensor(b, dtype=torch.float64), dil)
     y.backward(torch.tensor(dy, dtype=torch.float64))
     want_y = torch.relu(y).detach().numpy() / 0.5 * mask
@@ -182,7 +184,15 @@ def test_every_plan_variant_on_small_awkward_shapes(env, shape):
             got_dx = ops.conv_dgrad(dyg, wg, dil, gate=gg, gate_scale=2.0).cpu().numpy()
         assert _rel(got_y, want_y) < 2e-5, (variant, cus, splitk)
         assert _rel(got_dx, want_dx) < 2e-5, (variant, cus, splitk)
-    assert ops.tune_get("fp32_tile") == 0 and ops.tune_get("plan_cus") == 0
+    # both generations of the filter-gradient kernel (128x128 wave-specialised; 256x256 LDS-DMA), with the CU count the
+    # split-M plan is laid out for varied: single pass, and several pixel splits with a ragged last one
+    for gen, cus in [(1, 0), (1, 1), (2, 0), (2, 1), (2, 3)]:
+        with ops.tuned(wgrad_gen=gen, plan_cus=cus):
+            got_dw = ops.conv_wgrad(xg, dyg, k, k, dil).cpu().numpy()
+            again = ops.conv_wgrad(xg, dyg, k, k, dil).cpu().numpy()
+        assert _rel(got_dw, wt.grad.numpy()) < 2e-5, (gen, cus)
+        assert np.array_equal(got_dw, again), "filter gradient must repeat bitwise"
+    assert ops.tune_get("fp32_tile") == 0 and ops.tune_get("plan_cus") == 0 and ops.tune_get("wgrad_gen") == 0
     if M > 1024 and max(Cin, Cout) >= 40:
         assert any(v == 2 and rows_split for v, rows_split, _, _ in seen), "no forced plan split the rows: %s" % seen
     if M > 1024 and Cin % 16 == 0 and Cout % 16 == 0 and k * k <= 32:
