@@ -22,6 +22,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                   bounded sample (N = 1 only).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -51,15 +52,25 @@ def parse():
                          "headline); bf16 = bf16 operands with fp32 accumulation (configs[2]/[3]); bf16x6 = fp32-grade "
                          "results from six bf16 MFMAs per product over the exact 3-way bf16 split of both fp32 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-batch", type=int, default=16, help="images per CPU-baseline step (BASELINE.md section 4: 16)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (median is reported)")
+    ap.add_argument("--cpu-warmup", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = cgroup quota / affinity")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: initialise torch.distributed and the gradient exchange even with one rank")
+    ap.add_argument("--overlap-trace", action="store_true",
+                    help="N > 1: add per-bucket launch offsets / join stalls of the last update's gradient exchange")
+    ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the data-parallel flow on a single GPU)")
     return ap.parse_args()
+
+
+def workload_key(args):
+    """What identifies the profiled workload (profiles/*_traffic.json carry the same dict)."""
+    return {"dtype": args.dtype, "preset": args.preset, "size": args.size, "classes": args.classes, "batch": args.batch,
+            "width": args.width}
 
 
 def host_cores():
@@ -103,27 +114,36 @@ def cpu_baseline(args):
     S = do.output_size(args.size, oracle.specs)
     perms = eo.draw_perms(5, args.classes, seed=3)
 
+    t_estep = [0.0]
+
     def one_step():
         masks = {l: (rng.random((B, S, S, plist[l][1].shape[0])) < args.keep_prob) for l in ("fc6", "fc7")}
         r = oracle.micro_step({k: (v[0], v[1]) for k, v in plist.items()}, images, labels, perms, weight_decay=1e-5,
                               keep_prob=args.keep_prob, masks=masks)
+        t_estep[0] = r.get("estep_seconds", 0.0)
         acc = {k: [g[0], g[1]] for k, g in r["grads"].items()}
         do.momentum_update(plist, vel, acc, 1e-3, 0.9)
 
-    one_step()  # warm-up
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    for _ in range(args.cpu_warmup):
         one_step()
-    dt = time.perf_counter() - t0
+    times, shares = [], []
+    for _ in range(max(args.cpu_steps, 1)):
+        t0 = time.perf_counter()
+        one_step()
+        times.append(time.perf_counter() - t0)
+        shares.append(t_estep[0] / times[-1])
+    med = sorted(times)[len(times) // 2]
     return {
-        "value": round(B * args.cpu_steps / dt, 4),
+        "value": round(B / med, 4),
         "unit": "images/s",
         "cores": int(torch.get_num_threads()),
         "cpu_model": cpu_model(),
         "kind": "port",
-        "sample": "%d images/step x %d timed steps (after 1 warm-up) of the same step: %dx%d, %d classes, preset %s, "
-                  "fp32, PyTorch-CPU convs + NumPy E-step oracle; %.1f s" % (B, args.cpu_steps, args.size, args.size,
-                                                                            args.classes, args.preset, dt),
+        "batch": B,
+        "estep_share": round(sorted(shares)[len(shares) // 2], 4),
+        "sample": "median of %d timed steps of %d images (after %d warm-up) of the same step: %dx%d, %d classes, preset %s, "
+                  "fp32, PyTorch-CPU convs + NumPy E-step oracle (stand-in for the reference's TF-CPU path); %.1f s timed" % (
+                      len(times), B, args.cpu_warmup, args.size, args.size, args.classes, args.preset, sum(times)),
     }
 
 
@@ -153,6 +173,10 @@ def main():
         # stdout carries exactly one JSON line: RCCL prints its NCCL_DEBUG=VERSION banner (set on the GPU boxes) with a
         # bare printf when the communicator is created, so file descriptor 1 points at stderr while that happens
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # --force-dist started without a launcher: a one-rank job
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
@@ -177,7 +201,7 @@ def main():
 
     cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
-           "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist)}
+           "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb}
     data = SyntheticData(dict(cfg, seed=0, unique_batches=2))   # SyntheticData mixes the rank into its seed
     adapt = ADAPT(dict(cfg, data=data))
     adapt.build()
@@ -205,6 +229,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    if adapt._gradsync is not None:
+        adapt._gradsync.stats(reset=True)
+        adapt._gradsync.trace = bool(args.overlap_trace)
     if not args.no_prof:
         ops.prof_reset()
         ops.prof_enable(True)
@@ -218,9 +245,12 @@ def main():
         ops.prof_enable(False)
         prof = ops.prof_collect()
         ops.prof_reset()
+    gs_stats = adapt._gradsync.stats() if adapt._gradsync is not None else None
     if distributed:
         from em_adapt_tensorflow_amd.dist import all_reduce_max
         dt = all_reduce_max(dt, device)
+        if gs_stats is not None and gs_stats["exposed_ms"] is not None:
+            gs_stats["exposed_ms_max_over_ranks"] = all_reduce_max(gs_stats["exposed_ms"], device)
     loss = float(adapt.loss["norm"].cpu())
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss in the benchmark step")
@@ -250,6 +280,7 @@ def main():
                                 {"fp32": "fp32", "bf16": "bf16 conv operands / fp32 accumulate, fp32 master weights, bf16 activation storage",
                                  "bf16x6": "fp32 tensors, conv products as six bf16 MFMAs over the exact 3-way bf16 split "
                                            "(fp32-grade), fp32 accumulate"}[args.dtype], args.keep_prob),
+                "workload_key": workload_key(args),
                 "global_batch": global_batch,
                 "parallelism": "dp%d" % world,
                 "gflop_per_image_fwd_bwd": round(fb_flops / 1e9, 1),
@@ -282,24 +313,40 @@ def main():
             }
             # HBM (L2-miss) bytes per launch of the dominant class: PMC counters need their own rocprofv3 passes
             # (scripts/make_profiles.sh); their per-class summary is committed under profiles/ and used when it was taken
-            # on exactly this workload
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                 {"fp32": "r01_traffic.json", "bf16": "r01_bf16_traffic.json"}.get(args.dtype, "none.json"))
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == out["config"]["workload"] and tj.get("dtype") == args.dtype:
+            # on exactly this workload (matched on its structured key, not on prose)
+            key = workload_key(args)
+            here = os.path.dirname(os.path.abspath(__file__))
+            for tpath in sorted(glob.glob(os.path.join(here, "profiles", "r*_traffic*.json")), reverse=True):
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("key") != key:
+                        continue
                     per_step = tj["per_step"][dom]
                     calls = d["launches"] / max(args.steps, 1)
                     out["roofline"]["traffic"] = round((per_step["read_bytes"] + per_step["write_bytes"]) / max(calls, 1))
-                    out["roofline"]["traffic_unit"] = "bytes per launch (HBM-side reads + writes, %s)" % os.path.relpath(tpath, os.path.dirname(os.path.abspath(__file__)))
-            except (OSError, KeyError, ValueError):
-                pass
+                    out["roofline"]["traffic_unit"] = "bytes per launch (HBM-side reads + writes, %s)" % os.path.relpath(tpath, here)
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
             out["kernel_ms_per_step"] = {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in prof.items()}
             e = prof["estep"]
             if e["ms"] > 0:
                 out["estep"] = {"ms": round(e["ms"] / max(e["launches"], 1), 4),
                                 "achieved_GBps": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 2), "bound": "hbm",
                                 "peak_GBps": 8000}
+        if gs_stats is not None:
+            # data-parallel evidence: how much of the gradient all-reduce was NOT hidden under backward
+            out["allreduce"] = {
+                "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
+                "ranks": gs_stats["world_size"],
+                "bytes_per_update": gs_stats["bytes_per_update"],
+                "buckets": gs_stats["buckets"],
+                "bucket_mb": args.bucket_mb,
+                "exposed_ms_per_step": None if gs_stats["exposed_ms"] is None else round(gs_stats.get("exposed_ms_max_over_ranks", gs_stats["exposed_ms"]), 3),
+                "backward_window_ms": None if gs_stats["backward_window_ms"] is None else round(gs_stats["backward_window_ms"], 3),
+            }
+            if "trace" in gs_stats:
+                out["allreduce"]["trace_last_update"] = gs_stats["trace"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

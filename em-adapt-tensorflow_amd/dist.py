@@ -34,9 +34,22 @@ class GradSync:
         self._watermark = 0
         self._works = []
         self.launched_bytes = 0
+        # measurement (bench.py): time the compute stream spends blocked in wait(), per update, from HIP events on the
+        # compute stream; with `trace` on, also where in the backward pass each bucket was launched
+        self.timing = bool(flat.is_cuda)
+        self.trace = False
+        self._ev = []          # per update: (backward-start, [launch events], wait-start, [after-bucket events])
+        self._cur = None
+
+    def _event(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
 
     def segment_ready(self, start, end):
         """Gradients of flat[start:end] are final for this update; segments arrive in increasing offset order."""
+        if self.timing and self._cur is None:
+            self._cur = dict(t0=self._event(), launch=[], wait0=None, done=[])
         if start != self._watermark:
             raise RuntimeError("segments must complete in layout order (got %d, expected %d)" % (start, self._watermark))
         self._watermark = end
@@ -48,6 +61,8 @@ class GradSync:
             if e > self._watermark:
                 break
             view = self.flat[s:e]
+            if self.timing and self.trace:
+                self._cur["launch"].append(self._event())
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.launched_bytes += view.numel() * view.element_size()
             self._next_bucket += 1
@@ -57,11 +72,40 @@ class GradSync:
         if self._watermark < self.total:
             raise RuntimeError("wait() before every segment was reported ready")
         self._launch_ready()
+        if self.timing and self._cur is not None:
+            self._cur["wait0"] = self._event()
         for w in self._works:
-            w.wait()
+            w.wait()   # the compute stream waits for the collective; the host does not block
+            if self.timing and self.trace and self._cur is not None:
+                self._cur["done"].append(self._event())
+        if self.timing and self._cur is not None:
+            self._cur["wait1"] = self._event()
+            self._ev.append(self._cur)
+            self._cur = None
         self._works = []
         self._next_bucket = 0
         self._watermark = 0
+
+    def stats(self, reset=True):
+        """Since the last reset: updates seen, mean milliseconds per update the compute stream was blocked on the
+        gradient exchange (the EXPOSED part of the all-reduce; 0 = fully hidden under backward), payload bytes per update,
+        bucket count, and -- with `trace` on -- for the last update the offset of every bucket's launch from the start of
+        the gradient exchange window and the stall observed when it was joined (ms)."""
+        out = dict(updates=len(self._ev), world_size=self.world_size, buckets=len(self.buckets),
+                   bytes_per_update=self.total * self.flat.element_size(), exposed_ms=None, backward_window_ms=None)
+        if self._ev:
+            torch.cuda.synchronize(self.flat.device)
+            out["exposed_ms"] = sum(e["wait0"].elapsed_time(e["wait1"]) for e in self._ev) / len(self._ev)
+            out["backward_window_ms"] = sum(e["t0"].elapsed_time(e["wait0"]) for e in self._ev) / len(self._ev)
+            last = self._ev[-1]
+            if last["launch"]:
+                marks = [last["wait0"]] + last["done"]
+                out["trace"] = [dict(bucket=i, launched_at_ms=round(last["t0"].elapsed_time(l), 3),
+                                     stall_at_join_ms=round(marks[i].elapsed_time(marks[i + 1]), 3) if i + 1 < len(marks) else None)
+                                for i, l in enumerate(last["launch"])]
+        if reset:
+            self._ev = []
+        return out
 
 
 def all_reduce_max(value, device):

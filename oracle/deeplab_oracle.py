@@ -224,17 +224,21 @@ class DeepLabOracle:
         acts = self.forward(tp, images, keep_prob, masks)
         logits = acts["output"]
         lnp = logits.detach().to(torch.float32).numpy()
+        import time as _time
+        t_e = _time.perf_counter()
         if labels_override is None:
             labels, _ = self.estep_labels(lnp, label_full, perms)
         else:
             labels = labels_override
+        t_e = _time.perf_counter() - t_e
         lt = torch.as_tensor(labels.reshape(-1), dtype=torch.int64)
         norm = F.cross_entropy(logits.reshape(-1, self.C), lt, reduction="mean")
         l2 = sum((w * w).sum() / 2 for (w, _) in tp.values())
         total = norm + weight_decay * l2
         total.backward()
         grads = {k: (w.grad.detach().numpy().copy(), b.grad.detach().numpy().copy()) for k, (w, b) in tp.items()}
-        return dict(loss_norm=float(norm.detach()), loss_l2=float(l2.detach()), logits=lnp, labels=labels, grads=grads)
+        return dict(loss_norm=float(norm.detach()), loss_l2=float(l2.detach()), logits=lnp, labels=labels, grads=grads,
+                    estep_seconds=t_e)
 
 
 def momentum_update(params, velocity, accum, lr, momentum):

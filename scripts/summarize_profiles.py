@@ -5,7 +5,6 @@ import collections
 import csv
 import glob
 import os
-import os
 import re
 import shutil
 import subprocess
@@ -23,7 +22,7 @@ os.makedirs(DST, exist_ok=True)
 
 
 def short(name):
-    m = re.search(r"((?:igemm|wgrad)(?:_ws)?_kernel<[^>]*>|\w+_kernel\w*)", name)
+    m = re.search(r"((?:igemm|wgrad)(?:_ws|2)?_kernel<[^>]*>|\w+_kernel\w*)", name)
     return m.group(1) if m else name[:50]
 
 
@@ -110,6 +109,7 @@ line = json.load(open(SRC + "/bench_line.json"))
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/make_profiles.sh over bench.py --steps 1 --warmup 1; "
                      "read = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md), write = WRITE_SIZE KiB; "
                      "L2-miss (fabric) traffic, Infinity-Cache hits included",
-           "dtype": line["dtype"], "workload": line["config"]["workload"], "per_step": traffic},
+           "dtype": line["dtype"], "workload": line["config"]["workload"], "key": line["config"].get("workload_key"),
+           "per_step": traffic},
           open("%s/%s_traffic.json" % (DST, R), "w"), indent=1)
 print("\n".join(out))

@@ -33,7 +33,7 @@ def layers(size=321, C=21, preset="ref", width=64):
 
 
 def short(name):
-    m = re.search(r"(igemm_ws_kernel<\w+>|wgrad_ws_kernel<\d+>|igemm_kernel<[^>]*>|wgrad_kernel<[^>]*>|igemm_bf16_kernel|wgrad_bf16_kernel<\d+>)", name)
+    m = re.search(r"(igemm_ws_kernel<\w+>|wgrad_ws_kernel<\d+>|igemm2?_kernel<[^>]*>|wgrad2_kernel|wgrad_kernel<[^>]*>|igemm_bf16\w*_kernel|wgrad_bf16_kernel<\d+>)", name)
     return m.group(1) if m else name[:40]
 
 
@@ -44,16 +44,20 @@ def main():
     C = int(sys.argv[4]) if len(sys.argv) > 4 else 21
     preset = sys.argv[5] if len(sys.argv) > 5 else "ref"
     L = layers(size, C, preset)
-    rows = [r for r in csv.DictReader(open(path)) if re.search(r"igemm(_ws|_bf16)?_kernel|wgrad(_ws|_bf16)?_kernel", r["Kernel_Name"])]
+    rows = [r for r in csv.DictReader(open(path)) if re.search(r"igemm(_ws|_bf16\w*|2)?_kernel|wgrad(_ws|_bf16|2)?_kernel", r["Kernel_Name"])]
     global PEAK
     if any("bf16" in r["Kernel_Name"] for r in rows):
         PEAK = 2516.6e12
-    # group "256x256 main + igemm_ws tail" pairs into one logical launch
+    # group "256x256 main + igemm_ws tail" pairs into one logical launch: a big-tile launch whose grid is a whole
+    # number of rounds of the 256 CUs is followed by the wave-specialised launch over the remaining rows
     groups = []
     i = 0
     while i < len(rows):
         g = [rows[i]]
-        if "igemm_kernel<256, 256" in rows[i]["Kernel_Name"] and i + 1 < len(rows) and "igemm_ws_kernel" in rows[i + 1]["Kernel_Name"]:
+        n = rows[i]["Kernel_Name"]
+        big = "igemm_kernel<256, 256" in n or "igemm2_kernel" in n
+        wgs = int(rows[i]["Grid_Size_X"]) // int(rows[i]["Workgroup_Size_X"])
+        if big and wgs % 256 == 0 and i + 1 < len(rows) and "igemm_ws_kernel" in rows[i + 1]["Kernel_Name"]:
             g.append(rows[i + 1])
             i += 1
         groups.append(g)
