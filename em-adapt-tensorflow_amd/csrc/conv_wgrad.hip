@@ -222,7 +222,7 @@ __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(Wgrad
     constexpr int TK = 2, TN = 4;
     constexpr int X_BUF = BMR * BKO, Y_BUF = BMR * BN;
     constexpr int IPW = BMR / PW;   // pixel rows (= DMA instructions) per loader wave, step and operand
-    static_assert(NBUF >= DIST + 1 && (DIST - 1) * 2 * IPW <= 63, "ring depth / vmcnt range");
+    static_assert(NBUF >= DIST + 1 && DIST >= 2 && (DIST - 2) * 2 * IPW <= 63 && (BMR / 2) % 2 == 0, "ring depth / vmcnt range");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Xs = lds;                  // [NBUF][BMR][BKO]
@@ -291,13 +291,15 @@ __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(Wgrad
 #pragma unroll
         for (int d = 0; d < DIST; d++)
             if (d < nsteps) fill(d, d);
-        if (nsteps >= DIST) wait_vmcnt<(DIST - 1) * 2 * IPW>();
+        // (the consumers read the first fragments of step st + 1 during step st: the barrier that ends step st - 1 must
+        // already cover step st + 1, so the loaders wait for all but their DIST - 2 youngest fills; see igemm_v2.h)
+        if (nsteps >= DIST) wait_vmcnt<(DIST - 2) * 2 * IPW>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         for (int st = 0; st < nsteps; st++) {
             if (st + DIST < nsteps) {
                 fill((st + DIST) % NBUF, st + DIST);
-                wait_vmcnt<(DIST - 1) * 2 * IPW>();   // step st + 1 has landed: all but the DIST - 1 youngest fills
+                wait_vmcnt<(DIST - 2) * 2 * IPW>();   // step st + 2 has landed
             } else {
                 wait_vmcnt<0>();
             }
@@ -319,20 +321,25 @@ __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(Wgrad
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     const int x_idx = lh * BKO + wk * 64 + l31 * TK;
     const int y_idx = lh * BN + wn * 128 + l31 * TN;
+    float2 xv[2];
+    float4 yv[2];
     __syncthreads();
+    if (nsteps > 0) {
+        xv[0] = *reinterpret_cast<const float2 *>(Xs + x_idx);
+        yv[0] = *reinterpret_cast<const float4 *>(Ys + y_idx);
+    }
     for (int st = 0; st < nsteps; st++) {
-        const int cur = st % NBUF;
+        const int cur = st % NBUF, nxt = (st + 1) % NBUF;
         const float *xs = Xs + cur * X_BUF + x_idx;
         const float *ys = Ys + cur * Y_BUF + y_idx;
-        float2 xv[2];
-        float4 yv[2];
-        xv[0] = *reinterpret_cast<const float2 *>(xs);
-        yv[0] = *reinterpret_cast<const float4 *>(ys);
 #pragma unroll
         for (int kk = 0; kk < BMR / 2; kk++) {
             if (kk + 1 < BMR / 2) {
                 xv[(kk + 1) & 1] = *reinterpret_cast<const float2 *>(xs + (kk + 1) * 2 * BKO);
                 yv[(kk + 1) & 1] = *reinterpret_cast<const float4 *>(ys + (kk + 1) * 2 * BN);
+            } else if (st + 1 < nsteps) {   // first fragments of the next step (landed before the previous barrier)
+                xv[0] = *reinterpret_cast<const float2 *>(Xs + nxt * X_BUF + x_idx);
+                yv[0] = *reinterpret_cast<const float4 *>(Ys + nxt * Y_BUF + y_idx);
             }
             __builtin_amdgcn_sched_barrier(0);
             const float2 x2 = xv[kk & 1];

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     constexpr int A_N = BM / RPI / PW;        // DMA instructions per loader wave and K step for A
     constexpr int B_N = BT ? BN / RPI / PW : BK * (BN / 256) / PW;   // fwd: one instruction = 256 floats of one k row
     static_assert(A_N >= 1 && B_N >= 1 && (BM / RPI) % PW == 0 && BN % 256 == 0, "tile / loader shape");
-    static_assert(NBUF >= DIST + 1 && DIST >= 1 && (DIST - 1) * (A_N + B_N) <= 63, "ring depth / vmcnt range");
+    static_assert(NBUF >= DIST + 1 && DIST >= 2 && (DIST - 2) * (A_N + B_N) <= 63 && (BK / 4) % 2 == 0, "ring depth / vmcnt range");
     // Swizzle of a k-contiguous row: chunk q of row r is stored at chunk position q ^ swz(r), swz in 0..3 (the low two
     // bits of the position: the addresses of chunks q and q + 4 differ by an immediate).  A rows: swz from the row bits
     // above those that share a 256-byte bank line; dgrad filter rows (read at rows 4*l31 + j): swz = l31 & 3.
@@ -183,17 +183,18 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
 #pragma unroll
         for (int d = 0; d < DIST; d++)
             if (d < nk) fill(d, kt0 + d);
-        if (nk >= DIST) wait_vmcnt<(DIST - 1) * (A_N + B_N)>();   // tile 0 has landed (all but the DIST - 1 youngest fills)
+        // The consumers fetch the first fragments of tile kt + 1 while they still multiply tile kt (no LDS round trip in
+        // front of the first MFMA after a barrier), so the barrier that ends step kt - 1 must already cover tile kt + 1:
+        // the loaders wait for all but their DIST - 2 youngest fills.
+        if (nk >= DIST) wait_vmcnt<(DIST - 2) * (A_N + B_N)>();   // tiles 0 and 1 have landed
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; kt++) {
-            // The consumers multiply buffer kt % NBUF during this step.  Buffer (kt + DIST) % NBUF was last read in step
-            // kt + DIST - NBUF <= kt - 1: free since the barrier that ended that step (every consumer drains its LDS reads
-            // before arriving there).  Before the barrier that ends this step, tile kt + 1 must have landed: all but the
-            // DIST - 1 youngest fills of this wave.
+            // Buffer (kt + DIST) % NBUF was last read for tile kt + DIST - NBUF <= kt - 1, whose reads were drained before the
+            // barrier that ended step kt - 1: free.  Before the barrier that ends this step, tile kt + 2 must have landed.
             if (kt + DIST < nk) {
                 fill((kt + DIST) % NBUF, kt0 + kt + DIST);
-                wait_vmcnt<(DIST - 1) * (A_N + B_N)>();
+                wait_vmcnt<(DIST - 2) * (A_N + B_N)>();
             } else {
                 wait_vmcnt<0>();
             }
@@ -226,31 +227,34 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     } else {
         b_idx[0] = (lh * 2) * BN + wn * 128 + l31 * TN;        // [k][n]: row 4q + 2*lh + (kk & 1)
     }
+    // the operands of k-pairs 2q and 2q+1 come from one 8-byte read per k-contiguous row, one 16-byte read per [k][n] row
+    float2 av[2][TM];
+    float2 bt[2][BT ? TN : 1];
+    float4 bf[2][BT ? 1 : 2];
+    auto read_q = [&](int buf, int q, int slot) {
+        const float *as = As + buf * A_BUF;
+        const float *bs = Bs + buf * B_BUF;
+        const int hi = (q >> 2) * 16;   // chunks 4..7 of a 32-float row
+#pragma unroll
+        for (int i = 0; i < TM; i++) av[slot][i] = *reinterpret_cast<const float2 *>(as + a_idx[q & 3] + hi + i * 32 * BK);
+        if constexpr (BT) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) bt[slot][j] = *reinterpret_cast<const float2 *>(bs + b_idx[q & 3] + hi + j * BK);
+        } else {
+            bf[slot][0] = *reinterpret_cast<const float4 *>(bs + b_idx[0] + (4 * q + 0) * BN);
+            bf[slot][1] = *reinterpret_cast<const float4 *>(bs + b_idx[0] + (4 * q + 1) * BN);
+        }
+    };
     __syncthreads();
+    if (nk > 0) read_q(0, 0, 0);
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt % NBUF;
-        const float *as = As + cur * A_BUF;
-        const float *bs = Bs + cur * B_BUF;
-        // the operands of k-pairs 2q and 2q+1 come from one 8-byte read per k-contiguous row, one 16-byte read per [k][n] row
-        float2 av[2][TM];
-        float2 bt[2][BT ? TN : 1];
-        float4 bf[2][BT ? 1 : 2];
-        auto read_q = [&](int q, int slot) {
-            const int hi = (q >> 2) * 16;   // chunks 4..7 of a 32-float row
-#pragma unroll
-            for (int i = 0; i < TM; i++) av[slot][i] = *reinterpret_cast<const float2 *>(as + a_idx[q & 3] + hi + i * 32 * BK);
-            if constexpr (BT) {
-#pragma unroll
-                for (int j = 0; j < TN; j++) bt[slot][j] = *reinterpret_cast<const float2 *>(bs + b_idx[q & 3] + hi + j * BK);
-            } else {
-                bf[slot][0] = *reinterpret_cast<const float4 *>(bs + b_idx[0] + (4 * q + 0) * BN);
-                bf[slot][1] = *reinterpret_cast<const float4 *>(bs + b_idx[0] + (4 * q + 1) * BN);
-            }
-        };
-        read_q(0, 0);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
-            if (q + 1 < NQ) read_q(q + 1, (q + 1) & 1);
+            // fragments one group ahead of the MFMAs; the last group of a step fetches the first one of the NEXT tile (it
+            // landed before the previous barrier), so no LDS latency sits between a barrier and the MFMAs behind it
+            if (q + 1 < NQ) read_q(cur, q + 1, (q + 1) & 1);
+            else if (kt + 1 < nk) read_q((kt + 1) % NBUF, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             const int s = q & 1;
 #pragma unroll
