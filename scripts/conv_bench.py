@@ -44,6 +44,8 @@ for n in names:
     y = torch.empty(B, H, W, Cout, device="cuda"); dx = torch.empty_like(x); dw = torch.empty_like(w)
     fl = 2.0 * B * H * W * k * k * Cin * Cout
     if BF16:
+        if "--f32store" not in sys.argv and Cin % 8 == 0 and Cout % 8 == 0:   # bf16-stored activations, as the model keeps them
+            x, dy, y, dx = x.bfloat16(), dy.bfloat16(), y.bfloat16(), dx.bfloat16()
         wf, wd = ops.weights_to_bf16(w)
         kinds = (("fwd", lambda: ops.conv_fwd_bf16(x, wf, (k, k), b, dil, out=y)),
                  ("dgrad", lambda: ops.conv_dgrad_bf16(dy, wd, (k, k), dil, out=dx)),
@@ -64,6 +66,7 @@ for n in names:
     for kind, fn in kinds:
         if len(tiles) > 1 and kind not in ("fwd", "dgrad"):
             continue
+        tkey = "bf16_tile" if BF16 else "fp32_tile"
         if len(wgens) > 1:
             if kind != "wgrad":
                 continue
@@ -78,15 +81,16 @@ for n in names:
         best = {}
         for rnd in range(3 if len(tiles) > 1 else 1):      # interleaved rounds, minimum per variant
             for t in tiles:
-                if len(tiles) > 1: ops.tune_set("fp32_tile", t)
+                if len(tiles) > 1: ops.tune_set(tkey, t)
                 ms = timeit(fn)
                 best[t] = min(best.get(t, 1e9), ms)
         for t in tiles:
-            if len(tiles) > 1: ops.tune_set("fp32_tile", t)
+            if len(tiles) > 1: ops.tune_set(tkey, t)
             ms = best[t]
             plan = ""
             if not BF16 and not X6 and kind in ("fwd", "dgrad"):
                 plan = " plan %s" % (ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=kind == "dgrad"),)
-            print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  %s%s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / peak * 100,
-                                                                 "bf16" if BF16 else "bf16x6" if X6 else "fp32", plan), flush=True)
-        if len(tiles) > 1: ops.tune_set("fp32_tile", 0)
+            print("%-10s %-5s %8.3f ms %7.1f TF  %5.1f%%  %s%s%s" % (n, kind, ms, fl / ms / 1e9, fl / ms / 1e9 / peak * 100,
+                                                                   "bf16" if BF16 else "bf16x6" if X6 else "fp32", plan,
+                                                                   " tile %d" % t if len(tiles) > 1 else ""), flush=True)
+        if len(tiles) > 1: ops.tune_set(tkey, 0)
