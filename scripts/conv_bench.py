@@ -31,8 +31,12 @@ X6 = "--x6" in sys.argv
 names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["fc6", "conv4_2", "conv2_2"]
 tiles = [0]
 wgens = [0]
+ab_key, ab_vals = None, []   # --ab=<tune key>:<v1>,<v2>,..  generic in-process A/B over any launch-plan knob
 for a in sys.argv[1:]:
     if a.startswith("--wgens="): wgens = [int(t) for t in a.split("=")[1].split(",")]
+    if a.startswith("--ab="):
+        ab_key, v = a.split("=", 1)[1].split(":")
+        ab_vals = [int(t) for t in v.split(",")]
     if a.startswith("--tile="): ops.tune_set("fp32_tile", int(a.split("=")[1]))
     if a.startswith("--tiles="): tiles = [int(t) for t in a.split("=")[1].split(",")]   # A/B in ONE process (devices differ)
     if a.startswith("--splitk="): ops.tune_set("splitk", int(a.split("=")[1]))
@@ -67,6 +71,15 @@ for n in names:
         if len(tiles) > 1 and kind not in ("fwd", "dgrad"):
             continue
         tkey = "bf16_tile" if BF16 else "fp32_tile"
+        if ab_key:
+            best = {}
+            for rnd in range(3):
+                for v in ab_vals:
+                    ops.tune_set(ab_key, v)
+                    best[v] = min(best.get(v, 1e9), timeit(fn))
+            ops.tune_set(ab_key, 0)
+            print("%-10s %-5s  " % (n, kind) + "   ".join("%s=%d: %7.3f ms %5.1f%%" % (ab_key, v, best[v], fl / best[v] / 1e9 / peak * 100) for v in ab_vals), flush=True)
+            continue
         if len(wgens) > 1:
             if kind != "wgrad":
                 continue
