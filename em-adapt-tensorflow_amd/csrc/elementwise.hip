@@ -56,20 +56,22 @@ template <> struct ByteVec<8> { typedef unsigned long long type; };
 // ------------------------------------------------------------------------------------------
 // tf.nn.max_pool 3x3, SAME (deeplab.py:77,82)
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// I = index type: unsigned when the element count fits 31 bits (always, for DeepLab's maps), else long long -- the
+// decomposition of the linear index costs four divisions by run-time divisors per thread, and 64-bit ones are ~10x the
+// instructions of 32-bit ones on this hardware.
+template <typename T, typename I>
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ x, int B, int H, int W, int CV,
                                                         int stride, int OH, int OW, int pt, int pl,
                                                         T *__restrict__ y, unsigned char *__restrict__ idx) {
     constexpr int N = VW<T>::N;  // channels per thread; CV = C / N
-    const long long n = (long long)B * OH * OW * CV;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
-         t += (long long)gridDim.x * blockDim.x) {
-        const int cv = (int)(t % CV);
-        long long r = t / CV;
-        const int ow = (int)(r % OW);
-        r /= OW;
-        const int oh = (int)(r % OH);
-        const int b = (int)(r / OH);
+    const I n = (I)B * OH * OW * CV;
+    for (I t = (I)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (I)gridDim.x * blockDim.x) {
+        const int cv = (int)(t % (I)CV);
+        I r = t / (I)CV;
+        const int ow = (int)(r % (I)OW);
+        r /= (I)OW;
+        const int oh = (int)(r % (I)OH);
+        const int b = (int)(r / (I)OH);
         float best[N];
         int bi[N];
 #pragma unroll
@@ -90,33 +92,32 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ 
                     if (bi[e] < 0 || v[e] > best[e]) { best[e] = v[e]; bi[e] = tap; }  // first maximum wins
             }
         }
-        stv(y + t * N, best);
+        stv(y + (long long)t * N, best);
         if (idx) {
             typename ByteVec<N>::type pk = 0;
 #pragma unroll
             for (int e = 0; e < N; e++) pk |= (typename ByteVec<N>::type)(unsigned char)bi[e] << (8 * e);
-            *reinterpret_cast<typename ByteVec<N>::type *>(idx + t * N) = pk;
+            *reinterpret_cast<typename ByteVec<N>::type *>(idx + (long long)t * N) = pk;
         }
     }
 }
 
 // MaxPoolGrad (+ ReluGrad of the producing layer): gather form, one thread per input pixel x 4 channels.
-template <typename T>
+template <typename T, typename I>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ dy,
                                                         const unsigned char *__restrict__ idx,
                                                         const T *__restrict__ gate, int B, int H, int W, int CV,
                                                         int stride, int OH, int OW, int pt, int pl,
                                                         T *__restrict__ dx) {
     constexpr int N = VW<T>::N;
-    const long long n = (long long)B * H * W * CV;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n;
-         t += (long long)gridDim.x * blockDim.x) {
-        const int cv = (int)(t % CV);
-        long long r = t / CV;
-        const int w = (int)(r % W);
-        r /= W;
-        const int h = (int)(r % H);
-        const int b = (int)(r / H);
+    const I n = (I)B * H * W * CV;
+    for (I t = (I)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (I)gridDim.x * blockDim.x) {
+        const int cv = (int)(t % (I)CV);
+        I r = t / (I)CV;
+        const int w = (int)(r % (I)W);
+        r /= (I)W;
+        const int h = (int)(r % (I)H);
+        const int b = (int)(r / (I)H);
         float acc[N];
 #pragma unroll
         for (int e = 0; e < N; e++) acc[e] = 0.f;
@@ -144,11 +145,11 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ 
         }
         if (gate) {
             float a[N];
-            ldv(gate + t * N, a);
+            ldv(gate + (long long)t * N, a);
 #pragma unroll
             for (int e = 0; e < N; e++) acc[e] = a[e] > 0.f ? acc[e] : 0.f;
         }
-        stv(dx + t * N, acc);
+        stv(dx + (long long)t * N, acc);
     }
 }
 
@@ -415,8 +416,12 @@ int maxpool_fwd_t(const T *x, int B, int H, int W, int C, int stride, T *y, uint
     const long long n = (long long)B * OH * OW * (C / N);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)B * H * W * C * sizeof(T) + (double)n * N * (sizeof(T) + 1.0), stream);
-    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W, C / N,
-                       stride, OH, OW, pt, pl, y, idx);
+    if (n < (1LL << 31) - (1LL << 23) && (long long)B * H * W * (C / N) < (1LL << 31))
+        hipLaunchKernelGGL((maxpool_fwd_kernel<T, unsigned>), dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W,
+                           C / N, stride, OH, OW, pt, pl, y, idx);
+    else
+        hipLaunchKernelGGL((maxpool_fwd_kernel<T, long long>), dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W,
+                           C / N, stride, OH, OW, pt, pl, y, idx);
     return launch_status();
 }
 
@@ -433,8 +438,12 @@ int maxpool_bwd_t(const T *dy, const uint8_t *idx, const T *gate, int B, int H, 
     const long long n = (long long)B * H * W * (C / N);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * N * sizeof(T) * (gate ? 2.0 : 1.0) + (double)B * OH * OW * C * (sizeof(T) + 1.0), stream);
-    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, dy, idx, gate, B, H,
-                       W, C / N, stride, OH, OW, pt, pl, dx);
+    if (n < (1LL << 31) - (1LL << 23))   // (headroom for the grid-stride increment)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<T, unsigned>), dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, dy, idx, gate,
+                           B, H, W, C / N, stride, OH, OW, pt, pl, dx);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_kernel<T, long long>), dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, dy, idx,
+                           gate, B, H, W, C / N, stride, OH, OW, pt, pl, dx);
     return launch_status();
 }
 

@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(IgemmArgs a) {
     const long long mn = (long long)(a.m_end - a.m_begin) * a.N;  // one slab
     const long long n4 = mn / 4;
     const long long o0 = (long long)a.m_begin * a.N;
+    const bool small = (long long)a.m_end * a.N < (1LL << 31);   // 32-bit column arithmetic (a 64-bit modulo is ~10x the work)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 v = *reinterpret_cast<const float4 *>(a.slab + i * 4);
         for (int sp = 1; sp < a.splits; sp++) {
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_kernel(IgemmArgs a) {
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         const long long o = o0 + i * 4;
-        const int col = (int)(o % a.N);
+        const int col = small ? (int)((unsigned)o % (unsigned)a.N) : (int)(o % a.N);
         v.x = epilogue(a, v.x, col + 0, o + 0);
         v.y = epilogue(a, v.y, col + 1, o + 1);
         v.z = epilogue(a, v.z, col + 2, o + 2);
