@@ -21,8 +21,10 @@
 //     k-pairs 2q and 2q + 1, i.e. k-pair 2q multiplies columns {4q, 4q+2}, k-pair 2q+1 columns {4q+1, 4q+3} -- the same
 //     products, summed in a slightly different order than the round-1 kernels (both are valid fp32 sums; the parity
 //     tests hold both to the same bar).  The forward filter tile is read at rows 4q + 2*lh + (kk & 1) accordingly.
-//   * the lane's four B tiles are four ADJACENT output columns (l31*4 + j, not l31 + 32*j): the epilogue is direct
-//     16-byte stores (512 contiguous bytes per row and wave), no staging through LDS.
+//   * forward: the lane's four B tiles are four ADJACENT output columns (l31*4 + j, not l31 + 32*j): the epilogue is
+//     direct 16-byte stores (512 contiguous bytes per row and wave), no staging through LDS.  The data gradient keeps the
+//     l31 + 32*j columns (its filter tile is k-contiguous per column: adjacent columns would put a read's 32 lanes on 4
+//     bank pairs) and the LDS-staged vector epilogue of the round-1 kernels.
 //
 // Configuration <WMW, WNW, BK, PW, NBUF, DIST>: consumer waves WMW x WNW (64 x 128 each), loader waves PW, LDS ring
 //   <4, 2, 16, 4, 4, 3>  256 x 256 x 16, 12 waves, 128 KB LDS, one workgroup per CU
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             for (int j = 0; j < B_N; j++) {
                 const int r = (j * PW + pw) * RPI + rl;
                 const int n = n0 + r;
-                const int q = pos ^ ((r >> 2) & 3);
+                const int q = pos ^ ((r >> SWA_SHIFT) & 3);
                 b_off[j] = ((unsigned)(n * a.Cx + q * 4) * 4u) | (n < a.N ? 0u : kOOB);
             }
         }
@@ -222,8 +224,11 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
 #pragma unroll
     for (int q = 0; q < 4; q++) a_idx[q] = arow * BK + ((q ^ ((arow >> SWA_SHIFT) & 3)) * 4) + lh * 2;
     if constexpr (BT) {
+        // dgrad filter tile [n][k]: the lane's four columns are l31 + 32*j (consecutive rows across the lanes of a read:
+        // 2-way bank conflicts like A; the adjacent-column mapping l31*4 + j puts all 32 lanes of a read on 4 bank
+        // pairs -- 8-way, 2.4e9 conflict cycles per step in the first PMC pass)
 #pragma unroll
-        for (int q = 0; q < 4; q++) b_idx[q] = (wn * 128 + l31 * TN) * BK + ((q ^ (l31 & 3)) * 4) + lh * 2;
+        for (int q = 0; q < 4; q++) b_idx[q] = (wn * 128 + l31) * BK + ((q ^ ((l31 >> SWA_SHIFT) & 3)) * 4) + lh * 2;
     } else {
         b_idx[0] = (lh * 2) * BN + wn * 128 + l31 * TN;        // [k][n]: row 4q + 2*lh + (kk & 1)
     }
@@ -239,7 +244,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         for (int i = 0; i < TM; i++) av[slot][i] = *reinterpret_cast<const float2 *>(as + a_idx[q & 3] + hi + i * 32 * BK);
         if constexpr (BT) {
 #pragma unroll
-            for (int j = 0; j < TN; j++) bt[slot][j] = *reinterpret_cast<const float2 *>(bs + b_idx[q & 3] + hi + j * BK);
+            for (int j = 0; j < TN; j++) bt[slot][j] = *reinterpret_cast<const float2 *>(bs + b_idx[q & 3] + hi + j * 32 * BK);
         } else {
             bf[slot][0] = *reinterpret_cast<const float4 *>(bs + b_idx[0] + (4 * q + 0) * BN);
             bf[slot][1] = *reinterpret_cast<const float4 *>(bs + b_idx[0] + (4 * q + 1) * BN);
@@ -280,11 +285,19 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         __syncthreads();
     }
 
-    // ---- epilogue: a lane holds, for each of its 2 x 16 rows, four consecutive output columns -> 16-byte stores.
+    float *slab_ = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+    if constexpr (BT) {
+        // data gradient: columns l31 + 32*j -> the LDS-staged vector epilogue of the round-1 kernels (igemm_common.h); the
+        // ring is dead after the last barrier
+        static_assert(CONS * 16 * (128 + 4) <= NBUF * (A_BUF + B_BUF), "epilogue slabs must fit in the ring");
+        store_acc_tile<TM, TN, 16, false>(a, acc, lds + wave * (16 * (128 + 4)), lane, m0 + wm * 64, n0 + wn * 128, slab_);
+        return;
+    }
+    // ---- forward epilogue: a lane holds, for each of its 2 x 16 rows, four consecutive output columns -> 16-byte stores.
     // C/D layout of the 32x32 MFMA: row in tile = (r&3) + 8*(r>>2) + 4*lh, column = l31 (here: column l31*4 + j).
     const int col = n0 + wn * 128 + l31 * TN;
     if (col >= a.N) return;   // N % 4 == 0: the quad is all in or all out
-    float *slab = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+    float *slab = slab_;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!slab && a.epi != EMADAPT_EPI_NONE && a.bias) bias4 = *reinterpret_cast<const float4 *>(a.bias + col);
 #pragma unroll
