@@ -524,7 +524,7 @@ class ADAPT(Network):
                 (torch.distributed.get_world_size() > 1 or self.config.get("force_gradsync", False)):
             from .dist import GradSync
             self._gradsync = GradSync(self._flat["accum"], [(s["start"], s["end"]) for s in self._bucket_order()],
-                                      bucket_bytes=int(self.config.get("bucket_mb", 64)) << 20)
+                                      bucket_bytes=int(self.config.get("bucket_mb", 32)) << 20)
 
     def _bucket_order(self):
         return [self._segments[op.name] for op in reversed(self._plan) if op.kind == "conv"]
