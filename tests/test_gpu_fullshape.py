@@ -206,7 +206,7 @@ def test_one_wide_filters_and_one_pixel_wide_maps(env):
     rng = np.random.default_rng(8)
     for (B, H, W, Cin, Cout, kh, kw, dil) in [(2, 9, 11, 16, 72, 3, 1, 1), (2, 9, 11, 16, 72, 1, 3, 2),
                                               (2, 1, 37, 16, 72, 3, 3, 1), (2, 37, 1, 16, 72, 3, 3, 2),
-                                              (1, 1, 1, 8, 8, 3, 3, 1)]:
+                                              (1, 1, 1, 8, 8, 3, 3, 1), (2, 9, 11, 32, 48, 3, 1, 2), (2, 9, 11, 32, 48, 1, 4, 1)]:
         x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
         w = rng.normal(0, 0.2, (kh, kw, Cin, Cout)).astype(np.float32)
         dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
@@ -216,6 +216,10 @@ def test_one_wide_filters_and_one_pixel_wide_maps(env):
         y.backward(torch.tensor(dy, dtype=torch.float64))
         xg, wg, dyg = _t(torch, x), _t(torch, w), _t(torch, dy)
         case = (B, H, W, Cin, Cout, kh, kw, dil)
-        assert _rel(ops.conv_fwd(xg, wg, None, dil).cpu(), y.detach()) < 2e-5, case
-        assert _rel(ops.conv_dgrad(dyg, wg, dil).cpu(), xt.grad) < 2e-5, case
-        assert _rel(ops.conv_wgrad(xg, dyg, kh, kw, dil).cpu(), wt.grad) < 2e-5, case
+        for variant in (0, 4):     # automatic plan, and the second-generation kernel's tap masks on non-square filters
+            with ops.tuned(fp32_tile=variant):
+                assert _rel(ops.conv_fwd(xg, wg, None, dil).cpu(), y.detach()) < 2e-5, (case, variant)
+                assert _rel(ops.conv_dgrad(dyg, wg, dil).cpu(), xt.grad) < 2e-5, (case, variant)
+        for gen in (0, 2):
+            with ops.tuned(wgrad_gen=gen):
+                assert _rel(ops.conv_wgrad(xg, dyg, kh, kw, dil).cpu(), wt.grad) < 2e-5, (case, gen)
