@@ -153,6 +153,68 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ 
     }
 }
 
+// The same gather, laid out by rows: one block walks (part of) one input row, so the image/row split of the index is
+// scalar work and each thread divides once (by CV, a multiply-high).  The windows that cover an input pixel are enumerated
+// directly -- for stride 2 the tap parity is fixed by the pixel's, which leaves at most 2 x 2 of the 9 taps, for stride 1
+// all 3 x 3 -- in the same (kh, kw) order as above, so the sums round identically.
+template <typename T, int STRIDE>
+__global__ void __launch_bounds__(256) maxpool_bwd_rows_kernel(const T *__restrict__ dy,
+                                                             const unsigned char *__restrict__ idx,
+                                                             const T *__restrict__ gate, int H, int W, int CV, int OH,
+                                                             int OW, int pt, int pl, unsigned cv_magic,
+                                                             T *__restrict__ dx) {
+    constexpr int N = VW<T>::N;
+    constexpr int NC = STRIDE == 2 ? 2 : 3;   // candidate taps per dimension
+    const int bh = blockIdx.x;
+    const int b = bh / H, h = bh - b * H;
+    int r_oh[NC], r_kh[NC];
+#pragma unroll
+    for (int a = 0; a < NC; a++) {
+        const int kh = STRIDE == 2 ? ((h + pt) & 1) + 2 * a : a;
+        const int th = h + pt - kh;
+        const int oh = STRIDE == 2 ? th >> 1 : th;
+        r_kh[a] = kh;
+        r_oh[a] = (kh < 3 && th >= 0 && oh < OH) ? oh : -1;
+    }
+    const int row_n = W * CV;
+    const long long row_base = (long long)bh * row_n;
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < row_n; t += gridDim.y * 256) {
+        const int w = (int)div_magic((unsigned)t, cv_magic);
+        const int cv = t - w * CV;
+        float acc[N];
+#pragma unroll
+        for (int e = 0; e < N; e++) acc[e] = 0.f;
+#pragma unroll
+        for (int a = 0; a < NC; a++) {
+            if (r_oh[a] < 0) continue;   // uniform over the block
+            const long long orow = ((long long)b * OH + r_oh[a]) * OW;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int kw = STRIDE == 2 ? ((w + pl) & 1) + 2 * c : c;
+                const int tw = w + pl - kw;
+                const int ow = STRIDE == 2 ? tw >> 1 : tw;
+                if (kw >= 3 || tw < 0 || ow >= OW) continue;
+                const long long o = ((orow + ow) * CV + cv) * N;
+                const typename ByteVec<N>::type id = *reinterpret_cast<const typename ByteVec<N>::type *>(idx + o);
+                float g[N];
+                ldv(dy + o, g);
+                const unsigned tap = r_kh[a] * 3 + kw;
+#pragma unroll
+                for (int e = 0; e < N; e++)
+                    if (((unsigned)(id >> (8 * e)) & 0xffu) == tap) acc[e] += g[e];
+            }
+        }
+        const long long xo = (row_base + t) * N;
+        if (gate) {
+            float g[N];
+            ldv(gate + xo, g);
+#pragma unroll
+            for (int e = 0; e < N; e++) acc[e] = g[e] > 0.f ? acc[e] : 0.f;
+        }
+        stv(dx + xo, acc);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // generic deterministic reductions
 // ------------------------------------------------------------------------------------------
@@ -193,7 +255,15 @@ __global__ void __launch_bounds__(256) bias_grad_partial_kernel(const T *__restr
 #pragma unroll
     for (int e = 0; e < N; e++) acc[e] = 0.f;
     if (q < NV) {
-        for (long long r = r0 + ty; r < r1; r += RL) {
+        long long r = r0 + ty;
+        for (; r + 3 * RL < r1; r += 4 * RL) {   // four independent 16-byte loads in flight per lane
+            float v[4][N];
+#pragma unroll
+            for (int u = 0; u < 4; u++) ldv(dy + ((r + u * RL) * NV + q) * N, v[u]);
+#pragma unroll
+            for (int e = 0; e < N; e++) acc[e] += (v[0][e] + v[1][e]) + (v[2][e] + v[3][e]);
+        }
+        for (; r < r1; r += RL) {
             float v[N];
             ldv(dy + (r * NV + q) * N, v);
 #pragma unroll
@@ -438,12 +508,22 @@ int maxpool_bwd_t(const T *dy, const uint8_t *idx, const T *gate, int B, int H, 
     const long long n = (long long)B * H * W * (C / N);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * N * sizeof(T) * (gate ? 2.0 : 1.0) + (double)B * OH * OW * C * (sizeof(T) + 1.0), stream);
-    if (n < (1LL << 31) - (1LL << 23))   // (headroom for the grid-stride increment)
-        hipLaunchKernelGGL((maxpool_bwd_kernel<T, unsigned>), dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, dy, idx, gate,
-                           B, H, W, C / N, stride, OH, OW, pt, pl, dx);
-    else
+    const long long rows = (long long)B * H, row_n = (long long)W * (C / N);
+    if (rows < (1LL << 31) && row_n * (C / N) < (1LL << 32) && row_n < (1LL << 30)) {   // (div_magic is exact for t * CV < 2^32)
+        long long chunks = ceil_div(row_n, 256);
+        const long long want = ceil_div(16384, rows);          // ~16 K blocks; rows of wide maps are walked in a loop
+        if (chunks > want) chunks = want;
+        const dim3 grid((unsigned)rows, (unsigned)chunks);
+        if (stride == 2)
+            hipLaunchKernelGGL((maxpool_bwd_rows_kernel<T, 2>), grid, dim3(256), 0, stream, dy, idx, gate, H, W, C / N, OH, OW,
+                               pt, pl, magic_u32(C / N), dx);
+        else
+            hipLaunchKernelGGL((maxpool_bwd_rows_kernel<T, 1>), grid, dim3(256), 0, stream, dy, idx, gate, H, W, C / N, OH, OW,
+                               pt, pl, magic_u32(C / N), dx);
+    } else {   // very wide channel counts: the generic index arithmetic
         hipLaunchKernelGGL((maxpool_bwd_kernel<T, long long>), dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, dy, idx,
                            gate, B, H, W, C / N, stride, OH, OW, pt, pl, dx);
+    }
     return launch_status();
 }
 

@@ -150,7 +150,13 @@ def test_split_k_path_keeps_the_fused_epilogue(env):
 
 
 @pytest.mark.parametrize("shape", [(2, 21, 21, 8, 2), (1, 16, 18, 16, 2), (2, 11, 11, 12, 1), (1, 41, 41, 64, 1),
-                                   (1, 33, 33, 4, 2)])
+                                   (1, 33, 33, 4, 2),
+                                   (2, 40, 50, 64, 2),          # even sizes: SAME pads only bottom/right
+                                   (3, 1, 9, 8, 2), (3, 9, 1, 8, 1), (2, 1, 1, 4, 2),
+                                   (40, 420, 40, 32, 2),        # > 16 K rows: one block per row, looping along it
+                                   (40, 420, 40, 32, 1),
+                                   (1, 3, 70, 32768, 2),        # W * (C/4)^2 >= 2^32: the generic-index gradient kernel
+                                   (1, 2, 70, 32768, 1)])
 def test_maxpool(env, shape):
     ops, do, torch = env
     B, H, W, C, stride = shape
