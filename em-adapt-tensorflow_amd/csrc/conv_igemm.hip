@@ -614,7 +614,13 @@ int launch_variant(int cfg, IgemmArgs &a, hipStream_t stream) {
     switch (cfg) {
         case 1: return launch_igemm<256, 64, 16, 64, BT>(a, stream);
         case 2: return launch_igemm<256, 256, 32, 128, BT>(a, stream);
-        case 4: return launch_igemm2<4, 2, 16, 4, 4, 3, BT>(a, stream);
+        case 4: {
+            const int nt = tune(TUNE_FP32_LOADER) == 1 ? 0 : a.ntaps;
+            if (nt == 1) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1>(a, stream);
+            if (nt == 9) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 9>(a, stream);
+            if (nt == 16) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 16>(a, stream);
+            return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 0>(a, stream);
+        }
         default: return launch_igemm_ws<BT>(a, stream);
     }
 }

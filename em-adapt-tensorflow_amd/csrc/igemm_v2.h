@@ -45,6 +45,12 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float *lds_base,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)lds_base, 16, (int)voffset, 0, 0, 0);
 }
 
+// The same with a wave-uniform byte offset added by the address unit (SGPR operand of the instruction): the per-lane
+// offset stays constant over the K loop, the loop only moves the scalar.
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, float *lds_base, unsigned voffset, unsigned soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)lds_base, 16, (int)voffset, (int)soffset, 0, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -52,7 +58,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // NBUF LDS buffers, tiles are fetched DIST K steps ahead of their use (NBUF >= DIST + 1): a DMA has DIST - 1 whole K steps
 // plus the rest of its own to land (with DIST = 1 the kernel ran at the mercy of the L2 / HBM latency: 66 % on conv4_x).
-template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT>
+// NT = filter taps the loaders are specialised for (1, 9, 16; 0 = any count up to 32, per-step vector arithmetic): with NT
+// known, a loader keeps one ready-made per-lane offset per (row group, tap) -- validity folded in as the out-of-range bit --
+// and a K step issues its DMAs with no vector instruction at all (the loaders share their SIMD's issue port with two MFMA waves).
+template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT, int NT>
 __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmArgs a) {
     constexpr int CONS = WMW * WNW;          // consumer (MFMA) waves
     constexpr int BM = WMW * 64, BN = WNW * 128;
@@ -103,7 +112,20 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         // ================================ LOADER wavefronts ================================
         const int lane = threadIdx.x & 63;
         const int pw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) - CONS);   // loader wave index (uniform)
-        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, (int)a.x_bytes, 0x00020000);
+        // The tap offset travels in the instruction's scalar operand, which the address unit adds as an UNSIGNED number: the
+        // buffer starts `bias` bytes before the tensor, so that offset + bias >= 0 for every tap (nothing below a.x is touched:
+        // lanes whose tap falls outside the image carry the out-of-range bit).
+        int min_dh = a.sign * (0 - a.pad_h), min_dw = a.sign * (0 - a.pad_w);
+        {
+            const int KH = a.ntaps / a.KW;
+            const int dh1 = a.sign * ((KH - 1) * a.dil - a.pad_h), dw1 = a.sign * ((a.KW - 1) * a.dil - a.pad_w);
+            min_dh = dh1 < min_dh ? dh1 : min_dh;
+            min_dw = dw1 < min_dw ? dw1 : min_dw;
+        }
+        const int min_sp = min_dh * a.W + min_dw;
+        const unsigned bias = NT > 0 && min_sp < 0 ? (unsigned)(-min_sp * a.Cx) * 4u : 0u;
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(a.x)) - bias, 0, (int)(a.x_bytes + bias), 0x00020000);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
         constexpr unsigned kOOB = 0x80000000u;
         // instruction j of this wave fills rows [(j*PW + pw)*RPI, +RPI) of the tile; lane -> (row in group, chunk position)
@@ -157,6 +179,14 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             }
         }
 
+        unsigned va[A_N][NT > 0 ? NT : 1];   // NT > 0: per-(row group, tap) offsets, out-of-range bit set where the tap is outside
+        if constexpr (NT > 0) {
+#pragma unroll
+            for (int j = 0; j < A_N; j++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) va[j][t] = a_off[j] | ((a_bad[j] >> t) & 1u ? kOOB : 0u);
+        }
+
         // Fill LDS buffer `buf` with the tile of K step kt (DMA; the caller awaits completion).
         auto fill = [&](int buf, int kt) {
             const unsigned chunk = __umulhi((unsigned)kt, a.magic_nt);
@@ -173,6 +203,22 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             else woff = (unsigned)((int)tap_u * a.N * a.Cx + (int)chunk_u * BK) * 4u;
             float *as = As + buf * A_BUF;
             float *bs = Bs + buf * B_BUF;
+            if constexpr (NT > 0) {
+                const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(toff + bias));
+                const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)woff);
+#pragma unroll
+                for (int j = 0; j < B_N; j++) {
+                    if constexpr (!BT) dma16s(wr, bs + (j * PW + pw) * 256, b_off[j], s_w);
+                    else dma16s(wr, bs + (j * PW + pw) * RPI * BK, b_off[j], s_w);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if (tap_u != (unsigned)t) continue;   // scalar compare chain: the tap is wave-uniform
+#pragma unroll
+                    for (int j = 0; j < A_N; j++) dma16s(xr, as + (j * PW + pw) * RPI * BK, va[j][t], s_x);
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < (A_N > B_N ? A_N : B_N); j++) {
                 if (j < A_N && !ABL(1)) dma16(xr, as + (j * PW + pw) * RPI * BK, (a_off[j] + toff) | ((a_bad[j] << sh) & kOOB));
@@ -207,7 +253,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
 
     // ================================ CONSUMER wavefronts ================================
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: kept in a scalar register)
     const int wm = wave % WMW, wn = wave / WMW;
     const int l31 = lane & 31, lh = lane >> 5;
     f32x16 acc[TM][TN];
@@ -228,17 +274,25 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         // 2-way bank conflicts like A; the adjacent-column mapping l31*4 + j puts all 32 lanes of a read on 4 bank
         // pairs -- 8-way, 2.4e9 conflict cycles per step in the first PMC pass)
 #pragma unroll
-        for (int q = 0; q < 4; q++) b_idx[q] = (wn * 128 + l31) * BK + ((q ^ ((l31 >> SWA_SHIFT) & 3)) * 4) + lh * 2;
+        for (int q = 0; q < 4; q++) {
+            // measured from the start of LDS and opaque to the optimiser: the rest of an address (ring position, column block)
+            // is then below 64 KB and rides in the instruction's offset field; folded together with the B region's 64 KB start
+            // it would not fit, and the compiler kept one address register per (chunk, ring position) -- and spilled
+            b_idx[q] = NBUF * A_BUF + (wn * 128 + l31) * BK + ((q ^ ((l31 >> SWA_SHIFT) & 3)) * 4) + lh * 2;
+            asm volatile("" : "+v"(b_idx[q]));
+        }
     } else {
         b_idx[0] = (lh * 2) * BN + wn * 128 + l31 * TN;        // [k][n]: row 4q + 2*lh + (kk & 1)
     }
     // the operands of k-pairs 2q and 2q+1 come from one 8-byte read per k-contiguous row, one 16-byte read per [k][n] row
+    // (the data gradient's four extra fragment addresses leave no room for the unrolled form: it spills, and measured slower)
+    constexpr bool UNROLL_RING = NT > 0;
     float2 av[2][TM];
     float2 bt[2][BT ? TN : 1];
     float4 bf[2][BT ? 1 : 2];
     auto read_q = [&](int buf, int q, int slot) {
         const float *as = As + buf * A_BUF;
-        const float *bs = Bs + buf * B_BUF;
+        const float *bs = (BT ? lds : Bs) + buf * B_BUF;   // (BT: b_idx already counts from the start of LDS)
         const int hi = (q >> 2) * 16;   // chunks 4..7 of a 32-float row
 #pragma unroll
         for (int i = 0; i < TM; i++) av[slot][i] = *reinterpret_cast<const float2 *>(as + a_idx[q & 3] + hi + i * 32 * BK);
@@ -252,14 +306,14 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     };
     __syncthreads();
     if (nk > 0) read_q(0, 0, 0);
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt % NBUF;
+    // one K step on buffer `cur`
+    auto k_step = [&](int cur, int nxt, bool more) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             // fragments one group ahead of the MFMAs; the last group of a step fetches the first one of the NEXT tile (it
             // landed before the previous barrier), so no LDS latency sits between a barrier and the MFMAs behind it
             if (q + 1 < NQ) read_q(cur, q + 1, (q + 1) & 1);
-            else if (kt + 1 < nk) read_q((kt + 1) % NBUF, 0, 0);
+            else if (more) read_q(nxt, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             const int s = q & 1;
 #pragma unroll
@@ -283,6 +337,19 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+    };
+    if constexpr (UNROLL_RING) {
+        // the ring position is a compile-time constant in the unrolled body: every LDS address is a register + immediate and
+        // the MFMA waves issue no vector-ALU instruction at all between their reads and MFMAs
+        for (int kt = 0; kt < nk; kt += NBUF) {
+#pragma unroll
+            for (int u = 0; u < NBUF; u++) {
+                if (kt + u >= nk) break;
+                k_step(u, (u + 1) % NBUF, kt + u + 1 < nk);
+            }
+        }
+    } else {
+        for (int kt = 0; kt < nk; kt++) k_step(kt % NBUF, (kt + 1) % NBUF, kt + 1 < nk);
     }
 
     float *slab_ = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
@@ -339,19 +406,19 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     }
 }
 
-template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT>
+template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT, int NT>
 int launch_igemm2(IgemmArgs &a, hipStream_t stream) {
     constexpr int BM = WMW * 64, BN = WNW * 128;
     constexpr int THREADS = (WMW * WNW + PW) * 64;
     constexpr size_t lds = sizeof(float) * NBUF * (BM + BN) * BK;
     static DynLdsAttr attr;
-    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT>), lds);
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT>), lds);
     if (rc) return rc;
     a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
     const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT>), dim3((unsigned)nblk), dim3(THREADS), lds, stream, a);
+    hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT>), dim3((unsigned)nblk), dim3(THREADS), lds, stream, a);
     rc = launch_status();
     if (rc || a.splits <= 1) return rc;
     return launch_splitk_epilogue(a, stream);
