@@ -206,8 +206,12 @@ __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
 // in memory, [pixel][k] and [pixel][n] -- the reduction index is the slow one, so ONE ds_read_b64 / ds_read_b128 with an
 // immediate offset brings a lane's operands of a k-pair (its tile rows are k = l31*2 + i, its tile columns n = l31*4 + j:
 // adjacent, not 32 apart) -- and are filled by LDS-DMA, 16 pixels per step, through a ring of 4 buffers fetched 3 steps
-// ahead.  A loader instruction is one pixel row of 256 k (resp. n): the pixel's (oh, ow) is wave-uniform (SALU), each
-// lane adds its own tap offset and bounds check (~7 VALU per instruction).
+// ahead.  A loader instruction is one pixel row of 256 k (resp. n): the pixel's (oh, ow) is wave-uniform (SALU).
+// UT ("uniform tap", Cin % 256 == 0: every layer this kernel is chosen for): the 256 k of a tile are one tap's channels, so
+// the tap's offset and its validity at the pixel are scalars too -- the per-lane offset is a constant, the row's offset rides
+// in the instruction's scalar operand and an out-of-image tap selects an empty buffer descriptor (all lanes read zeros): the
+// loaders issue no vector-ALU instruction per step.  Otherwise each lane adds its own tap offset and bounds check (4 VALU
+// per pixel row).  The MFMA waves' loop is unrolled over the ring like igemm2_kernel's (LDS addresses = register + immediate).
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int N>
@@ -217,6 +221,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 constexpr int W2_BMR = 16, W2_NBUF = 4, W2_DIST = 3, W2_CONS = 8, W2_PW = 4;
 
+template <bool UT>
 __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(WgradArgs a) {
     constexpr int BKO = 256, BN = 256, BMR = W2_BMR, NBUF = W2_NBUF, DIST = W2_DIST, CONS = W2_CONS, PW = W2_PW;
     constexpr int TK = 2, TN = 4;
@@ -270,11 +275,29 @@ __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(Wgrad
         const unsigned x_off = (unsigned)(((dh * a.W + dw) * a.Cin + c) * 4);
         const int n = n0 + lane * 4;
         const unsigned y_off = ((unsigned)n * 4u) | (n < a.N ? 0u : kOOB);
+        // UT: scalars of this tile's tap, per-lane constants
+        const int tap_s = k0 / a.Cin, c0_s = k0 - tap_s * a.Cin;
+        const int dh_s = (tap_s / a.KW) * a.dil - a.pad_h, dw_s = (tap_s % a.KW) * a.dil - a.pad_w;
+        const unsigned xv_c = ((unsigned)(c0_s + lane * 4) * 4u) | (kvalid ? 0u : kOOB);
+        const __amdgpu_buffer_rsrc_t nullr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, 0, 0x00020000);
         auto fill = [&](int buf, int st) {
             float *xs = Xs + buf * X_BUF, *ys = Ys + buf * Y_BUF;
 #pragma unroll
             for (int j = 0; j < IPW; j++) {
                 const int row = j * PW + pw;                       // pixel row of the step (wave-uniform)
+                if constexpr (UT) {
+                    const int m = __builtin_amdgcn_readfirstlane(m_begin + st * BMR + row);
+                    const unsigned t2 = div_magic((unsigned)m, a.magic_w);
+                    const int ow = m - (int)t2 * a.W;
+                    const int oh = (int)(t2 - div_magic(t2, a.magic_h) * (unsigned)a.H);
+                    const bool live = m < m_end;
+                    const bool ok = live && (unsigned)(oh + dh_s) < (unsigned)a.H && (unsigned)(ow + dw_s) < (unsigned)a.W;
+                    const unsigned sx = ok ? (unsigned)((m + dh_s * a.W + dw_s) * a.Cin) * 4u : 0u;
+                    const unsigned sy = live ? (unsigned)(m * a.N) * 4u : 0u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ok ? xr : nullr, (lds_void_t *)(xs + row * BKO), 16, (int)xv_c, (int)sx, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(live ? yr : nullr, (lds_void_t *)(ys + row * BN), 16, (int)y_off, (int)sy, 0, 0);
+                    continue;
+                }
                 const int m = m_begin + st * BMR + row;
                 const unsigned t2 = div_magic((unsigned)m, a.magic_w);   // pixel -> (oh, ow): scalar arithmetic
                 const int ow = m - (int)t2 * a.W;
@@ -309,7 +332,7 @@ __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(Wgrad
     }
 
     // ================================ CONSUMER wavefronts ================================
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave & 3, wn = wave >> 2;
     const int l31 = lane & 31, lh = lane >> 5;
     f32x16 acc[TK][TN];
@@ -319,42 +342,56 @@ __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(Wgrad
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    // per-lane fragment addresses (floats from the start of LDS); the y one is opaque to the optimiser so that ring position and
+    // row stay in the instructions' 16-bit offset fields instead of one address register per combination (see igemm_v2.h)
     const int x_idx = lh * BKO + wk * 64 + l31 * TK;
-    const int y_idx = lh * BN + wn * 128 + l31 * TN;
-    float2 xv[2];
-    float4 yv[2];
-    __syncthreads();
-    if (nsteps > 0) {
-        xv[0] = *reinterpret_cast<const float2 *>(Xs + x_idx);
-        yv[0] = *reinterpret_cast<const float4 *>(Ys + y_idx);
-    }
-    for (int st = 0; st < nsteps; st++) {
-        const int cur = st % NBUF, nxt = (st + 1) % NBUF;
-        const float *xs = Xs + cur * X_BUF + x_idx;
-        const float *ys = Ys + cur * Y_BUF + y_idx;
+    int y_idx = NBUF * X_BUF + lh * BN + wn * 128 + l31 * TN;
+    asm volatile("" : "+v"(y_idx));
+    // fragments are fetched in groups of two k-pairs (pixel rows 4g + lh and 4g + 2 + lh): one two-address 8-byte read for x,
+    // two 16-byte reads for dy per sixteen MFMAs
+    constexpr int NG = BMR / 4;
+    float2 xv[2][2];
+    float4 yv[2][2];
+    auto read_g = [&](int buf, int g, int slot) {
+        const float *xs = lds + buf * X_BUF + x_idx + g * 4 * BKO;
+        const float *ys = lds + buf * Y_BUF + y_idx + g * 4 * BN;
 #pragma unroll
-        for (int kk = 0; kk < BMR / 2; kk++) {
-            if (kk + 1 < BMR / 2) {
-                xv[(kk + 1) & 1] = *reinterpret_cast<const float2 *>(xs + (kk + 1) * 2 * BKO);
-                yv[(kk + 1) & 1] = *reinterpret_cast<const float4 *>(ys + (kk + 1) * 2 * BN);
-            } else if (st + 1 < nsteps) {   // first fragments of the next step (landed before the previous barrier)
-                xv[0] = *reinterpret_cast<const float2 *>(Xs + nxt * X_BUF + x_idx);
-                yv[0] = *reinterpret_cast<const float4 *>(Ys + nxt * Y_BUF + y_idx);
-            }
+        for (int h = 0; h < 2; h++) {
+            xv[slot][h] = *reinterpret_cast<const float2 *>(xs + h * 2 * BKO);
+            yv[slot][h] = *reinterpret_cast<const float4 *>(ys + h * 2 * BN);
+        }
+    };
+    __syncthreads();
+    if (nsteps > 0) read_g(0, 0, 0);
+    auto k_step = [&](int cur, int nxt, bool more) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            if (g + 1 < NG) read_g(cur, g + 1, (g + 1) & 1);
+            else if (more) read_g(nxt, 0, 0);   // first fragments of the next step (landed before the previous barrier)
             __builtin_amdgcn_sched_barrier(0);
-            const float2 x2 = xv[kk & 1];
-            const float4 y4 = yv[kk & 1];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.y, acc[0][1], 0, 0, 0);
-            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.z, acc[0][2], 0, 0, 0);
-            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.w, acc[0][3], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.y, acc[1][1], 0, 0, 0);
-            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.z, acc[1][2], 0, 0, 0);
-            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.w, acc[1][3], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float2 x2 = xv[g & 1][h];
+                const float4 y4 = yv[g & 1][h];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.y, acc[0][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.z, acc[0][2], 0, 0, 0);
+                acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.x, y4.w, acc[0][3], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.y, acc[1][1], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.z, acc[1][2], 0, 0, 0);
+                acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(x2.y, y4.w, acc[1][3], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+    };
+    for (int st = 0; st < nsteps; st += NBUF) {
+#pragma unroll
+        for (int u = 0; u < NBUF; u++) {
+            if (st + u >= nsteps) break;
+            k_step(u, (u + 1) % NBUF, st + u + 1 < nsteps);
+        }
     }
     // tile row of the 32x32 MFMA = (r&3) + 8*(r>>2) + 4*lh -> filter row k0 + wk*64 + row*2 + i; the lane's four
     // accumulator tiles j are four adjacent filter columns: 16-byte stores
@@ -439,14 +476,15 @@ int launch_wgrad(const WgradArgs &a, hipStream_t stream) {
     return launch_status();
 }
 
+template <bool UT>
 int launch_wgrad2(const WgradArgs &a, hipStream_t stream) {
     constexpr size_t lds = sizeof(float) * W2_NBUF * W2_BMR * (256 + 256);
     static DynLdsAttr attr;
-    int rc = attr.ensure(reinterpret_cast<const void *>(&wgrad2_kernel), lds);
+    int rc = attr.ensure(reinterpret_cast<const void *>(&wgrad2_kernel<UT>), lds);
     if (rc) return rc;
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(wgrad2_kernel, dim3((unsigned)nblk), dim3((W2_CONS + W2_PW) * 64), lds, stream, a);
+    hipLaunchKernelGGL(wgrad2_kernel<UT>, dim3((unsigned)nblk), dim3((W2_CONS + W2_PW) * 64), lds, stream, a);
     return launch_status();
 }
 
@@ -487,7 +525,8 @@ int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    rc = p.gen == 2 ? launch_wgrad2(a, stream) : (p.bn == 64) ? launch_wgrad<64>(a, stream) : launch_wgrad<128>(a, stream);
+    const bool ut = d->Cin % 256 == 0 && tune(TUNE_FP32_LOADER) != 1;   // a 256-wide k tile lies inside one tap
+    rc = p.gen == 2 ? (ut ? launch_wgrad2<true>(a, stream) : launch_wgrad2<false>(a, stream)) : (p.bn == 64) ? launch_wgrad<64>(a, stream) : launch_wgrad<128>(a, stream);
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
     return rc;
