@@ -580,9 +580,16 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
         split4 = t4 < t3 * 0.98;
     }
     int cfg = a.N <= 64 ? 1 : big ? (v2_ok(a, 16) ? 4 : 2) : split4 ? 4 : 3;
-    if (force >= 1 && force <= 4 && !(force == 4 && !v2_ok(a, 16))) cfg = force;
+    // Variant 5 = the 256x256 kernel with the stream-K work split (igemm_v2.h): whenever the tile count is not a whole number
+    // of rounds and every CU still gets a few dozen K steps.  N <= 1024 bounds the slab levels ([rows][N] each); the
+    // N = 4096 layers keep the rows-of-whole-rounds + tail plan (8 % of their rows run on the 128x128 kernel).
+    const int nk16 = a.K / 16;
+    if (cfg != 1 && v2_ok(a, 16) && a.N >= 256 && a.N <= 1024 && t256 % cus != 0 && t256 * nk16 / cus >= 32) cfg = 5;
+    if (force >= 1 && force <= 5 && !(force >= 4 && !v2_ok(a, 16))) cfg = force;
     p.cfg = cfg;
-    if (cfg == 4 && t256 < cus) {
+    if (cfg == 5) {
+        p.main_splits = streamk_levels(t256, nk16, cus);   // slab levels (0: every tile is run by one workgroup)
+    } else if (cfg == 4 && t256 < cus) {
         p.main_splits = choose_splits(a.M, a.N, a.K, 256, 256, 16, 256.0, 142e12);
     } else if (cfg == 2 || cfg == 4) {
         const long long tn = ceil_div(a.N, 256), tm = ceil_div(a.M, 256);
@@ -603,6 +610,7 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
 
 size_t igemm_workspace_bytes(const IgemmArgs &a) {
     const LaunchPlan p = plan_launches(a);
+    if (p.cfg == 5) return (size_t)p.main_splits * a.M * a.N * sizeof(float);
     size_t b = p.main_splits > 1 ? (size_t)p.main_splits * p.main_rows * a.N * sizeof(float) : 0;
     if (p.tail_splits > 1) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
     return b;
@@ -616,10 +624,17 @@ int launch_variant(int cfg, IgemmArgs &a, hipStream_t stream) {
         case 2: return launch_igemm<256, 256, 32, 128, BT>(a, stream);
         case 4: {
             const int nt = tune(TUNE_FP32_LOADER) == 1 ? 0 : a.ntaps;
-            if (nt == 1) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1>(a, stream);
-            if (nt == 9) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 9>(a, stream);
-            if (nt == 16) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 16>(a, stream);
-            return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 0>(a, stream);
+            if (nt == 1) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1, false>(a, stream);
+            if (nt == 9) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 9, false>(a, stream);
+            if (nt == 16) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 16, false>(a, stream);
+            return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 0, false>(a, stream);
+        }
+        case 5: {   // (a.splits = workgroups, a.slab = slab levels: dispatch_igemm)
+            const int nt = tune(TUNE_FP32_LOADER) == 1 ? 0 : a.ntaps;
+            if (nt == 1) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1, true>(a, stream);
+            if (nt == 9) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 9, true>(a, stream);
+            if (nt == 16) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 16, true>(a, stream);
+            return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 0, true>(a, stream);
         }
         default: return launch_igemm_ws<BT>(a, stream);
     }
@@ -634,8 +649,16 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
 #endif
     LaunchPlan p = plan_launches(a);
     if (!workspace || workspace_bytes < igemm_workspace_bytes(a)) {  // no room for slabs: unsplit, same result
-        p.main_splits = 1;
+        if (p.cfg == 5 && p.main_splits > 0) p.cfg = 3;
+        if (p.cfg != 5) p.main_splits = 1;
         if (p.tail_splits > 1) p.tail_splits = 1;
+    }
+    if (p.cfg == 5) {
+        a.m_begin = 0;
+        a.m_end = a.M;
+        a.splits = plan_cus();
+        a.slab = p.main_splits > 0 ? static_cast<float *>(workspace) : nullptr;
+        return launch_variant<BT>(5, a, stream);
     }
     a.m_begin = 0;
     a.m_end = p.main_rows;

@@ -91,7 +91,8 @@ __device__ __forceinline__ float epilogue(const IgemmArgs &a, float v, int col, 
 //   YBF  = output (and gate) stored as bf16 (N % 8 == 0), else f32 (N % 4 == 0)
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-template <int TM, int TN, int ROWS, bool YBF>
+//   ADJ  = the lane's TN accumulator tiles are TN ADJACENT columns (column l31*TN + j) instead of l31 + 32*j
+template <int TM, int TN, int ROWS, bool YBF, bool ADJ = false>
 __device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 (&acc)[TM][TN], float *stage, int lane,
                                                int row0, int col0, float *slab) {
     constexpr int WN = TN * 32;
@@ -108,7 +109,7 @@ __device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 
 #pragma unroll
                 for (int rr = 0; rr < ROWS / 2; rr++) {
                     const int r = h * (ROWS / 2) + rr;  // accumulator register; its row inside the slab:
-                    stage[((r & 3) + 8 * ((r >> 2) % (ROWS / 8)) + 4 * lh) * SP + j * 32 + l31] = acc[i][j][r];
+                    stage[((r & 3) + 8 * ((r >> 2) % (ROWS / 8)) + 4 * lh) * SP + (ADJ ? l31 * TN + j : j * 32 + l31)] = acc[i][j][r];
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

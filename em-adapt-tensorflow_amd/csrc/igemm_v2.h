@@ -56,12 +56,20 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Stream-K work split (SK kernels): the K steps of all tiles, tile after tile, form one line of U = tiles * nk units that
+// is cut into G equal pieces, one per workgroup (G = number of CUs): a workgroup runs the tail of one tile, possibly whole
+// tiles, and the head of the next.  Whole tiles get the fused epilogue; a piece of a tile goes to slab level
+// (workgroup - first workgroup of that tile), and streamk_fixup_kernel adds a tile's pieces in workgroup order
+// (= ascending k: deterministic) and applies the epilogue.  No CU idles in a partial last round, whatever the tile count.
+__host__ __device__ inline long long sk_start(long long v, long long U, int G) { return v * U / G; }
+__host__ __device__ inline int sk_owner(long long u, long long U, int G) { return (int)(((u + 1) * G - 1) / U); }   // piece holding unit u
+
 // NBUF LDS buffers, tiles are fetched DIST K steps ahead of their use (NBUF >= DIST + 1): a DMA has DIST - 1 whole K steps
 // plus the rest of its own to land (with DIST = 1 the kernel ran at the mercy of the L2 / HBM latency: 66 % on conv4_x).
 // NT = filter taps the loaders are specialised for (1, 9, 16; 0 = any count up to 32, per-step vector arithmetic): with NT
 // known, a loader keeps one ready-made per-lane offset per (row group, tap) -- validity folded in as the out-of-range bit --
 // and a K step issues its DMAs with no vector instruction at all (the loaders share their SIMD's issue port with two MFMA waves).
-template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT, int NT>
+template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT, int NT, bool SK>
 __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmArgs a) {
     constexpr int CONS = WMW * WNW;          // consumer (MFMA) waves
     constexpr int BM = WMW * 64, BN = WNW * 128;
@@ -84,29 +92,57 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     float *As = lds;                     // [NBUF][A_BUF]
     float *Bs = lds + NBUF * A_BUF;      // [NBUF][B_BUF]
 
-    // XCD-aware tile order (see igemm_kernel)
-    int tile_m, tile_n, split;
+    // Work of this workgroup: one (tile, K range) piece, or with SK a sequence of them (next_piece()).
+    const int nk_all = a.K / BK;  // Cx % BK == 0: every K step is one tap x one BK-channel chunk
+    int tile_m = 0, tile_n = 0, kt0 = 0, nk = 0;
+    int lvl = -1;                 // slab level the piece's partial sums go to; -1: the whole reduction -> fused epilogue
+    int sk_u = 0, sk_end = 0, sk_units = 0;   // (tiles * nk_all < 2^31: checked by the launcher)
+    int sk_v = 0;
     {
+        // XCD-aware order (see igemm_kernel): consecutive work items run on one XCD and share operands in its L2
         const int ntile = a.tiles_m * a.tiles_n;
-        const int nblk = ntile * a.splits;
+        const int nblk = SK ? (int)gridDim.x : ntile * a.splits;
         const int bid = blockIdx.x;
         const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
         int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        split = t / ntile;
-        t -= split * ntile;
-        constexpr int GM = 8;
-        const int per_group = GM * a.tiles_n;
-        const int g = t / per_group;
-        const int first_m = g * GM;
-        const int gsz = (a.tiles_m - first_m < GM) ? (a.tiles_m - first_m) : GM;
-        const int in_g = t - g * per_group;
-        tile_m = first_m + in_g % gsz;
-        tile_n = in_g / gsz;
+        if constexpr (SK) {
+            // (wave-uniform values that come out of vector-ALU divisions are moved to scalar registers by hand: left in vector
+            // registers, the piece list's state spilled the accumulators)
+            sk_v = t;
+            sk_units = ntile * nk_all;
+            sk_u = __builtin_amdgcn_readfirstlane((int)sk_start(t, sk_units, nblk));
+            sk_end = __builtin_amdgcn_readfirstlane((int)sk_start(t + 1, sk_units, nblk));
+        } else {
+            const int split = t / ntile;
+            t -= split * ntile;
+            constexpr int GM = 8;
+            const int per_group = GM * a.tiles_n;
+            const int g = t / per_group;
+            const int first_m = g * GM;
+            const int gsz = (a.tiles_m - first_m < GM) ? (a.tiles_m - first_m) : GM;
+            const int in_g = t - g * per_group;
+            tile_m = first_m + in_g % gsz;
+            tile_n = in_g / gsz;
+            kt0 = (int)((long long)nk_all * split / a.splits);
+            nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
+            lvl = a.splits > 1 ? split : -1;
+        }
     }
-    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
-    const int nk_all = a.K / BK;  // Cx % BK == 0: every K step is one tap x one BK-channel chunk
-    const int kt0 = (int)((long long)nk_all * split / a.splits);
-    const int nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
+    auto next_piece = [&]() -> bool {   // SK: the next piece of [sk_u, sk_end); every wave of the workgroup walks the same list
+        if (sk_u >= sk_end) return false;
+        const int t = __builtin_amdgcn_readfirstlane(sk_u / nk_all);
+        kt0 = sk_u - t * nk_all;
+        const int left = sk_end - sk_u;
+        nk = (nk_all - kt0 < left) ? nk_all - kt0 : left;
+        tile_m = __builtin_amdgcn_readfirstlane(t / a.tiles_n);
+        tile_n = t - tile_m * a.tiles_n;
+        lvl = nk == nk_all ? -1 : sk_v - __builtin_amdgcn_readfirstlane(sk_owner((long long)t * nk_all, sk_units, (int)gridDim.x));
+        sk_u += nk;
+        return true;
+    };
+    if constexpr (SK) {
+        if (!next_piece()) return;   // (more workgroups than units: nothing to do, for every wave alike)
+    }
 
     if (threadIdx.x >= CONS * 64) {
         // ================================ LOADER wavefronts ================================
@@ -130,6 +166,8 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         constexpr unsigned kOOB = 0x80000000u;
         // instruction j of this wave fills rows [(j*PW + pw)*RPI, +RPI) of the tile; lane -> (row in group, chunk position)
         const int rl = lane / CPR, pos = lane % CPR;
+        do {   // one piece of work (SK: several)
+        const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
         unsigned a_off[A_N], a_bad[A_N];
 #pragma unroll
         for (int j = 0; j < A_N; j++) {
@@ -248,6 +286,8 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             }
             __builtin_amdgcn_s_barrier();
         }
+        if constexpr (SK) __builtin_amdgcn_s_barrier();   // the MFMA waves are done with the ring (their epilogue may stage through it)
+        } while (SK && next_piece());
         return;
     }
 
@@ -257,12 +297,6 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     const int wm = wave % WMW, wn = wave / WMW;
     const int l31 = lane & 31, lh = lane >> 5;
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     // Fragment addresses (float indices inside a buffer) for the chunks q = 0..3; chunk q + 4 (BK = 32) is 16 floats on,
     // the wave's second row block 32 rows on, the dgrad filter's columns j one row on: all immediates.
     const int arow = wm * 64 + l31;
@@ -304,8 +338,6 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             bf[slot][1] = *reinterpret_cast<const float4 *>(bs + b_idx[0] + (4 * q + 1) * BN);
         }
     };
-    __syncthreads();
-    if (nk > 0) read_q(0, 0, 0);
     // one K step on buffer `cur`
     auto k_step = [&](int cur, int nxt, bool more) {
 #pragma unroll
@@ -338,6 +370,16 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         }
         __syncthreads();
     };
+    do {   // one piece of work (SK: several)
+    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    __syncthreads();
+    if (nk > 0) read_q(0, 0, 0);
     if constexpr (UNROLL_RING) {
         // the ring position is a compile-time constant in the unrolled body: every LDS address is a register + immediate and
         // the MFMA waves issue no vector-ALU instruction at all between their reads and MFMAs
@@ -352,76 +394,152 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         for (int kt = 0; kt < nk; kt++) k_step(kt % NBUF, (kt + 1) % NBUF, kt + 1 < nk);
     }
 
-    float *slab_ = a.splits > 1 ? a.slab + ((long long)split * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+    float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+    // the epilogue derives its lane coordinates afresh (opaque to the optimiser): hoisted out of the piece loop they would
+    // stay live through the MFMA loop, which has no vector register to spare (the compiler then spills operand fragments)
+    int lane_e = tid & 63;
+    asm volatile("" : "+v"(lane_e));
+    const int l31e = lane_e & 31, lhe = lane_e >> 5;
     if constexpr (BT) {
         // data gradient: columns l31 + 32*j -> the LDS-staged vector epilogue of the round-1 kernels (igemm_common.h); the
         // ring is dead after the last barrier
         static_assert(CONS * 16 * (128 + 4) <= NBUF * (A_BUF + B_BUF), "epilogue slabs must fit in the ring");
-        store_acc_tile<TM, TN, 16, false>(a, acc, lds + wave * (16 * (128 + 4)), lane, m0 + wm * 64, n0 + wn * 128, slab_);
-        return;
-    }
-    // ---- forward epilogue: a lane holds, for each of its 2 x 16 rows, four consecutive output columns -> 16-byte stores.
-    // C/D layout of the 32x32 MFMA: row in tile = (r&3) + 8*(r>>2) + 4*lh, column = l31 (here: column l31*4 + j).
-    const int col = n0 + wn * 128 + l31 * TN;
-    if (col >= a.N) return;   // N % 4 == 0: the quad is all in or all out
-    float *slab = slab_;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!slab && a.epi != EMADAPT_EPI_NONE && a.bias) bias4 = *reinterpret_cast<const float4 *>(a.bias + col);
+        store_acc_tile<TM, TN, 16, false>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+    } else if constexpr (SK) {
+        // (forward, stream-K: the same staged epilogue with the adjacent-column mapping -- inside the piece loop the direct
+        // form below made the compiler spill operand fragments in the MFMA loop)
+        store_acc_tile<TM, TN, 16, false, true>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+    } else {
+        // ---- forward epilogue: a lane holds, for each of its 2 x 16 rows, four consecutive output columns -> 16-byte stores.
+        // C/D layout of the 32x32 MFMA: row in tile = (r&3) + 8*(r>>2) + 4*lh, column = l31 (here: column l31*4 + j).
+        const int col = n0 + wn * 128 + l31e * TN;
+        float *slab = slab_;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < a.N && !slab && a.epi != EMADAPT_EPI_NONE && a.bias) bias4 = *reinterpret_cast<const float4 *>(a.bias + col);
+        if (col < a.N) {   // N % 4 == 0: the quad is all in or all out
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
+            for (int i = 0; i < TM; i++) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row >= a.m_end) continue;
-            const long long o = (long long)row * a.N + col;
-            float v[4] = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-            if (slab) {
-                *reinterpret_cast<float4 *>(slab + o) = make_float4(v[0], v[1], v[2], v[3]);
-                continue;
-            }
-            v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;   // (bias4 = 0 when there is no bias)
-            if (a.epi == EMADAPT_EPI_BIAS_RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                if (a.keep < 1.0f) {
-                    unsigned mk = 0;
-                    if (a.mask) mk = *reinterpret_cast<const unsigned *>(a.mask + o);   // four keep bytes (o % 4 == 0)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const bool kp = a.mask ? (((mk >> (8 * e)) & 0xFFu) != 0)
-                                               : dropout_keep(a.seed, (unsigned long long)(o + e), a.keep);
-                        v[e] = kp ? v[e] / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
+                for (int r = 0; r < 16; r++) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhe;
+                    if (row >= a.m_end) continue;
+                    const long long o = (long long)row * a.N + col;
+                    float v[4] = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                    if (slab) {
+                        *reinterpret_cast<float4 *>(slab + o) = make_float4(v[0], v[1], v[2], v[3]);
+                        continue;
                     }
+                    v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;   // (bias4 = 0 when there is no bias)
+                    if (a.epi == EMADAPT_EPI_BIAS_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        if (a.keep < 1.0f) {
+                            unsigned mk = 0;
+                            if (a.mask) mk = *reinterpret_cast<const unsigned *>(a.mask + o);   // four keep bytes (o % 4 == 0)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const bool kp = a.mask ? (((mk >> (8 * e)) & 0xFFu) != 0)
+                                                       : dropout_keep(a.seed, (unsigned long long)(o + e), a.keep);
+                                v[e] = kp ? v[e] / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
+                            }
+                        }
+                    }
+                    if (a.gate) {
+                        const float4 g = *reinterpret_cast<const float4 *>(a.gate + o);
+                        v[0] = g.x > 0.f ? v[0] * a.scale : 0.f;
+                        v[1] = g.y > 0.f ? v[1] * a.scale : 0.f;
+                        v[2] = g.z > 0.f ? v[2] * a.scale : 0.f;
+                        v[3] = g.w > 0.f ? v[3] * a.scale : 0.f;
+                    }
+                    *reinterpret_cast<float4 *>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
-            if (a.gate) {
-                const float4 g = *reinterpret_cast<const float4 *>(a.gate + o);
-                v[0] = g.x > 0.f ? v[0] * a.scale : 0.f;
-                v[1] = g.y > 0.f ? v[1] * a.scale : 0.f;
-                v[2] = g.z > 0.f ? v[2] * a.scale : 0.f;
-                v[3] = g.w > 0.f ? v[3] * a.scale : 0.f;
-            }
-            *reinterpret_cast<float4 *>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
         }
+    }
+    if constexpr (SK) __syncthreads();   // pairs with the loaders' barrier: the ring may be refilled
+    } while (SK && next_piece());
+}
+
+// Stream-K second stage: the tiles that more than one workgroup worked on.  One block = 16 rows of one 256 x 256 tile.
+__global__ void __launch_bounds__(256) streamk_fixup_kernel(IgemmArgs a, int G, int nk_all) {
+    const int t = blockIdx.x >> 4, part = blockIdx.x & 15;
+    const long long U = (long long)a.tiles_m * a.tiles_n * nk_all;
+    const int vf = sk_owner((long long)t * nk_all, U, G), vl = sk_owner((long long)(t + 1) * nk_all - 1, U, G);
+    const int cnt = vl - vf + 1;
+    if (cnt <= 1) return;   // one workgroup ran the whole reduction of this tile and wrote it with the fused epilogue
+    const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
+    const long long mn = (long long)(a.m_end - a.m_begin) * a.N;   // one slab level
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int idx = it * 256 + threadIdx.x;
+        const int row = a.m_begin + tile_m * 256 + part * 16 + (idx >> 6);
+        const int col = tile_n * 256 + (idx & 63) * 4;
+        if (row >= a.m_end || col >= a.N) continue;
+        const long long o = (long long)row * a.N + col;
+        const float *sp = a.slab + (o - (long long)a.m_begin * a.N);
+        float4 v = *reinterpret_cast<const float4 *>(sp);
+        for (int l = 1; l < cnt; l++) {
+            const float4 u = *reinterpret_cast<const float4 *>(sp + l * mn);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        v.x = epilogue(a, v.x, col + 0, o + 0);
+        v.y = epilogue(a, v.y, col + 1, o + 1);
+        v.z = epilogue(a, v.z, col + 2, o + 2);
+        v.w = epilogue(a, v.w, col + 3, o + 3);
+        *reinterpret_cast<float4 *>(a.y + o) = v;
     }
 }
 
-template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT, int NT>
+// Workgroups of a stream-K launch: one per CU, but never more than units (every piece list is then non-empty, so the
+// workgroups of a tile are consecutive and its slab levels dense).
+inline int streamk_grid(long long tiles, int nk_all, int cus) {
+    const long long U = tiles * nk_all;
+    return (int)(U < cus ? (U > 0 ? U : 1) : cus);
+}
+
+// Slab levels a stream-K launch over `tiles` tiles of nk_all K steps on `cus` CUs needs (0: every tile is whole).
+inline int streamk_levels(long long tiles, int nk_all, int cus) {
+    const long long U = tiles * nk_all;
+    const int G = streamk_grid(tiles, nk_all, cus);
+    int levels = 0;
+    for (long long t = 0; t < tiles; t++) {
+        const int cnt = sk_owner((t + 1) * nk_all - 1, U, G) - sk_owner(t * nk_all, U, G) + 1;
+        if (cnt > 1 && cnt > levels) levels = cnt;
+    }
+    return levels;
+}
+
+template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT, int NT, bool SK>
 int launch_igemm2(IgemmArgs &a, hipStream_t stream) {
     constexpr int BM = WMW * 64, BN = WNW * 128;
     constexpr int THREADS = (WMW * WNW + PW) * 64;
     constexpr size_t lds = sizeof(float) * NBUF * (BM + BN) * BK;
     static DynLdsAttr attr;
-    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT>), lds);
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT, SK>), lds);
     if (rc) return rc;
     a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
-    const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
-    if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT>), dim3((unsigned)nblk), dim3(THREADS), lds, stream, a);
-    rc = launch_status();
-    if (rc || a.splits <= 1) return rc;
-    return launch_splitk_epilogue(a, stream);
+    if constexpr (SK) {
+        // a.splits = CUs to lay the pieces out for, a.slab = streamk_levels(...) slabs of [rows][N]
+        const int nk_all = a.K / BK;
+        const long long tiles = (long long)a.tiles_m * a.tiles_n;
+        if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * 16 > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        const int G = streamk_grid(tiles, nk_all, a.splits);
+        const int levels = streamk_levels(tiles, nk_all, a.splits);
+        if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
+        hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT, true>), dim3((unsigned)G), dim3(THREADS), lds, stream, a);
+        rc = launch_status();
+        if (rc || levels == 0) return rc;
+        hipLaunchKernelGGL(streamk_fixup_kernel, dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, a, G, nk_all);
+        return launch_status();
+    } else {
+        const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
+        if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT, false>), dim3((unsigned)nblk), dim3(THREADS), lds, stream, a);
+        rc = launch_status();
+        if (rc || a.splits <= 1) return rc;
+        return launch_splitk_epilogue(a, stream);
+    }
 }
 
 }  // namespace

@@ -43,13 +43,13 @@ def _t(torch, a, dtype=None):
 
 # name, (B, H, W, Cin, Cout, k, dil), expected forward plan variant, expected dgrad plan variant
 FULL_SHAPES = [
-    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 4, 4),      # deeplab.py:92,145: 44.8 % of the MACs (dgrad: variant 4 split-K)
+    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 4, 5),      # deeplab.py:92,145: 44.8 % of the MACs (dgrad: 212 tiles, stream-K)
     ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 4, 4),     # deeplab.py:95,147
     ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 2),       # deeplab.py:95,149 (21 classes padded to 24: dgrad K = 24)
-    ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 3, 3),   # few tiles: split-K by 3 on 844 tiles
-    ("conv5_2", (16, 41, 41, 512, 512, 3, 2), 3, 3),   # atrous rate 2 (deeplab.py:65)
-    ("conv3_2", (16, 81, 81, 256, 256, 3, 1), 4, 4),   # 411 tiles of 256x256: one whole round + a tail
-    ("conv3_1", (16, 81, 81, 128, 256, 3, 1), 4, 3),   # dgrad has N = 128
+    ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 5, 5),   # 212 tiles of 256x256 on 256 CUs: stream-K pieces of 238.5 K steps
+    ("conv5_2", (16, 41, 41, 512, 512, 3, 2), 5, 5),   # atrous rate 2 (deeplab.py:65)
+    ("conv3_2", (16, 81, 81, 256, 256, 3, 1), 5, 5),   # 411 tiles: 1.6 rounds -> stream-K
+    ("conv3_1", (16, 81, 81, 128, 256, 3, 1), 5, 3),   # dgrad has N = 128
 ]
 
 
@@ -62,10 +62,10 @@ def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgra
     assert pf[0] == fwd_variant and pd[0] == dgrad_variant, (pf, pd)
     if fwd_variant in (2, 4):  # rows of whole rounds on 256x256 tiles + a split launch of smaller tiles over the rest
         assert 0 < pf[1] < B * H * W and pf[1] % 256 == 0 and pf[3] >= 1, pf
-    if name.startswith("conv4") or name.startswith("conv5"):
-        assert pf[2] > 1 and pd[2] > 1, (pf, pd)     # split-K plans
+    if fwd_variant == 5:
+        assert pf[1] == B * H * W and pf[2] >= 2 and pf[3] == 0, pf     # one launch over all rows, >= 2 slab levels
     if name == "fc6":
-        assert pd[1] == B * H * W and pd[2] > 1, pd  # 212 big tiles on 256 CUs: split-K over the 65536-long reduction
+        assert pd[1] == B * H * W and pd[2] >= 2, pd  # 212 big tiles on 256 CUs: pieces of the 65536-long reductions
 
     rng = np.random.default_rng(__import__("zlib").crc32(name.encode()))
     fan_in = k * k * Cin
@@ -140,12 +140,14 @@ SMALL = [
     (1, 37, 35, 272, 48, 3, 2),     # channels % 16 == 0 but not % 32
     (3, 17, 19, 96, 544, 1, 1),     # 1x1 (one tap), N tail of the 256-wide tile
     (2, 21, 21, 32, 160, 4, 4),     # 16 taps, dilation 4
+    (1, 19, 17, 256, 272, 3, 2),    # Cin % 256 == 0: the filter-gradient loaders' uniform-tap form, with out-of-image taps
+    (2, 11, 13, 512, 264, 1, 1),    # the same for a 1x1 filter (two k tiles inside the one tap)
 ]
 
 
 def _eligible(variant, Cx, k):
     """csrc/conv_igemm.hip v2_ok: what a forced second-generation variant needs (otherwise the automatic plan is used)."""
-    bk = {4: 16}.get(variant)
+    bk = {4: 16, 5: 16}.get(variant)
     return bk is None or (Cx % bk == 0 and k * k <= 32 and k * k * Cx >= 2 * bk)
 
 
@@ -172,9 +174,14 @@ def test_every_plan_variant_on_small_awkward_shapes(env, shape):
     seen = set()
     # variant x CU count the plan is laid out for x forced split-K: reaches row splits at m_begin > 0, partial last
     # tiles in both launches, and the tail launch's slab at workspace offset 0
-    for variant, cus, splitk in [(1, 0, 0), (1, 2, 2), (3, 0, 0), (3, 2, 3), (2, 0, 0), (2, 2, 0), (2, 3, 0), (2, 4, 2),
-                                 (2, 5, 3), (4, 0, 0), (4, 2, 0), (4, 3, 2), (4, 5, 3)]:
-        with ops.tuned(fp32_tile=variant, plan_cus=cus, splitk=splitk):
+    for variant, cus, splitk, *rest in [(1, 0, 0), (1, 2, 2), (3, 0, 0), (3, 2, 3), (2, 0, 0), (2, 2, 0), (2, 3, 0), (2, 4, 2),
+                                 (2, 5, 3), (4, 0, 0), (4, 2, 0), (4, 3, 2), (4, 5, 3),
+                                 # stream-K: more workgroups than K steps per tile (pieces of 1-2 steps, many slab levels),
+                                 # and few workgroups (whole tiles between a tail piece and a head piece); loader = 1: the
+                                 # generic (any tap count) loaders of variants 4 / 5 and of the filter gradient
+                                 (5, 0, 0), (5, 3, 0), (5, 7, 0), (5, 16, 0), (5, 5, 0, 1), (4, 3, 2, 1)]:
+        loader = rest[0] if rest else 0
+        with ops.tuned(fp32_tile=variant, plan_cus=cus, splitk=splitk, fp32_loader=loader):
             for dgrad in (False, True):
                 plan = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=dgrad)
                 if _eligible(variant, Cout if dgrad else Cin, k):
@@ -182,15 +189,15 @@ def test_every_plan_variant_on_small_awkward_shapes(env, shape):
                 seen.add((plan[0], plan[1] < M, plan[2] > 1, plan[3] > 1))
             got_y = ops.conv_fwd(xg, wg, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg).cpu().numpy()
             got_dx = ops.conv_dgrad(dyg, wg, dil, gate=gg, gate_scale=2.0).cpu().numpy()
-        assert _rel(got_y, want_y) < 2e-5, (variant, cus, splitk)
-        assert _rel(got_dx, want_dx) < 2e-5, (variant, cus, splitk)
+        assert _rel(got_y, want_y) < 2e-5, (variant, cus, splitk, loader)
+        assert _rel(got_dx, want_dx) < 2e-5, (variant, cus, splitk, loader)
     # both generations of the filter-gradient kernel (128x128 wave-specialised; 256x256 LDS-DMA), with the CU count the
     # split-M plan is laid out for varied: single pass, and several pixel splits with a ragged last one
-    for gen, cus in [(1, 0), (1, 1), (2, 0), (2, 1), (2, 3)]:
-        with ops.tuned(wgrad_gen=gen, plan_cus=cus):
+    for gen, cus, loader in [(1, 0, 0), (1, 1, 0), (2, 0, 0), (2, 1, 0), (2, 3, 0), (2, 3, 1)]:
+        with ops.tuned(wgrad_gen=gen, plan_cus=cus, fp32_loader=loader):
             got_dw = ops.conv_wgrad(xg, dyg, k, k, dil).cpu().numpy()
             again = ops.conv_wgrad(xg, dyg, k, k, dil).cpu().numpy()
-        assert _rel(got_dw, wt.grad.numpy()) < 2e-5, (gen, cus)
+        assert _rel(got_dw, wt.grad.numpy()) < 2e-5, (gen, cus, loader)
         assert np.array_equal(got_dw, again), "filter gradient must repeat bitwise"
     assert ops.tune_get("fp32_tile") == 0 and ops.tune_get("plan_cus") == 0 and ops.tune_get("wgrad_gen") == 0
     if M > 1024 and max(Cin, Cout) >= 40:

@@ -106,9 +106,11 @@ def test_launch_plans_at_the_benchmark_shapes():
     assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1, dgrad=True)[:2] == (4, 24576)
     assert ops.conv_plan(16, 41, 41, 4096, 24, 1, 1, dgrad=True)[0] == 2           # fc8 dgrad (N = 4096, K = 24: round-1 kernel)
     p = ops.conv_plan(16, 41, 41, 512, 4096, 4, 4, dgrad=True)                     # fc6 dgrad (N = 512: 212 big tiles < 256 CUs,
-    assert p[0] == 4 and p[1] == M and p[2] > 1                                    #   K = 65536: variant 4 split-K)
-    assert ops.conv_plan(16, 41, 41, 512, 512, 3, 1) == (3, M, 3, 0)               # conv4_x / conv5_x: split-K by 3
-    assert ops.conv_plan(16, 81, 81, 256, 256, 3, 1)[:2] == (4, 65536)             # conv3_x: one whole round of 256 tiles + tail
+    assert p[0] == 5 and p[1] == M and p[2] >= 2 and p[3] == 0                     #   K = 65536): stream-K, pieces of 3392 K steps
+    assert ops.conv_plan(16, 41, 41, 512, 512, 3, 1) == (5, M, 3, 0)               # conv4_x / conv5_x: stream-K, a tile has <= 3 pieces
+    assert ops.conv_plan(16, 81, 81, 256, 256, 3, 1)[:2] == (5, 16 * 81 * 81)      # conv3_x: 411 tiles = 1.6 rounds -> stream-K
+    with ops.tuned(plan_cus=137):                                                  # 411 = 3 x 137 tiles: whole rounds, no split at all
+        assert ops.conv_plan(16, 81, 81, 256, 256, 3, 1) == (4, 16 * 81 * 81, 1, 0)
     assert ops.conv_plan(16, 161, 161, 128, 128, 3, 1)[0] == 3                     # conv2_2: N = 128
     assert ops.conv_plan(16, 321, 321, 64, 64, 3, 1)[0] == 1                       # conv1_2: N <= 64
     with ops.tuned(fp32_tile=2, plan_cus=4):
