@@ -33,7 +33,7 @@ def layers(size=321, C=21, preset="ref", width=64):
 
 
 def short(name):
-    m = re.search(r"(igemm_ws_kernel<\w+>|wgrad_ws_kernel<\d+>|igemm2?_kernel<[^>]*>|wgrad2_kernel|wgrad_kernel<[^>]*>|igemm_bf16\w*_kernel|wgrad_bf16_kernel<\d+>)", name)
+    m = re.search(r"(igemm_ws_kernel<\w+>|wgrad_ws_kernel<\d+>|igemm2?_kernel<[^>]*>|wgrad2_kernel(?:<\w+>)?|wgrad_kernel<[^>]*>|igemm_bf16\w*_kernel|wgrad_bf16_kernel<\d+>)", name)
     return m.group(1) if m else name[:40]
 
 
@@ -45,6 +45,7 @@ def main():
     preset = sys.argv[5] if len(sys.argv) > 5 else "ref"
     L = layers(size, C, preset)
     rows = [r for r in csv.DictReader(open(path)) if re.search(r"igemm(_ws|_bf16\w*|2)?_kernel|wgrad(_ws|_bf16|2)?_kernel", r["Kernel_Name"])]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))   # (the trace file is not always in launch order)
     global PEAK
     if any("bf16" in r["Kernel_Name"] for r in rows):
         PEAK = 2516.6e12
@@ -55,7 +56,8 @@ def main():
     while i < len(rows):
         g = [rows[i]]
         n = rows[i]["Kernel_Name"]
-        big = "igemm_kernel<256, 256" in n or "igemm2_kernel" in n
+        stream_k = re.search(r"igemm2_kernel<[^>]*, true>", n) is not None   # one launch over all rows: never has a tail launch
+        big = ("igemm_kernel<256, 256" in n or "igemm2_kernel" in n) and not stream_k
         wgs = int(rows[i]["Grid_Size_X"]) // int(rows[i]["Workgroup_Size_X"])
         if big and wgs % 256 == 0 and i + 1 < len(rows) and "igemm_ws_kernel" in rows[i + 1]["Kernel_Name"]:
             g.append(rows[i + 1])
