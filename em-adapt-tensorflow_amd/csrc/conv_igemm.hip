@@ -600,6 +600,14 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
                 p.main_rows = (int)(tm_full * 256);
                 p.tail_cfg = 3;
                 p.tail_splits = splits_for(a, p.tail_cfg, a.M - p.main_rows);
+                // the rows of the partial last round as a stream-K launch of the same 256x256 kernel (variant 4 only: its
+                // reduction is a whole number of 16-wide steps): few tiles, all workgroups on the same rows -- the filter
+                // stays L2-resident there -- and slab levels of tail rows only
+                const long long tail_tiles = (tm - tm_full) * tn;
+                if (cfg == 4 && tail_tiles * nk16 / cus >= 32 && tune(TUNE_FP32_TILE) == 0) {
+                    p.tail_cfg = 5;
+                    p.tail_splits = streamk_levels(tail_tiles, nk16, cus);
+                }
             }
         }
     } else {
@@ -612,7 +620,8 @@ size_t igemm_workspace_bytes(const IgemmArgs &a) {
     const LaunchPlan p = plan_launches(a);
     if (p.cfg == 5) return (size_t)p.main_splits * a.M * a.N * sizeof(float);
     size_t b = p.main_splits > 1 ? (size_t)p.main_splits * p.main_rows * a.N * sizeof(float) : 0;
-    if (p.tail_splits > 1) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
+    if (p.tail_cfg == 5) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
+    else if (p.tail_splits > 1) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
     return b;
 }
 
@@ -651,7 +660,8 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
     if (!workspace || workspace_bytes < igemm_workspace_bytes(a)) {  // no room for slabs: unsplit, same result
         if (p.cfg == 5 && p.main_splits > 0) p.cfg = 3;
         if (p.cfg != 5) p.main_splits = 1;
-        if (p.tail_splits > 1) p.tail_splits = 1;
+        if (p.tail_cfg == 5 && p.tail_splits > 0) p.tail_cfg = 3;
+        if (p.tail_cfg != 5 && p.tail_splits > 1) p.tail_splits = 1;
     }
     if (p.cfg == 5) {
         a.m_begin = 0;
@@ -665,11 +675,16 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
     a.splits = p.main_splits;
     a.slab = p.main_splits > 1 ? static_cast<float *>(workspace) : nullptr;
     int rc = launch_variant<BT>(p.cfg, a, stream);
-    if (rc || p.tail_splits == 0) return rc;
+    if (rc || p.tail_cfg == 0) return rc;
     a.m_begin = p.main_rows;
     a.m_end = a.M;
-    a.splits = p.tail_splits;
-    a.slab = p.tail_splits > 1 ? static_cast<float *>(workspace) : nullptr;  // the main launch of a split plan uses no slab
+    if (p.tail_cfg == 5) {
+        a.splits = plan_cus();
+        a.slab = p.tail_splits > 0 ? static_cast<float *>(workspace) : nullptr;
+    } else {
+        a.splits = p.tail_splits;
+        a.slab = p.tail_splits > 1 ? static_cast<float *>(workspace) : nullptr;  // the main launch of a split plan uses no slab
+    }
     return launch_variant<BT>(p.tail_cfg, a, stream);
 }
 

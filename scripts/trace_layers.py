@@ -59,7 +59,8 @@ def main():
         stream_k = re.search(r"igemm2_kernel<[^>]*, true>", n) is not None   # one launch over all rows: never has a tail launch
         big = ("igemm_kernel<256, 256" in n or "igemm2_kernel" in n) and not stream_k
         wgs = int(rows[i]["Grid_Size_X"]) // int(rows[i]["Workgroup_Size_X"])
-        if big and wgs % 256 == 0 and i + 1 < len(rows) and "igemm_ws_kernel" in rows[i + 1]["Kernel_Name"]:
+        nxt = rows[i + 1]["Kernel_Name"] if i + 1 < len(rows) else ""
+        if big and wgs % 256 == 0 and ("igemm_ws_kernel" in nxt or re.search(r"igemm2_kernel<[^>]*, true>", nxt)):   # + its tail launch
             g.append(rows[i + 1])
             i += 1
         groups.append(g)
