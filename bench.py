@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--bucket-mb", type=int, default=32,
                     help="gradient all-reduce bucket size; the LAST bucket (conv1..conv4 gradients) only leaves when backward ends, "
                          "so it is what stays exposed: 32 MB buckets keep it small at 8 collectives per update")
+    ap.add_argument("--release-at", default="conv2_2",
+                    help="N > 1: layer of the backward pass at which the gradient all-reduces may start (\"none\" = as soon as a "
+                         "bucket is complete).  fc6..conv3 run kernels of exactly one workgroup per CU, which a collective holding "
+                         "CUs would push into a second round; conv2_2..conv1_1 (~6 ms) are thousands of small workgroups")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the data-parallel flow on a single GPU)")
     return ap.parse_args()
@@ -208,7 +212,8 @@ def main():
 
     cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
-           "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb}
+           "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb,
+           "allreduce_release_at": None if args.release_at == "none" else args.release_at}
     data = SyntheticData(dict(cfg, seed=0, unique_batches=2))   # SyntheticData mixes the rank into its seed
     adapt = ADAPT(dict(cfg, data=data))
     adapt.build()
@@ -356,6 +361,7 @@ def main():
                 "bytes_per_update": gs_stats["bytes_per_update"],
                 "buckets": gs_stats["buckets"],
                 "bucket_mb": args.bucket_mb,
+                "release_at": args.release_at,
                 "exposed_ms_per_step": None if gs_stats["exposed_ms"] is None else round(gs_stats.get("exposed_ms_max_over_ranks", gs_stats["exposed_ms"]), 3),
                 "backward_window_ms": None if gs_stats["backward_window_ms"] is None else round(gs_stats["backward_window_ms"], 3),
             }

@@ -625,6 +625,16 @@ size_t igemm_workspace_bytes(const IgemmArgs &a) {
     return b;
 }
 
+// Tap count the second-generation kernel's loaders are specialised for (0: the generic loaders).  The specialised form
+// reads the activation through a buffer that starts up to (pad_h * W + pad_w) pixels before the tensor: its extent must
+// still fit the 31 bits of a buffer offset.
+int specialised_taps(const IgemmArgs &a) {
+    if (tune(TUNE_FP32_LOADER) == 1) return 0;
+    const long long reach = ((long long)(a.ntaps / a.KW - 1) * a.dil * a.W + (long long)(a.KW - 1) * a.dil) * a.Cx * 4;
+    if ((long long)a.x_bytes + reach >= (1LL << 31)) return 0;
+    return a.ntaps;
+}
+
 template <bool BT>
 int launch_variant(int cfg, IgemmArgs &a, hipStream_t stream) {
     a.tap_inner = (a.ntaps > 1 && a.Cx % (cfg == 1 ? 16 : 32) == 0) ? 1 : 0;   // (variants 4 / 5 always use that order)
@@ -632,14 +642,14 @@ int launch_variant(int cfg, IgemmArgs &a, hipStream_t stream) {
         case 1: return launch_igemm<256, 64, 16, 64, BT>(a, stream);
         case 2: return launch_igemm<256, 256, 32, 128, BT>(a, stream);
         case 4: {
-            const int nt = tune(TUNE_FP32_LOADER) == 1 ? 0 : a.ntaps;
+            const int nt = specialised_taps(a);
             if (nt == 1) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1, false>(a, stream);
             if (nt == 9) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 9, false>(a, stream);
             if (nt == 16) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 16, false>(a, stream);
             return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 0, false>(a, stream);
         }
         case 5: {   // (a.splits = workgroups, a.slab = slab levels: dispatch_igemm)
-            const int nt = tune(TUNE_FP32_LOADER) == 1 ? 0 : a.ntaps;
+            const int nt = specialised_taps(a);
             if (nt == 1) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1, true>(a, stream);
             if (nt == 9) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 9, true>(a, stream);
             if (nt == 16) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 16, true>(a, stream);

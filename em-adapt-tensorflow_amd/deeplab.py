@@ -550,9 +550,17 @@ class ADAPT(Network):
         plan = self._plan
         bf16 = self.compute_dtype == "bf16"
         x6 = self.compute_dtype == "bf16x6"
+        # data parallel: the gradient exchange starts when backward reaches `allreduce_release_at` (dist.py: the kernels
+        # before it occupy every CU with exactly one workgroup and must not find CUs taken by a collective)
+        sync = self._gradsync if last_micro else None
+        release_at = self.config.get("allreduce_release_at", "conv2_2")
+        if sync is not None and release_at is not None and any(o.name == release_at for o in plan):
+            sync.hold()
         for i in range(len(plan) - 1, -1, -1):
             op = plan[i]
             prev = plan[i - 1] if i > 0 else None
+            if sync is not None and op.name == release_at:
+                sync.release()
             if op.kind == "conv":
                 x_in = bufs["act"][prev.name] if prev is not None else bufs["x_in"]
                 if bf16:

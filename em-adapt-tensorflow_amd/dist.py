@@ -13,6 +13,13 @@ which runs the collective on its own HIP stream behind the compute stream's curr
 fc8/fc7/fc6 gradients -- 77 % of the bytes -- travel while conv5..conv1 are still being differentiated.
 ``wait()`` joins the outstanding collectives before the optimiser step.  Works unchanged on CPU tensors
 with the gloo backend (tests).
+
+WHEN the collectives may start is the caller's decision (``hold()`` / ``release()``): the kernels of fc6 .. conv3 are laid
+out as exactly one workgroup per CU with no register room for anything beside them (stream-K forward / data gradient, 256-
+or 512-workgroup filter gradients), so a collective's workgroups that hold a few CUs while such a kernel starts would push
+its displaced workgroups into a second round -- twice the kernel's time.  The training step therefore holds the completed
+buckets back until backward reaches the layers whose kernels are thousands of small workgroups (conv2_2 .. conv1_1, ~6 ms),
+and the whole exchange (260 MB) runs under those.
 """
 import torch
 import torch.distributed as dist
@@ -33,6 +40,7 @@ class GradSync:
         self._next_bucket = 0
         self._watermark = 0
         self._works = []
+        self._held = False
         self.launched_bytes = 0
         # measurement (bench.py): time the compute stream spends blocked in wait(), per update, from HIP events on the
         # compute stream; with `trace` on, also where in the backward pass each bucket was launched
@@ -55,7 +63,18 @@ class GradSync:
         self._watermark = end
         self._launch_ready()
 
+    def hold(self):
+        """Completed buckets are queued instead of launched, until release() (or wait())."""
+        self._held = True
+
+    def release(self):
+        """Launch every bucket that is complete by now, and from here on each one as soon as it completes."""
+        self._held = False
+        self._launch_ready()
+
     def _launch_ready(self):
+        if self._held:
+            return
         while self._next_bucket < len(self.buckets):
             s, e = self.buckets[self._next_bucket]
             if e > self._watermark:
@@ -71,6 +90,7 @@ class GradSync:
         """Join all collectives of this update (the compute stream waits; the host does not block on CUDA)."""
         if self._watermark < self.total:
             raise RuntimeError("wait() before every segment was reported ready")
+        self._held = False
         self._launch_ready()
         if self.timing and self._cur is not None:
             self._cur["wait0"] = self._event()

@@ -47,10 +47,17 @@ def _worker(rank, world, port, out_dir):
     assert launched == [0, 2, 3], launched  # bucket k goes out as soon as the watermark passes its end
     gs.wait()
     assert gs.launched_bytes == total * 4
-    # second round re-uses the object (state reset by wait)
+    # second round re-uses the object (state reset by wait); this time the exchange is held back until the last layer
+    # (the training step's policy: dist.py hold / release)
     flat2_before = flat.clone()
-    for s, e in segs:
-        gs.segment_ready(s, e)
+    gs.hold()
+    gs.segment_ready(*segs[0])
+    gs.segment_ready(*segs[1])
+    assert gs._next_bucket == 0, "held buckets must not be launched"
+    gs.release()
+    assert gs._next_bucket == 2
+    gs.segment_ready(*segs[2])
+    assert gs._next_bucket == 3
     gs.wait()
     np.save(os.path.join(out_dir, "mine%d.npy" % rank), mine.numpy())
     np.save(os.path.join(out_dir, "sum%d.npy" % rank), flat2_before.numpy())
