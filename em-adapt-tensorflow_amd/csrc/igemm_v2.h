@@ -246,12 +246,13 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
                 const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)woff);
 #pragma unroll
                 for (int j = 0; j < B_N; j++) {
+                    if (ABL(16)) break;
                     if constexpr (!BT) dma16s(wr, bs + (j * PW + pw) * 256, b_off[j], s_w);
                     else dma16s(wr, bs + (j * PW + pw) * RPI * BK, b_off[j], s_w);
                 }
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                    if (tap_u != (unsigned)t) continue;   // scalar compare chain: the tap is wave-uniform
+                    if (tap_u != (unsigned)t || ABL(8)) continue;   // scalar compare chain: the tap is wave-uniform
 #pragma unroll
                     for (int j = 0; j < A_N; j++) dma16s(xr, as + (j * PW + pw) * RPI * BK, va[j][t], s_x);
                 }
