@@ -285,7 +285,9 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  * part of the numerics.  Process-wide; returns EMADAPT_ERR_INVALID for an unknown key.
  *   "fp32_tile"  1: 256x64x16 | 2: 256x256x32 for the rows that fill whole rounds of the CUs + a smaller-tile split-K
  *                launch for the rest | 3: 128x128x32 wave-specialised | 4: 256x256x16 second generation (LDS-DMA
- *                loaders, wide fragment reads; needs Cin resp. Cout % 16 == 0, <= 32 taps), rows split like 2.
+ *                loaders, wide fragment reads; needs Cin resp. Cout % 16 == 0, <= 32 taps), rows split like 2 |
+ *                5: the same kernel with the stream-K work split (one workgroup per CU walks an equal share of all
+ *                tiles' K steps; pieces of a tile are summed in a fixed order by a second pass).
  *                A forced variant the shape is not eligible for is ignored.
  *   "wgrad_gen"  1: 128x128 wave-specialised filter-gradient kernel | 2: 256x256 second generation (LDS-DMA loaders)
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
@@ -297,8 +299,9 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  * ---------------------------------------------------------------------------------------- */
 int emadapt_tune_set(const char *key, int value);
 /* The plan emadapt_conv_fwd (dgrad = 0) / emadapt_conv_dgrad (dgrad = 1) will use for this shape, given enough workspace:
- * plan[0] = tile variant ("fp32_tile" numbering), plan[1] = rows of the main launch, plan[2] = its split-K factor,
- * plan[3] = split-K factor of the 128x128 launch over the remaining rows (0 = there is none). */
+ * plan[0] = tile variant ("fp32_tile" numbering), plan[1] = rows of the main launch, plan[2] = its split-K factor
+ * (variant 5: the number of partial-sum slab levels), plan[3] = split-K factor / slab levels of the launch over the
+ * remaining rows (0 = there is none). */
 int emadapt_conv_plan(const emadapt_conv_desc *d, int dgrad, int plan[4]);
 int emadapt_tune_get(const char *key, int *value);
 
