@@ -54,17 +54,18 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
-// keep decision of the built-in dropout generator: uniform 24-bit draw per (seed, element).
+// keep decision of the built-in dropout generator: a uniform 24-bit draw per (seed, element).  A 32-bit multiply-xorshift
+// finaliser over a linear mix of the element index and the seed (different odd multipliers, so two seeds give unrelated
+// streams): ~9 vector instructions per element -- the 64-bit mixer it replaces cost 0.13 ms per fc6 / fc7 forward launch.
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float keep) {
-    const unsigned u = (unsigned)(mix64(seed ^ (idx * 0xD1342543DE82EF95ull)) >> 40);
-    return (float)u * (1.0f / 16777216.0f) < keep;
+    unsigned h = (unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0x27D4EB2Fu + (unsigned)seed * 0x85EBCA77u +
+                 (unsigned)(seed >> 32) * 0xC2B2AE3Du;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 12;
+    h *= 0x297A2D39u;
+    h ^= h >> 15;
+    return (float)(h >> 8) * (1.0f / 16777216.0f) < keep;
 }
 
 // bias / ReLU / dropout (tf.nn.dropout: x / keep_prob * mask) or the ReLU-gradient gate, on one output element.
