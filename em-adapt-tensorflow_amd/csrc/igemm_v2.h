@@ -21,6 +21,14 @@
 //     k-pairs 2q and 2q + 1, i.e. k-pair 2q multiplies columns {4q, 4q+2}, k-pair 2q+1 columns {4q+1, 4q+3} -- the same
 //     products, summed in a slightly different order than the round-1 kernels (both are valid fp32 sums; the parity
 //     tests hold both to the same bar).  The forward filter tile is read at rows 4q + 2*lh + (kk & 1) accordingly.
+//   * the loader waves issue their gathers with CONSTANT per-lane offsets (template parameter NT: one ready-made offset per
+//     row group and tap, validity folded in as the out-of-range bit; what moves from K step to K step rides in the load's
+//     scalar offset operand) and the MFMA waves' loop is unrolled over the ring (LDS addresses = register + immediate):
+//     no wave issues a vector-ALU instruction in the steady state -- a VALU instruction of a LOADER wave waits for the
+//     matrix pipe like anyone else's, and the 4-5 per gather of the first version made the loaders the slow side
+//     (forward 90 -> 93.5 %, data gradient 89 -> 93 %, and 88 -> 98 % for the filter-gradient kernel built the same way);
+//   * SK (stream-K): one workgroup per CU walks an equal share of all tiles' K steps (see sk_start below) -- for layers
+//     whose tile count is not a whole number of rounds of the CUs;
 //   * forward: the lane's four B tiles are four ADJACENT output columns (l31*4 + j, not l31 + 32*j): the epilogue is
 //     direct 16-byte stores (512 contiguous bytes per row and wave), no staging through LDS.  The data gradient keeps the
 //     l31 + 32*j columns (its filter tile is k-contiguous per column: adjacent columns would put a read's 32 lanes on 4
@@ -320,7 +328,8 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         b_idx[0] = (lh * 2) * BN + wn * 128 + l31 * TN;        // [k][n]: row 4q + 2*lh + (kk & 1)
     }
     // the operands of k-pairs 2q and 2q+1 come from one 8-byte read per k-contiguous row, one 16-byte read per [k][n] row
-    // (the data gradient's four extra fragment addresses leave no room for the unrolled form: it spills, and measured slower)
+    // the K loop is unrolled over the ring wherever the loaders are the specialised (vector-ALU-free) ones; the generic
+    // form keeps the round-2a loop (run-time ring position)
     constexpr bool UNROLL_RING = NT > 0;
     float2 av[2][TM];
     float2 bt[2][BT ? TN : 1];
