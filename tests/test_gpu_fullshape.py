@@ -104,6 +104,26 @@ def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgra
     assert _rel(ops.bias_grad(dyg).cpu(), dy.astype(np.float64).sum((0, 1, 2))) < 1e-5
 
 
+def test_builtin_dropout_draws_do_not_depend_on_the_launch_plan(env):
+    """The counter-hash dropout generator is keyed by the GLOBAL output element, so every tile variant -- row splits,
+    split-K second stages, stream-K pieces and their fix-up pass -- must drop exactly the same elements for a seed."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = 2, 23, 29, 64, 288, 3, 1
+    rng = np.random.default_rng(3)
+    xg = _t(torch, np.abs(rng.normal(0, 1, (B, H, W, Cin))).astype(np.float32))
+    wg = _t(torch, np.abs(rng.normal(0, 0.1, (k, k, Cin, Cout))).astype(np.float32))
+    bg = _t(torch, np.full((Cout,), 0.5, np.float32))     # all pre-activations positive: zero <=> dropped
+    ref = None
+    for variant, cus, splitk in [(3, 0, 0), (1, 2, 2), (2, 3, 0), (3, 2, 3), (4, 0, 0), (4, 3, 2), (5, 0, 0), (5, 3, 0), (5, 7, 0)]:
+        with ops.tuned(fp32_tile=variant, plan_cus=cus, splitk=splitk):
+            y = ops.conv_fwd(xg, wg, bg, dil, relu=True, keep_prob=0.5, drop_seed=(9 << 32) + 1234)
+        kept = y != 0
+        if ref is None:
+            ref = kept
+            assert abs(float(kept.float().mean()) - 0.5) < 5e-3
+        assert torch.equal(kept, ref), (variant, cus, splitk)
+
+
 def test_builtin_dropout_on_the_big_tile_path(env):
     """fc7 at batch 16 with the counter-hash generator: the element index fed to the hash must be the global one in
     both launches of the plan (rows below and above main_rows): kept values equal relu(y)/keep exactly, the keep rate
