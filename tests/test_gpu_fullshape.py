@@ -104,6 +104,31 @@ def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgra
     assert _rel(ops.bias_grad(dyg).cpu(), dy.astype(np.float64).sum((0, 1, 2))) < 1e-5
 
 
+def test_stream_k_tail_launch_on_a_small_shape(env):
+    """The automatic plan of the N > 1024 layers (fc6 / fc7 at batch 16): rows of whole rounds on the 256x256 kernel + the
+    remaining rows as a stream-K launch of the same kernel starting at m_begin > 0, here with the plan laid out for 4 CUs
+    so that a small shape takes it (30 tiles = 7 rounds + 2 tiles; the tail's 5 tiles x 36 K steps over 4 workgroups)."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = 2, 23, 29, 64, 1040, 3, 1
+    rng = np.random.default_rng(8)
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    w = rng.normal(0, 0.1, (k, k, Cin, Cout)).astype(np.float32)
+    b = rng.normal(0, 0.5, (Cout,)).astype(np.float32)
+    mask = (rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8)
+    y = do.conv_same(torch.tensor(x, dtype=torch.float64), torch.tensor(w, dtype=torch.float64),
+                     torch.tensor(b, dtype=torch.float64), dil)
+    want = torch.relu(y).numpy() / 0.5 * mask
+    with ops.tuned(plan_cus=4):
+        plan = ops.conv_plan(B, H, W, Cin, Cout, k, dil)
+        assert plan[0] == 4 and plan[1] == 1280 and plan[3] >= 1, plan
+        got = ops.conv_fwd(_t(torch, x), _t(torch, w), _t(torch, b), dil, relu=True, keep_prob=0.5,
+                           drop_mask=_t(torch, mask, torch.uint8)).cpu().numpy()
+        again = ops.conv_fwd(_t(torch, x), _t(torch, w), _t(torch, b), dil, relu=True, keep_prob=0.5,
+                             drop_mask=_t(torch, mask, torch.uint8)).cpu().numpy()
+    assert _rel(got, want) < 2e-5
+    assert np.array_equal(got, again)
+
+
 def test_builtin_dropout_draws_do_not_depend_on_the_launch_plan(env):
     """The counter-hash dropout generator is keyed by the GLOBAL output element, so every tile variant -- row splits,
     split-K second stages, stream-K pieces and their fix-up pass -- must drop exactly the same elements for a seed."""
