@@ -177,3 +177,38 @@ def test_latest_checkpoint_is_chosen_by_step_number_or_index(tmp_path):
     (tmp_path / "empty").mkdir()
     with pytest.raises(FileNotFoundError):
         latest_checkpoint(str(tmp_path / "empty"))
+
+
+def test_stream_k_plans_and_their_workspace_are_consistent():
+    """Launch plans need no device: over a sweep of shapes and CU counts the stream-K plans (variant 5) report their slab
+    levels, and the workspace query asks for exactly levels x rows x N floats (main launch) plus the tail launch's slabs."""
+    import ctypes
+    from em_adapt_tensorflow_amd import _lib, ops
+    lib = _lib.load()
+    lib.emadapt_conv_fwd_workspace_bytes.restype = ctypes.c_size_t
+    lib.emadapt_conv_dgrad_workspace_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(0)
+    seen = set()
+    for _ in range(300):
+        B, H, W = int(rng.integers(1, 17)), int(rng.integers(5, 90)), int(rng.integers(5, 90))
+        Cin, Cout = int(rng.choice([16, 32, 64, 128, 256, 512, 1024])), int(rng.choice([24, 64, 128, 256, 512, 1040, 4096]))
+        k, dil = int(rng.choice([1, 3, 4])), int(rng.choice([1, 2, 4]))
+        cus = int(rng.choice([0, 3, 7, 64, 256]))
+        M = B * H * W
+        with ops.tuned(plan_cus=cus):
+            for dgrad in (False, True):
+                cfg, main_rows, main_s, tail_s = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=dgrad)
+                N = Cin if dgrad else Cout
+                d = ops.conv_desc(B, H, W, Cin, Cout, k, k, dil)
+                ws = (lib.emadapt_conv_dgrad_workspace_bytes if dgrad else lib.emadapt_conv_fwd_workspace_bytes)(ctypes.byref(d))
+                assert 1 <= cfg <= 5 and 0 < main_rows <= M and main_s >= 0 and tail_s >= 0
+                seen.add(cfg)
+                if cfg == 5:
+                    assert main_rows == M and tail_s == 0 and ws == main_s * M * N * 4, (cfg, main_rows, main_s, tail_s, ws)
+                    assert main_s != 1, "a tile with partial sums has at least two pieces"
+                elif main_rows < M:
+                    assert cfg in (2, 4) and main_rows % 256 == 0
+                    assert ws >= (M - main_rows) * N * 4 * (tail_s if tail_s > 1 else 0)
+                else:
+                    assert ws == (main_s * M * N * 4 if main_s > 1 else 0)
+    assert {1, 3, 4, 5} <= seen, seen
