@@ -56,7 +56,8 @@ enum TuneKey {
     TUNE_X6_TILE,      // 128 | 256
     TUNE_PLAN_CUS,     // CU count the launch plans are laid out for (default 256)
     TUNE_FP32_LOADER,  // 1: loaders of the 256x256 fp32 kernel compute their offsets per K step for any tap count (the
-                       //    automatic choice only for filters other than 1x1 / 3x3 / 4x4); 0: tap-specialised where available
+                       //    automatic choice only for filters other than 1x1 / 3x3 / 4x4); 0: tap-specialised where available,
+                       //    filter gradient skips out-of-image pixel-tap pairs; 2: tap-specialised, no skipping
     TUNE_ESTEP_STOP,   // diagnostic builds only (-DEMADAPT_ABLATE_BUILD): leave the E-step kernel after phase n
     TUNE_ABLATE,       // diagnostic builds only: ablation bit mask of the fp32 igemm kernel
     TUNE_COUNT

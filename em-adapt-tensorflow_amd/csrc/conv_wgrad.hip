@@ -36,6 +36,9 @@ struct WgradArgs {
     int rows_per_split;  // multiple of BMR
     unsigned x_bytes, y_bytes;      // extents for the bounds-checked buffer loads (< 2 GiB each)
     unsigned magic_w, magic_h;      // ceil(2^32/W), ceil(2^32/H): pixel -> (oh, ow) by v_mul_hi_u32
+    int skip;                       // wgrad2_kernel<UT>: walk only the pixels at which the tile's tap is inside the image
+    unsigned char korder[256];      // with skip: k tile run by the workgroups of logical k index i (balances the taps' unequal
+                                    // pixel counts over the XCDs: see order_k_tiles)
 };
 
 // 16-byte buffer load with hardware range checking (offsets with bit 31 set are out of range -> zeros).
@@ -252,10 +255,40 @@ __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(Wgrad
         tile_k = first_k + in_g % gsz;
         tile_n = in_g / gsz;
     }
+    if (UT && a.skip) {
+        // Pixel skipping makes the tiles unequal (a corner tap of a dilated filter walks fewer pixels than a central one), so
+        // the block order is the tiles sorted by work, heaviest first (a.korder), with no XCD regrouping: the hardware deals
+        // consecutive blocks to the XCDs in turn -- every XCD gets an even sample, in descending order, and a CU that
+        // finishes a light tile of the first round picks up the heaviest one still queued (longest-processing-time order).
+        const int per_k = a.tiles_n * a.splits;
+        const int kr = (int)blockIdx.x / per_k, r = (int)blockIdx.x - kr * per_k;
+        tile_k = a.korder[kr];
+        tile_n = r / a.splits;
+        split = r - tile_n * a.splits;
+    }
     const int k0 = tile_k * BKO, n0 = tile_n * BN;
-    const int m_begin = split * a.rows_per_split;
-    int m_end = m_begin + a.rows_per_split;
-    if (m_end > a.M) m_end = a.M;
+    // Pixels this workgroup reduces over.  UT with a.skip: a tile's 256 k are one tap's channels, and the pixels at which that tap
+    // reads inside the image form a box [h0, h1) x [w0, w1) of every image -- outside it the x operand is all zeros.  The
+    // reduction walks a compact index i over the boxes only (fc6, 4x4 rate 4 on 41x41 maps: 81 % of the pixel-tap pairs;
+    // LargeFOV's 3x3 rate 12: 65 %); i -> (image, row, column) is scalar arithmetic in the loaders.
+    const int tap_s = k0 / a.Cin;
+    const int dh_s = (tap_s / a.KW) * a.dil - a.pad_h, dw_s = (tap_s % a.KW) * a.dil - a.pad_w;
+    const bool compact = UT && a.skip != 0;
+    int h0 = 0, w0 = 0, vw = a.W, pv = a.H * a.W;
+    if (compact) {
+        h0 = dh_s < 0 ? -dh_s : 0;
+        w0 = dw_s < 0 ? -dw_s : 0;
+        const int h1 = dh_s > 0 ? a.H - dh_s : a.H, w1 = dw_s > 0 ? a.W - dw_s : a.W;
+        const int vh = h1 > h0 ? h1 - h0 : 0;
+        vw = w1 > w0 ? w1 - w0 : 0;
+        pv = vh * vw;
+    }
+    const int m_total = compact ? (a.M / (a.H * a.W)) * pv : a.M;
+    const int rps = compact ? (int)((((long long)m_total + a.splits - 1) / a.splits + W2_BMR - 1) / W2_BMR) * W2_BMR : a.rows_per_split;
+    const int m_begin = __builtin_amdgcn_readfirstlane(split * rps);
+    int m_end = m_begin + rps;
+    if (m_end > m_total) m_end = m_total;
+    m_end = __builtin_amdgcn_readfirstlane(m_end);
     const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BMR - 1) / BMR : 0;
 
     if (threadIdx.x >= CONS * 64) {
@@ -276,8 +309,11 @@ __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(Wgrad
         const int n = n0 + lane * 4;
         const unsigned y_off = ((unsigned)n * 4u) | (n < a.N ? 0u : kOOB);
         // UT: scalars of this tile's tap, per-lane constants
-        const int tap_s = k0 / a.Cin, c0_s = k0 - tap_s * a.Cin;
-        const int dh_s = (tap_s / a.KW) * a.dil - a.pad_h, dw_s = (tap_s % a.KW) * a.dil - a.pad_w;
+        const int c0_s = k0 - tap_s * a.Cin;
+        // compact index -> (image, row, column): divisions by the box sizes as multiply-high (the reciprocals cost one real
+        // division each, once per kernel)
+        const unsigned magic_pv = compact && pv > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)((0x100000000ULL + (unsigned)pv - 1) / (unsigned)pv)) : 0u;
+        const unsigned magic_vw = compact && vw > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)((0x100000000ULL + (unsigned)vw - 1) / (unsigned)vw)) : 0u;
         const unsigned xv_c = ((unsigned)(c0_s + lane * 4) * 4u) | (kvalid ? 0u : kOOB);
         const __amdgpu_buffer_rsrc_t nullr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, 0, 0x00020000);
         auto fill = [&](int buf, int st) {
@@ -286,11 +322,22 @@ __global__ void __launch_bounds__((W2_CONS + W2_PW) * 64, 3) wgrad2_kernel(Wgrad
             for (int j = 0; j < IPW; j++) {
                 const int row = j * PW + pw;                       // pixel row of the step (wave-uniform)
                 if constexpr (UT) {
-                    const int m = __builtin_amdgcn_readfirstlane(m_begin + st * BMR + row);
-                    const unsigned t2 = div_magic((unsigned)m, a.magic_w);
-                    const int ow = m - (int)t2 * a.W;
-                    const int oh = (int)(t2 - div_magic(t2, a.magic_h) * (unsigned)a.H);
-                    const bool live = m < m_end;
+                    const int i = __builtin_amdgcn_readfirstlane(m_begin + st * BMR + row);
+                    const bool live = i < m_end;
+                    int m, oh, ow;
+                    if (compact) {
+                        const unsigned img = div_magic((unsigned)i, magic_pv);
+                        const unsigned r = (unsigned)i - img * (unsigned)pv;
+                        const unsigned rh = div_magic(r, magic_vw);
+                        oh = h0 + (int)rh;
+                        ow = w0 + (int)(r - rh * (unsigned)vw);
+                        m = ((int)img * a.H + oh) * a.W + ow;
+                    } else {
+                        m = i;
+                        const unsigned t2 = div_magic((unsigned)m, a.magic_w);
+                        ow = m - (int)t2 * a.W;
+                        oh = (int)(t2 - div_magic(t2, a.magic_h) * (unsigned)a.H);
+                    }
                     const bool ok = live && (unsigned)(oh + dh_s) < (unsigned)a.H && (unsigned)(ow + dw_s) < (unsigned)a.W;
                     const unsigned sx = ok ? (unsigned)((m + dh_s * a.W + dw_s) * a.Cin) * 4u : 0u;
                     const unsigned sy = live ? (unsigned)(m * a.N) * 4u : 0u;
@@ -464,6 +511,27 @@ int check_desc(const emadapt_conv_desc *d) {
     return EMADAPT_OK;
 }
 
+// With pixel skipping a k tile's work is the pixel count of its tap's box: corner taps of a dilated filter walk fewer pixels
+// than central ones (fc6: 35x35 .. 39x39 of 41x41).  korder = the k tiles sorted by that work, heaviest first (stable).
+void order_k_tiles(WgradArgs &a) {
+    const int nt = a.tiles_k;
+    int work[256], idx[256];
+    for (int t = 0; t < nt; t++) {
+        const int tap = t * 256 / a.Cin;
+        const int dh = (tap / a.KW) * a.dil - a.pad_h, dw = (tap % a.KW) * a.dil - a.pad_w;
+        const int vh = a.H - (dh < 0 ? -dh : dh), vw = a.W - (dw < 0 ? -dw : dw);
+        work[t] = (vh > 0 ? vh : 0) * (vw > 0 ? vw : 0);
+        idx[t] = t;
+    }
+    for (int i = 1; i < nt; i++) {   // insertion sort, descending work, stable
+        const int v = idx[i];
+        int j = i - 1;
+        while (j >= 0 && work[idx[j]] < work[v]) { idx[j + 1] = idx[j]; j--; }
+        idx[j + 1] = v;
+    }
+    for (int i = 0; i < nt; i++) a.korder[i] = (unsigned char)idx[i];
+}
+
 template <int BN>
 int launch_wgrad(const WgradArgs &a, hipStream_t stream) {
     constexpr size_t lds = sizeof(float) * 2 * BMR * (128 + BN);
@@ -526,6 +594,10 @@ int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
     const bool ut = d->Cin % 256 == 0 && tune(TUNE_FP32_LOADER) != 1;   // a 256-wide k tile lies inside one tap
+    // skip the pixels at which a tile's tap is outside the image (fp32_loader = 2 keeps the dense walk: tests, A/B); the
+    // compact index is divided by multiply-high: exact while pixels x box size < 2^32
+    a.skip = ut && a.ntaps > 1 && tune(TUNE_FP32_LOADER) != 2 && (long long)a.M * d->H * d->W < (1LL << 32) && p.tiles_k <= 256;
+    if (a.skip) order_k_tiles(a);
     rc = p.gen == 2 ? (ut ? launch_wgrad2<true>(a, stream) : launch_wgrad2<false>(a, stream)) : (p.bn == 64) ? launch_wgrad<64>(a, stream) : launch_wgrad<128>(a, stream);
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);

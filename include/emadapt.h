@@ -293,8 +293,10 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
  *   "bf16_tile"  128 | 256          "x6_tile"  128 | 256
  *   "plan_cus"   number of CUs the launch plans are laid out for (default 256: MI355X)
- *   "fp32_loader" 1: the 256x256 fp32 kernel's loader waves compute their offsets per K step (works for any tap count);
- *                0: loaders specialised for 1x1 / 3x3 / 4x4 filters where the filter has that many taps
+ *   "fp32_loader" 1: the 256x256 fp32 kernels' loader waves compute their offsets per K step (works for any tap count);
+ *                0: loaders specialised for 1x1 / 3x3 / 4x4 filters where the filter has that many taps, and the
+ *                filter-gradient kernel walks only the pixels at which a tile's tap is inside the image; 2: like 0
+ *                but every pixel is walked (out-of-image taps contribute zeros)
  *   "estep_stop", "ablate": honoured by diagnostic builds only (-DEMADAPT_ABLATE_BUILD), ignored otherwise
  * ---------------------------------------------------------------------------------------- */
 int emadapt_tune_set(const char *key, int value);

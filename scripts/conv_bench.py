@@ -14,7 +14,7 @@ SHAPES = {  # name: (B, H, W, Cin, Cout, k, dil)
     "conv5_2": (16, 41, 41, 512, 512, 3, 2), "conv3_2": (16, 81, 81, 256, 256, 3, 1), "conv2_2": (16, 161, 161, 128, 128, 3, 1),
     "conv1_2": (16, 321, 321, 64, 64, 3, 1), "conv4_2x8": (128, 41, 41, 512, 512, 3, 1), "conv4_1": (16, 41, 41, 256, 512, 3, 1),
     "conv3_1": (16, 81, 81, 128, 256, 3, 1), "conv2_1": (16, 161, 161, 64, 128, 3, 1), "conv1_1": (16, 321, 321, 4, 64, 3, 1),
-    "fc8": (16, 41, 41, 4096, 24, 1, 1),
+    "fc8": (16, 41, 41, 4096, 24, 1, 1), "fc6lf": (16, 41, 41, 512, 1024, 3, 12), "fc6c5": (10, 65, 65, 512, 1024, 3, 12),
     "fc7p": (16, 41, 41, 4096 + 64, 4096 + 64, 1, 1), "fc7h": (16, 41, 41, 2048, 2048, 1, 1), "fc7hp": (16, 41, 41, 2048 + 32, 2048 + 32, 1, 1),
 }
 
