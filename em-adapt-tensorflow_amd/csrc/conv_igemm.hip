@@ -547,6 +547,7 @@ struct LaunchPlan {
     int main_splits;
     int tail_cfg;    // tile variant of the launch over rows [main_rows, M)
     int tail_splits; // its split-K factor (0 = no tail)
+    int bands;       // variant 5 with row bands (RowClasses): the filter rows that lie outside the image are skipped
 };
 
 inline bool v2_ok(const IgemmArgs &a, int bk) { return a.Cx % bk == 0 && a.ntaps <= 32 && a.K >= 2 * bk; }
@@ -567,6 +568,7 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
     p.tail_cfg = 0;
     p.tail_splits = 0;
     p.main_splits = 1;
+    p.bands = 0;
     // 256x256 tiles pay when they fill at least one whole round of the CUs and N uses the tile's width; with fewer tiles
     // (fc6's data gradient: 212 tiles, K = 65536) variant 4 runs split-K when the reduction is long enough to carry the
     // slab traffic -- decided by the estimated times of the two plans (rates: sustained TFLOP/s of each main loop)
@@ -586,6 +588,18 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
     const int nk16 = a.K / 16;
     if (cfg != 1 && v2_ok(a, 16) && a.N >= 256 && a.N <= 1024 && t256 % cus != 0 && t256 * nk16 / cus >= 32) cfg = 5;
     if (force >= 1 && force <= 5 && !(force >= 4 && !v2_ok(a, 16))) cfg = force;
+    // Dilated filters on small maps multiply a lot of padding (fc6, 4x4 rate 4 on 41x41: filter rows -6 / +6 are outside the
+    // image for 6 of its 41 rows each): with row bands (igemm_common.h RowClasses) a stream-K launch skips the filter rows that
+    // are wholly outside, whatever N is (fp32_loader = 2 keeps the dense reduction: tests, A/B).
+    if ((force == 0 || force == 5) && cfg != 1 && v2_ok(a, 16) && a.N >= 256 && tune(TUNE_FP32_LOADER) != 2) {
+        IgemmArgs b = a;
+        if (build_row_classes(b) && b.rc.unit0[b.rc.n] / cus >= 32) {
+            p.cfg = 5;
+            p.bands = b.rc.n;
+            p.main_splits = streamk_levels_banded(b.rc, (int)ceil_div(a.N, 256), cus);
+            return p;
+        }
+    }
     p.cfg = cfg;
     if (cfg == 5) {
         p.main_splits = streamk_levels(t256, nk16, cus);   // slab levels (0: every tile is run by one workgroup)
@@ -673,7 +687,9 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
         if (p.tail_cfg == 5 && p.tail_splits > 0) p.tail_cfg = 3;
         if (p.tail_cfg != 5 && p.tail_splits > 1) p.tail_splits = 1;
     }
+    a.rc.n = 0;
     if (p.cfg == 5) {
+        if (p.bands && !build_row_classes(a)) return EMADAPT_ERR_INVALID;   // (the plan was made from the same geometry)
         a.m_begin = 0;
         a.m_end = a.M;
         a.splits = plan_cus();
@@ -733,7 +749,7 @@ int emadapt_conv_plan(const emadapt_conv_desc *d, int dgrad, int plan[4]) {
     plan[0] = p.cfg;
     plan[1] = p.main_rows;
     plan[2] = p.main_splits;
-    plan[3] = p.tail_splits;
+    plan[3] = p.cfg == 5 && p.bands ? p.bands : p.tail_splits;
     return EMADAPT_OK;
 }
 

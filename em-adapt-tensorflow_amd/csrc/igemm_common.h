@@ -22,6 +22,24 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ABL(bit) 0
 #endif
 
+// Row classes of the stream-K launches that skip padding (igemm_v2.h).  A filter row kh reads input row oh + dh(kh); for the
+// output rows near the top and bottom edges of an image some filter rows lie wholly outside it and their part of the
+// reduction multiplies zeros.  The output rows whose set of inside filter rows is the same form a band [oh0, oh0 + noh)
+// of every image (a 4x4 rate-4 filter on a 41-row map: [0,2) [2,6) [6,35) [35,39) [39,41)).  The GEMM's rows are the pixels
+// band after band (image-major inside a band), every M tile lies inside one band, and its K loop runs over the band's
+// filter rows [kh0, kh0 + nkh) only.  n = 0: rows are the pixels in memory order, nothing is skipped.
+struct RowClasses {
+    int n;
+    int tile0[7];            // first M tile of band c (tile0[n] = number of M tiles)
+    int unit0[7];            // first stream-K unit of band c (units = K steps of all its tiles, tile after tile)
+    int oh0[6], noh[6];
+    int kh0[6], nkh[6];
+    int rows[6];             // pixels of the band: images * noh * W
+    int nk[6];               // K steps of one of its tiles: (Cx / 16) * nkh * KW
+    unsigned magic_img[6];   // ceil(2^32 / (noh * W)): band row -> image
+    unsigned magic_nt[6];    // ceil(2^32 / (nkh * KW)): K step -> channel chunk
+};
+
 struct IgemmArgs {
     const float *x;     // activation to gather from: [B,H,W,Cx]
     const float *w;     // filter, HWIO
@@ -43,6 +61,8 @@ struct IgemmArgs {
     float *slab;         // [splits][M][N] fp32 partials when splits > 1
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
     unsigned magic_nt;   // ceil(2^32/ntaps)
+    RowClasses rc;       // stream-K launches that skip padding (rc.n > 0)
+    unsigned magic_w;    // ceil(2^32 / W)
     int ablate;  // diagnostic builds only (tune "ablate"): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
 };
 
@@ -92,10 +112,27 @@ __device__ __forceinline__ float epilogue(const IgemmArgs &a, float v, int col, 
 //   YBF  = output (and gate) stored as bf16 (N % 8 == 0), else f32 (N % 4 == 0)
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
+// GEMM row -> pixel.  PixelRows: the rows ARE the pixels (every kernel but the padding-skipping stream-K launches).
+struct PixelRows {
+    __device__ __forceinline__ int operator()(const IgemmArgs &a, int row) const { return row < a.m_end ? row : -1; }
+};
+// BandRows: row = index inside band c (RowClasses); -1 past the band's end (the band's last tile is partly empty).
+struct BandRows {
+    int c;
+    __device__ __forceinline__ int operator()(const IgemmArgs &a, int j) const {
+        if (j >= a.rc.rows[c]) return -1;
+        const unsigned img = div_magic((unsigned)j, a.rc.magic_img[c]);
+        const unsigned rem = (unsigned)j - img * (unsigned)(a.rc.noh[c] * a.W);
+        const unsigned rh = div_magic(rem, a.magic_w);
+        return ((int)img * a.H + a.rc.oh0[c] + (int)rh) * a.W + (int)(rem - rh * (unsigned)a.W);
+    }
+};
+
 //   ADJ  = the lane's TN accumulator tiles are TN ADJACENT columns (column l31*TN + j) instead of l31 + 32*j
-template <int TM, int TN, int ROWS, bool YBF, bool ADJ = false>
+//   RM   = GEMM row -> pixel (row0 is then a GEMM row)
+template <int TM, int TN, int ROWS, bool YBF, bool ADJ = false, typename RM = PixelRows>
 __device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 (&acc)[TM][TN], float *stage, int lane,
-                                               int row0, int col0, float *slab) {
+                                               int row0, int col0, float *slab, RM rm = RM()) {
     constexpr int WN = TN * 32;
     constexpr int SP = WN + 4;   // slab pitch in floats (rows stay 16-byte aligned)
     constexpr int CPR = WN / 8;  // 8-column chunks per slab row
@@ -119,11 +156,11 @@ __device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 
             for (int it = 0; it < ROWS * CPR / 64; it++) {
                 const int idx = it * 64 + lane;
                 const int row_l = idx / CPR, ch = idx % CPR;
-                const int row = row0 + i * 32 + h * ROWS + row_l;
+                const int row = rm(a, row0 + i * 32 + h * ROWS + row_l);
                 const int col = col0 + ch * 8;
                 const float4 v0 = *reinterpret_cast<const float4 *>(stage + row_l * SP + ch * 8);
                 const float4 v1 = *reinterpret_cast<const float4 *>(stage + row_l * SP + ch * 8 + 4);
-                if (row >= a.m_end || col >= a.N) continue;
+                if (row < 0 || col >= a.N) continue;
                 const bool hi = col + 4 < a.N;  // N % 4 == 0: the chunk holds one or two whole quads
                 const long long o = (long long)row * a.N + col;
                 if (slab) {
@@ -261,6 +298,7 @@ void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
     a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * a.Cx;
     a.x_bytes = (unsigned)((long long)a.M * a.Cx * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
     a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
+    a.magic_w = magic_u32(a.W); a.rc.n = 0;
 }
 
 }  // namespace

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             // (wave-uniform values that come out of vector-ALU divisions are moved to scalar registers by hand: left in vector
             // registers, the piece list's state spilled the accumulators)
             sk_v = t;
-            sk_units = ntile * nk_all;
+            sk_units = a.rc.n > 0 ? a.rc.unit0[a.rc.n] : ntile * nk_all;
             sk_u = __builtin_amdgcn_readfirstlane((int)sk_start(t, sk_units, nblk));
             sk_end = __builtin_amdgcn_readfirstlane((int)sk_start(t + 1, sk_units, nblk));
         } else {
@@ -136,15 +136,26 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             lvl = a.splits > 1 ? split : -1;
         }
     }
+    int band = 0;        // row band of the current tile (a.rc.n > 0: stream-K launches that skip padding rows of the filter)
+    int nk_tile = nk_all;   // K steps of the current tile (band-dependent)
     auto next_piece = [&]() -> bool {   // SK: the next piece of [sk_u, sk_end); every wave of the workgroup walks the same list
         if (sk_u >= sk_end) return false;
-        const int t = __builtin_amdgcn_readfirstlane(sk_u / nk_all);
-        kt0 = sk_u - t * nk_all;
+        int ubase = 0, tbase = 0;   // first unit / first tile of the band
+        if (a.rc.n > 0) {
+            band = 0;
+            while (band + 1 < a.rc.n && sk_u >= a.rc.unit0[band + 1]) band++;
+            ubase = a.rc.unit0[band];
+            tbase = a.rc.tile0[band] * a.tiles_n;
+            nk_tile = a.rc.nk[band];
+        }
+        const int t_in = __builtin_amdgcn_readfirstlane((sk_u - ubase) / nk_tile);
+        kt0 = sk_u - ubase - t_in * nk_tile;
+        const int t = tbase + t_in;
         const int left = sk_end - sk_u;
-        nk = (nk_all - kt0 < left) ? nk_all - kt0 : left;
+        nk = (nk_tile - kt0 < left) ? nk_tile - kt0 : left;
         tile_m = __builtin_amdgcn_readfirstlane(t / a.tiles_n);
         tile_n = t - tile_m * a.tiles_n;
-        lvl = nk == nk_all ? -1 : sk_v - __builtin_amdgcn_readfirstlane(sk_owner((long long)t * nk_all, sk_units, (int)gridDim.x));
+        lvl = nk == nk_tile ? -1 : sk_v - __builtin_amdgcn_readfirstlane(sk_owner((long long)(sk_u - kt0), sk_units, (int)gridDim.x));
         sk_u += nk;
         return true;
     };
@@ -175,14 +186,19 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         // instruction j of this wave fills rows [(j*PW + pw)*RPI, +RPI) of the tile; lane -> (row in group, chunk position)
         const int rl = lane / CPR, pos = lane % CPR;
         do {   // one piece of work (SK: several)
-        const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
+        const bool banded = SK && a.rc.n > 0;
+        const int m0 = banded ? (tile_m - a.rc.tile0[band]) * BM : a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (banded: row inside the band)
+        // taps of this tile's K loop: filter rows [kh_first, kh_first + nkh) x all columns, tap-inner order
+        const int kh_first = banded ? a.rc.kh0[band] : 0;
+        const int ntaps_t = banded ? a.rc.nkh[band] * a.KW : a.ntaps;
+        const unsigned magic_nt_t = banded ? a.rc.magic_nt[band] : a.magic_nt;
         unsigned a_off[A_N], a_bad[A_N];
 #pragma unroll
         for (int j = 0; j < A_N; j++) {
             const int r = (j * PW + pw) * RPI + rl;
-            const int m = m0 + r;
+            const int m = banded ? BandRows{band}(a, m0 + r) : (m0 + r < a.m_end ? m0 + r : -1);
             const int q = pos ^ ((r >> SWA_SHIFT) & 3);   // the channel chunk this lane fetches
-            if (m < a.m_end) {
+            if (m >= 0) {
                 const int t2 = m / a.W;
                 const int oh = t2 % a.H, ow = m - t2 * a.W;
                 a_off[j] = (unsigned)(m * a.Cx + q * 4) * 4u;
@@ -235,9 +251,9 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
 
         // Fill LDS buffer `buf` with the tile of K step kt (DMA; the caller awaits completion).
         auto fill = [&](int buf, int kt) {
-            const unsigned chunk = __umulhi((unsigned)kt, a.magic_nt);
-            const unsigned tap_u = a.ntaps > 1 ? (unsigned)kt - chunk * (unsigned)a.ntaps : 0u;
-            const unsigned chunk_u = a.ntaps > 1 ? chunk : (unsigned)kt;
+            const unsigned chunk = __umulhi((unsigned)kt, magic_nt_t);
+            const unsigned tap_u = (ntaps_t > 1 ? (unsigned)kt - chunk * (unsigned)ntaps_t : 0u) + (unsigned)(kh_first * a.KW);
+            const unsigned chunk_u = ntaps_t > 1 ? chunk : (unsigned)kt;
             const unsigned kh = div_magic(tap_u, a.magic_kw);
             const int kw = (int)(tap_u - kh * (unsigned)a.KW);
             const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
@@ -381,7 +397,8 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         __syncthreads();
     };
     do {   // one piece of work (SK: several)
-    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
+    const bool banded = SK && a.rc.n > 0;
+    const int m0 = banded ? (tile_m - a.rc.tile0[band]) * BM : a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (banded: row inside the band)
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -414,11 +431,19 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         // data gradient: columns l31 + 32*j -> the LDS-staged vector epilogue of the round-1 kernels (igemm_common.h); the
         // ring is dead after the last barrier
         static_assert(CONS * 16 * (128 + 4) <= NBUF * (A_BUF + B_BUF), "epilogue slabs must fit in the ring");
-        store_acc_tile<TM, TN, 16, false>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+        if (banded)
+            store_acc_tile<TM, TN, 16, false, false, BandRows>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128,
+                                                               slab_, BandRows{band});
+        else
+            store_acc_tile<TM, TN, 16, false>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
     } else if constexpr (SK) {
         // (forward, stream-K: the same staged epilogue with the adjacent-column mapping -- inside the piece loop the direct
         // form below made the compiler spill operand fragments in the MFMA loop)
-        store_acc_tile<TM, TN, 16, false, true>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+        if (banded)
+            store_acc_tile<TM, TN, 16, false, true, BandRows>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128,
+                                                              slab_, BandRows{band});
+        else
+            store_acc_tile<TM, TN, 16, false, true>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
     } else {
         // ---- forward epilogue: a lane holds, for each of its 2 x 16 rows, four consecutive output columns -> 16-byte stores.
         // C/D layout of the 32x32 MFMA: row in tile = (r&3) + 8*(r>>2) + 4*lh, column = l31 (here: column l31*4 + j).
@@ -473,18 +498,28 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
 // Stream-K second stage: the tiles that more than one workgroup worked on.  One block = 16 rows of one 256 x 256 tile.
 __global__ void __launch_bounds__(256) streamk_fixup_kernel(IgemmArgs a, int G, int nk_all) {
     const int t = blockIdx.x >> 4, part = blockIdx.x & 15;
-    const long long U = (long long)a.tiles_m * a.tiles_n * nk_all;
-    const int vf = sk_owner((long long)t * nk_all, U, G), vl = sk_owner((long long)(t + 1) * nk_all - 1, U, G);
+    const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
+    // the tile's K steps on the unit line
+    long long U = (long long)a.tiles_m * a.tiles_n * nk_all, u0 = (long long)t * nk_all;
+    int nk_tile = nk_all, band = 0;
+    if (a.rc.n > 0) {
+        while (band + 1 < a.rc.n && tile_m >= a.rc.tile0[band + 1]) band++;
+        nk_tile = a.rc.nk[band];
+        U = a.rc.unit0[a.rc.n];
+        u0 = a.rc.unit0[band] + (long long)((tile_m - a.rc.tile0[band]) * a.tiles_n + tile_n) * nk_tile;
+    }
+    const int vf = sk_owner(u0, U, G), vl = sk_owner(u0 + nk_tile - 1, U, G);
     const int cnt = vl - vf + 1;
     if (cnt <= 1) return;   // one workgroup ran the whole reduction of this tile and wrote it with the fused epilogue
-    const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
     const long long mn = (long long)(a.m_end - a.m_begin) * a.N;   // one slab level
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int idx = it * 256 + threadIdx.x;
-        const int row = a.m_begin + tile_m * 256 + part * 16 + (idx >> 6);
+        const int r = part * 16 + (idx >> 6);
+        const int row = a.rc.n > 0 ? BandRows{band}(a, (tile_m - a.rc.tile0[band]) * 256 + r)
+                                   : PixelRows()(a, a.m_begin + tile_m * 256 + r);
         const int col = tile_n * 256 + (idx & 63) * 4;
-        if (row >= a.m_end || col >= a.N) continue;
+        if (row < 0 || col >= a.N) continue;
         const long long o = (long long)row * a.N + col;
         const float *sp = a.slab + (o - (long long)a.m_begin * a.N);
         float4 v = *reinterpret_cast<const float4 *>(sp);
@@ -500,12 +535,10 @@ __global__ void __launch_bounds__(256) streamk_fixup_kernel(IgemmArgs a, int G, 
     }
 }
 
-// Workgroups of a stream-K launch: one per CU, but never more than units (every piece list is then non-empty, so the
-// workgroups of a tile are consecutive and its slab levels dense).
-inline int streamk_grid(long long tiles, int nk_all, int cus) {
-    const long long U = tiles * nk_all;
-    return (int)(U < cus ? (U > 0 ? U : 1) : cus);
-}
+// Workgroups of a stream-K launch over U units: one per CU, but never more than units (every piece list is then non-empty, so
+// the workgroups of a tile are consecutive and its slab levels dense).
+inline int streamk_grid_units(long long U, int cus) { return (int)(U < cus ? (U > 0 ? U : 1) : cus); }
+inline int streamk_grid(long long tiles, int nk_all, int cus) { return streamk_grid_units(tiles * nk_all, cus); }
 
 // Slab levels a stream-K launch over `tiles` tiles of nk_all K steps on `cus` CUs needs (0: every tile is whole).
 inline int streamk_levels(long long tiles, int nk_all, int cus) {
@@ -517,6 +550,84 @@ inline int streamk_levels(long long tiles, int nk_all, int cus) {
         if (cnt > 1 && cnt > levels) levels = cnt;
     }
     return levels;
+}
+
+// The same for a launch with row bands (tiles of band c have rc.nk[c] K steps).
+inline int streamk_levels_banded(const RowClasses &rc, int tiles_n, int cus) {
+    const long long U = rc.unit0[rc.n];
+    const int G = streamk_grid_units(U, cus);
+    int levels = 0;
+    for (int c = 0; c < rc.n; c++) {
+        const long long nt = (long long)(rc.tile0[c + 1] - rc.tile0[c]) * tiles_n;
+        for (long long t = 0; t < nt; t++) {
+            const long long u0 = rc.unit0[c] + t * rc.nk[c];
+            const int cnt = sk_owner(u0 + rc.nk[c] - 1, U, G) - sk_owner(u0, U, G) + 1;
+            if (cnt > 1 && cnt > levels) levels = cnt;
+        }
+    }
+    return levels;
+}
+
+// Row bands of a convolution (RowClasses) for 256-row tiles; returns false (rc.n = 0) when the filter has no rows to skip, the
+// bands do not fit the struct, or the padded tile rows would eat the saving (< 3 % fewer row-tap products).
+inline bool build_row_classes(IgemmArgs &a) {
+    RowClasses &rc = a.rc;
+    rc.n = 0;
+    const int KH = a.ntaps / a.KW;
+    if (KH < 2 || KH > 5 || a.Cx % 16 != 0 || a.N % 4 != 0) return false;
+    if ((long long)a.M * a.H * a.W >= (1LL << 32) || a.M % (a.H * a.W) != 0) return false;   // (div_magic ranges; whole images)
+    const int nimg = a.M / (a.H * a.W);
+    int cuts[16], nc = 0;
+    cuts[nc++] = 0;
+    cuts[nc++] = a.H;
+    for (int kh = 0; kh < KH; kh++) {
+        const int dh = a.sign * (kh * a.dil - a.pad_h);   // input row = oh + dh: inside for oh in [-dh, H - dh)
+        const int lo = -dh, hi = a.H - dh;
+        if (lo > 0 && lo < a.H) cuts[nc++] = lo;
+        if (hi > 0 && hi < a.H) cuts[nc++] = hi;
+    }
+    for (int i = 1; i < nc; i++) {   // sort
+        const int v = cuts[i];
+        int j = i - 1;
+        while (j >= 0 && cuts[j] > v) { cuts[j + 1] = cuts[j]; j--; }
+        cuts[j + 1] = v;
+    }
+    int n = 0;
+    long long tiles = 0, units = 0, dense = ceil_div(a.M, 256) * 256 * (long long)KH, banded = 0;
+    for (int i = 0; i + 1 < nc; i++) {
+        if (cuts[i + 1] == cuts[i]) continue;
+        if (n == 6) return false;
+        const int oh0 = cuts[i], noh = cuts[i + 1] - cuts[i];
+        int kh0 = -1, nkh = 0;
+        for (int kh = 0; kh < KH; kh++) {
+            const int ih = oh0 + a.sign * (kh * a.dil - a.pad_h);
+            if (ih >= 0 && ih < a.H) {
+                if (kh0 < 0) kh0 = kh;
+                if (kh != kh0 + nkh) return false;   // (the inside filter rows of a band are consecutive)
+                nkh++;
+            }
+        }
+        if (nkh == 0) return false;   // a band no filter row reaches: leave it to the plain kernels
+        rc.oh0[n] = oh0; rc.noh[n] = noh; rc.kh0[n] = kh0; rc.nkh[n] = nkh;
+        rc.rows[n] = nimg * noh * a.W;
+        rc.nk[n] = (a.Cx / 16) * nkh * a.KW;
+        rc.magic_img[n] = magic_u32(noh * a.W);
+        rc.magic_nt[n] = magic_u32(nkh * a.KW);
+        rc.tile0[n] = (int)tiles;
+        if (units > 0x7fffffffLL) return false;
+        rc.unit0[n] = (int)units;
+        const long long tm = ceil_div(rc.rows[n], 256);
+        tiles += tm;
+        units += tm * ceil_div(a.N, 256) * rc.nk[n];
+        banded += tm * 256 * nkh;
+        n++;
+    }
+    if (n < 2 || units > 0x7fffffffLL || tiles > 0x7fffffffLL) return false;
+    rc.tile0[n] = (int)tiles;
+    rc.unit0[n] = (int)units;
+    if (banded * 100 > dense * 97) return false;
+    rc.n = n;
+    return true;
 }
 
 template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT, int NT, bool SK>
@@ -532,10 +643,11 @@ int launch_igemm2(IgemmArgs &a, hipStream_t stream) {
     if constexpr (SK) {
         // a.splits = CUs to lay the pieces out for, a.slab = streamk_levels(...) slabs of [rows][N]
         const int nk_all = a.K / BK;
+        if (a.rc.n > 0) a.tiles_m = a.rc.tile0[a.rc.n];   // (row bands: every band ends with its own partial tile)
         const long long tiles = (long long)a.tiles_m * a.tiles_n;
         if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * 16 > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-        const int G = streamk_grid(tiles, nk_all, a.splits);
-        const int levels = streamk_levels(tiles, nk_all, a.splits);
+        const int G = a.rc.n > 0 ? streamk_grid_units(a.rc.unit0[a.rc.n], a.splits) : streamk_grid(tiles, nk_all, a.splits);
+        const int levels = a.rc.n > 0 ? streamk_levels_banded(a.rc, a.tiles_n, a.splits) : streamk_levels(tiles, nk_all, a.splits);
         if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
         hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT, true>), dim3((unsigned)G), dim3(THREADS), lds, stream, a);
         rc = launch_status();

@@ -43,7 +43,8 @@ def _t(torch, a, dtype=None):
 
 # name, (B, H, W, Cin, Cout, k, dil), expected forward plan variant, expected dgrad plan variant
 FULL_SHAPES = [
-    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 4, 5),      # deeplab.py:92,145: 44.8 % of the MACs (dgrad: 212 tiles, stream-K)
+    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 5, 5),      # deeplab.py:92,145: 44.8 % of the MACs; stream-K over row bands (the
+                                                       # filter rows -6 / +6 lie outside the image for 6 of its 41 rows each)
     ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 4, 4),     # deeplab.py:95,147
     ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 2),       # deeplab.py:95,149 (21 classes padded to 24: dgrad K = 24)
     ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 5, 5),   # 212 tiles of 256x256 on 256 CUs: stream-K pieces of 238.5 K steps
@@ -63,7 +64,8 @@ def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgra
     if fwd_variant in (2, 4):  # rows of whole rounds on 256x256 tiles + a split launch of smaller tiles over the rest
         assert 0 < pf[1] < B * H * W and pf[1] % 256 == 0 and pf[3] >= 1, pf
     if fwd_variant == 5:
-        assert pf[1] == B * H * W and pf[2] >= 2 and pf[3] == 0, pf     # one launch over all rows, >= 2 slab levels
+        # one launch over all rows, >= 2 slab levels; fc6 (4x4 rate 4): over its 5 row bands
+        assert pf[1] == B * H * W and pf[2] >= 2 and pf[3] == (5 if name == "fc6" else 0), pf
     if name == "fc6":
         assert pd[1] == B * H * W and pd[2] >= 2, pd  # 212 big tiles on 256 CUs: pieces of the 65536-long reductions
 
@@ -102,6 +104,45 @@ def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgra
     assert _rel(dw1, wt.grad.numpy()) < 1e-4
     assert np.array_equal(dw1, ops.conv_wgrad(xg, dyg, k, k, dil).cpu().numpy()), "filter gradient must repeat bitwise"
     assert _rel(ops.bias_grad(dyg).cpu(), dy.astype(np.float64).sum((0, 1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("shape,cus", [((2, 29, 9, 256, 256, 3, 8), 3), ((2, 29, 9, 256, 256, 5, 12), 3),
+                                        ((2, 29, 16, 256, 256, 4, 8), 3), ((3, 37, 12, 272, 288, 4, 6), 5),
+                                        ((4, 45, 9, 256, 288, 3, 12), 7)])
+def test_stream_k_over_row_bands_on_small_shapes(env, shape, cus):
+    """Dilated filters on short maps: the automatic plan is a stream-K launch over row bands (the GEMM's rows are the pixels
+    band after band; a band's tiles reduce only over the filter rows that reach into the image).  Forward with bias + ReLU +
+    dropout mask and data gradient with the gate against the fp64 oracle, bitwise repeatable, and equal to the dense plan
+    (fp32_loader = 2) to rounding."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    rng = np.random.default_rng(sum(shape) + cus)
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    w = rng.normal(0, 0.2, (k, k, Cin, Cout)).astype(np.float32)
+    b = rng.normal(0, 0.5, (Cout,)).astype(np.float32)
+    dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
+    gate = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    mask = (rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    y = do.conv_same(xt, torch.tensor(w, dtype=torch.float64), torch.tensor(b, dtype=torch.float64), dil)
+    y.backward(torch.tensor(dy, dtype=torch.float64))
+    want_y = torch.relu(y).detach().numpy() / 0.5 * mask
+    want_dx = np.where(gate > 0, xt.grad.numpy() * 2.0, 0.0)
+    xg, wg, bg, dyg, gg, mg = (_t(torch, x), _t(torch, w), _t(torch, b), _t(torch, dy), _t(torch, gate), _t(torch, mask, torch.uint8))
+    with ops.tuned(plan_cus=cus):
+        pf = ops.conv_plan(B, H, W, Cin, Cout, k, dil)
+        assert pf[0] == 5 and pf[3] >= 2, pf          # row bands in use
+        got_y = ops.conv_fwd(xg, wg, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg).cpu().numpy()
+        again = ops.conv_fwd(xg, wg, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg).cpu().numpy()
+        pd = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=True)
+        assert pd[0] == 5 and pd[3] >= 2, pd
+        got_dx = ops.conv_dgrad(dyg, wg, dil, gate=gg, gate_scale=2.0).cpu().numpy()
+        with ops.tuned(fp32_loader=2):
+            assert ops.conv_plan(B, H, W, Cin, Cout, k, dil)[3] == 0
+            dense_y = ops.conv_fwd(xg, wg, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg).cpu().numpy()
+    assert _rel(got_y, want_y) < 2e-5 and np.array_equal(got_y, again)
+    assert _rel(got_dx, want_dx) < 2e-5, pd
+    assert _rel(got_y, dense_y) < 2e-6
 
 
 def test_stream_k_tail_launch_on_a_small_shape(env):

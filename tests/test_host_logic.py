@@ -100,13 +100,14 @@ def test_launch_plans_at_the_benchmark_shapes():
     256x256 tiles on the rows that fill whole rounds of the 256 CUs and a split 128x128 launch on the rest."""
     from em_adapt_tensorflow_amd import ops
     M = 16 * 41 * 41
-    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4)[:3] == (4, 24576, 1)         # fc6 fwd: 96 x 16 tiles = 6 rounds
-    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4)[3] > 1                       #   + the other 2320 rows split-K
+    assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4)[:2] == (5, M)                # fc6 fwd: stream-K over row bands (padding rows
+    with ops.tuned(fp32_loader=2):                                                 #   of the dilated filter skipped); without them:
+        assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4)[:3] == (4, 24576, 1)     #   96 x 16 tiles = 6 rounds + a tail launch
     assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1)[:2] == (4, 24576)           # fc7 fwd
     assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1, dgrad=True)[:2] == (4, 24576)
     assert ops.conv_plan(16, 41, 41, 4096, 24, 1, 1, dgrad=True)[0] == 2           # fc8 dgrad (N = 4096, K = 24: round-1 kernel)
     p = ops.conv_plan(16, 41, 41, 512, 4096, 4, 4, dgrad=True)                     # fc6 dgrad (N = 512: 212 big tiles < 256 CUs,
-    assert p[0] == 5 and p[1] == M and p[2] >= 2 and p[3] == 0                     #   K = 65536): stream-K, pieces of 3392 K steps
+    assert p[0] == 5 and p[1] == M and p[2] >= 2 and p[3] == 5                     #   K = 65536): stream-K over the 5 row bands
     assert ops.conv_plan(16, 41, 41, 512, 512, 3, 1) == (5, M, 3, 0)               # conv4_x / conv5_x: stream-K, a tile has <= 3 pieces
     assert ops.conv_plan(16, 81, 81, 256, 256, 3, 1)[:2] == (5, 16 * 81 * 81)      # conv3_x: 411 tiles = 1.6 rounds -> stream-K
     with ops.tuned(plan_cus=137):                                                  # 411 = 3 x 137 tiles: whole rounds, no split at all
@@ -203,8 +204,8 @@ def test_stream_k_plans_and_their_workspace_are_consistent():
                 ws = (lib.emadapt_conv_dgrad_workspace_bytes if dgrad else lib.emadapt_conv_fwd_workspace_bytes)(ctypes.byref(d))
                 assert 1 <= cfg <= 5 and 0 < main_rows <= M and main_s >= 0 and tail_s >= 0
                 seen.add(cfg)
-                if cfg == 5:
-                    assert main_rows == M and tail_s == 0 and ws == main_s * M * N * 4, (cfg, main_rows, main_s, tail_s, ws)
+                if cfg == 5:   # (plan[3] = number of row bands of a padding-skipping launch, 0 or >= 2)
+                    assert main_rows == M and tail_s != 1 and tail_s <= 6 and ws == main_s * M * N * 4, (cfg, main_rows, main_s, tail_s, ws)
                     assert main_s != 1, "a tile with partial sums has at least two pieces"
                 elif main_rows < M:
                     assert cfg in (2, 4) and main_rows % 256 == 0
