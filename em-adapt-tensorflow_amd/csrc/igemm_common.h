@@ -22,22 +22,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ABL(bit) 0
 #endif
 
-// Row classes of the stream-K launches that skip padding (igemm_v2.h).  A filter row kh reads input row oh + dh(kh); for the
-// output rows near the top and bottom edges of an image some filter rows lie wholly outside it and their part of the
-// reduction multiplies zeros.  The output rows whose set of inside filter rows is the same form a band [oh0, oh0 + noh)
-// of every image (a 4x4 rate-4 filter on a 41-row map: [0,2) [2,6) [6,35) [35,39) [39,41)).  The GEMM's rows are the pixels
-// band after band (image-major inside a band), every M tile lies inside one band, and its K loop runs over the band's
-// filter rows [kh0, kh0 + nkh) only.  n = 0: rows are the pixels in memory order, nothing is skipped.
+// Pixel bands of the stream-K launches that skip padding (igemm_v2.h).  Filter row kh reads input row oh + dh(kh), filter
+// column kw input column ow + dw(kw); for the output pixels near the edges of an image some filter rows / columns lie wholly
+// outside it and their part of the reduction multiplies zeros.  The output rows that see the same set of filter rows form a
+// band [oh0, oh0 + noh) (a 4x4 rate-4 filter on a 41-row map: [0,2) [2,6) [6,35) [35,39) [39,41)), likewise the columns;
+// a CLASS is a row band x a column band (or a row band x all columns, whichever leaves fewer products after padding the
+// classes to whole tiles).  The GEMM's rows are the pixels class after class (image-major inside a class), every M tile lies
+// inside one class, and its K loop runs over the class's filter rows [kh0, kh0 + nkh) x columns [kw0, kw0 + nkw) only.
+// n = 0: the rows are the pixels in memory order, nothing is skipped.
+constexpr int kMaxRowClasses = 36;
 struct RowClasses {
     int n;
-    int tile0[7];            // first M tile of band c (tile0[n] = number of M tiles)
-    int unit0[7];            // first stream-K unit of band c (units = K steps of all its tiles, tile after tile)
-    int oh0[6], noh[6];
-    int kh0[6], nkh[6];
-    int rows[6];             // pixels of the band: images * noh * W
-    int nk[6];               // K steps of one of its tiles: (Cx / 16) * nkh * KW
-    unsigned magic_img[6];   // ceil(2^32 / (noh * W)): band row -> image
-    unsigned magic_nt[6];    // ceil(2^32 / (nkh * KW)): K step -> channel chunk
+    int tile0[kMaxRowClasses + 1];   // first M tile of class c (tile0[n] = number of M tiles)
+    int unit0[kMaxRowClasses + 1];   // first stream-K unit of class c (units = K steps of all its tiles, tile after tile)
+    unsigned short oh0[kMaxRowClasses], noh[kMaxRowClasses], ow0[kMaxRowClasses], now[kMaxRowClasses];
+    unsigned char kh0[kMaxRowClasses], nkh[kMaxRowClasses], kw0[kMaxRowClasses], nkw[kMaxRowClasses];
+    int rows[kMaxRowClasses];             // pixels of the class: images * noh * now
+    int nk[kMaxRowClasses];               // K steps of one of its tiles: (Cx / 16) * nkh * nkw
+    unsigned magic_img[kMaxRowClasses];   // ceil(2^32 / (noh * now)): class row -> image
+    unsigned magic_now[kMaxRowClasses];   // ceil(2^32 / now)
+    unsigned magic_nt[kMaxRowClasses];    // ceil(2^32 / (nkh * nkw)): K step -> channel chunk
+    unsigned magic_nkw[kMaxRowClasses];   // ceil(2^32 / nkw): tap of the class -> (filter row, filter column)
 };
 
 struct IgemmArgs {
@@ -116,15 +121,16 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 struct PixelRows {
     __device__ __forceinline__ int operator()(const IgemmArgs &a, int row) const { return row < a.m_end ? row : -1; }
 };
-// BandRows: row = index inside band c (RowClasses); -1 past the band's end (the band's last tile is partly empty).
+// BandRows: row = index inside class c (RowClasses); -1 past the class's end (its last tile is partly empty).
 struct BandRows {
     int c;
     __device__ __forceinline__ int operator()(const IgemmArgs &a, int j) const {
         if (j >= a.rc.rows[c]) return -1;
+        const unsigned now = a.rc.now[c];
         const unsigned img = div_magic((unsigned)j, a.rc.magic_img[c]);
-        const unsigned rem = (unsigned)j - img * (unsigned)(a.rc.noh[c] * a.W);
-        const unsigned rh = div_magic(rem, a.magic_w);
-        return ((int)img * a.H + a.rc.oh0[c] + (int)rh) * a.W + (int)(rem - rh * (unsigned)a.W);
+        const unsigned rem = (unsigned)j - img * ((unsigned)a.rc.noh[c] * now);
+        const unsigned rh = div_magic(rem, a.rc.magic_now[c]);
+        return ((int)img * a.H + a.rc.oh0[c] + (int)rh) * a.W + a.rc.ow0[c] + (int)(rem - rh * now);
     }
 };
 

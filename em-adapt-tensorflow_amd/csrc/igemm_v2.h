@@ -189,9 +189,11 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         const bool banded = SK && a.rc.n > 0;
         const int m0 = banded ? (tile_m - a.rc.tile0[band]) * BM : a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (banded: row inside the band)
         // taps of this tile's K loop: filter rows [kh_first, kh_first + nkh) x all columns, tap-inner order
-        const int kh_first = banded ? a.rc.kh0[band] : 0;
-        const int ntaps_t = banded ? a.rc.nkh[band] * a.KW : a.ntaps;
+        const int kh_first = banded ? a.rc.kh0[band] : 0, kw_first = banded ? a.rc.kw0[band] : 0;
+        const int nkw_t = banded ? a.rc.nkw[band] : a.KW;
+        const int ntaps_t = banded ? a.rc.nkh[band] * nkw_t : a.ntaps;
         const unsigned magic_nt_t = banded ? a.rc.magic_nt[band] : a.magic_nt;
+        const unsigned magic_nkw_t = banded ? a.rc.magic_nkw[band] : a.magic_kw;
         unsigned a_off[A_N], a_bad[A_N];
 #pragma unroll
         for (int j = 0; j < A_N; j++) {
@@ -252,10 +254,12 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         // Fill LDS buffer `buf` with the tile of K step kt (DMA; the caller awaits completion).
         auto fill = [&](int buf, int kt) {
             const unsigned chunk = __umulhi((unsigned)kt, magic_nt_t);
-            const unsigned tap_u = (ntaps_t > 1 ? (unsigned)kt - chunk * (unsigned)ntaps_t : 0u) + (unsigned)(kh_first * a.KW);
+            const unsigned tap_l = ntaps_t > 1 ? (unsigned)kt - chunk * (unsigned)ntaps_t : 0u;   // tap inside the tile's tap box
             const unsigned chunk_u = ntaps_t > 1 ? chunk : (unsigned)kt;
-            const unsigned kh = div_magic(tap_u, a.magic_kw);
-            const int kw = (int)(tap_u - kh * (unsigned)a.KW);
+            const unsigned khl = div_magic(tap_l, magic_nkw_t);
+            const unsigned kh = (unsigned)kh_first + khl;
+            const int kw = kw_first + (int)(tap_l - khl * (unsigned)nkw_t);
+            const unsigned tap_u = kh * (unsigned)a.KW + (unsigned)kw;
             const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
             const int dw = a.sign * (kw * a.dil - a.pad_w);
             const unsigned toff = (unsigned)(((dh * a.W + dw) * a.Cx + (int)chunk_u * BK) * 4);
@@ -568,64 +572,95 @@ inline int streamk_levels_banded(const RowClasses &rc, int tiles_n, int cus) {
     return levels;
 }
 
-// Row bands of a convolution (RowClasses) for 256-row tiles; returns false (rc.n = 0) when the filter has no rows to skip, the
-// bands do not fit the struct, or the padded tile rows would eat the saving (< 3 % fewer row-tap products).
-inline bool build_row_classes(IgemmArgs &a) {
-    RowClasses &rc = a.rc;
-    rc.n = 0;
-    const int KH = a.ntaps / a.KW;
-    if (KH < 2 || KH > 5 || a.Cx % 16 != 0 || a.N % 4 != 0) return false;
-    if ((long long)a.M * a.H * a.W >= (1LL << 32) || a.M % (a.H * a.W) != 0) return false;   // (div_magic ranges; whole images)
-    const int nimg = a.M / (a.H * a.W);
+// Pixel classes of a convolution (RowClasses) for 256-row tiles; returns false (rc.n = 0) when the filter has nothing to
+// skip, the classes do not fit the struct, or padding them to whole tiles would eat the saving (< 8 % fewer products).
+// One dimension at a time: bands of output rows (resp. columns) that see the same filter rows (columns).
+struct Band1D { int o0, no, k0, nk; };
+inline int bands_1d(int size, int K, int dil, int pad, int sign, Band1D *out, int max_out) {
     int cuts[16], nc = 0;
     cuts[nc++] = 0;
-    cuts[nc++] = a.H;
-    for (int kh = 0; kh < KH; kh++) {
-        const int dh = a.sign * (kh * a.dil - a.pad_h);   // input row = oh + dh: inside for oh in [-dh, H - dh)
-        const int lo = -dh, hi = a.H - dh;
-        if (lo > 0 && lo < a.H) cuts[nc++] = lo;
-        if (hi > 0 && hi < a.H) cuts[nc++] = hi;
+    cuts[nc++] = size;
+    for (int k = 0; k < K; k++) {
+        const int d = sign * (k * dil - pad);   // input index = o + d: inside for o in [-d, size - d)
+        const int lo = -d, hi = size - d;
+        if (lo > 0 && lo < size) cuts[nc++] = lo;
+        if (hi > 0 && hi < size) cuts[nc++] = hi;
     }
-    for (int i = 1; i < nc; i++) {   // sort
+    for (int i = 1; i < nc; i++) {
         const int v = cuts[i];
         int j = i - 1;
         while (j >= 0 && cuts[j] > v) { cuts[j + 1] = cuts[j]; j--; }
         cuts[j + 1] = v;
     }
     int n = 0;
-    long long tiles = 0, units = 0, dense = ceil_div(a.M, 256) * 256 * (long long)KH, banded = 0;
     for (int i = 0; i + 1 < nc; i++) {
         if (cuts[i + 1] == cuts[i]) continue;
-        if (n == 6) return false;
-        const int oh0 = cuts[i], noh = cuts[i + 1] - cuts[i];
-        int kh0 = -1, nkh = 0;
-        for (int kh = 0; kh < KH; kh++) {
-            const int ih = oh0 + a.sign * (kh * a.dil - a.pad_h);
-            if (ih >= 0 && ih < a.H) {
-                if (kh0 < 0) kh0 = kh;
-                if (kh != kh0 + nkh) return false;   // (the inside filter rows of a band are consecutive)
-                nkh++;
+        if (n == max_out) return -1;
+        Band1D b = {cuts[i], cuts[i + 1] - cuts[i], -1, 0};
+        for (int k = 0; k < K; k++) {
+            const int in = b.o0 + sign * (k * dil - pad);
+            if (in >= 0 && in < size) {
+                if (b.k0 < 0) b.k0 = k;
+                if (k != b.k0 + b.nk) return -1;   // (the inside filter rows of a band are consecutive)
+                b.nk++;
             }
         }
-        if (nkh == 0) return false;   // a band no filter row reaches: leave it to the plain kernels
-        rc.oh0[n] = oh0; rc.noh[n] = noh; rc.kh0[n] = kh0; rc.nkh[n] = nkh;
-        rc.rows[n] = nimg * noh * a.W;
-        rc.nk[n] = (a.Cx / 16) * nkh * a.KW;
-        rc.magic_img[n] = magic_u32(noh * a.W);
-        rc.magic_nt[n] = magic_u32(nkh * a.KW);
-        rc.tile0[n] = (int)tiles;
-        if (units > 0x7fffffffLL) return false;
-        rc.unit0[n] = (int)units;
-        const long long tm = ceil_div(rc.rows[n], 256);
-        tiles += tm;
-        units += tm * ceil_div(a.N, 256) * rc.nk[n];
-        banded += tm * 256 * nkh;
-        n++;
+        if (b.nk == 0) return -1;   // a band no filter row reaches: leave the layer to the plain kernels
+        out[n++] = b;
     }
-    if (n < 2 || units > 0x7fffffffLL || tiles > 0x7fffffffLL) return false;
+    return n;
+}
+
+inline bool build_row_classes(IgemmArgs &a) {
+    RowClasses &rc = a.rc;
+    rc.n = 0;
+    const int KH = a.ntaps / a.KW;
+    if (KH > 5 || a.KW > 5 || a.ntaps < 2 || a.Cx % 16 != 0 || a.N % 4 != 0 || a.H > 65535 || a.W > 65535) return false;
+    if ((long long)a.M * a.H * a.W >= (1LL << 32) || a.M % (a.H * a.W) != 0) return false;   // (div_magic ranges; whole images)
+    const int nimg = a.M / (a.H * a.W);
+    Band1D hb[6], wb[6];
+    const int nh = bands_1d(a.H, KH, a.dil, a.pad_h, a.sign, hb, 6), nw = bands_1d(a.W, a.KW, a.dil, a.pad_w, a.sign, wb, 6);
+    if (nh < 1 || nw < 1) return false;
+    const Band1D wall = {0, a.W, 0, a.KW};
+    // products (tile rows x taps) of: row bands x all columns, and row bands x column bands; dense for comparison
+    auto cost = [&](bool cols) {
+        long long c = 0;
+        for (int i = 0; i < nh; i++)
+            for (int j = 0; j < (cols ? nw : 1); j++) {
+                const Band1D &w = cols ? wb[j] : wall;
+                c += ceil_div((long long)nimg * hb[i].no * w.no, 256) * 256 * hb[i].nk * w.nk;
+            }
+        return c;
+    };
+    const long long dense = ceil_div(a.M, 256) * 256 * (long long)a.ntaps;
+    const long long c1 = cost(false), c2 = nh * nw <= kMaxRowClasses ? cost(true) : c1 + 1;
+    const bool cols = c2 < c1;
+    if ((cols ? c2 : c1) * 100 > dense * 92) return false;   // (measured: conv5_x, 3x3 rate 2 on 41x41, would save 4.5 % of its
+                                                             //  products and loses more than that to its nine classes' partial tiles)
+    int n = 0;
+    long long tiles = 0, units = 0;
+    for (int i = 0; i < nh; i++)
+        for (int j = 0; j < (cols ? nw : 1); j++) {
+            const Band1D &h = hb[i], &w = cols ? wb[j] : wall;
+            rc.oh0[n] = (unsigned short)h.o0; rc.noh[n] = (unsigned short)h.no; rc.kh0[n] = (unsigned char)h.k0; rc.nkh[n] = (unsigned char)h.nk;
+            rc.ow0[n] = (unsigned short)w.o0; rc.now[n] = (unsigned short)w.no; rc.kw0[n] = (unsigned char)w.k0; rc.nkw[n] = (unsigned char)w.nk;
+            rc.rows[n] = nimg * h.no * w.no;
+            rc.nk[n] = (a.Cx / 16) * h.nk * w.nk;
+            rc.magic_img[n] = magic_u32(h.no * w.no);
+            rc.magic_now[n] = magic_u32(w.no);
+            rc.magic_nt[n] = magic_u32(h.nk * w.nk);
+            rc.magic_nkw[n] = magic_u32(w.nk);
+            rc.tile0[n] = (int)tiles;
+            rc.unit0[n] = (int)units;
+            const long long tm = ceil_div(rc.rows[n], 256);
+            tiles += tm;
+            units += tm * ceil_div(a.N, 256) * rc.nk[n];
+            if (units > 0x7fffffffLL || tiles > 0x7fffffffLL) return false;
+            n++;
+        }
+    if (n < 2) return false;
     rc.tile0[n] = (int)tiles;
     rc.unit0[n] = (int)units;
-    if (banded * 100 > dense * 97) return false;
     rc.n = n;
     return true;
 }

@@ -64,8 +64,8 @@ def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgra
     if fwd_variant in (2, 4):  # rows of whole rounds on 256x256 tiles + a split launch of smaller tiles over the rest
         assert 0 < pf[1] < B * H * W and pf[1] % 256 == 0 and pf[3] >= 1, pf
     if fwd_variant == 5:
-        # one launch over all rows, >= 2 slab levels; fc6 (4x4 rate 4): over its 5 row bands
-        assert pf[1] == B * H * W and pf[2] >= 2 and pf[3] == (5 if name == "fc6" else 0), pf
+        # one launch over all rows, >= 2 slab levels; dilated filters: over their pixel classes (fc6, 4x4 rate 4: 5 x 5)
+        assert pf[1] == B * H * W and pf[2] >= 2 and pf[3] == {"fc6": 25}.get(name, 0), pf
     if name == "fc6":
         assert pd[1] == B * H * W and pd[2] >= 2, pd  # 212 big tiles on 256 CUs: pieces of the 65536-long reductions
 
