@@ -325,6 +325,8 @@ def main():
                 "timed_steps_with_events": "%d of %d (every %d%s)" % (prof_steps, args.steps, every, "th" if every > 3 else ""),
                 "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                 "flop_per_launch": d["flops"] / max(d["launches"], 1),
+                "flop_accounting": "algorithmic (2*M*K*N per launch, zero-padding products included: SURVEY 8d); the fp32 kernels "
+                                   "skip the padding of dilated filters (~5.5 % of the ref preset's products)",
                 "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None,
                 "step_tflops": round(fb_flops * args.batch / (ms * 1e-3) / 1e12, 2),
             }
