@@ -145,6 +145,33 @@ def test_stream_k_over_row_bands_on_small_shapes(env, shape, cus):
     assert _rel(got_y, dense_y) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 29, 9, 256, 256, 3, 8), (3, 21, 13, 512, 264, 4, 4), (2, 33, 12, 256, 288, 3, 12)])
+def test_filter_gradient_skips_padding_without_changing_a_bit(env, shape):
+    """Cin % 256 == 0: a k tile of the 256x256 filter-gradient kernel is one tap, and its reduction walks only the pixels at
+    which that tap reads inside the image.  The products it leaves out are exact zeros and the order of the others is kept,
+    so with an unsplit reduction (plan laid out for 1 CU: no pixel splits) the result equals the dense walk bit for bit;
+    with pixel splits (the split points move) it agrees to rounding.  Both against the fp64 oracle."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    dy = rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)
+    wt = torch.zeros((k, k, Cin, Cout), dtype=torch.float64, requires_grad=True)
+    do.conv_same(torch.tensor(x, dtype=torch.float64), wt, torch.zeros(Cout, dtype=torch.float64), dil).backward(
+        torch.tensor(dy, dtype=torch.float64))
+    xg, dyg = _t(torch, x), _t(torch, dy)
+    for cus, exact in ((1, True), (0, False)):
+        with ops.tuned(wgrad_gen=2, plan_cus=cus):
+            skip = ops.conv_wgrad(xg, dyg, k, k, dil)
+            with ops.tuned(fp32_loader=2):
+                dense = ops.conv_wgrad(xg, dyg, k, k, dil)
+        assert _rel(skip.cpu(), wt.grad) < 2e-5 and _rel(dense.cpu(), wt.grad) < 2e-5
+        if exact:
+            assert torch.equal(skip, dense), "skipping zero products must not change the sum"
+        else:
+            assert _rel(skip.cpu(), dense.cpu()) < 2e-6
+
+
 def test_stream_k_tail_launch_on_a_small_shape(env):
     """The automatic plan of the N > 1024 layers (fc6 / fc7 at batch 16): rows of whole rounds on the 256x256 kernel + the
     remaining rows as a stream-K launch of the same kernel starting at m_begin > 0, here with the plan laid out for 4 CUs
