@@ -69,10 +69,11 @@ def parse():
     ap.add_argument("--bucket-mb", type=int, default=32,
                     help="gradient all-reduce bucket size; the LAST bucket (conv1..conv4 gradients) only leaves when backward ends, "
                          "so it is what stays exposed: 32 MB buckets keep it small at 8 collectives per update")
-    ap.add_argument("--release-at", default="conv2_2",
-                    help="N > 1: layer of the backward pass at which the gradient all-reduces may start (\"none\" = as soon as a "
-                         "bucket is complete).  fc6..conv3 run kernels of exactly one workgroup per CU, which a collective holding "
-                         "CUs would push into a second round; conv2_2..conv1_1 (~6 ms) are thousands of small workgroups")
+    ap.add_argument("--release-at", default="none",
+                    help="N > 1: layer of the backward pass at which the gradient all-reduces may start; \"none\" (default, as in "
+                         "the library) = each bucket as soon as it is complete.  E.g. conv2_2 holds everything back until the "
+                         "~6.5 ms of many-small-workgroup kernels at the end of backward (dist.py); compare the two by "
+                         "allreduce.exposed_ms_per_step and the step time on a multi-GPU node")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the data-parallel flow on a single GPU)")
     return ap.parse_args()
@@ -242,6 +243,7 @@ def main():
         step(i)
     fence()
     if adapt._gradsync is not None:
+        adapt._gradsync.timing = True
         adapt._gradsync.stats(reset=True)
         adapt._gradsync.trace = bool(args.overlap_trace)
     every = max(args.prof_every, 1)

@@ -79,14 +79,27 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// keep decision of the built-in dropout generator: a uniform 24-bit draw per (seed, element).  A 32-bit multiply-xorshift
-// finaliser over a linear mix of the element index and the seed (different odd multipliers, so two seeds give unrelated
-// streams): ~9 vector instructions per element -- the 64-bit mixer it replaces cost 0.13 ms per fc6 / fc7 forward launch.
+// keep decision of the built-in dropout generator: a uniform 24-bit draw per (seed, element).  The seed is hashed on its
+// own into two words (it is a kernel argument, so this is scalar-ALU work once per wave): one is XORed into the element
+// index's linear mix before a 32-bit multiply-xorshift finaliser, the other added between the finaliser's two rounds.  A
+// 32-bit state means every seed draws from the same 2^32 values, but two seeds visit them in unrelated orders (XOR and add
+// do not commute with the multiplies, so no seed's stream is a shifted copy of another's -- scripts/dropout_quality.py
+// checks the cross-seed correlation).  ~10 vector instructions per element.
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float keep) {
-    unsigned h = (unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0x27D4EB2Fu + (unsigned)seed * 0x85EBCA77u +
-                 (unsigned)(seed >> 32) * 0xC2B2AE3Du;
+    const unsigned s1 = fmix32((unsigned)seed ^ fmix32((unsigned)(seed >> 32) + 0x9E3779B9u));
+    const unsigned s2 = fmix32(s1 + 0x7F4A7C15u);
+    unsigned h = ((unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0x27D4EB2Fu) ^ s1;
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
+    h += s2;
     h ^= h >> 12;
     h *= 0x297A2D39u;
     h ^= h >> 15;

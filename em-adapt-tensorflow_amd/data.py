@@ -141,8 +141,12 @@ class dataset:
             box = [int(np.random.SeedSequence().entropy % (1 << 31))]
             torch.distributed.broadcast_object_list(box, src=0)
             seed = box[0]
-        self.perm_rng = np.random.default_rng(seed)
-        self.rng = np.random.default_rng(None if seed is None else [int(seed), self.rank])
+        if seed is None:
+            seed = int(np.random.SeedSequence().entropy % (1 << 31))
+        # the permutation of (category, epoch) is a pure function of the seed, so no call order on one rank (a rank-0-only
+        # pass over "val", say) can shift the shards of the ranks against each other
+        self.perm_seed = int(seed)
+        self.rng = np.random.default_rng([int(seed), self.rank])
         self.img_mean = np.ones((self.w, self.h, 3))
         self.img_mean[:, :, 0] *= 104.00698793
         self.img_mean[:, :, 1] *= 116.66876762
@@ -179,8 +183,13 @@ class dataset:
         for category in self.categorys:
             self.info["epoch"][category] = 0
             self.info["index"][category] = 0
-            self.info["perm"][category] = self.perm_rng.permutation(self.data_len[category])
+            self.info["perm"][category] = self.epoch_perm(category, 0)
         return self.info
+
+    def epoch_perm(self, category, epoch):
+        """The sample order of `epoch` over `category`: identical on every rank, independent of what was drawn before."""
+        rng = np.random.default_rng([self.perm_seed, self.categorys.index(category), int(epoch)])
+        return rng.permutation(self.data_len[category])
 
     def get_info(self, key="epoch", category=None):
         return self.info[key][category or self.default_category]
@@ -227,7 +236,7 @@ class dataset:
 
     def sample_order(self, category=None, batch_size=None, epoches=-1):
         """Iterator over (epoch, position, sample indices) of this rank's batches.  One permutation per epoch, shared
-        by all ranks (common ``perm_rng``); a global batch is ``batch_size * world`` consecutive entries of it and rank r
+        by all ranks (``epoch_perm``: a function of seed, category and epoch); a global batch is ``batch_size * world`` consecutive entries of it and rank r
         takes entries [r*batch_size, (r+1)*batch_size) -- ranks never see the same sample within an epoch.  With one
         rank a short final batch is yielded as is (tf.data ``batch``); with several ranks the ragged remainder of an
         epoch is dropped so that every rank always holds the same number of samples (the gradient all-reduce averages
@@ -236,16 +245,17 @@ class dataset:
         batch_size = batch_size or self.config.get("batch_size", 1)
         n = self.data_len[category]
         gb = batch_size * self.world
+        if n == 0 or (self.world > 1 and n < gb):
+            raise ValueError("category %r holds %d samples: fewer than one global batch of %d x %d ranks" % (
+                category, n, batch_size, self.world))
         ep = 0
         while epoches < 0 or ep < epoches:
-            perm = self.perm_rng.permutation(n)
+            perm = self.epoch_perm(category, ep)
             self.info["perm"][category] = perm
             stop = n if self.world == 1 else (n // gb) * gb
             for s in range(0, stop, gb):
                 yield ep, s, perm[s + self.rank * batch_size:s + (self.rank + 1) * batch_size]
             ep += 1
-            if stop == 0:
-                return
 
     def next_batch(self, category=None, batch_size=None, epoches=-1):
         import concurrent.futures

@@ -550,10 +550,11 @@ class ADAPT(Network):
         plan = self._plan
         bf16 = self.compute_dtype == "bf16"
         x6 = self.compute_dtype == "bf16x6"
-        # data parallel: the gradient exchange starts when backward reaches `allreduce_release_at` (dist.py: the kernels
-        # before it occupy every CU with exactly one workgroup and must not find CUs taken by a collective)
+        # data parallel: every bucket's all-reduce is launched as soon as its gradients are final (default), or -- opt-in,
+        # config "allreduce_release_at": a layer name -- held until backward reaches that layer (dist.py: a policy to be
+        # chosen by measurement on a multi-GPU node; bench.py reports the exposed time of either)
         sync = self._gradsync if last_micro else None
-        release_at = self.config.get("allreduce_release_at", "conv2_2")
+        release_at = self.config.get("allreduce_release_at", None)
         if sync is not None and release_at is not None and any(o.name == release_at for o in plan):
             sync.hold()
         for i in range(len(plan) - 1, -1, -1):
@@ -663,8 +664,8 @@ class ADAPT(Network):
 
         def save(which, name, step):
             path = self.saver[which].save(None, os.path.join(saver_dir, name), global_step=step)
-            if world > 1:
-                torch.distributed.barrier()
+            if world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+                torch.distributed.barrier()   # (rank / world given by the config alone: nothing to meet at)
             return path
 
         while epoch < epoches and (max_iterations is None or i < max_iterations):

@@ -14,13 +14,21 @@ fc8/fc7/fc6 gradients -- 77 % of the bytes -- travel while conv5..conv1 are stil
 ``wait()`` joins the outstanding collectives before the optimiser step.  Works unchanged on CPU tensors
 with the gloo backend (tests).
 
-WHEN the collectives may start is the caller's decision (``hold()`` / ``release()``): the kernels of fc6 .. conv3 are laid
-out as exactly one workgroup per CU with no register room for anything beside them (stream-K forward / data gradient, 256-
-or 512-workgroup filter gradients), so a collective's workgroups that hold a few CUs while such a kernel starts would push
-its displaced workgroups into a second round -- twice the kernel's time.  The training step therefore holds the completed
-buckets back until backward reaches the layers whose kernels are thousands of small workgroups (conv2_2 .. conv1_1, ~6 ms),
-and the whole exchange (260 MB) runs under those.
+WHEN the collectives may start is the caller's decision.  The default is launch-on-completion: the exchange has nearly the
+whole backward pass (~55 ms in fp32) to hide in.  ``hold()`` / ``release()`` let a step keep completed buckets back until a
+chosen layer instead (config ``allreduce_release_at``).  Why one might: the kernels of fc6 .. conv3 are laid out as exactly
+one workgroup per CU with no register or LDS room for anything beside them, so the workgroups of a collective that occupy a
+few CUs when such a kernel starts delay the workgroups displaced from those CUs by the collective's duration (a few hundred
+microseconds per 32 MB bucket), whereas conv2_2 .. conv1_1 (~6.5 ms, thousands of small workgroups) lose a few CUs
+gracefully -- but then the whole 260 MB exchange must fit under those 6.5 ms or stay exposed.  Neither policy has been
+measured on more than one GPU (no multi-GPU node was available to this build), so the conservative one is the default and
+bench.py reports ``allreduce.exposed_ms_per_step`` for whichever is selected (``--release-at``).
+
+Timing is OFF by default (a long training run must not pile up HIP events); bench.py and the tests switch it on, and the
+record kept is bounded.
 """
+import collections
+
 import torch
 import torch.distributed as dist
 
@@ -44,9 +52,10 @@ class GradSync:
         self.launched_bytes = 0
         # measurement (bench.py): time the compute stream spends blocked in wait(), per update, from HIP events on the
         # compute stream; with `trace` on, also where in the backward pass each bucket was launched
-        self.timing = bool(flat.is_cuda)
+        self.timing = False    # bench.py / tests: set True (CUDA tensors only) to collect the events stats() reads
         self.trace = False
-        self._ev = []          # per update: (backward-start, [launch events], wait-start, [after-bucket events])
+        # per update: (backward-start, [launch events], wait-start, [after-bucket events]); the last `keep` updates only
+        self._ev = collections.deque(maxlen=256)
         self._cur = None
 
     def _event(self):
@@ -124,7 +133,7 @@ class GradSync:
                                      stall_at_join_ms=round(marks[i].elapsed_time(marks[i + 1]), 3) if i + 1 < len(marks) else None)
                                 for i, l in enumerate(last["launch"])]
         if reset:
-            self._ev = []
+            self._ev.clear()
         return out
 
 

@@ -12,11 +12,13 @@ State dicts keep the reference's names: ``net``, ``weights``, ``loss``, ``saver`
 import json
 import os
 import re
+import warnings
 
 import numpy as np
 import torch
 
 from . import ops
+from .data import dist_rank_world
 
 
 def round_up(v, m):
@@ -104,6 +106,7 @@ class Network:
 
 
 _INDEX = "checkpoint"   # the index file tf.train.Saver keeps next to its checkpoints
+_LEGACY_MOMENTUM = "__momentum__"   # round-1 checkpoints: the flat momentum buffer as a single array
 
 
 def _step_of(path):
@@ -156,7 +159,7 @@ class _Saver:
         if global_step is not None:
             path = "%s-%d" % (path, int(global_step))
         final = os.path.abspath(path + ".npz")
-        if _rank() != 0:          # data-parallel runs: the replicas are identical, rank 0 writes
+        if dist_rank_world(n.config)[0] != 0:   # data-parallel runs: the replicas are identical, rank 0 writes
             return final
         os.makedirs(os.path.dirname(final), exist_ok=True)
         blob = {}
@@ -193,21 +196,30 @@ class _Saver:
         n = self.netobj
         if not path.endswith(".npz"):
             path = path + ".npz"
+        flat = getattr(n, "_flat", None)
         with np.load(path) as z:
+            slots = 0
             for layer, (w, b) in n.weights.items():
                 w.copy_(torch.from_numpy(z[layer + "_weights"]).to(w.device))
                 b.copy_(torch.from_numpy(z[layer + "_bias"]).to(b.device))
-                if getattr(n, "_flat", None) is not None and layer + "_weights/Momentum" in z.files:
+                if flat is not None and layer + "_weights/Momentum" in z.files:
                     vw, vb = self._momentum_views(layer)
                     vw.copy_(torch.from_numpy(z[layer + "_weights/Momentum"]).to(vw.device))
                     vb.copy_(torch.from_numpy(z[layer + "_bias/Momentum"]).to(vb.device))
-        if getattr(n, "_flat", None) is not None:
+                    slots += 1
+            if flat is not None and slots == 0:
+                # round-1 files hold the whole (padded) momentum buffer as one array: usable when the layout still matches
+                if _LEGACY_MOMENTUM in z.files and z[_LEGACY_MOMENTUM].size == flat["momentum"].numel():
+                    flat["momentum"].copy_(torch.from_numpy(z[_LEGACY_MOMENTUM]).reshape(-1).to(flat["momentum"].device))
+                else:
+                    why = ("its %r array does not fit this run's buffer layout" % _LEGACY_MOMENTUM
+                           if _LEGACY_MOMENTUM in z.files else "it holds no momentum slots")
+                    warnings.warn("checkpoint %s: %s -- weights restored, momentum left as it is (zero in a fresh run), "
+                                  "as with the reference's weights-only Saver" % (path, why))
+            elif flat is not None and slots != len(n.weights):
+                raise ValueError("checkpoint %s holds momentum slots for %d of %d layers" % (path, slots, len(n.weights)))
+        if flat is not None:
             n._flat["params"].add_(0)   # bump torch's version counter: derived filter images are refreshed
-
-
-def _rank():
-    d = torch.distributed
-    return d.get_rank() if d.is_available() and d.is_initialized() else 0
 
 
 __all__ = ["Network", "ops", "round_up", "latest_checkpoint"]

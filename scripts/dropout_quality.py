@@ -18,3 +18,15 @@ print("lag-1 correlation along channels %.5f, along pixels %.5f" % (
     float(((f[:, 1:] - .5) * (f[:, :-1] - .5)).mean() * 4), float(((f[1:] - .5) * (f[:-1] - .5)).mean() * 4)))
 pc = f.mean(0)
 print("per-channel rate: min %.4f max %.4f (n = %d per channel, sigma = %.4f)" % (float(pc.min()), float(pc.max()), f.shape[0], 0.5 / f.shape[0] ** 0.5))
+# cross-seed structure: the masks of two seeds must not be shifted copies of one another (the generator once mixed seed and
+# index linearly, which made every seed the same sequence at an offset).  Circular cross-correlation at every lag, by FFT.
+def max_xcorr(a, b):
+    a = a.reshape(-1).double() - a.double().mean(); b = b.reshape(-1).double() - b.double().mean()
+    n = a.numel()
+    c = torch.fft.irfft(torch.fft.rfft(a) * torch.fft.rfft(b).conj(), n=n) / (a.norm() * b.norm())
+    return float(c.abs().max()), n
+for sa, sb in ((7, 8), (64 * 3 + 14, 64 * 8 + 14), (7, (1 << 32) + 7)):
+    c, n = max_xcorr(mask(sa), mask(sb))
+    print("max |cross-correlation| over all %d lags, seeds %d / %d: %.5f (noise level ~%.5f)" % (n, sa, sb, c, (2 * torch.log(torch.tensor(float(n))) / n) ** 0.5))
+c, n = max_xcorr(m1, m1)
+print("self-correlation (sanity, must be 1): %.5f" % c)

@@ -37,6 +37,7 @@ def _worker(rank, world, port, out_dir):
     mine = flat.clone()
     gs = GradSync(flat, segs, bucket_bytes=2048 * 4)  # several buckets, boundaries inside segments
     assert gs.world_size == world and len(gs.buckets) == 3
+    assert gs.timing is False and gs._ev.maxlen is not None   # no events unless asked for, and a bounded record when asked
     # segments must be reported in layout (= backward) order
     with pytest.raises(RuntimeError):
         gs.segment_ready(1088, 5248)
@@ -48,7 +49,7 @@ def _worker(rank, world, port, out_dir):
     gs.wait()
     assert gs.launched_bytes == total * 4
     # second round re-uses the object (state reset by wait); this time the exchange is held back until the last layer
-    # (the training step's policy: dist.py hold / release)
+    # (an opt-in policy of the training step: dist.py hold / release, config "allreduce_release_at")
     flat2_before = flat.clone()
     gs.hold()
     gs.segment_ready(*segs[0])

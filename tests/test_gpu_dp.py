@@ -57,6 +57,7 @@ def _worker(rank, world, port, out_dir, dtype):
     B = CFG["B"]
     a = _build(torch, params, B, dtype)
     assert a._gradsync is not None and a._gradsync.world_size == world and len(a._gradsync.buckets) > 1
+    a._gradsync.timing = True   # off by default (a training run must not pile up events); stats() below reads them
     sl = slice(rank * B, (rank + 1) * B)
     for _ in range(2):  # two updates: the second exercises momentum and the re-armed GradSync
         a.micro_step(images[sl], labels[sl], keep_prob=1.0, perms=perms)

@@ -236,3 +236,37 @@ def test_saver_keeps_the_last_two_and_resumes_from_the_newest(env, tmp_path):
         assert torch.equal(b.weights[layer][0], w) and torch.equal(b.weights[layer][1], bias)
         va, vb = a.saver["norm"]._momentum_views(layer), b.saver["norm"]._momentum_views(layer)
         assert torch.equal(va[0], vb[0]) and torch.equal(va[1], vb[1]) and float(va[0].abs().max()) > 0
+
+
+def test_restore_accepts_the_legacy_momentum_array_and_warns_without_one(env, tmp_path):
+    """Checkpoints of the first build hold the whole momentum buffer as one "__momentum__" array: restored when it fits the
+    run's layout; a file without any momentum (the reference's weights-only Saver, a converted init model) restores the
+    weights and says so instead of silently restarting the momentum."""
+    ops, ADAPT, do, torch = env
+    cfg = {"input_size": (33, 33), "category_num": 5, "width": 8, "batch_size": 2, "accum_num": 1}
+    a = ADAPT(dict(cfg))
+    a.build()
+    a.pre_train(1e-2, 1e-5, 0.9, 2)
+    images, labels = do.synthetic_batch(2, 33, 5, seed=1)
+    a.micro_step(images / 50, labels, keep_prob=1.0)
+    a.apply_update()
+    blob = {}
+    for layer, (w, b) in a.weights.items():
+        blob[layer + "_weights"] = w.cpu().numpy()
+        blob[layer + "_bias"] = b.cpu().numpy()
+    np.savez(tmp_path / "weights_only.npz", **blob)
+    np.savez(tmp_path / "legacy.npz", __momentum__=a._flat["momentum"].cpu().numpy(), **blob)
+    np.savez(tmp_path / "legacy_other_layout.npz", __momentum__=np.zeros(7, np.float32), **blob)
+    b = ADAPT(dict(cfg))
+    b.build()
+    b.pre_train(1e-2, 1e-5, 0.9, 2)
+    b.restore_from_model(b.saver["norm"], str(tmp_path / "legacy"))
+    assert torch.equal(b._flat["momentum"], a._flat["momentum"]) and float(b._flat["momentum"].abs().max()) > 0
+    assert torch.equal(b._flat["params"], a._flat["params"])
+    for name in ("weights_only", "legacy_other_layout"):
+        c = ADAPT(dict(cfg))
+        c.build()
+        c.pre_train(1e-2, 1e-5, 0.9, 2)
+        with pytest.warns(UserWarning, match="momentum left as it is"):
+            c.restore_from_model(c.saver["norm"], str(tmp_path / name))
+        assert torch.equal(c._flat["params"], a._flat["params"]) and float(c._flat["momentum"].abs().max()) == 0

@@ -159,6 +159,29 @@ def test_dataset_shards_every_global_batch_across_ranks(tmp_path):
     assert [len(i) for _, _, i in single] == [3, 2]
 
 
+def test_dataset_epoch_order_is_stateless_and_small_sets_fail_loudly(tmp_path):
+    """A rank-local pass (rank 0 evaluating on "val", say) must not shift that rank's later "train" shards against the
+    other ranks': the permutation of (category, epoch) is a function of the seed alone.  A set smaller than one global
+    batch is an error at the first draw, not a bare StopIteration out of the training loop."""
+    world, bs, n = 2, 3, 20
+    r0 = _list_only_dataset(tmp_path, n, seed=5, rank=0, world_size=world)
+    r1 = _list_only_dataset(tmp_path, n, seed=5, rank=1, world_size=world)
+    list(r0.sample_order("val", bs, epoches=3))                      # only rank 0 walks "val"
+    o0 = list(r0.sample_order("train", bs, epoches=2))
+    o1 = list(r1.sample_order("train", bs, epoches=2))
+    for (_, _, i0), (_, _, i1) in zip(o0, o1):
+        assert not set(i0.tolist()) & set(i1.tolist())
+    for ep in range(2):
+        seen = [i for o in (o0, o1) for e, s, idx in o if e == ep for i in idx.tolist()]
+        assert len(seen) == len(set(seen))
+    assert np.array_equal(r0.epoch_perm("train", 1), r1.epoch_perm("train", 1))
+    assert not np.array_equal(r0.epoch_perm("train", 0), r0.epoch_perm("train", 1))
+    assert not np.array_equal(r0.epoch_perm("train", 0), r0.epoch_perm("val", 0))
+    small = _list_only_dataset(tmp_path, 5, seed=1, rank=0, world_size=2)
+    with pytest.raises(ValueError, match="fewer than one global batch"):
+        next(small.sample_order("train", 3))
+
+
 def test_synthetic_data_differs_per_rank():
     from em_adapt_tensorflow_amd.data import SyntheticData
     cfg = {"input_size": (33, 33), "category_num": 21, "device": "cpu", "seed": 0}
