@@ -51,6 +51,7 @@ def parse():
                     help="arithmetic of the conv inner products: fp32 = native fp32 MFMA (BASELINE configs[1], the "
                          "headline); bf16 = bf16 operands with fp32 accumulation (configs[2]/[3]); bf16x6 = fp32-grade "
                          "results from six bf16 MFMAs per product over the exact 3-way bf16 split of both fp32 operands")
+    ap.add_argument("--tune", default="", help="launch-plan overrides for A/B runs, e.g. fp32_loader=2,plan_cus=256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="images per CPU-baseline step (BASELINE.md section 4: 16)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (median is reported)")
@@ -215,6 +216,8 @@ def main():
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
            "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb,
            "allreduce_release_at": None if args.release_at == "none" else args.release_at}
+    for kv in filter(None, args.tune.split(",")):
+        ops.tune_set(kv.split("=")[0], int(kv.split("=")[1]))
     data = SyntheticData(dict(cfg, seed=0, unique_batches=2))   # SyntheticData mixes the rank into its seed
     adapt = ADAPT(dict(cfg, data=data))
     adapt.build()

@@ -64,7 +64,8 @@ for n in names:
                  ("kmaj", lambda: ops.filter_kmajor(w, wk)))
         peak = 2516.6 / 6  # six bf16 MFMAs per fp32 product
     else:
-        kinds = (("fwd", lambda: ops.conv_fwd(x, w, b, dil, out=y)), ("dgrad", lambda: ops.conv_dgrad(dy, w, dil, out=dx)),
+        gate = torch.randn(B, H, W, Cin, device="cuda") if "--gate" in sys.argv else None   # dgrad with the ReLU gate, as in the step
+        kinds = (("fwd", lambda: ops.conv_fwd(x, w, b, dil, out=y)), ("dgrad", lambda: ops.conv_dgrad(dy, w, dil, gate=gate, out=dx)),
                  ("wgrad", lambda: ops.conv_wgrad(x, dy, k, k, dil, out=dw)))
         peak = 157.3
     for kind, fn in kinds:
