@@ -1,9 +1,10 @@
 // E-step (weak-label assignment) for gfx950.
 //
 // Replaces the reference's estep.py:33-84 (estep_py) + tf.argmax (deeplab.py:123) and the native
-// entry estep/weaklabel.cpp:7-124.  One 256-thread workgroup per image:
+// entry estep/weaklabel.cpp:7-124.  One 512-thread workgroup per image (eight waves, two per SIMD: the kernel is a chain
+// of dependent LDS round trips and short instruction runs, which a second wave per SIMD fills):
 //
-//   * every thread owns the pixels  i = tid + 256*e  (e < EPT): their running per-pixel maximum
+//   * every thread owns the pixels  i = tid + 512*e  (e < EPT): their running per-pixel maximum
 //     stays in registers, the channels of the classes present in the image stay in LDS
 //     ([slot][pixel], conflict-free for the pixel-strided access), so one (iteration, class) step
 //     never touches HBM;
@@ -11,13 +12,21 @@
 //     coalesced 16-byte loads and every later pass -- suppress, maxima, sweeps, argmax -- runs out of LDS;
 //   * the k-th smallest of (max - channel) -- np.partition in the reference -- is found exactly by a 3-pass
 //     radix select on the raw IEEE bits (order-preserving for the non-negative differences): 11+10+10 bits,
-//     each pass = LDS histogram (ds_add_u32) + a block-wide prefix scan (wavefront __shfl_up + one LDS word per
-//     wave) that locates the bin holding rank k; no sorting, 12 barriers per selection;
+//     each pass = LDS histogram (ds_add_u32, two 16-bit counts per word) + a two-level prefix scan every wave runs
+//     for itself (packed adds, DPP wave scan, ballot); no sorting, 3 barriers per selection (radix_select);
+//   * every loop over a thread's pixels is written classes-outside / pixels-inside with unconditional (clamped)
+//     loads, so that EPT independent loads are in flight instead of one dependent chain;
 //   * arithmetic is fp32 add / sub / compare only, in the reference's order, and the two np.mean()
-//     calls follow NumPy's pairwise summation tree, so label maps AND float maps are bit-identical;
-//   * the class visiting order (random.shuffle in the reference) is an input.
+//     calls follow NumPy's pairwise summation tree (its leaf / combine program is built on the host: it depends on
+//     H*W alone), so label maps AND float maps are bit-identical;
+//   * the class visiting order (random.shuffle in the reference) is an input; it is staged in LDS and compacted to
+//     the classes present in the image before the sweeps.
 //
-// Traffic: logits are read from HBM once (the second pass of the suppress step hits L1/L2), the
+// Round 3 (profiles/r03_estep_bench.txt): 192 -> 90 us at 16 x 41x41x21, 685 -> 467 us at 10 x 65x65x41.  What the
+// first version lost: 12 barriers + 18 ds_bpermute steps per selection, FLAT loads / stores where one pointer could be
+// LDS or HBM, ~50 serial LDS-stack steps of thread 0 building the pairwise-sum program, one load in flight per thread.
+//
+// Traffic: logits are read from HBM once (plus once by the batch-maximum pre-kernel), the
 // int64 label map is written once; the float map is written only when the caller asks for it.
 #include <float.h>
 #include <math.h>
@@ -39,41 +48,44 @@ using namespace emadapt;
 #define ESTEP_STOP(n) do { } while (0)
 #endif
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;   // 8 waves: two per SIMD (one wave per SIMD leaves every LDS / issue latency of this
+                                // dependency-bound kernel in the open)
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxC = 256;       // classes
 constexpr int kMaxLeaves = 192;  // leaves of NumPy's pairwise-sum tree for HW <= 8192
-constexpr int kMaxEPT = 32;      // pixels per thread -> HW <= 8192
+constexpr int kMaxEPT = 16;      // pixels per thread -> HW <= 8192
 constexpr size_t kLdsBudget = 160 * 1024;
 constexpr int kHistBins = 2048;  // 11-bit first radix pass
 constexpr int kPermCap = 1024;   // visiting-order entries (num_iter * (C-1)) staged in LDS; beyond that: read from HBM
 
-__device__ __forceinline__ unsigned f2key(float f) {
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(unsigned k) {
-    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
-
-// Batch-global maximum of the logits (np.amax(feature_map), estep.py:50) as an order-preserving key.
+// Batch-global maximum of the logits (np.amax(feature_map), estep.py:50), first stage: one maximum per block into
+// out[blockIdx.x] (kGmaxBlocks floats of workspace; the E-step kernel folds them -- no memset, no atomics, one launch less
+// in front of the kernel).  A 16-lane group reads whole rows with 16-byte loads when the row pitch allows it.
+constexpr int kGmaxBlocks = 64;
 __global__ void __launch_bounds__(256) estep_gmax_kernel(const float *__restrict__ logits, long long rows,
-                                                       int C, long long ldl, unsigned *out) {
+                                                       int C, long long ldl, float *__restrict__ out) {
     float m = -INFINITY;
-    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows;
-         r += (long long)gridDim.x * blockDim.x) {
-        const float *p = logits + r * ldl;
-        for (int c = 0; c < C; c++) m = fmaxf(m, p[c]);
+    if ((ldl & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        const long long q4 = ldl >> 2, n4 = rows * q4;
+        for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (long long)gridDim.x * blockDim.x) {
+            const float4 v = *reinterpret_cast<const float4 *>(logits + g * 4);
+            const int c = (int)(g % q4) * 4;
+            if (c + 0 < C) m = fmaxf(m, v.x);
+            if (c + 1 < C) m = fmaxf(m, v.y);
+            if (c + 2 < C) m = fmaxf(m, v.z);
+            if (c + 3 < C) m = fmaxf(m, v.w);
+        }
+    } else {
+        for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
+            const float *p = logits + r * ldl;
+            for (int c = 0; c < C; c++) m = fmaxf(m, p[c]);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     __shared__ float s[4];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-        atomicMax(out, f2key(m));
-    }
+    if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
 }
 
 struct EstepArgs {
@@ -86,14 +98,51 @@ struct EstepArgs {
     int HW, C, suppress, num_iter;
     float margin;
     int k_bg, k_fg;
-    const unsigned *gmax_key;
+    const float *gmax_part;   // [kGmaxBlocks] per-block maxima of estep_gmax_kernel
     float *map_out;
     long long *labels_out;
     int p_res;  // present-channel slots resident in LDS
     int hwp;    // HW rounded up to a multiple of 4 (LDS row pitch)
     int full;   // 1: all C channels are staged into LDS, indexed by class (p_res == C)
     int stop_after;  // diagnostic builds (tune "estep_stop"): leave the kernel after phase n (0 = run everything)
+    // NumPy's pairwise-summation tree for n = HW (it depends on HW alone): leaves and the post-order combine program, built
+    // on the host (pairwise_program).  On the device it was ~50 dependent LDS-stack steps of thread 0: 20 us of the kernel.
+    int nleaf, nprog;
+    unsigned short leaf_off[kMaxLeaves];
+    unsigned char leaf_n[kMaxLeaves];        // <= 128
+    unsigned char prog[2 * kMaxLeaves];      // 0 = push next leaf, 1 = add
 };
+
+// np.add.reduce of a contiguous float32 array (numpy/core/src/umath/loops_utils.h.src, pairwise_sum): blocks of <= 128 are
+// summed with eight running sums, larger ones are split at n/2 rounded down to a multiple of 8.
+void pairwise_program(EstepArgs &a, int HW) {
+    int nleaf = 0, nprog = 0, sp = 1;
+    int s_off[32], s_n[32], s_st[32];
+    s_off[0] = 0; s_n[0] = HW; s_st[0] = 0;
+    while (sp > 0) {
+        const int off = s_off[sp - 1], n = s_n[sp - 1], st = s_st[sp - 1];
+        if (n <= 128) {
+            a.leaf_off[nleaf] = (unsigned short)off; a.leaf_n[nleaf] = (unsigned char)n; nleaf++;
+            a.prog[nprog++] = 0;
+            sp--;
+        } else {
+            int n2 = n / 2;
+            n2 -= n2 % 8;
+            if (st == 0) {
+                s_st[sp - 1] = 1;
+                s_off[sp] = off; s_n[sp] = n2; s_st[sp] = 0; sp++;
+            } else if (st == 1) {
+                s_st[sp - 1] = 2;
+                s_off[sp] = off + n2; s_n[sp] = n - n2; s_st[sp] = 0; sp++;
+            } else {
+                a.prog[nprog++] = 1;
+                sp--;
+            }
+        }
+    }
+    a.nleaf = nleaf;
+    a.nprog = nprog;
+}
 
 // One leaf (n <= 128) of NumPy's float32 pairwise summation.
 __device__ float np_leaf_sum(const float *a, int n) {
@@ -191,53 +240,94 @@ __device__ float np_mean_lds(const Lds &l, int HW, int tid) {
 // floats); unused slots hold 0xFFFFFFFF and never match a prefix.  Three passes over 11 + 10 + 10 bits from the top:
 // histogram the digit of every key that still matches the selected prefix, scan the histogram to find the bin
 // containing rank k, descend into it.  Every thread returns the same value.
-template <int EPT>
-__device__ unsigned radix_select(const unsigned (&key)[EPT], int k, const Lds &l, int tid, int lane, int wave) {
-    unsigned prefix = 0;
-    unsigned kk = (unsigned)k;
-    int shift = 31;
-#pragma unroll 1
-    for (int pass = 0; pass < 3; pass++) {
-        const int bits = pass == 0 ? 11 : 10;
-        shift -= bits;  // 20, 10, 0
-        const int nb = 1 << bits;
-        for (int h = tid; h < nb; h += kThreads) l.hist[h] = 0u;
-        __syncthreads();
+//
+// ONE barrier per pass (round 3; the first version needed four -- clear, count, scan, broadcast -- and the 5 x P dependent
+// selections of an image, 12 barriers each, were two thirds of the kernel's time):
+//   * each pass has a histogram of its own, so nothing is cleared between counting and scanning: a pass's buffer is zeroed
+//     one barrier after its scan, by which time every wave is past it (h0 after the second barrier, h1 after the third, h2
+//     after the first barrier of the NEXT selection; all three are zero when the sweeps start);
+//   * after the barrier that ends the counting EVERY wave scans the whole histogram by itself (32 / 16 bins per lane, wave
+//     prefix sum, ballot for the owning lane): no partial sums cross waves, no result is broadcast through LDS;
+//   * counts are at most HW <= 8192, so two bins share a 32-bit word (bin b = half b & 1 of word b >> 1, incremented by
+//     1 << 16 * (b & 1)): the three histograms fit the 8 KB the single 2048-bin one had -- LDS is full at 41 x 41 x 21.
+constexpr int kH1 = 1024, kH2 = 1536;   // word offsets of the 1024-bin histograms behind the 2048-bin one
+
+// Inclusive prefix sum over the 64 lanes with data-parallel-primitive moves (six dependent v_add ... dpp, a few cycles each;
+// __shfl_up goes through ds_bpermute, ~100 cycles per step): Kogge-Stone inside the rows of 16 lanes (row_shr 1, 2, 4, 8;
+// lanes without a source add 0), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3
+// (row_bcast:31).
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+__device__ __forceinline__ void hist_add(unsigned *h, unsigned bin) { atomicAdd(&h[bin >> 1], 1u << (16u * (bin & 1u))); }
+
+// Locate rank kk in a histogram of 64 * WPL * 2 bins (WPL words per lane); returns the bin, updates kk to the rank inside it.
+// Two levels, both a wave prefix sum + ballot: first over the lanes' segment totals (the segment's words are added PACKED, two
+// 16-bit counts per add -- no sum exceeds HW <= 8192), then over the 2 * WPL bins of the owning segment, one bin per lane
+// (a 16-bit LDS read).  ~45 instructions: eight waves run this redundantly, so its length is what a selection waits for.
+template <int WPL>
+__device__ __forceinline__ unsigned hist_locate(const unsigned *h, unsigned &kk, int lane) {
+    static_assert(WPL % 4 == 0 && 2 * WPL <= 64, "words per lane");
+    unsigned acc = 0;
 #pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            const unsigned x = key[e];
-            if ((x >> (shift + bits)) == prefix) atomicAdd(&l.hist[(x >> shift) & (unsigned)(nb - 1)], 1u);
-        }
-        __syncthreads();
-        const int per = nb / kThreads;  // 8 or 4 consecutive bins per thread
-        unsigned local = 0;
-        for (int j = 0; j < per; j++) local += l.hist[tid * per + j];
-        unsigned incl = local;  // inclusive scan over the wavefront
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned n = __shfl_up(incl, d);
-            if (lane >= d) incl += n;
-        }
-        if (lane == 63) l.red[wave] = (int)incl;
-        __syncthreads();
-        unsigned base = 0;
-        for (int w = 0; w < wave; w++) base += (unsigned)l.red[w];
-        const unsigned excl = base + incl - local;
-        if (kk >= excl && kk < excl + local) {  // exactly one thread owns the bin that holds rank kk
-            unsigned c = excl;
-            int j = 0;
-            for (; j < per - 1; j++) {
-                const unsigned hc = l.hist[tid * per + j];
-                if (kk < c + hc) break;
-                c += hc;
-            }
-            l.sel[0] = tid * per + j;
-            l.sel[1] = (int)(kk - c);
-        }
-        __syncthreads();
-        prefix = (prefix << bits) | (unsigned)l.sel[0];
-        kk = (unsigned)l.sel[1];
+    for (int j = 0; j < WPL; j += 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(h + lane * WPL + j);
+        acc += v.x + v.y + v.z + v.w;
     }
-    return prefix;
+    const unsigned local = (acc & 0xFFFFu) + (acc >> 16);
+    const unsigned incl = wave_inclusive_sum(local);
+    const bool mine = kk >= incl - local && kk < incl;   // exactly one lane (the histogram holds more than kk keys)
+    const int owner = __ffsll((long long)__ballot(mine)) - 1;   // wave-uniform (a scalar register)
+    const unsigned r = (unsigned)__builtin_amdgcn_readlane((int)(kk - (incl - local)), owner);   // rank inside the segment
+    const unsigned short *seg = reinterpret_cast<const unsigned short *>(h + owner * WPL);   // bin b = half-word b
+    const unsigned c = lane < 2 * WPL ? (unsigned)seg[lane] : 0u;
+    const unsigned incl2 = wave_inclusive_sum(c);
+    const bool mine2 = r >= incl2 - c && r < incl2;
+    const int l2 = __ffsll((long long)__ballot(mine2)) - 1;
+    kk = (unsigned)__builtin_amdgcn_readlane((int)(r - (incl2 - c)), l2);
+    return (unsigned)(owner * WPL * 2 + l2);
+}
+
+// (abl: diagnostic builds only -- timing with parts of the selection left out; results are then garbage)
+#ifdef EMADAPT_ABLATE_BUILD
+#define SEL_ABL(bit) (abl & (bit))
+#else
+#define SEL_ABL(bit) 0
+#endif
+template <int EPT>
+__device__ unsigned radix_select(const unsigned (&key)[EPT], int k, const Lds &l, int tid, int lane, int abl = 0) {
+    unsigned *h0 = l.hist, *h1 = l.hist + kH1, *h2 = l.hist + kH2;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    unsigned kk = (unsigned)k;
+    // ---- bits 30..20
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+        if (key[e] < 0x80000000u && !SEL_ABL(16)) hist_add(h0, key[e] >> 20);
+    if (!SEL_ABL(64)) __syncthreads();
+    if (tid < 128) *reinterpret_cast<uint4 *>(h2 + tid * 4) = zero4;   // the previous selection's last histogram
+    unsigned prefix = SEL_ABL(32) ? 0u : hist_locate<16>(h0, kk, lane);
+    if (SEL_ABL(128)) return prefix << 20;
+    // ---- bits 19..10
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+        if ((key[e] >> 20) == prefix && !SEL_ABL(16)) hist_add(h1, (key[e] >> 10) & 1023u);
+    if (!SEL_ABL(64)) __syncthreads();
+    if (tid < 256) *reinterpret_cast<uint4 *>(h0 + tid * 4) = zero4;
+    prefix = (prefix << 10) | (SEL_ABL(32) ? 0u : hist_locate<8>(h1, kk, lane));
+    // ---- bits 9..0
+#pragma unroll
+    for (int e = 0; e < EPT; e++)
+        if ((key[e] >> 10) == prefix && !SEL_ABL(16)) hist_add(h2, key[e] & 1023u);
+    if (!SEL_ABL(64)) __syncthreads();
+    if (tid < 128) *reinterpret_cast<uint4 *>(h1 + tid * 4) = zero4;
+    return (prefix << 10) | (SEL_ABL(32) ? 0u : hist_locate<8>(h2, kk, lane));
 }
 
 template <int EPT>
@@ -259,6 +349,7 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
 
     // ---- image-level label set (estep.py:35-44) ----
     for (int c = tid; c < kMaxC; c += kThreads) l.slot[c] = 0;
+    for (int h = tid; h < kHistBins; h += kThreads) l.hist[h] = 0u;   // radix_select expects its histograms zeroed
     __syncthreads();
     if (a.label_kind == EMADAPT_LABEL_MULTIHOT) {
         const unsigned char *mh = static_cast<const unsigned char *>(a.label) + (size_t)b * C;
@@ -278,46 +369,32 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    if (full) {   // slot of class c == c: nothing to count
+        for (int c = tid; c < C; c += kThreads) l.slot[c] = l.slot[c] != 0 ? c : -1;
+    } else if (tid == 0) {
         int P = 0;
         for (int c = 0; c < C; c++) {
             const bool present = l.slot[c] != 0;
-            l.slot[c] = present ? (full ? c : P) : -1;
+            l.slot[c] = present ? P : -1;
             P += present ? 1 : 0;
         }
         l.misc[0] = P;
-        // NumPy pairwise-sum tree for n = HW: leaves + post-order combine program.
-        int nleaf = 0, nprog = 0, sp = 0;
-        int *s_off = l.stk, *s_n = l.stk + 16, *s_st = l.stk + 32;
-        s_off[0] = 0; s_n[0] = HW; s_st[0] = 0; sp = 1;
-        while (sp > 0) {
-            const int off = s_off[sp - 1], n = s_n[sp - 1], st = s_st[sp - 1];
-            if (n <= 128) {
-                l.leaf_off[nleaf] = off; l.leaf_n[nleaf] = n; nleaf++;
-                l.prog[nprog++] = 0;
-                sp--;
-            } else {
-                int n2 = n / 2;
-                n2 -= n2 % 8;
-                if (st == 0) {
-                    s_st[sp - 1] = 1;
-                    s_off[sp] = off; s_n[sp] = n2; s_st[sp] = 0; sp++;
-                } else if (st == 1) {
-                    s_st[sp - 1] = 2;
-                    s_off[sp] = off + n2; s_n[sp] = n - n2; s_st[sp] = 0; sp++;
-                } else {
-                    l.prog[nprog++] = 1;
-                    sp--;
-                }
-            }
-        }
-        l.misc[1] = nleaf;
-        l.misc[2] = nprog;
     }
+    if (tid == 0) {
+        l.misc[1] = a.nleaf;
+        l.misc[2] = a.nprog;
+    }
+    for (int t = tid; t < a.nleaf; t += kThreads) { l.leaf_off[t] = a.leaf_off[t]; l.leaf_n[t] = a.leaf_n[t]; }
+    for (int t = tid; t < a.nprog; t += kThreads) l.prog[t] = a.prog[t];
     __syncthreads();
 
     ESTEP_STOP(1);
-    const float gmax = a.suppress ? key2f(*a.gmax_key) : 0.f;
+    float gmax = 0.f;
+    if (a.suppress) {   // fold the per-block maxima (max is exact: any order gives the same float)
+        float g = a.gmax_part[lane];
+        for (int o = 32; o > 0; o >>= 1) g = fmaxf(g, __shfl_xor(g, o));
+        gmax = g;
+    }
     const bool suppress = a.suppress != 0;
     float mx[EPT];
 
@@ -326,14 +403,26 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
         const float *img = a.logits + (size_t)b * HW * a.ldl;
         if ((a.ldl & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.logits) & 15) == 0)) {
             const int q4 = (int)(a.ldl >> 2);
-            for (int g = tid; g < HW * q4; g += kThreads) {
-                const int row = g / q4, q = g - row * q4;
-                const float4 v = *reinterpret_cast<const float4 *>(img + (size_t)g * 4);
-                const int c = q * 4;
-                if (c + 0 < C) l.chan[(size_t)(c + 0) * hwp + row] = v.x;
-                if (c + 1 < C) l.chan[(size_t)(c + 1) * hwp + row] = v.y;
-                if (c + 2 < C) l.chan[(size_t)(c + 2) * hwp + row] = v.z;
-                if (c + 3 < C) l.chan[(size_t)(c + 3) * hwp + row] = v.w;
+            const int n4 = HW * q4;
+            constexpr int U = 8;   // loads in flight per thread (one at a time, every load's full latency was in the open)
+            for (int g0 = tid; g0 < n4; g0 += kThreads * U) {
+                float4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int g = g0 + u * kThreads;
+                    v[u] = *reinterpret_cast<const float4 *>(img + (size_t)(g < n4 ? g : g0) * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int g = g0 + u * kThreads;
+                    if (g >= n4) break;
+                    const int row = g / q4, q = g - row * q4;
+                    const int c = q * 4;
+                    if (c + 0 < C) l.chan[(size_t)(c + 0) * hwp + row] = v[u].x;
+                    if (c + 1 < C) l.chan[(size_t)(c + 1) * hwp + row] = v[u].y;
+                    if (c + 2 < C) l.chan[(size_t)(c + 2) * hwp + row] = v[u].z;
+                    if (c + 3 < C) l.chan[(size_t)(c + 3) * hwp + row] = v[u].w;
+                }
             }
         } else {
             for (int g = tid; g < HW * C; g += kThreads) {
@@ -343,33 +432,111 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
         }
         __syncthreads();
         // ---- suppress absent classes (estep.py:46-55) in place, per-pixel max ----
-#pragma unroll 1
-        for (int e = 0; e < EPT; e++) {
-            const int i = tid + e * kThreads;
-            if (i < HW) {
-                float m = FLT_MAX;
-                if (suppress) {
-                    for (int c = 0; c < C; c++) {
-                        const float v = l.chan[(size_t)c * hwp + i];
-                        const float t = (l.slot[c] >= 0) ? v : v + gmax;
-                        m = (t < m) ? t : m;
-                    }
+        // (class loop outside, the thread's pixels inside: EPT independent compare chains instead of one dependent LDS
+        //  read after another; whether a class is present is wave-uniform)
+        float m[EPT], mxv[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) m[e] = FLT_MAX;
+        // (pixels past the end re-read the last one: every load is unconditional and the EPT of a class are in flight together)
+        int ii[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) ii[e] = min(tid + e * kThreads, HW - 1);
+        if (suppress) {
+            for (int c = 0; c < C; c++) {
+                const bool present = __builtin_amdgcn_readfirstlane(l.slot[c]) >= 0;
+                const float *ch = l.chan + (size_t)c * hwp;
+                float v[EPT];
+#pragma unroll
+                for (int e = 0; e < EPT; e++) v[e] = ch[ii[e]];
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const float t = present ? v[e] : v[e] + gmax;
+                    m[e] = (t < m[e]) ? t : m[e];
                 }
-                const float repl = m - a.margin;
-                float mxv = 0.f;
-                for (int c = 0; c < C; c++) {
-                    float v = l.chan[(size_t)c * hwp + i];
-                    if (suppress && l.slot[c] < 0 && v > m) {
-                        v = repl;
-                        l.chan[(size_t)c * hwp + i] = v;
-                    }
-                    mxv = (c == 0 || v > mxv) ? v : mxv;
-                }
-                l.mx[i] = mxv;
             }
         }
+        for (int c = 0; c < C; c++) {
+            const bool absent = suppress && __builtin_amdgcn_readfirstlane(l.slot[c]) < 0;
+            float *ch = l.chan + (size_t)c * hwp;
+            float v[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) v[e] = ch[ii[e]];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                if (absent && v[e] > m[e]) {
+                    v[e] = m[e] - a.margin;
+                    if (tid + e * kThreads < HW) ch[ii[e]] = v[e];
+                }
+                mxv[e] = (c == 0 || v[e] > mxv[e]) ? v[e] : mxv[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = tid + e * kThreads;
+            if (i < HW) l.mx[i] = mxv[e];
+        }
+    } else if ((a.ldl & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0) {
+        // ---- suppress absent classes (estep.py:46-55), per-pixel max, present channels -> LDS: the logits come from HBM.
+        // Quads of classes outside, the thread's pixels inside: EPT independent 16-byte loads in flight (a thread walking its
+        // pixels one after the other, one dependent scalar load per class, took 210 us at 65 x 65 x 41).
+        const int nq = (C + 3) >> 2;
+        const float *rowp[EPT];
+        bool ok[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = tid + e * kThreads;
+            ok[e] = i < HW;
+            rowp[e] = a.logits + ((size_t)b * HW + (ok[e] ? i : HW - 1)) * a.ldl;
+        }
+        float m[EPT], mxv[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) { m[e] = FLT_MAX; mxv[e] = 0.f; }
+        if (suppress) {
+            for (int q = 0; q < nq; q++) {
+                float4 v[EPT];
+#pragma unroll
+                for (int e = 0; e < EPT; e++) v[e] = *reinterpret_cast<const float4 *>(rowp[e] + 4 * q);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int c = 4 * q + k;
+                    if (c >= C) break;
+                    const bool present = __builtin_amdgcn_readfirstlane(l.slot[c]) >= 0;
+#pragma unroll
+                    for (int e = 0; e < EPT; e++) {
+                        const float x = k == 0 ? v[e].x : k == 1 ? v[e].y : k == 2 ? v[e].z : v[e].w;
+                        const float t = present ? x : x + gmax;
+                        m[e] = (t < m[e]) ? t : m[e];
+                    }
+                }
+            }
+        }
+        for (int q = 0; q < nq; q++) {
+            float4 v[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) v[e] = *reinterpret_cast<const float4 *>(rowp[e] + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = 4 * q + k;
+                if (c >= C) break;
+                const int sl = __builtin_amdgcn_readfirstlane(l.slot[c]);
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    float x = k == 0 ? v[e].x : k == 1 ? v[e].y : k == 2 ? v[e].z : v[e].w;
+                    if (suppress && sl < 0 && x > m[e]) x = m[e] - a.margin;
+                    mxv[e] = (c == 0 || x > mxv[e]) ? x : mxv[e];
+                    if (ok[e]) {
+                        const int i = tid + e * kThreads;
+                        if (sl >= 0 && sl < p_res) l.chan[(size_t)sl * hwp + i] = x;
+                        else if (a.map_out) a.map_out[((size_t)b * HW + i) * C + c] = x;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+            if (ok[e]) l.mx[tid + e * kThreads] = mxv[e];
     } else
-    // ---- suppress absent classes (estep.py:46-55), per-pixel max, present channels -> LDS ----
+    // (row pitch not a multiple of four floats: one pixel after the other, scalar loads)
 #pragma unroll 1
     for (int e = 0; e < EPT; e++) {
         const int i = tid + e * kThreads;
@@ -408,10 +575,27 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
     ESTEP_STOP(3);
 
     // ---- num_iter sweeps over the classes in the given order (estep.py:62-79) ----
+    // The staged order is first compacted to the PRESENT classes (thread `it` rewrites row `it` in place; the counts go where
+    // the set-up kept its stack): the sweep then walks P entries per iteration instead of testing all C classes -- each test
+    // two dependent LDS reads with nothing to overlap them.
+    const bool compact = perm_lds && a.num_iter <= 48;
+    if (compact) {
+        if (tid < a.num_iter) {
+            unsigned short *row = l.perm + tid * (C - 1);
+            int n = 0;
+            for (int q = 0; q < C - 1; q++) {
+                const int j = row[q];
+                if ((unsigned)j < (unsigned)C && l.slot[j] >= 0) row[n++] = (unsigned short)j;
+            }
+            l.stk[tid] = n;
+        }
+        __syncthreads();
+    }
     for (int it = 0; it < a.num_iter; it++) {
-        for (int q = 0; q < C; q++) {
-            const int pi = it * (C - 1) + (q - 1);
-            const int j = (q == 0) ? 0 : (perm_lds ? (int)l.perm[pi] : a.perms[pi]);
+        const int nvis = compact ? l.stk[it] : C - 1;
+        for (int q = -1; q < nvis; q++) {   // class 0 first (estep.py:64), then the (compacted) order
+            const int pi = it * (C - 1) + q;
+            const int j = (q < 0) ? 0 : (perm_lds ? (int)l.perm[pi] : a.perms[pi]);
             if ((unsigned)j >= (unsigned)C) continue;
             const int s = l.slot[j];
             if (s < 0) continue;
@@ -419,25 +603,44 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
             const bool in_lds = s < p_res;
             float *gch = a.map_out + (size_t)b * HW * C + j;  // non-resident channel lives in map_out
 
+            // (two copies of the loads / stores, chosen by a wave-uniform branch: one pointer that may be LDS or HBM makes
+            //  every access a FLAT instruction, and the read-modify-write below a chain of dependent FLAT round trips)
             unsigned key[EPT];
+            if (in_lds) {
+                const float *ch = l.chan + (size_t)s * hwp;
 #pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                const int i = tid + e * kThreads;
-                key[e] = 0xFFFFFFFFu;
-                if (i < HW) {
-                    const float ch = in_lds ? l.chan[(size_t)s * hwp + i] : gch[(size_t)i * C];
-                    key[e] = __float_as_uint(mx[e] - ch);  // >= +0: raw bits are order-preserving
+                for (int e = 0; e < EPT; e++) {
+                    const int i = tid + e * kThreads;
+                    key[e] = (i < HW) ? __float_as_uint(mx[e] - ch[i]) : 0xFFFFFFFFu;  // >= +0: raw bits are order-preserving
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const int i = tid + e * kThreads;
+                    key[e] = (i < HW) ? __float_as_uint(mx[e] - gch[(size_t)i * C]) : 0xFFFFFFFFu;
                 }
             }
-            const float t = __uint_as_float(radix_select<EPT>(key, k, l, tid, lane, wave));  // np.partition(d, k)[k]
+            const float t = __uint_as_float(radix_select<EPT>(key, k, l, tid, lane, a.stop_after));  // np.partition(d, k)[k]
+            if (in_lds) {
+                float *ch = l.chan + (size_t)s * hwp;
 #pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                const int i = tid + e * kThreads;
-                if (i < HW) {
-                    float *pc = in_lds ? &l.chan[(size_t)s * hwp + i] : &gch[(size_t)i * C];
-                    const float v = *pc + t;
-                    *pc = v;
-                    mx[e] = (v > mx[e]) ? v : mx[e];
+                for (int e = 0; e < EPT; e++) {
+                    const int i = tid + e * kThreads;
+                    if (i < HW) {
+                        const float v = ch[i] + t;
+                        ch[i] = v;
+                        mx[e] = (v > mx[e]) ? v : mx[e];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const int i = tid + e * kThreads;
+                    if (i < HW) {
+                        const float v = gch[(size_t)i * C] + t;
+                        gch[(size_t)i * C] = v;
+                        mx[e] = (v > mx[e]) ? v : mx[e];
+                    }
                 }
             }
         }
@@ -457,18 +660,21 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
     const float shift = l.scal[0];
 
     if (full) {
-#pragma unroll 1
+        int best[EPT];
+        float bv[EPT];
+        for (int c = 0; c < C; c++) {
+            const float *ch = l.chan + (size_t)c * hwp;
+            float v[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) v[e] = ch[min(tid + e * kThreads, HW - 1)] + shift;
+#pragma unroll
+            for (int e = 0; e < EPT; e++)
+                if (c == 0 || v[e] > bv[e]) { bv[e] = v[e]; best[e] = c; }
+        }
+#pragma unroll
         for (int e = 0; e < EPT; e++) {
             const int i = tid + e * kThreads;
-            if (i < HW) {
-                int best = 0;
-                float bv = 0.f;
-                for (int c = 0; c < C; c++) {
-                    const float v = l.chan[(size_t)c * hwp + i] + shift;
-                    if (c == 0 || v > bv) { bv = v; best = c; }
-                }
-                a.labels_out[(size_t)b * HW + i] = best;  // consecutive lanes -> consecutive int64: coalesced
-            }
+            if (i < HW) a.labels_out[(size_t)b * HW + i] = best[e];  // consecutive lanes -> consecutive int64: coalesced
         }
         if (a.map_out) {  // float map of estep.py:82, written with coalesced stores
             float *mo = a.map_out + (size_t)b * HW * C;
@@ -477,6 +683,41 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
                 mo[g] = l.chan[(size_t)c * hwp + row] + shift;
             }
         }
+        return;
+    }
+    if (a.map_out) {
+        // the channels that are not LDS-resident live in the float map: classes outside, the thread's pixels inside (EPT loads
+        // in flight), values re-centred in place
+        int best[EPT];
+        float bv[EPT];
+        size_t ro[EPT];
+        bool ok[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = tid + e * kThreads;
+            ok[e] = i < HW;
+            ro[e] = (size_t)b * HW + (ok[e] ? i : HW - 1);
+        }
+        for (int c = 0; c < C; c++) {
+            const int sl = __builtin_amdgcn_readfirstlane(l.slot[c]);
+            float v[EPT];
+            if (sl >= 0 && sl < p_res) {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) v[e] = l.chan[(size_t)sl * hwp + (ro[e] - (size_t)b * HW)];
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) v[e] = a.map_out[ro[e] * C + c];
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                v[e] = v[e] + shift;
+                if (ok[e]) a.map_out[ro[e] * C + c] = v[e];
+                if (c == 0 || v[e] > bv[e]) { bv[e] = v[e]; best[e] = c; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; e++)
+            if (ok[e]) a.labels_out[ro[e]] = best[e];
         return;
     }
 #pragma unroll 1
@@ -625,7 +866,7 @@ extern "C" {
 
 size_t emadapt_estep_workspace_bytes(int B, int H, int W, int C) {
     (void)B; (void)H; (void)W; (void)C;
-    return 256;  // batch-max key (+ padding)
+    return kGmaxBlocks * sizeof(float);  // per-block maxima of the batch-max pre-kernel
 }
 
 int emadapt_estep_needs_map(int H, int W, int C) {
@@ -658,24 +899,22 @@ int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label
     if (p_res < 0) return EMADAPT_ERR_UNSUPPORTED;
     if (p_res < C && !map_out) return EMADAPT_ERR_WORKSPACE;  // more classes may be present than fit in LDS
 
-    unsigned *gkey = static_cast<unsigned *>(workspace);
+    float *gpart = static_cast<float *>(workspace);
     const double bytes = (double)B * HW * (C * 4.0 + 8.0) + (map_out ? (double)B * HW * C * 4.0 : 0.0);
     ProfScope prof(EMADAPT_K_ESTEP, 0.0, bytes, stream);
     if (suppress_others) {
-        EMADAPT_HIP_TRY(hipMemsetAsync(gkey, 0, 16, stream));
-        const long long rows = (long long)B * HW;
-        int grid = (int)ceil_div(rows, 256);
-        if (grid > 1024) grid = 1024;
-        hipLaunchKernelGGL(estep_gmax_kernel, dim3(grid), dim3(256), 0, stream, logits, rows, C, (long long)ldl, gkey);
+        static_assert(kGmaxBlocks == 64, "the E-step kernel folds one value per lane");
+        hipLaunchKernelGGL(estep_gmax_kernel, dim3(kGmaxBlocks), dim3(256), 0, stream, logits, (long long)B * HW, C, (long long)ldl, gpart);
         int rc = launch_status();
         if (rc) return rc;
     }
     EstepArgs a;
     a.logits = logits; a.ldl = ldl; a.label = label; a.label_kind = label_kind; a.label_len = label_len;
     a.perms = perms; a.HW = (int)HW; a.C = C; a.suppress = suppress_others ? 1 : 0; a.num_iter = num_iter;
-    a.margin = margin_others; a.k_bg = k_bg; a.k_fg = k_fg; a.gmax_key = gkey; a.map_out = map_out;
+    a.margin = margin_others; a.k_bg = k_bg; a.k_fg = k_fg; a.gmax_part = gpart; a.map_out = map_out;
     a.labels_out = reinterpret_cast<long long *>(labels_out); a.p_res = p_res; a.hwp = hwp;
     a.full = (p_res >= C) ? 1 : 0;
+    pairwise_program(a, (int)HW);
 #ifdef EMADAPT_ABLATE_BUILD
     a.stop_after = tune(TUNE_ESTEP_STOP);
 #else
@@ -684,9 +923,9 @@ int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label
     const size_t lds = align_up(lds_bytes(hwp, p_res), 16);
     const int ept = (int)ceil_div(HW, kThreads);
     if (ept <= 1) return launch_estep<1>(a, B, lds, stream);
-    if (ept <= 7) return launch_estep<7>(a, B, lds, stream);   // 41x41 = 1681 (321x321 input)
-    if (ept <= 17) return launch_estep<17>(a, B, lds, stream); // 65x65 = 4225 (513x513 input)
-    return launch_estep<32>(a, B, lds, stream);
+    if (ept <= 4) return launch_estep<4>(a, B, lds, stream);   // 41x41 = 1681 (321x321 input)
+    if (ept <= 9) return launch_estep<9>(a, B, lds, stream);   // 65x65 = 4225 (513x513 input)
+    return launch_estep<16>(a, B, lds, stream);
 }
 
 int emadapt_resize_nearest(const float *in, int B, int H, int W, float *out, int oh, int ow, void *stream_) {

@@ -298,6 +298,8 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  *                filter-gradient kernel walks only the pixels at which a tile's tap is inside the image; 2: like 0
  *                but every pixel is walked (out-of-image taps contribute zeros)
  *   "estep_stop", "ablate": honoured by diagnostic builds only (-DEMADAPT_ABLATE_BUILD), ignored otherwise
+ *                ("estep_stop" 1..4: leave the E-step kernel after that phase; bits 16 / 32 / 64 / 128: run its rank selection
+ *                without the LDS atomics / the histogram scans / the barriers / after the first pass -- timing only)
  * ---------------------------------------------------------------------------------------- */
 int emadapt_tune_set(const char *key, int value);
 /* The plan emadapt_conv_fwd (dgrad = 0) / emadapt_conv_dgrad (dgrad = 1) will use for this shape, given enough workspace:
