@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(256) splitk_epilogue_t_kernel(IgemmArgs a) {
 
 // Storage types: XBF = the gathered activation (x, or dy for the data gradient) is bf16 in memory (Cx % 8 == 0; 16-byte
 // loads carry 8 channels and go to LDS unconverted); YBF = the output (and the gate of the data gradient) is bf16.
-template <int BM, int BN, int WN, bool XBF, bool YBF>
+// ABLM: diagnostic builds only (scripts/bf16_ablate.py) -- parts of the kernel compiled out; 0 in every shipped instantiation.
+template <int BM, int BN, int WN, bool XBF, bool YBF, int ABLM = 0>
 __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 4 : 3) igemm_bf16_kernel(IgemmArgs a, int Cxp) {
     constexpr int BK = 64, WM = 64;
     constexpr int WAVES_N = BN / WN;
@@ -242,14 +243,17 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
         auto load_a = [&](int j) {
             const int ih = (int)(a_hw[j] >> 16) + dh, iw = (int)(a_hw[j] & 0xffffu) + dw;
             const bool ok = kvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            if constexpr ((ABLM & 1) || (ABLM & 8)) return;   // (diagnostic builds: no loads / no A loads -- the registers keep what they held)
             ra[j] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(((unsigned)(toff + j * a_rstride) * ABY) | (ok ? 0u : kOOB)), 0, 0);
         };
         auto load_b = [&](int j) {
             const int n = n0 + b_r0 + j * B_RSTEP;
             const unsigned off = boff + (unsigned)(j * B_RSTEP * Cxp) * 2u;
+            if constexpr ((ABLM & 1) || (ABLM & 16)) return;
             rb[j] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(off | ((bvalid && n < a.N) ? 0u : kOOB)), 0, 0);
         };
         auto store_a = [&](int buf, int j) {
+            if constexpr ((ABLM & 2) != 0) return;   // no LDS stores
             if constexpr (XBF) {
                 *reinterpret_cast<u32x4 *>(As + buf * TILE_A + (a_r0 + j * A_RSTEP) * kPitchG + a_kq * 16) = ra[j];
             } else {
@@ -259,6 +263,7 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
             }
         };
         auto store_b = [&](int buf, int j) {
+            if constexpr ((ABLM & 2) != 0) return;
             *reinterpret_cast<u32x4 *>(Bs + buf * TILE_B + (b_r0 + j * B_RSTEP) * kPitchG + b_kc * 16) = rb[j];
         };
         step_setup(kt0);
@@ -281,7 +286,7 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
             for (int j = 0; j < A_N; j++) { store_a(buf, j); load_a(j); }
 #pragma unroll
             for (int j = 0; j < B_N; j++) { store_b(buf, j); load_b(j); }
-            __syncthreads();
+            if constexpr (!(ABLM & 4)) __syncthreads();
         }
         return;
     }
@@ -332,17 +337,23 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
             // 128 accumulator registers leave room for one fragment set plus the next step's A fragments; the second
             // consumer wave of the SIMD covers the LDS latency of the B fragments
             bf16x8 av[2][TM], bv[TN];
+            const bool rd = !(ABLM & 32) || kt == 0;   // (diagnostic builds, bit 32: fragments are read in the first K step only)
+            if (rd) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) av[0][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG);
+                for (int i = 0; i < TM; i++) av[0][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG);
+            }
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ks++) {
+                if (rd) {
 #pragma unroll
-                for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * kPitchG + ks * 32);
-                if (ks + 1 < BK / 16) {
+                    for (int j = 0; j < TN; j++) bv[j] = *reinterpret_cast<const bf16x8 *>(bs + j * 32 * kPitchG + ks * 32);
+                    if (ks + 1 < BK / 16) {
 #pragma unroll
-                    for (int i = 0; i < TM; i++)
-                        av[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG + (ks + 1) * 32);
+                        for (int i = 0; i < TM; i++)
+                            av[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * kPitchG + (ks + 1) * 32);
+                    }
                 }
+                if constexpr ((ABLM & 64) != 0) continue;   // bit 64: no MFMAs
 #pragma unroll
                 for (int j = 0; j < TN; j++)
 #pragma unroll
@@ -350,7 +361,7 @@ __global__ void __launch_bounds__(((BM / 64) * (BN / WN) + 4) * 64, BM == 128 ? 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[ks & 1][i], bv[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();
+        if constexpr (!(ABLM & 4)) __syncthreads();
     }
     // ---- epilogue through LDS (igemm_common.h: store_acc_tile): the operand tiles are dead after the last barrier
     constexpr int SLAB = 32 * (WN + 4);  // floats per wave
@@ -390,20 +401,20 @@ size_t igemm_bf16_workspace_bytes(const IgemmArgs &a) {
     return s > 1 ? (size_t)s * a.M * a.N * sizeof(float) : 0;
 }
 
-template <int BM, int BN, int WN, bool XBF, bool YBF>
+template <int BM, int BN, int WN, bool XBF, bool YBF, int ABLM = 0>
 int launch_igemm_bf16(IgemmArgs &a, int Cxp, hipStream_t stream) {
     constexpr size_t lds = 2 * (BM + BN) * kPitchG;
     constexpr int threads = ((BM / 64) * (BN / WN) + 4) * 64;
     static DynLdsAttr attr;
     {
-        const int arc = attr.ensure(reinterpret_cast<const void *>(&igemm_bf16_kernel<BM, BN, WN, XBF, YBF>), lds);
+        const int arc = attr.ensure(reinterpret_cast<const void *>(&igemm_bf16_kernel<BM, BN, WN, XBF, YBF, ABLM>), lds);
         if (arc) return arc;
     }
     a.tiles_m = (int)ceil_div(a.M, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
     const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WN, XBF, YBF>), dim3((unsigned)nblk), dim3(threads), lds, stream, a, Cxp);
+    hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, WN, XBF, YBF, ABLM>), dim3((unsigned)nblk), dim3(threads), lds, stream, a, Cxp);
     int rc = launch_status();
     if (rc || a.splits <= 1) return rc;
     long long g = ((long long)a.M * a.N / 4 + 255) / 256;
@@ -416,12 +427,28 @@ template <bool XBF, bool YBF>
 int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     PlanG p = plan_bf16(a);
     if (p.splits > 1 && (!workspace || workspace_bytes < igemm_bf16_workspace_bytes(a))) p.splits = 1;
+#ifdef EMADAPT_ABLATE_BUILD
+    a.ablate = tune(TUNE_ABLATE);
+#else
     a.ablate = 0;
+#endif
     a.tap_inner = (a.ntaps > 1 && Cxp % 64 == 0) ? 1 : 0;
     a.m_begin = 0;
     a.m_end = a.M;
     a.splits = p.splits;
     a.slab = p.splits > 1 ? static_cast<float *>(workspace) : nullptr;
+#ifdef EMADAPT_ABLATE_BUILD
+    if constexpr (XBF && YBF) {   // diagnostic builds: the 256x256 kernel on bf16-stored tensors with parts compiled out
+        if (p.big)
+            switch (a.ablate) {
+#define EMADAPT_ABL_CASE(m) case m: return launch_igemm_bf16<256, 256, 128, true, true, m>(a, Cxp, stream);
+                EMADAPT_ABL_CASE(1) EMADAPT_ABL_CASE(8) EMADAPT_ABL_CASE(16) EMADAPT_ABL_CASE(2) EMADAPT_ABL_CASE(3) EMADAPT_ABL_CASE(7)
+                EMADAPT_ABL_CASE(32) EMADAPT_ABL_CASE(64) EMADAPT_ABL_CASE(96) EMADAPT_ABL_CASE(35) EMADAPT_ABL_CASE(39) EMADAPT_ABL_CASE(4)
+#undef EMADAPT_ABL_CASE
+                default: break;
+            }
+    }
+#endif
     return p.big ? launch_igemm_bf16<256, 256, 128, XBF, YBF>(a, Cxp, stream)
                  : launch_igemm_bf16<128, 128, 64, XBF, YBF>(a, Cxp, stream);
 }
