@@ -99,7 +99,7 @@ __device__ __forceinline__ float epilogue_t(const IgemmArgs &a, float v, int col
         v = v > 0.f ? v : 0.f;
         if (a.keep < 1.0f) {
             const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
-            v = kp ? v / a.keep : 0.f;
+            v = kp ? drop_scale(a, v) : 0.f;
         }
     }
     if (a.gate) {
@@ -793,7 +793,7 @@ int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype
     fill_geometry_bf16(a, Cxp, d, false);
     a.x = static_cast<const float *>(x); a.w = static_cast<const float *>(w_fwd_bf16); a.y = static_cast<float *>(y);
     a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
-    a.epi = epilogue; a.scale = 1.f; a.keep = keep_prob; a.seed = drop_seed;
+    a.epi = epilogue; a.scale = 1.f; set_keep(a, keep_prob); a.seed = drop_seed;
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N, 0.0, stream);
     return dispatch_igemm_bf16_dt(a, Cxp, x_dtype, y_dtype, workspace, workspace_bytes, stream);
@@ -813,7 +813,7 @@ int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const void *dy, int dy_d
     fill_geometry_bf16(a, Cxp, d, true);
     a.x = static_cast<const float *>(dy); a.w = static_cast<const float *>(w_dgrad_bf16); a.y = static_cast<float *>(dx);
     a.bias = nullptr; a.gate = static_cast<const float *>(gate); a.mask = nullptr;
-    a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; a.keep = 1.f; a.seed = 0;
+    a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; set_keep(a, 1.f); a.seed = 0;
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N, 0.0, stream);
     return dispatch_igemm_bf16_dt(a, Cxp, dy_dtype, dx_dtype, workspace, workspace_bytes, stream);

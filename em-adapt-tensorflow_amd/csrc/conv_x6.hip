@@ -580,7 +580,7 @@ int emadapt_conv_fwd_x6(const emadapt_conv_desc *d, const float *x, const float 
     IgemmArgs a;
     fill_geometry(a, d, false);
     a.x = x; a.w = w_kmajor; a.y = y; a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
-    a.epi = epilogue; a.scale = 1.f; a.keep = keep_prob; a.seed = drop_seed;
+    a.epi = epilogue; a.scale = 1.f; set_keep(a, keep_prob); a.seed = drop_seed;
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
     return dispatch_igemm_x6(a, workspace, workspace_bytes, stream);
@@ -596,7 +596,7 @@ int emadapt_conv_dgrad_x6(const emadapt_conv_desc *d, const float *dy, const flo
     IgemmArgs a;
     fill_geometry(a, d, true);
     a.x = dy; a.w = w; a.y = dx; a.bias = nullptr; a.gate = gate; a.mask = nullptr;
-    a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; a.keep = 1.f; a.seed = 0;
+    a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; set_keep(a, 1.f); a.seed = 0;
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
     return dispatch_igemm_x6(a, workspace, workspace_bytes, stream);

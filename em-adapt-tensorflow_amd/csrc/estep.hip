@@ -685,9 +685,9 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
         }
         return;
     }
-    if (a.map_out) {
-        // the channels that are not LDS-resident live in the float map: classes outside, the thread's pixels inside (EPT loads
-        // in flight), values re-centred in place
+    {
+        // Not every class fits in LDS: the host demands a float map then (emadapt_estep_needs_map), and the channels that are not
+        // LDS-resident live in it.  Classes outside, the thread's pixels inside (EPT loads in flight), values re-centred in place
         int best[EPT];
         float bv[EPT];
         size_t ro[EPT];
@@ -718,40 +718,6 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
 #pragma unroll
         for (int e = 0; e < EPT; e++)
             if (ok[e]) a.labels_out[ro[e]] = best[e];
-        return;
-    }
-#pragma unroll 1
-    for (int e = 0; e < EPT; e++) {
-        const int i = tid + e * kThreads;
-        if (i < HW) {
-            const size_t row = (size_t)b * HW + i;
-            const float *p = a.logits + row * a.ldl;
-            float m = FLT_MAX;
-            if (suppress && !a.map_out) {
-                for (int c = 0; c < C; c++) {
-                    const float v = p[c];
-                    const float t = (l.slot[c] >= 0) ? v : v + gmax;
-                    m = (t < m) ? t : m;
-                }
-            }
-            const float repl = m - a.margin;
-            int best = 0;
-            float bv = 0.f;
-            for (int c = 0; c < C; c++) {
-                const int s = l.slot[c];
-                float v;
-                if (s >= 0 && s < p_res) v = l.chan[(size_t)s * hwp + i];
-                else if (a.map_out) v = a.map_out[row * C + c];
-                else {
-                    v = p[c];
-                    if (suppress && s < 0 && v > m) v = repl;
-                }
-                v = v + shift;
-                if (a.map_out) a.map_out[row * C + c] = v;
-                if (c == 0 || v > bv) { bv = v; best = c; }
-            }
-            a.labels_out[row] = best;
-        }
     }
 }
 

@@ -57,6 +57,7 @@ struct IgemmArgs {
     int epi;            // EMADAPT_EPI_*
     float scale;        // gate scale
     float keep;         // dropout keep probability (1 = off)
+    float inv_keep;     // 1.0f / keep (set_keep): what the kept elements are multiplied by
     unsigned long long seed;
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes;  // extents for the bounds-checked buffer loads (< 2 GiB each)
@@ -79,12 +80,15 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// keep decision of the built-in dropout generator: a uniform 24-bit draw per (seed, element).  The seed is hashed on its
-// own into two words (it is a kernel argument, so this is scalar-ALU work once per wave): one is XORed into the element
-// index's linear mix before a 32-bit multiply-xorshift finaliser, the other added between the finaliser's two rounds.  A
-// 32-bit state means every seed draws from the same 2^32 values, but two seeds visit them in unrelated orders (XOR and add
-// do not commute with the multiplies, so no seed's stream is a shifted copy of another's -- scripts/dropout_quality.py
-// checks the cross-seed correlation).  ~10 vector instructions per element.
+// keep decision of the built-in dropout generator: a uniform 16-bit draw per (seed, element), two elements to one 32-bit hash
+// (element idx takes half idx & 1 of the hash of idx >> 1: the decision is a function of (seed, idx) alone, whatever kernel or
+// vector width evaluates it, and adjacent elements -- every epilogue handles 4 or 8 of them per lane -- share the work; keep
+// probabilities resolve to 2^-16).  The seed is hashed on its own into two words (it is a kernel argument, so this is
+// scalar-ALU work once per wave): one is XORed into the pair index's linear mix before a 32-bit multiply-xorshift finaliser,
+// the other added between the finaliser's two rounds.  A 32-bit state means every seed draws from the same 2^32 values, but
+// two seeds visit them in unrelated orders (XOR and add do not commute with the multiplies, so no seed's stream is a shifted
+// copy of another's -- scripts/dropout_quality.py checks the cross-seed correlation).  ~6 vector instructions per element:
+// the fc6 / fc7 forward epilogues draw 110 M + 110 M of these per step inside waves that share their SIMD with the MFMAs.
 __device__ __forceinline__ unsigned fmix32(unsigned h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
@@ -96,14 +100,44 @@ __device__ __forceinline__ unsigned fmix32(unsigned h) {
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float keep) {
     const unsigned s1 = fmix32((unsigned)seed ^ fmix32((unsigned)(seed >> 32) + 0x9E3779B9u));
     const unsigned s2 = fmix32(s1 + 0x7F4A7C15u);
-    unsigned h = ((unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0x27D4EB2Fu) ^ s1;
+    const unsigned long long pair = idx >> 1;
+    unsigned h = ((unsigned)pair * 0x9E3779B1u + (unsigned)(pair >> 32) * 0x27D4EB2Fu) ^ s1;
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
     h += s2;
     h ^= h >> 12;
     h *= 0x297A2D39u;
     h ^= h >> 15;
-    return (float)(h >> 8) * (1.0f / 16777216.0f) < keep;
+    const unsigned r = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+    return (float)r * (1.0f / 65536.0f) < keep;
+}
+
+// tf.nn.dropout scales the kept elements by 1 / keep_prob.  TF 1.x did that as x / keep_prob up to 1.12 and as
+// x * (1 / keep_prob) from 1.13 on (the reference pins no version); for keep_prob = 2^-n -- 0.5 in the reference's training loop,
+// deeplab.py:266 -- the two are the same number bit for bit.  Here: x * inv_keep with inv_keep = 1.0f / keep_prob rounded once
+// on the host.  (A true fp32 division is ~10 vector instructions per element, unrolled 128 times in every fused epilogue: it
+// cost registers the accumulators needed -- the dropout section of the epilogues was where these kernels spilled.)
+inline void set_keep(IgemmArgs &a, float keep_prob) {
+    a.keep = keep_prob;
+    a.inv_keep = 1.0f / keep_prob;
+}
+__device__ __forceinline__ float drop_scale(const IgemmArgs &a, float v) { return v * a.inv_keep; }
+
+// Two adjacent elements (idx0 even, idx0 + 1) from one hash -- what dropout_keep() returns for each, without relying on the
+// compiler to see that the two share their pair index.
+__device__ __forceinline__ void dropout_keep2(unsigned long long seed, unsigned long long idx0, float keep, bool &k0, bool &k1) {
+    const unsigned s1 = fmix32((unsigned)seed ^ fmix32((unsigned)(seed >> 32) + 0x9E3779B9u));
+    const unsigned s2 = fmix32(s1 + 0x7F4A7C15u);
+    const unsigned long long pair = idx0 >> 1;
+    unsigned h = ((unsigned)pair * 0x9E3779B1u + (unsigned)(pair >> 32) * 0x27D4EB2Fu) ^ s1;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h += s2;
+    h ^= h >> 12;
+    h *= 0x297A2D39u;
+    h ^= h >> 15;
+    k0 = (float)(h & 0xFFFFu) * (1.0f / 65536.0f) < keep;
+    k1 = (float)(h >> 16) * (1.0f / 65536.0f) < keep;
 }
 
 // bias / ReLU / dropout (tf.nn.dropout: x / keep_prob * mask) or the ReLU-gradient gate, on one output element.
@@ -113,7 +147,7 @@ __device__ __forceinline__ float epilogue(const IgemmArgs &a, float v, int col, 
         v = v > 0.f ? v : 0.f;
         if (a.keep < 1.0f) {
             const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
-            v = kp ? v / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
+            v = kp ? drop_scale(a, v) : 0.f;  // tf.nn.dropout divides by keep_prob
         }
     }
     if (a.gate) v = a.gate[o] > 0.f ? v * a.scale : 0.f;
@@ -199,10 +233,13 @@ __device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 
                     for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
                     if (a.keep < 1.0f) {
 #pragma unroll
-                        for (int e = 0; e < 8; e++) {
+                        for (int e = 0; e < 8; e += 2) {   // (o is a multiple of 4: (o + e, o + e + 1) is a pair of the generator)
                             if (e >= 4 && !hi) break;
-                            const bool kp = a.mask ? (a.mask[o + e] != 0) : dropout_keep(a.seed, (unsigned long long)(o + e), a.keep);
-                            v[e] = kp ? v[e] / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
+                            bool k0, k1;
+                            if (a.mask) { k0 = a.mask[o + e] != 0; k1 = a.mask[o + e + 1] != 0; }
+                            else dropout_keep2(a.seed, (unsigned long long)(o + e), a.keep, k0, k1);
+                            v[e] = k0 ? drop_scale(a, v[e]) : 0.f;
+                            v[e + 1] = k1 ? drop_scale(a, v[e + 1]) : 0.f;
                         }
                     }
                 }

@@ -476,10 +476,12 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
                             unsigned mk = 0;
                             if (a.mask) mk = *reinterpret_cast<const unsigned *>(a.mask + o);   // four keep bytes (o % 4 == 0)
 #pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                const bool kp = a.mask ? (((mk >> (8 * e)) & 0xFFu) != 0)
-                                                       : dropout_keep(a.seed, (unsigned long long)(o + e), a.keep);
-                                v[e] = kp ? v[e] / a.keep : 0.f;  // tf.nn.dropout divides by keep_prob
+                            for (int e = 0; e < 4; e += 2) {   // (o % 4 == 0: (o + e, o + e + 1) is a pair of the generator)
+                                bool k0, k1;
+                                if (a.mask) { k0 = ((mk >> (8 * e)) & 0xFFu) != 0; k1 = ((mk >> (8 * e + 8)) & 0xFFu) != 0; }
+                                else dropout_keep2(a.seed, (unsigned long long)(o + e), a.keep, k0, k1);
+                                v[e] = k0 ? drop_scale(a, v[e]) : 0.f;
+                                v[e + 1] = k1 ? drop_scale(a, v[e + 1]) : 0.f;
                             }
                         }
                     }

@@ -135,8 +135,9 @@ typedef struct emadapt_conv_desc {
 
 /* Forward: tf.nn.conv2d / tf.nn.atrous_conv2d + tf.nn.bias_add (+ tf.nn.relu (+ tf.nn.dropout))
  * -- deeplab.py:58-59,65-66,71,92-96,100,104.   x f32 [B,H,W,Cin]; w f32 HWIO [KH,KW,Cin,Cout];
- * bias f32 [Cout]; y f32 [B,H,W,Cout].  Dropout (only with EPI_BIAS_RELU): keep_prob < 1 scales kept
- * values by 1/keep_prob (tf.nn.dropout); the keep mask is drop_mask (uint8 [B,H,W,Cout], 1 = keep)
+ * bias f32 [Cout]; y f32 [B,H,W,Cout].  Dropout (only with EPI_BIAS_RELU): keep_prob < 1 multiplies kept
+ * values by the f32 number 1.0f / keep_prob (tf.nn.dropout as of TF 1.13; equal to x / keep_prob bit for bit
+ * when keep_prob is a power of two, e.g. the reference's 0.5); the keep mask is drop_mask (uint8 [B,H,W,Cout], 1 = keep)
  * when non-NULL, else a counter-based hash of (drop_seed, element index). */
 size_t emadapt_conv_fwd_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w, const float *bias,

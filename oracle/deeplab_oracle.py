@@ -11,7 +11,8 @@ vectors for it.  The TF semantics encoded below are th
     (dilated_k-1)//2 before and the rest after (3x3 rate r -> r/r; 4x4 rate 4 -> 6/6, taps -6,-2,+2,+6);
   * max_pool 3x3 SAME: out = ceil(in/stride), padding never wins (treated as -inf), gradient to the
     first maximum of the window;
-  * dropout: x / keep_prob * mask;  sparse_softmax_cross_entropy + reduce_mean over all B*H*W pixels;
+  * dropout: x / keep_prob * mask (TF <= 1.12; from 1.13 on x * (1 / keep_prob) * mask, which is what the HIP kernels compute --
+    the same number for keep_prob = 2^-n, i.e. the reference's 0.5, deeplab.py:266);  sparse_softmax_cross_entropy + reduce_mean over all B*H*W pixels;
   * l2_loss = sum(w^2)/2 over filter weights only;  MomentumOptimizer non-Nesterov: v = mu*v + g, w -= lr*v;
   * the LR multipliers of deeplab.py:194-200 are dead code (the loop rebinds a local) -> none applied;
   * the E-step sees a copy of the logits; the loss uses the untouched fc8 output (deeplab.py:182).

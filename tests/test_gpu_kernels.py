@@ -109,7 +109,7 @@ def test_dropout_epilogue(env):
     mask = (rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8)
     got = ops.conv_fwd(xg, wg, bg, 1, relu=True, keep_prob=0.5, drop_mask=_t(torch, mask, torch.uint8)).cpu().numpy()
     assert np.array_equal(got, np.where(mask > 0, base / np.float32(0.5), 0).astype(np.float32))
-    # built-in generator: kept values are exactly x/keep, the keep rate is ~keep, seeds differ, same seed repeats
+    # built-in generator: kept values are exactly x * (1/keep), the keep rate is ~keep, seeds differ, same seed repeats
     big = ops.conv_fwd(_t(torch, rng.normal(0, 1, (4, 32, 32, Cin)).astype(np.float32)), wg, bg, 1, relu=False)
     xb = _t(torch, np.abs(rng.normal(0, 1, (4, 32, 32, Cin))).astype(np.float32) + 0.1)
     wpos = _t(torch, np.abs(w))
@@ -120,7 +120,8 @@ def test_dropout_epilogue(env):
     assert np.array_equal(d1, d1b) and not np.array_equal(d1, d2)
     kept = d1 != 0
     assert abs(kept.mean() - 0.75) < 0.01
-    assert np.array_equal(d1[kept], (ref / np.float32(0.75))[kept])
+    # kept elements are x * (1 / keep_prob) (TF >= 1.13's dropout; the same number as x / keep_prob for keep_prob = 2^-n)
+    assert np.array_equal(d1[kept], (ref * (np.float32(1.0) / np.float32(0.75)))[kept])
     del big
 
 
