@@ -336,7 +336,6 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
     const Lds l = carve(smem, a.hwp, a.p_res);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
     const int b = blockIdx.x;
     const int HW = a.HW, C = a.C, hwp = a.hwp, p_res = a.p_res;
     const bool full = a.full != 0;  // all channels LDS-resident, slot of class c == c

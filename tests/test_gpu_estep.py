@@ -148,6 +148,29 @@ def test_random_large_batches_against_c_oracle(pkg):
         assert np.array_equal(fm, want_map)
 
 
+def test_every_pixels_per_thread_variant_against_c_oracle(pkg):
+    """The kernel is instantiated for 1 / 4 / 9 / 16 pixels per thread (512 threads per image); 41 x 41 and 65 x 65 take the
+    middle two.  Here the smallest and the largest, each with every class LDS-resident and with the LDS overflowing (the float
+    map then doubles as workspace), label maps and float maps bit for bit against the C restatement of estep.py:33-84."""
+    est, ops, torch = pkg
+    from oracle import estep_oracle as eo
+    from oracle import estep_oracle_c as eoc
+    rng = np.random.default_rng(11)
+    for (B, H, W, C) in [(3, 20, 25, 6), (2, 81, 81, 4), (1, 90, 90, 30), (2, 70, 71, 9)]:
+        logits = rng.normal(0, 2.5, (B, H, W, C)).astype(np.float32)
+        label = np.zeros((B, H, W), np.float32)
+        for b in range(B):
+            for c in rng.choice(np.arange(1, C), size=int(rng.integers(1, min(C, 6))), replace=False):
+                y, x = rng.integers(0, H - 8), rng.integers(0, W - 8)
+                label[b, y:y + 8, x:x + 8] = c
+        label[:, :2, :] = 255   # a border of void labels, as the synthetic batches have
+        perms = eo.draw_perms(5, C, seed=int(rng.integers(1 << 30)))
+        want_map, want = eoc.estep_oracle_c(logits, label, perms, True, 5, 1e-5, 0.4, 0.2)
+        fm, got = est.estep_labels(logits, label, True, 5, 1e-5, 0.4, 0.2, perm=perms)
+        assert np.array_equal(got, want), (B, H, W, C, int((got != want).sum()))
+        assert np.array_equal(fm, want_map), (B, H, W, C)
+
+
 def test_resize_nearest(pkg):
     _, ops, torch = pkg
     from oracle import estep_oracle as eo
