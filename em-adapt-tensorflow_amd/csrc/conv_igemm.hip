@@ -547,7 +547,7 @@ struct LaunchPlan {
     int main_splits;
     int tail_cfg;    // tile variant of the launch over rows [main_rows, M)
     int tail_splits; // its split-K factor (0 = no tail)
-    int bands;       // variant 5 with row bands (RowClasses): the filter rows that lie outside the image are skipped
+    int bands;       // variant 5 over packed rows (RowPack): pixel classes of the launch; their tap boxes' padding is skipped
 };
 
 inline bool v2_ok(const IgemmArgs &a, int bk) { return a.Cx % bk == 0 && a.ntaps <= 32 && a.K >= 2 * bk; }
@@ -589,14 +589,15 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
     if (cfg != 1 && v2_ok(a, 16) && a.N >= 256 && a.N <= 1024 && t256 % cus != 0 && t256 * nk16 / cus >= 32) cfg = 5;
     if (force >= 1 && force <= 5 && !(force >= 4 && !v2_ok(a, 16))) cfg = force;
     // Dilated filters on small maps multiply a lot of padding (fc6, 4x4 rate 4 on 41x41: filter rows -6 / +6 are outside the
-    // image for 6 of its 41 rows each): with row bands (igemm_common.h RowClasses) a stream-K launch skips the filter rows that
-    // are wholly outside, whatever N is (fp32_loader = 2 keeps the dense reduction: tests, A/B).
+    // image for 6 of its 41 rows each): over packed rows (igemm_common.h RowPack) a stream-K launch skips the filter rows and
+    // columns that are wholly outside, whatever N is (fp32_loader = 2 keeps the dense reduction: tests, A/B).
     if ((force == 0 || force == 5) && cfg != 1 && v2_ok(a, 16) && a.N >= 256 && tune(TUNE_FP32_LOADER) != 2) {
         IgemmArgs b = a;
-        if (build_row_classes(b) && b.rc.unit0[b.rc.n] / cus >= 32) {
+        const int tn = (int)ceil_div(a.N, 256);
+        if (build_row_pack(b, tn) && b.pk.run_u0[b.pk.nruns] / cus >= 32) {
             p.cfg = 5;
-            p.bands = b.rc.n;
-            p.main_splits = streamk_levels_banded(b.rc, (int)ceil_div(a.N, 256), cus);
+            p.bands = b.pk.n;
+            p.main_splits = streamk_levels_packed(b, tn, cus);
             return p;
         }
     }
@@ -630,9 +631,12 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
     return p;
 }
 
+// (packed rows: the GEMM row -> pixel table sits behind the slab levels)
+inline size_t rowmap_bytes(const IgemmArgs &a) { return (size_t)ceil_div(a.M, 256) * 256 * sizeof(int); }
+
 size_t igemm_workspace_bytes(const IgemmArgs &a) {
     const LaunchPlan p = plan_launches(a);
-    if (p.cfg == 5) return (size_t)p.main_splits * a.M * a.N * sizeof(float);
+    if (p.cfg == 5) return (size_t)p.main_splits * a.M * a.N * sizeof(float) + (p.bands ? rowmap_bytes(a) : 0);
     size_t b = p.main_splits > 1 ? (size_t)p.main_splits * p.main_rows * a.N * sizeof(float) : 0;
     if (p.tail_cfg == 5) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
     else if (p.tail_splits > 1) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
@@ -681,15 +685,19 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
     a.ablate = 0;
 #endif
     LaunchPlan p = plan_launches(a);
-    if (!workspace || workspace_bytes < igemm_workspace_bytes(a)) {  // no room for slabs: unsplit, same result
-        if (p.cfg == 5 && p.main_splits > 0) p.cfg = 3;
+    if (!workspace || workspace_bytes < igemm_workspace_bytes(a)) {  // no room for slabs / the row table: unsplit, same result
+        if (p.cfg == 5 && (p.main_splits > 0 || p.bands)) { p.cfg = 3; p.bands = 0; }
         if (p.cfg != 5) p.main_splits = 1;
         if (p.tail_cfg == 5 && p.tail_splits > 0) p.tail_cfg = 3;
         if (p.tail_cfg != 5 && p.tail_splits > 1) p.tail_splits = 1;
     }
-    a.rc.n = 0;
+    a.pk.n = 0;
+    a.pk.rowmap = nullptr;
     if (p.cfg == 5) {
-        if (p.bands && !build_row_classes(a)) return EMADAPT_ERR_INVALID;   // (the plan was made from the same geometry)
+        if (p.bands) {
+            if (!build_row_pack(a, (int)ceil_div(a.N, 256))) return EMADAPT_ERR_INVALID;   // (the plan was made from the same geometry)
+            a.pk.rowmap = reinterpret_cast<const int *>(static_cast<char *>(workspace) + (size_t)p.main_splits * a.M * a.N * sizeof(float));
+        }
         a.m_begin = 0;
         a.m_end = a.M;
         a.splits = plan_cus();

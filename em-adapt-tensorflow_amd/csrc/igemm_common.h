@@ -22,27 +22,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ABL(bit) 0
 #endif
 
-// Pixel bands of the stream-K launches that skip padding (igemm_v2.h).  Filter row kh reads input row oh + dh(kh), filter
+// Row packing of the stream-K launches that skip padding (igemm_v2.h).  Filter row kh reads input row oh + dh(kh), filter
 // column kw input column ow + dw(kw); for the output pixels near the edges of an image some filter rows / columns lie wholly
 // outside it and their part of the reduction multiplies zeros.  The output rows that see the same set of filter rows form a
 // band [oh0, oh0 + noh) (a 4x4 rate-4 filter on a 41-row map: [0,2) [2,6) [6,35) [35,39) [39,41)), likewise the columns;
-// a CLASS is a row band x a column band (or a row band x all columns, whichever leaves fewer products after padding the
-// classes to whole tiles).  The GEMM's rows are the pixels class after class (image-major inside a class), every M tile lies
-// inside one class, and its K loop runs over the class's filter rows [kh0, kh0 + nkh) x columns [kw0, kw0 + nkw) only.
+// a CLASS is a row band x a column band, and its TAP BOX the filter rows x columns that reach into the image from its pixels.
+// The GEMM's rows are the pixels class after class (image-major inside a class) -- every pixel exactly once, so there are as
+// many M tiles as in the dense launch -- and a tile's K loop runs over the UNION of the tap boxes of the classes it holds rows
+// of (a tile inside one class: that class's box; a tile across a class boundary multiplies the padding of the smaller boxes).
+// Round 2 padded every class to whole tiles instead: 86.1 % of the dense products for fc6 at batch 16 against 83.6 % packed
+// (80.7 % exact), and no gain at all below batch 12 (25 classes x a partial tile each: the reference's own batch is 6).
+//   classes: GEMM rows [row0[c], row0[c+1]) are the pixels of class c; rowmap_kernel turns that into the table
+//            rowmap[GEMM row] = pixel (in the workspace), which the loaders, epilogues and the fix-up pass read
+//   runs:    consecutive M tiles with the same tap box; run r covers tiles [run_tile0[r], run_tile0[r+1]) and stream-K
+//            units [run_u0[r], run_u0[r+1]) (units = K steps of all tiles, tile after tile, N tiles fastest)
 // n = 0: the rows are the pixels in memory order, nothing is skipped.
 constexpr int kMaxRowClasses = 36;
-struct RowClasses {
-    int n;
-    int tile0[kMaxRowClasses + 1];   // first M tile of class c (tile0[n] = number of M tiles)
-    int unit0[kMaxRowClasses + 1];   // first stream-K unit of class c (units = K steps of all its tiles, tile after tile)
+constexpr int kMaxTileRuns = 112;
+struct RowPack {
+    int n;                 // classes (0 = off)
+    int nruns;
+    const int *rowmap;     // [tiles_m * 256]; -1 = row past the last pixel
+    int row0[kMaxRowClasses + 1];
     unsigned short oh0[kMaxRowClasses], noh[kMaxRowClasses], ow0[kMaxRowClasses], now[kMaxRowClasses];
-    unsigned char kh0[kMaxRowClasses], nkh[kMaxRowClasses], kw0[kMaxRowClasses], nkw[kMaxRowClasses];
-    int rows[kMaxRowClasses];             // pixels of the class: images * noh * now
-    int nk[kMaxRowClasses];               // K steps of one of its tiles: (Cx / 16) * nkh * nkw
     unsigned magic_img[kMaxRowClasses];   // ceil(2^32 / (noh * now)): class row -> image
     unsigned magic_now[kMaxRowClasses];   // ceil(2^32 / now)
-    unsigned magic_nt[kMaxRowClasses];    // ceil(2^32 / (nkh * nkw)): K step -> channel chunk
-    unsigned magic_nkw[kMaxRowClasses];   // ceil(2^32 / nkw): tap of the class -> (filter row, filter column)
+    int run_tile0[kMaxTileRuns + 1];
+    int run_u0[kMaxTileRuns + 1];
+    unsigned char run_kh0[kMaxTileRuns], run_nkh[kMaxTileRuns], run_kw0[kMaxTileRuns], run_nkw[kMaxTileRuns];
 };
 
 struct IgemmArgs {
@@ -67,7 +74,7 @@ struct IgemmArgs {
     float *slab;         // [splits][M][N] fp32 partials when splits > 1
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
     unsigned magic_nt;   // ceil(2^32/ntaps)
-    RowClasses rc;       // stream-K launches that skip padding (rc.n > 0)
+    RowPack pk;          // stream-K launches that skip padding (pk.n > 0)
     unsigned magic_w;    // ceil(2^32 / W)
     int ablate;  // diagnostic builds only (tune "ablate"): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
 };
@@ -168,17 +175,10 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 struct PixelRows {
     __device__ __forceinline__ int operator()(const IgemmArgs &a, int row) const { return row < a.m_end ? row : -1; }
 };
-// BandRows: row = index inside class c (RowClasses); -1 past the class's end (its last tile is partly empty).
-struct BandRows {
-    int c;
-    __device__ __forceinline__ int operator()(const IgemmArgs &a, int j) const {
-        if (j >= a.rc.rows[c]) return -1;
-        const unsigned now = a.rc.now[c];
-        const unsigned img = div_magic((unsigned)j, a.rc.magic_img[c]);
-        const unsigned rem = (unsigned)j - img * ((unsigned)a.rc.noh[c] * now);
-        const unsigned rh = div_magic(rem, a.rc.magic_now[c]);
-        return ((int)img * a.H + a.rc.oh0[c] + (int)rh) * a.W + a.rc.ow0[c] + (int)(rem - rh * now);
-    }
+// MapRows: the rows are packed class after class (RowPack); the table gives the pixel of a GEMM row, -1 past the last pixel.
+struct MapRows {
+    const int *map;
+    __device__ __forceinline__ int operator()(const IgemmArgs &, int j) const { return map[j]; }
 };
 
 //   ADJ  = the lane's TN accumulator tiles are TN ADJACENT columns (column l31*TN + j) instead of l31 + 32*j
@@ -354,7 +354,7 @@ void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
     a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * a.Cx;
     a.x_bytes = (unsigned)((long long)a.M * a.Cx * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
     a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
-    a.magic_w = magic_u32(a.W); a.rc.n = 0;
+    a.magic_w = magic_u32(a.W); a.pk.n = 0; a.pk.rowmap = nullptr;
 }
 
 }  // namespace

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             // (wave-uniform values that come out of vector-ALU divisions are moved to scalar registers by hand: left in vector
             // registers, the piece list's state spilled the accumulators)
             sk_v = t;
-            sk_units = a.rc.n > 0 ? a.rc.unit0[a.rc.n] : ntile * nk_all;
+            sk_units = a.pk.n > 0 ? a.pk.run_u0[a.pk.nruns] : ntile * nk_all;
             sk_u = __builtin_amdgcn_readfirstlane((int)sk_start(t, sk_units, nblk));
             sk_end = __builtin_amdgcn_readfirstlane((int)sk_start(t + 1, sk_units, nblk));
         } else {
@@ -136,25 +136,27 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             lvl = a.splits > 1 ? split : -1;
         }
     }
-    int band = 0;        // row band of the current tile (a.rc.n > 0: stream-K launches that skip padding rows of the filter)
-    int nk_tile = nk_all;   // K steps of the current tile (band-dependent)
+    int run = 0;            // run of the current tile (a.pk.n > 0: stream-K launches over packed rows, RowPack)
+    int nk_tile = nk_all;   // K steps of the current tile (its run's tap box)
     auto next_piece = [&]() -> bool {   // SK: the next piece of [sk_u, sk_end); every wave of the workgroup walks the same list
         if (sk_u >= sk_end) return false;
-        int ubase = 0, tbase = 0;   // first unit / first tile of the band
-        if (a.rc.n > 0) {
-            band = 0;
-            while (band + 1 < a.rc.n && sk_u >= a.rc.unit0[band + 1]) band++;
-            ubase = a.rc.unit0[band];
-            tbase = a.rc.tile0[band] * a.tiles_n;
-            nk_tile = a.rc.nk[band];
+        if (a.pk.n > 0) {
+            while (run + 1 < a.pk.nruns && sk_u >= a.pk.run_u0[run + 1]) run++;
+            nk_tile = (a.Cx / BK) * (int)a.pk.run_nkh[run] * (int)a.pk.run_nkw[run];
+            const int rel = sk_u - a.pk.run_u0[run];
+            const int t_in = __builtin_amdgcn_readfirstlane(rel / nk_tile);   // tile inside the run, N tiles fastest
+            kt0 = rel - t_in * nk_tile;
+            const int q = __builtin_amdgcn_readfirstlane(t_in / a.tiles_n);
+            tile_m = a.pk.run_tile0[run] + q;
+            tile_n = t_in - q * a.tiles_n;
+        } else {
+            const int t = __builtin_amdgcn_readfirstlane(sk_u / nk_tile);
+            kt0 = sk_u - t * nk_tile;
+            tile_m = __builtin_amdgcn_readfirstlane(t / a.tiles_n);
+            tile_n = t - tile_m * a.tiles_n;
         }
-        const int t_in = __builtin_amdgcn_readfirstlane((sk_u - ubase) / nk_tile);
-        kt0 = sk_u - ubase - t_in * nk_tile;
-        const int t = tbase + t_in;
         const int left = sk_end - sk_u;
         nk = (nk_tile - kt0 < left) ? nk_tile - kt0 : left;
-        tile_m = __builtin_amdgcn_readfirstlane(t / a.tiles_n);
-        tile_n = t - tile_m * a.tiles_n;
         lvl = nk == nk_tile ? -1 : sk_v - __builtin_amdgcn_readfirstlane(sk_owner((long long)(sk_u - kt0), sk_units, (int)gridDim.x));
         sk_u += nk;
         return true;
@@ -186,19 +188,20 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         // instruction j of this wave fills rows [(j*PW + pw)*RPI, +RPI) of the tile; lane -> (row in group, chunk position)
         const int rl = lane / CPR, pos = lane % CPR;
         do {   // one piece of work (SK: several)
-        const bool banded = SK && a.rc.n > 0;
-        const int m0 = banded ? (tile_m - a.rc.tile0[band]) * BM : a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (banded: row inside the band)
-        // taps of this tile's K loop: filter rows [kh_first, kh_first + nkh) x all columns, tap-inner order
-        const int kh_first = banded ? a.rc.kh0[band] : 0, kw_first = banded ? a.rc.kw0[band] : 0;
-        const int nkw_t = banded ? a.rc.nkw[band] : a.KW;
-        const int ntaps_t = banded ? a.rc.nkh[band] * nkw_t : a.ntaps;
-        const unsigned magic_nt_t = banded ? a.rc.magic_nt[band] : a.magic_nt;
-        const unsigned magic_nkw_t = banded ? a.rc.magic_nkw[band] : a.magic_kw;
+        const bool packed = SK && a.pk.n > 0;
+        const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (packed: m0 is a GEMM row, a.pk.rowmap gives the pixel)
+        // taps of this tile's K loop: filter rows [kh_first, kh_first + nkh) x columns [kw_first, kw_first + nkw), tap-inner order
+        const int kh_first = packed ? a.pk.run_kh0[run] : 0, kw_first = packed ? a.pk.run_kw0[run] : 0;
+        const int nkw_t = packed ? a.pk.run_nkw[run] : a.KW;
+        const int ntaps_t = packed ? a.pk.run_nkh[run] * nkw_t : a.ntaps;
+        // (the divisors are <= 25 and <= 5; one real division each per piece)
+        const unsigned magic_nt_t = packed ? (ntaps_t > 1 ? (unsigned)((0x100000000ULL + (unsigned)ntaps_t - 1) / (unsigned)ntaps_t) : 0u) : a.magic_nt;
+        const unsigned magic_nkw_t = packed ? (nkw_t > 1 ? (unsigned)((0x100000000ULL + (unsigned)nkw_t - 1) / (unsigned)nkw_t) : 0u) : a.magic_kw;
         unsigned a_off[A_N], a_bad[A_N];
 #pragma unroll
         for (int j = 0; j < A_N; j++) {
             const int r = (j * PW + pw) * RPI + rl;
-            const int m = banded ? BandRows{band}(a, m0 + r) : (m0 + r < a.m_end ? m0 + r : -1);
+            const int m = packed ? a.pk.rowmap[m0 + r] : (m0 + r < a.m_end ? m0 + r : -1);
             const int q = pos ^ ((r >> SWA_SHIFT) & 3);   // the channel chunk this lane fetches
             if (m >= 0) {
                 const int t2 = m / a.W;
@@ -401,8 +404,8 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         __syncthreads();
     };
     do {   // one piece of work (SK: several)
-    const bool banded = SK && a.rc.n > 0;
-    const int m0 = banded ? (tile_m - a.rc.tile0[band]) * BM : a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (banded: row inside the band)
+    const bool packed = SK && a.pk.n > 0;
+    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (packed: a GEMM row)
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -435,17 +438,17 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         // data gradient: columns l31 + 32*j -> the LDS-staged vector epilogue of the round-1 kernels (igemm_common.h); the
         // ring is dead after the last barrier
         static_assert(CONS * 16 * (128 + 4) <= NBUF * (A_BUF + B_BUF), "epilogue slabs must fit in the ring");
-        if (banded)
-            store_acc_tile<TM, TN, 16, false, false, BandRows>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128,
-                                                               slab_, BandRows{band});
+        if (packed)
+            store_acc_tile<TM, TN, 16, false, false, MapRows>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128,
+                                                              slab_, MapRows{a.pk.rowmap});
         else
             store_acc_tile<TM, TN, 16, false>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
     } else if constexpr (SK) {
         // (forward, stream-K: the same staged epilogue with the adjacent-column mapping -- inside the piece loop the direct
         // form below made the compiler spill operand fragments in the MFMA loop)
-        if (banded)
-            store_acc_tile<TM, TN, 16, false, true, BandRows>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128,
-                                                              slab_, BandRows{band});
+        if (packed)
+            store_acc_tile<TM, TN, 16, false, true, MapRows>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128,
+                                                             slab_, MapRows{a.pk.rowmap});
         else
             store_acc_tile<TM, TN, 16, false, true>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
     } else {
@@ -507,12 +510,13 @@ __global__ void __launch_bounds__(256) streamk_fixup_kernel(IgemmArgs a, int G, 
     const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
     // the tile's K steps on the unit line
     long long U = (long long)a.tiles_m * a.tiles_n * nk_all, u0 = (long long)t * nk_all;
-    int nk_tile = nk_all, band = 0;
-    if (a.rc.n > 0) {
-        while (band + 1 < a.rc.n && tile_m >= a.rc.tile0[band + 1]) band++;
-        nk_tile = a.rc.nk[band];
-        U = a.rc.unit0[a.rc.n];
-        u0 = a.rc.unit0[band] + (long long)((tile_m - a.rc.tile0[band]) * a.tiles_n + tile_n) * nk_tile;
+    int nk_tile = nk_all;
+    if (a.pk.n > 0) {
+        int run = 0;
+        while (run + 1 < a.pk.nruns && tile_m >= a.pk.run_tile0[run + 1]) run++;
+        nk_tile = (a.Cx / 16) * (int)a.pk.run_nkh[run] * (int)a.pk.run_nkw[run];
+        U = a.pk.run_u0[a.pk.nruns];
+        u0 = a.pk.run_u0[run] + (long long)((tile_m - a.pk.run_tile0[run]) * a.tiles_n + tile_n) * nk_tile;
     }
     const int vf = sk_owner(u0, U, G), vl = sk_owner(u0 + nk_tile - 1, U, G);
     const int cnt = vl - vf + 1;
@@ -522,8 +526,7 @@ __global__ void __launch_bounds__(256) streamk_fixup_kernel(IgemmArgs a, int G, 
     for (int it = 0; it < 4; it++) {
         const int idx = it * 256 + threadIdx.x;
         const int r = part * 16 + (idx >> 6);
-        const int row = a.rc.n > 0 ? BandRows{band}(a, (tile_m - a.rc.tile0[band]) * 256 + r)
-                                   : PixelRows()(a, a.m_begin + tile_m * 256 + r);
+        const int row = a.pk.n > 0 ? a.pk.rowmap[a.m_begin + tile_m * 256 + r] : PixelRows()(a, a.m_begin + tile_m * 256 + r);
         const int col = tile_n * 256 + (idx & 63) * 4;
         if (row < 0 || col >= a.N) continue;
         const long long o = (long long)row * a.N + col;
@@ -558,25 +561,44 @@ inline int streamk_levels(long long tiles, int nk_all, int cus) {
     return levels;
 }
 
-// The same for a launch with row bands (tiles of band c have rc.nk[c] K steps).
-inline int streamk_levels_banded(const RowClasses &rc, int tiles_n, int cus) {
-    const long long U = rc.unit0[rc.n];
+// The same for a launch over packed rows (RowPack: the tiles of run r have pack_run_nk(r) K steps).
+inline int pack_run_nk(const IgemmArgs &a, int r) { return (a.Cx / 16) * a.pk.run_nkh[r] * a.pk.run_nkw[r]; }
+inline int streamk_levels_packed(const IgemmArgs &a, int tiles_n, int cus) {
+    const RowPack &pk = a.pk;
+    const long long U = pk.run_u0[pk.nruns];
     const int G = streamk_grid_units(U, cus);
     int levels = 0;
-    for (int c = 0; c < rc.n; c++) {
-        const long long nt = (long long)(rc.tile0[c + 1] - rc.tile0[c]) * tiles_n;
+    for (int r = 0; r < pk.nruns; r++) {
+        const int nk = pack_run_nk(a, r);
+        const long long nt = (long long)(pk.run_tile0[r + 1] - pk.run_tile0[r]) * tiles_n;
         for (long long t = 0; t < nt; t++) {
-            const long long u0 = rc.unit0[c] + t * rc.nk[c];
-            const int cnt = sk_owner(u0 + rc.nk[c] - 1, U, G) - sk_owner(u0, U, G) + 1;
+            const long long u0 = pk.run_u0[r] + t * nk;
+            const int cnt = sk_owner(u0 + nk - 1, U, G) - sk_owner(u0, U, G) + 1;
             if (cnt > 1 && cnt > levels) levels = cnt;
         }
     }
     return levels;
 }
 
-// Pixel classes of a convolution (RowClasses) for 256-row tiles; returns false (rc.n = 0) when the filter has nothing to
-// skip, the classes do not fit the struct, or padding them to whole tiles would eat the saving (< 8 % fewer products).
-// One dimension at a time: bands of output rows (resp. columns) that see the same filter rows (columns).
+// GEMM row -> pixel for a launch over packed rows: row R lies in the class c with row0[c] <= R < row0[c + 1]; inside the class
+// the pixels go image by image, row by row of the class's box.  One thread per row; the table lives in the workspace.
+__global__ void __launch_bounds__(256) rowmap_kernel(IgemmArgs a, int *map) {
+    const int R = blockIdx.x * 256 + threadIdx.x;
+    int pix = -1;
+    if (R < a.M) {
+        int c = 0;
+        for (int i = 1; i < a.pk.n; i++) c = R >= a.pk.row0[i] ? i : c;   // (row0[] is a scalar load per step: <= 36 steps)
+        const unsigned j = (unsigned)(R - a.pk.row0[c]);
+        const unsigned now = a.pk.now[c];
+        const unsigned img = div_magic(j, a.pk.magic_img[c]);
+        const unsigned rem = j - img * ((unsigned)a.pk.noh[c] * now);
+        const unsigned rh = div_magic(rem, a.pk.magic_now[c]);
+        pix = ((int)img * a.H + a.pk.oh0[c] + (int)rh) * a.W + a.pk.ow0[c] + (int)(rem - rh * now);
+    }
+    map[R] = pix;
+}
+
+// One dimension of the classes: bands of output rows (resp. columns) that see the same filter rows (columns).
 struct Band1D { int o0, no, k0, nk; };
 inline int bands_1d(int size, int K, int dil, int pad, int sign, Band1D *out, int max_out) {
     int cuts[16], nc = 0;
@@ -613,57 +635,72 @@ inline int bands_1d(int size, int K, int dil, int pad, int sign, Band1D *out, in
     return n;
 }
 
-inline bool build_row_classes(IgemmArgs &a) {
-    RowClasses &rc = a.rc;
-    rc.n = 0;
+// The row packing of a convolution (RowPack) for 256-row tiles and K steps of 16 channels; returns false (pk.n = 0) when the
+// filter has nothing to skip, the classes / runs do not fit the struct, or fewer than 8 % of the products would be saved
+// (measured in round 2: conv5_x, 3x3 rate 2 on 41x41, would save ~5 %, about what the slab traffic of the stream-K launch it
+// would then need costs).  tiles_n = N tiles of the launch (a unit is one K step of one tile).
+inline bool build_row_pack(IgemmArgs &a, int tiles_n) {
+    RowPack &pk = a.pk;
+    pk.n = 0;
+    pk.nruns = 0;
+    pk.rowmap = nullptr;
     const int KH = a.ntaps / a.KW;
     if (KH > 5 || a.KW > 5 || a.ntaps < 2 || a.Cx % 16 != 0 || a.N % 4 != 0 || a.H > 65535 || a.W > 65535) return false;
     if ((long long)a.M * a.H * a.W >= (1LL << 32) || a.M % (a.H * a.W) != 0) return false;   // (div_magic ranges; whole images)
     const int nimg = a.M / (a.H * a.W);
     Band1D hb[6], wb[6];
     const int nh = bands_1d(a.H, KH, a.dil, a.pad_h, a.sign, hb, 6), nw = bands_1d(a.W, a.KW, a.dil, a.pad_w, a.sign, wb, 6);
-    if (nh < 1 || nw < 1) return false;
-    const Band1D wall = {0, a.W, 0, a.KW};
-    // products (tile rows x taps) of: row bands x all columns, and row bands x column bands; dense for comparison
-    auto cost = [&](bool cols) {
-        long long c = 0;
-        for (int i = 0; i < nh; i++)
-            for (int j = 0; j < (cols ? nw : 1); j++) {
-                const Band1D &w = cols ? wb[j] : wall;
-                c += ceil_div((long long)nimg * hb[i].no * w.no, 256) * 256 * hb[i].nk * w.nk;
-            }
-        return c;
-    };
-    const long long dense = ceil_div(a.M, 256) * 256 * (long long)a.ntaps;
-    const long long c1 = cost(false), c2 = nh * nw <= kMaxRowClasses ? cost(true) : c1 + 1;
-    const bool cols = c2 < c1;
-    if ((cols ? c2 : c1) * 100 > dense * 92) return false;   // (measured: conv5_x, 3x3 rate 2 on 41x41, would save 4.5 % of its
-                                                             //  products and loses more than that to its nine classes' partial tiles)
+    if (nh < 1 || nw < 1 || nh * nw < 2 || nh * nw > kMaxRowClasses) return false;
+    // classes in natural order (row band outside, column band inside): neighbours differ in one band, so the tiles that
+    // straddle a boundary pay for a small union
     int n = 0;
-    long long tiles = 0, units = 0;
+    int ckh0[kMaxRowClasses], ckh1[kMaxRowClasses], ckw0[kMaxRowClasses], ckw1[kMaxRowClasses];
+    long long rows = 0;
     for (int i = 0; i < nh; i++)
-        for (int j = 0; j < (cols ? nw : 1); j++) {
-            const Band1D &h = hb[i], &w = cols ? wb[j] : wall;
-            rc.oh0[n] = (unsigned short)h.o0; rc.noh[n] = (unsigned short)h.no; rc.kh0[n] = (unsigned char)h.k0; rc.nkh[n] = (unsigned char)h.nk;
-            rc.ow0[n] = (unsigned short)w.o0; rc.now[n] = (unsigned short)w.no; rc.kw0[n] = (unsigned char)w.k0; rc.nkw[n] = (unsigned char)w.nk;
-            rc.rows[n] = nimg * h.no * w.no;
-            rc.nk[n] = (a.Cx / 16) * h.nk * w.nk;
-            rc.magic_img[n] = magic_u32(h.no * w.no);
-            rc.magic_now[n] = magic_u32(w.no);
-            rc.magic_nt[n] = magic_u32(h.nk * w.nk);
-            rc.magic_nkw[n] = magic_u32(w.nk);
-            rc.tile0[n] = (int)tiles;
-            rc.unit0[n] = (int)units;
-            const long long tm = ceil_div(rc.rows[n], 256);
-            tiles += tm;
-            units += tm * ceil_div(a.N, 256) * rc.nk[n];
-            if (units > 0x7fffffffLL || tiles > 0x7fffffffLL) return false;
+        for (int j = 0; j < nw; j++) {
+            const Band1D &h = hb[i], &w = wb[j];
+            pk.row0[n] = (int)rows;
+            pk.oh0[n] = (unsigned short)h.o0; pk.noh[n] = (unsigned short)h.no;
+            pk.ow0[n] = (unsigned short)w.o0; pk.now[n] = (unsigned short)w.no;
+            pk.magic_img[n] = magic_u32(h.no * w.no);
+            pk.magic_now[n] = magic_u32(w.no);
+            ckh0[n] = h.k0; ckh1[n] = h.k0 + h.nk; ckw0[n] = w.k0; ckw1[n] = w.k0 + w.nk;
+            rows += (long long)nimg * h.no * w.no;
             n++;
         }
-    if (n < 2) return false;
-    rc.tile0[n] = (int)tiles;
-    rc.unit0[n] = (int)units;
-    rc.n = n;
+    pk.row0[n] = (int)rows;   // == a.M: every pixel exactly once
+    const long long tiles_m = ceil_div(a.M, 256);
+    if (tiles_m * tiles_n * (long long)(a.K / 16) > 0x7fffffffLL) return false;
+    // runs of tiles with the same union box; cost in (tile rows x taps)
+    long long cost = 0, units = 0;
+    int nruns = 0, c_lo = 0;
+    for (long long t = 0; t < tiles_m; t++) {
+        const long long lo = t * 256, hi = (t + 1) * 256 < a.M ? (t + 1) * 256 : a.M;
+        while (pk.row0[c_lo + 1] <= lo) c_lo++;
+        int kh0 = 99, kh1 = 0, kw0 = 99, kw1 = 0;
+        for (int c = c_lo; c < n && pk.row0[c] < hi; c++) {
+            kh0 = ckh0[c] < kh0 ? ckh0[c] : kh0; kh1 = ckh1[c] > kh1 ? ckh1[c] : kh1;
+            kw0 = ckw0[c] < kw0 ? ckw0[c] : kw0; kw1 = ckw1[c] > kw1 ? ckw1[c] : kw1;
+        }
+        const int nkh = kh1 - kh0, nkw = kw1 - kw0;
+        cost += 256LL * nkh * nkw;
+        if (nruns == 0 || pk.run_kh0[nruns - 1] != kh0 || pk.run_nkh[nruns - 1] != nkh || pk.run_kw0[nruns - 1] != kw0 ||
+            pk.run_nkw[nruns - 1] != nkw) {
+            if (nruns == kMaxTileRuns) return false;
+            pk.run_tile0[nruns] = (int)t;
+            pk.run_u0[nruns] = (int)units;
+            pk.run_kh0[nruns] = (unsigned char)kh0; pk.run_nkh[nruns] = (unsigned char)nkh;
+            pk.run_kw0[nruns] = (unsigned char)kw0; pk.run_nkw[nruns] = (unsigned char)nkw;
+            nruns++;
+        }
+        units += (long long)tiles_n * (a.Cx / 16) * nkh * nkw;
+    }
+    pk.run_tile0[nruns] = (int)tiles_m;
+    pk.run_u0[nruns] = (int)units;
+    const long long dense = tiles_m * 256 * (long long)a.ntaps;
+    if (cost * 100 > dense * 92) return false;
+    pk.nruns = nruns;
+    pk.n = n;
     return true;
 }
 
@@ -680,11 +717,16 @@ int launch_igemm2(IgemmArgs &a, hipStream_t stream) {
     if constexpr (SK) {
         // a.splits = CUs to lay the pieces out for, a.slab = streamk_levels(...) slabs of [rows][N]
         const int nk_all = a.K / BK;
-        if (a.rc.n > 0) a.tiles_m = a.rc.tile0[a.rc.n];   // (row bands: every band ends with its own partial tile)
         const long long tiles = (long long)a.tiles_m * a.tiles_n;
         if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * 16 > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-        const int G = a.rc.n > 0 ? streamk_grid_units(a.rc.unit0[a.rc.n], a.splits) : streamk_grid(tiles, nk_all, a.splits);
-        const int levels = a.rc.n > 0 ? streamk_levels_banded(a.rc, a.tiles_n, a.splits) : streamk_levels(tiles, nk_all, a.splits);
+        const int G = a.pk.n > 0 ? streamk_grid_units(a.pk.run_u0[a.pk.nruns], a.splits) : streamk_grid(tiles, nk_all, a.splits);
+        const int levels = a.pk.n > 0 ? streamk_levels_packed(a, a.tiles_n, a.splits) : streamk_levels(tiles, nk_all, a.splits);
+        if (a.pk.n > 0) {   // the row table first (a.pk.rowmap points into the workspace: dispatch_igemm)
+            if (!a.pk.rowmap || a.m_begin != 0 || a.m_end != a.M) return EMADAPT_ERR_INVALID;
+            hipLaunchKernelGGL(rowmap_kernel, dim3((unsigned)a.tiles_m), dim3(256), 0, stream, a, const_cast<int *>(a.pk.rowmap));
+            rc = launch_status();
+            if (rc) return rc;
+        }
         if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
         hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT, true>), dim3((unsigned)G), dim3(THREADS), lds, stream, a);
         rc = launch_status();

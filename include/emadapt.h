@@ -306,8 +306,10 @@ int emadapt_tune_set(const char *key, int value);
 /* The plan emadapt_conv_fwd (dgrad = 0) / emadapt_conv_dgrad (dgrad = 1) will use for this shape, given enough workspace:
  * plan[0] = tile variant ("fp32_tile" numbering), plan[1] = rows of the main launch, plan[2] = its split-K factor
  * (variant 5: the number of partial-sum slab levels), plan[3] = split-K factor / slab levels of the launch over the
- * remaining rows (0 = there is none; variant 5 has no second launch: plan[3] is then the number of row bands when the
- * launch skips the filter rows that lie outside the image, else 0). */
+ * remaining rows (0 = there is none; variant 5 has no second launch: plan[3] is then the number of pixel classes when the
+ * launch skips the filter rows / columns that lie outside the image -- its GEMM rows are the pixels class after class and a
+ * tile reduces over the union of its classes' tap boxes; the row -> pixel table takes ceil(M / 256) * 256 ints of the
+ * workspace behind the slab levels -- else 0). */
 int emadapt_conv_plan(const emadapt_conv_desc *d, int dgrad, int plan[4]);
 int emadapt_tune_get(const char *key, int *value);
 

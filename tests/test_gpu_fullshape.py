@@ -43,7 +43,7 @@ def _t(torch, a, dtype=None):
 
 # name, (B, H, W, Cin, Cout, k, dil), expected forward plan variant, expected dgrad plan variant
 FULL_SHAPES = [
-    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 5, 5),      # deeplab.py:92,145: 44.8 % of the MACs; stream-K over row bands (the
+    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 5, 5),      # deeplab.py:92,145: 44.8 % of the MACs; stream-K over packed rows (the
                                                        # filter rows -6 / +6 lie outside the image for 6 of its 41 rows each)
     ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 4, 4),     # deeplab.py:95,147
     ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 2),       # deeplab.py:95,149 (21 classes padded to 24: dgrad K = 24)
@@ -110,8 +110,8 @@ def test_benchmark_shape_against_fp32_oracle(env, name, shape, fwd_variant, dgra
                                         ((2, 29, 16, 256, 256, 4, 8), 3), ((3, 37, 12, 272, 288, 4, 6), 5),
                                         ((4, 45, 9, 256, 288, 3, 12), 7)])
 def test_stream_k_over_row_bands_on_small_shapes(env, shape, cus):
-    """Dilated filters on short maps: the automatic plan is a stream-K launch over row bands (the GEMM's rows are the pixels
-    band after band; a band's tiles reduce only over the filter rows that reach into the image).  Forward with bias + ReLU +
+    """Dilated filters on short maps: the automatic plan is a stream-K launch over packed rows (the GEMM's rows are the pixels
+    class after class; a tile reduces over the union of the tap boxes of the classes it holds rows of).  Forward with bias + ReLU +
     dropout mask and data gradient with the gate against the fp64 oracle, bitwise repeatable, and equal to the dense plan
     (fp32_loader = 2) to rounding."""
     ops, do, torch = env
@@ -131,7 +131,7 @@ def test_stream_k_over_row_bands_on_small_shapes(env, shape, cus):
     xg, wg, bg, dyg, gg, mg = (_t(torch, x), _t(torch, w), _t(torch, b), _t(torch, dy), _t(torch, gate), _t(torch, mask, torch.uint8))
     with ops.tuned(plan_cus=cus):
         pf = ops.conv_plan(B, H, W, Cin, Cout, k, dil)
-        assert pf[0] == 5 and pf[3] >= 2, pf          # row bands in use
+        assert pf[0] == 5 and pf[3] >= 2, pf          # pixel classes in use
         got_y = ops.conv_fwd(xg, wg, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg).cpu().numpy()
         again = ops.conv_fwd(xg, wg, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg).cpu().numpy()
         pd = ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=True)
@@ -143,6 +143,36 @@ def test_stream_k_over_row_bands_on_small_shapes(env, shape, cus):
     assert _rel(got_y, want_y) < 2e-5 and np.array_equal(got_y, again)
     assert _rel(got_dx, want_dx) < 2e-5, pd
     assert _rel(got_y, dense_y) < 2e-6
+
+
+@pytest.mark.parametrize("batch", [6, 1])
+def test_fc6_packed_rows_at_the_reference_batch(env, batch):
+    """fc6 (deeplab.py:92,145) at the reference's own batch of 6 (deeplab.py:288): 25 pixel classes of 6 x (2..29) x (2..29)
+    pixels, most of them a fraction of a tile -- the rows are packed across class boundaries and tiles reduce over union tap
+    boxes.  Forward (bias + ReLU + built-in dropout) and gated data gradient against the dense walk of the same kernels
+    (fp32_loader = 2), which the batch-16 test holds to the CPU oracle; batch 1 (too few K steps per CU for stream-K) stays
+    on the plain plan and must agree with itself."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = batch, 41, 41, 512, 4096, 4, 4
+    pf, pd = ops.conv_plan(B, H, W, Cin, Cout, k, dil), ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=True)
+    assert (pf[3], pd[3]) == ((25, 25) if batch == 6 else (0, 0)), (pf, pd)
+    g = torch.Generator(device="cuda:0").manual_seed(batch)
+    x = torch.relu(torch.randn((B, H, W, Cin), device="cuda:0", generator=g))
+    w = torch.randn((k, k, Cin, Cout), device="cuda:0", generator=g) * 0.02
+    b = torch.randn((Cout,), device="cuda:0", generator=g) * 0.1
+    dy = torch.randn((B, H, W, Cout), device="cuda:0", generator=g)
+    y = ops.conv_fwd(x, w, b, dil, relu=True, keep_prob=0.5, drop_seed=5)
+    dx = ops.conv_dgrad(dy, w, dil, gate=x, gate_scale=2.0)
+    assert torch.equal(y, ops.conv_fwd(x, w, b, dil, relu=True, keep_prob=0.5, drop_seed=5))
+    with ops.tuned(fp32_loader=2):
+        p0 = ops.conv_plan(B, H, W, Cin, Cout, k, dil)
+        assert not (p0[0] == 5 and p0[3] > 0), p0     # dense: no pixel classes (plan[3] of another variant = tail slab levels)
+        y0 = ops.conv_fwd(x, w, b, dil, relu=True, keep_prob=0.5, drop_seed=5)
+        dx0 = ops.conv_dgrad(dy, w, dil, gate=x, gate_scale=2.0)
+    assert torch.equal(y != 0, y0 != 0), "the same elements are dropped whatever the row order"
+    # two fp32 summation orders of K = 8192 (forward) / 65536 (data gradient) products: 1e-5 of the tensor's maximum
+    assert float((y - y0).abs().max() / y0.abs().max()) < 1e-5
+    assert float((dx - dx0).abs().max() / dx0.abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("shape", [(2, 29, 9, 256, 256, 3, 8), (3, 21, 13, 512, 264, 4, 4), (2, 33, 12, 256, 288, 3, 12)])

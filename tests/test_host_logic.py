@@ -108,6 +108,9 @@ def test_launch_plans_at_the_benchmark_shapes():
     assert ops.conv_plan(16, 41, 41, 4096, 24, 1, 1, dgrad=True)[0] == 2           # fc8 dgrad (N = 4096, K = 24: round-1 kernel)
     p = ops.conv_plan(16, 41, 41, 512, 4096, 4, 4, dgrad=True)                     # fc6 dgrad (N = 512: 212 big tiles < 256 CUs,
     assert p[0] == 5 and p[1] == M and p[2] >= 2 and p[3] == 25                    #   K = 65536): stream-K over 5 x 5 pixel classes
+    for batch in (2, 6, 8, 32):   # packed rows pay at every batch size (round 2's whole-tile classes: not below 12); the
+        assert ops.conv_plan(batch, 41, 41, 512, 4096, 4, 4)[::3] == (5, 25)       # reference's own batch is 6 (deeplab.py:288)
+    assert ops.conv_plan(10, 65, 65, 512, 4096, 4, 4)[::3] == (5, 25)              # BASELINE configs[4]: 65 x 65 maps
     assert ops.conv_plan(16, 41, 41, 512, 512, 3, 1) == (5, M, 3, 0)               # conv4_x: stream-K, a tile has <= 3 pieces
     assert ops.conv_plan(16, 41, 41, 512, 512, 3, 2)[3] == 0                       # conv5_x (rate 2): too little padding to skip
     assert ops.conv_plan(16, 41, 41, 512, 1024, 3, 12)[3] == 9                     # LargeFOV fc6 (rate 12): 3 x 3 pixel classes
@@ -229,8 +232,10 @@ def test_stream_k_plans_and_their_workspace_are_consistent():
                 ws = (lib.emadapt_conv_dgrad_workspace_bytes if dgrad else lib.emadapt_conv_fwd_workspace_bytes)(ctypes.byref(d))
                 assert 1 <= cfg <= 5 and 0 < main_rows <= M and main_s >= 0 and tail_s >= 0
                 seen.add(cfg)
-                if cfg == 5:   # (plan[3] = number of row bands of a padding-skipping launch, 0 or >= 2)
-                    assert main_rows == M and tail_s != 1 and tail_s <= 36 and ws == main_s * M * N * 4, (cfg, main_rows, main_s, tail_s, ws)
+                if cfg == 5:   # (plan[3] = number of pixel classes of a padding-skipping launch, 0 or >= 2; such a launch also
+                    #  keeps its GEMM row -> pixel table, one int per row of its whole tiles, behind the slab levels)
+                    table = -(-M // 256) * 256 * 4 if tail_s else 0
+                    assert main_rows == M and tail_s != 1 and tail_s <= 36 and ws == main_s * M * N * 4 + table, (cfg, main_rows, main_s, tail_s, ws)
                     assert main_s != 1, "a tile with partial sums has at least two pieces"
                 elif main_rows < M:
                     assert cfg in (2, 4) and main_rows % 256 == 0
