@@ -30,7 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // The GEMM's rows are the pixels class after class (image-major inside a class) -- every pixel exactly once, so there are as
 // many M tiles as in the dense launch -- and a tile's K loop runs over the UNION of the tap boxes of the classes it holds rows
 // of (a tile inside one class: that class's box; a tile across a class boundary multiplies the padding of the smaller boxes).
-// Round 2 padded every class to whole tiles instead: 86.1 % of the dense products for fc6 at batch 16 against 83.6 % packed
+// Round 2 padded every class to whole tiles instead: 86.1 % of the dense products for fc6 at batch 16 against 82.3 % packed
 // (80.7 % exact), and no gain at all below batch 12 (25 classes x a partial tile each: the reference's own batch is 6).
 //   classes: GEMM rows [row0[c], row0[c+1]) are the pixels of class c; rowmap_kernel turns that into the table
 //            rowmap[GEMM row] = pixel (in the workspace), which the loaders, epilogues and the fix-up pass read

@@ -651,13 +651,15 @@ inline bool build_row_pack(IgemmArgs &a, int tiles_n) {
     Band1D hb[6], wb[6];
     const int nh = bands_1d(a.H, KH, a.dil, a.pad_h, a.sign, hb, 6), nw = bands_1d(a.W, a.KW, a.dil, a.pad_w, a.sign, wb, 6);
     if (nh < 1 || nw < 1 || nh * nw < 2 || nh * nw > kMaxRowClasses) return false;
-    // classes in natural order (row band outside, column band inside): neighbours differ in one band, so the tiles that
-    // straddle a boundary pay for a small union
+    // classes in boustrophedon order (row band outside; column bands left to right, then right to left, ...): consecutive
+    // classes always differ in ONE band, so a tile that straddles a boundary pays for the smallest possible union (fc6 at
+    // batch 16: 82.3 % of the dense products; plain row-major order, whose row changes jump across the map: 83.6 %)
     int n = 0;
     int ckh0[kMaxRowClasses], ckh1[kMaxRowClasses], ckw0[kMaxRowClasses], ckw1[kMaxRowClasses];
     long long rows = 0;
     for (int i = 0; i < nh; i++)
-        for (int j = 0; j < nw; j++) {
+        for (int jj = 0; jj < nw; jj++) {
+            const int j = (i & 1) ? nw - 1 - jj : jj;
             const Band1D &h = hb[i], &w = wb[j];
             pk.row0[n] = (int)rows;
             pk.oh0[n] = (unsigned short)h.o0; pk.noh[n] = (unsigned short)h.no;

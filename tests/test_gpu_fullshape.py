@@ -169,7 +169,10 @@ def test_fc6_packed_rows_at_the_reference_batch(env, batch):
         assert not (p0[0] == 5 and p0[3] > 0), p0     # dense: no pixel classes (plan[3] of another variant = tail slab levels)
         y0 = ops.conv_fwd(x, w, b, dil, relu=True, keep_prob=0.5, drop_seed=5)
         dx0 = ops.conv_dgrad(dy, w, dil, gate=x, gate_scale=2.0)
-    assert torch.equal(y != 0, y0 != 0), "the same elements are dropped whatever the row order"
+    # the same elements are dropped whatever the row order: where one result is zero and the other is not, it is a
+    # pre-activation at the ReLU threshold (the two summation orders round it to either side), never a kept / dropped mismatch
+    flip = (y != 0) != (y0 != 0)
+    assert float(flip.float().mean()) < 1e-4 and (not bool(flip.any()) or float(torch.maximum(y.abs(), y0.abs())[flip].max()) < 1e-4)
     # two fp32 summation orders of K = 8192 (forward) / 65536 (data gradient) products: 1e-5 of the tensor's maximum
     assert float((y - y0).abs().max() / y0.abs().max()) < 1e-5
     assert float((dx - dx0).abs().max() / dx0.abs().max()) < 1e-5
