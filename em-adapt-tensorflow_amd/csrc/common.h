@@ -58,6 +58,8 @@ enum TuneKey {
     TUNE_FP32_LOADER,  // 1: loaders of the 256x256 fp32 kernel compute their offsets per K step for any tap count (the
                        //    automatic choice only for filters other than 1x1 / 3x3 / 4x4); 0: tap-specialised where available,
                        //    filter gradient skips out-of-image pixel-tap pairs; 2: tap-specialised, no skipping
+    TUNE_PACK_PCT,     // packed rows (igemm_common.h RowPack) are used when they save at least this many per cent of the dense
+                       //    launch's products (0 = the default, 5)
     TUNE_ESTEP_STOP,   // diagnostic builds only (-DEMADAPT_ABLATE_BUILD): leave the E-step kernel after phase n
     TUNE_ABLATE,       // diagnostic builds only: ablation bit mask of the fp32 igemm kernel
     TUNE_COUNT

@@ -636,9 +636,11 @@ inline int bands_1d(int size, int K, int dil, int pad, int sign, Band1D *out, in
 }
 
 // The row packing of a convolution (RowPack) for 256-row tiles and K steps of 16 channels; returns false (pk.n = 0) when the
-// filter has nothing to skip, the classes / runs do not fit the struct, or fewer than 8 % of the products would be saved
-// (measured in round 2: conv5_x, 3x3 rate 2 on 41x41, would save ~5 %, about what the slab traffic of the stream-K launch it
-// would then need costs).  tiles_n = N tiles of the launch (a unit is one K step of one tile).
+// filter has nothing to skip, the classes / runs do not fit the struct, or fewer than 5 % of the products would be saved
+// ("pack_pct"; measured, profiles/r03_fp32_experiments.txt: conv5_x, 3x3 rate 2 on 41x41, saves 6.2 % of its products and 3.8 /
+// 2.1 % of its forward / data-gradient time; the rate-1 layers' 2.7 % buy 1.6 / 0.5 % -- inside the noise of the step).
+// tiles_n = N tiles of the launch (a unit is one K step of one tile).
+constexpr int kPackMinSavingPct = 5;
 inline bool build_row_pack(IgemmArgs &a, int tiles_n) {
     RowPack &pk = a.pk;
     pk.n = 0;
@@ -700,7 +702,8 @@ inline bool build_row_pack(IgemmArgs &a, int tiles_n) {
     pk.run_tile0[nruns] = (int)tiles_m;
     pk.run_u0[nruns] = (int)units;
     const long long dense = tiles_m * 256 * (long long)a.ntaps;
-    if (cost * 100 > dense * 92) return false;
+    const int min_saving = tune(TUNE_PACK_PCT) > 0 ? tune(TUNE_PACK_PCT) : kPackMinSavingPct;
+    if (cost * 100 > dense * (100 - min_saving)) return false;
     pk.nruns = nruns;
     pk.n = n;
     return true;

@@ -298,6 +298,8 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  *                0: loaders specialised for 1x1 / 3x3 / 4x4 filters where the filter has that many taps, and the
  *                filter-gradient kernel walks only the pixels at which a tile's tap is inside the image; 2: like 0
  *                but every pixel is walked (out-of-image taps contribute zeros)
+ *   "pack_pct"   the fp32 forward / data-gradient launches run over packed rows (pixel classes, see emadapt_conv_plan) when
+ *                that saves at least this many per cent of the dense launch's products (0 = the built-in threshold)
  *   "estep_stop", "ablate": honoured by diagnostic builds only (-DEMADAPT_ABLATE_BUILD), ignored otherwise
  *                ("estep_stop" 1..4: leave the E-step kernel after that phase; bits 16 / 32 / 64 / 128: run its rank selection
  *                without the LDS atomics / the histogram scans / the barriers / after the first pass -- timing only)

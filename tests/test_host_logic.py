@@ -112,7 +112,10 @@ def test_launch_plans_at_the_benchmark_shapes():
         assert ops.conv_plan(batch, 41, 41, 512, 4096, 4, 4)[::3] == (5, 25)       # reference's own batch is 6 (deeplab.py:288)
     assert ops.conv_plan(10, 65, 65, 512, 4096, 4, 4)[::3] == (5, 25)              # BASELINE configs[4]: 65 x 65 maps
     assert ops.conv_plan(16, 41, 41, 512, 512, 3, 1) == (5, M, 3, 0)               # conv4_x: stream-K, a tile has <= 3 pieces
-    assert ops.conv_plan(16, 41, 41, 512, 512, 3, 2)[3] == 0                       # conv5_x (rate 2): too little padding to skip
+    assert ops.conv_plan(16, 41, 41, 512, 512, 3, 2)[3] == 9                       # conv5_x (rate 2): 3 x 3 classes, 6.2 % of the products
+    assert ops.conv_plan(16, 41, 41, 512, 512, 3, 1)[3] == 0                       # conv4_x (rate 1): 2.7 % -- below the threshold
+    with ops.tuned(pack_pct=2):
+        assert ops.conv_plan(16, 41, 41, 512, 512, 3, 1)[3] == 9
     assert ops.conv_plan(16, 41, 41, 512, 1024, 3, 12)[3] == 9                     # LargeFOV fc6 (rate 12): 3 x 3 pixel classes
     assert ops.conv_plan(16, 81, 81, 256, 256, 3, 1)[:2] == (5, 16 * 81 * 81)      # conv3_x: 411 tiles = 1.6 rounds -> stream-K
     with ops.tuned(plan_cus=137):                                                  # 411 = 3 x 137 tiles: whole rounds, no split at all
