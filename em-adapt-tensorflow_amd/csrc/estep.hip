@@ -22,7 +22,8 @@
 //   * the class visiting order (random.shuffle in the reference) is an input; it is staged in LDS and compacted to
 //     the classes present in the image before the sweeps.
 //
-// Round 3 (profiles/r03_estep_bench.txt): 192 -> 90 us at 16 x 41x41x21, 685 -> 467 us at 10 x 65x65x41.  What the
+// Round 3 (profiles/r03_estep_bench.txt): 192 -> 90 us at 16 x 41x41x21, 685 -> 232 us at 10 x 65x65x41 (there the classes
+// that do not fit in LDS live class-major in the workspace, not in the NHWC float map).  What the
 // first version lost: 12 barriers + 18 ds_bpermute steps per selection, FLAT loads / stores where one pointer could be
 // LDS or HBM, ~50 serial LDS-stack steps of thread 0 building the pairwise-sum program, one load in flight per thread.
 //
@@ -100,6 +101,7 @@ struct EstepArgs {
     int k_bg, k_fg;
     const float *gmax_part;   // [kGmaxBlocks] per-block maxima of estep_gmax_kernel
     float *map_out;
+    float *ovf;       // [B][C][hwp] class-major home of the channels that are not LDS-resident (workspace; used when p_res < C)
     long long *labels_out;
     int p_res;  // present-channel slots resident in LDS
     int hwp;    // HW rounded up to a multiple of 4 (LDS row pitch)
@@ -526,7 +528,7 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
                     if (ok[e]) {
                         const int i = tid + e * kThreads;
                         if (sl >= 0 && sl < p_res) l.chan[(size_t)sl * hwp + i] = x;
-                        else if (a.map_out) a.map_out[((size_t)b * HW + i) * C + c] = x;
+                        else a.ovf[((size_t)b * C + c) * hwp + i] = x;   // consecutive lanes -> consecutive pixels: coalesced
                     }
                 }
             }
@@ -558,7 +560,7 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
                 if (suppress && s < 0 && v > m) v = repl;
                 mxv = (c == 0 || v > mxv) ? v : mxv;
                 if (s >= 0 && s < p_res) l.chan[(size_t)s * hwp + i] = v;
-                else if (a.map_out) a.map_out[row * C + c] = v;
+                else a.ovf[((size_t)b * C + c) * hwp + i] = v;
             }
             l.mx[i] = mxv;
         }
@@ -600,7 +602,7 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
             if (s < 0) continue;
             const int k = (j == 0) ? a.k_bg : a.k_fg;
             const bool in_lds = s < p_res;
-            float *gch = a.map_out + (size_t)b * HW * C + j;  // non-resident channel lives in map_out
+            float *gch = a.ovf + ((size_t)b * C + j) * hwp;   // a non-resident channel lives in the overflow workspace, class-major
 
             // (two copies of the loads / stores, chosen by a wave-uniform branch: one pointer that may be LDS or HBM makes
             //  every access a FLAT instruction, and the read-modify-write below a chain of dependent FLAT round trips)
@@ -616,7 +618,7 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
 #pragma unroll
                 for (int e = 0; e < EPT; e++) {
                     const int i = tid + e * kThreads;
-                    key[e] = (i < HW) ? __float_as_uint(mx[e] - gch[(size_t)i * C]) : 0xFFFFFFFFu;
+                    key[e] = (i < HW) ? __float_as_uint(mx[e] - gch[i]) : 0xFFFFFFFFu;
                 }
             }
             const float t = __uint_as_float(radix_select<EPT>(key, k, l, tid, lane, a.stop_after));  // np.partition(d, k)[k]
@@ -636,8 +638,8 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
                 for (int e = 0; e < EPT; e++) {
                     const int i = tid + e * kThreads;
                     if (i < HW) {
-                        const float v = gch[(size_t)i * C] + t;
-                        gch[(size_t)i * C] = v;
+                        const float v = gch[i] + t;
+                        gch[i] = v;
                         mx[e] = (v > mx[e]) ? v : mx[e];
                     }
                 }
@@ -685,38 +687,40 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
         return;
     }
     {
-        // Not every class fits in LDS: the host demands a float map then (emadapt_estep_needs_map), and the channels that are not
-        // LDS-resident live in it.  Classes outside, the thread's pixels inside (EPT loads in flight), values re-centred in place
+        // Not every class fits in LDS: the others live class-major in the overflow workspace (round 2 kept them in the NHWC float
+        // map, which the host then demanded: 4-byte accesses 4*C bytes apart, 350 of the kernel's 470 us at 65 x 65 x 41).
+        // Classes outside, the thread's pixels inside (EPT loads in flight); the float map is written only when asked for.
         int best[EPT];
         float bv[EPT];
-        size_t ro[EPT];
+        int pi[EPT];
         bool ok[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; e++) {
             const int i = tid + e * kThreads;
             ok[e] = i < HW;
-            ro[e] = (size_t)b * HW + (ok[e] ? i : HW - 1);
+            pi[e] = ok[e] ? i : HW - 1;
         }
         for (int c = 0; c < C; c++) {
             const int sl = __builtin_amdgcn_readfirstlane(l.slot[c]);
+            const float *src = (sl >= 0 && sl < p_res) ? nullptr : a.ovf + ((size_t)b * C + c) * hwp;
             float v[EPT];
-            if (sl >= 0 && sl < p_res) {
+            if (src == nullptr) {
 #pragma unroll
-                for (int e = 0; e < EPT; e++) v[e] = l.chan[(size_t)sl * hwp + (ro[e] - (size_t)b * HW)];
+                for (int e = 0; e < EPT; e++) v[e] = l.chan[(size_t)sl * hwp + pi[e]];
             } else {
 #pragma unroll
-                for (int e = 0; e < EPT; e++) v[e] = a.map_out[ro[e] * C + c];
+                for (int e = 0; e < EPT; e++) v[e] = src[pi[e]];
             }
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
                 v[e] = v[e] + shift;
-                if (ok[e]) a.map_out[ro[e] * C + c] = v[e];
+                if (a.map_out && ok[e]) a.map_out[((size_t)b * HW + pi[e]) * C + c] = v[e];
                 if (c == 0 || v[e] > bv[e]) { bv[e] = v[e]; best[e] = c; }
             }
         }
 #pragma unroll
         for (int e = 0; e < EPT; e++)
-            if (ok[e]) a.labels_out[ro[e]] = best[e];
+            if (ok[e]) a.labels_out[(size_t)b * HW + pi[e]] = best[e];
     }
 }
 
@@ -829,18 +833,29 @@ uint64_t splitmix64(uint64_t &s) {
 
 extern "C" {
 
+// Workspace: the per-block maxima of the batch-maximum pre-kernel, then -- when not every class of an image fits in LDS (65 x 65
+// x 41) -- the class-major overflow [B][C][hwp] of the channels that do not.
+static size_t estep_ovf_offset() { return 256; }
 size_t emadapt_estep_workspace_bytes(int B, int H, int W, int C) {
-    (void)B; (void)H; (void)W; (void)C;
-    return kGmaxBlocks * sizeof(float);  // per-block maxima of the batch-max pre-kernel
+    static_assert(kGmaxBlocks * sizeof(float) <= 256, "per-block maxima");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return estep_ovf_offset();
+    const long long HW = (long long)H * W;
+    if (HW > (long long)kThreads * kMaxEPT || C > kMaxC) return estep_ovf_offset();
+    const int hwp = (int)((HW + 3) / 4 * 4);
+    const int p_res = choose_p_res(hwp, C);
+    if (p_res < 0 || p_res >= C) return estep_ovf_offset();
+    return estep_ovf_offset() + (size_t)B * C * hwp * sizeof(float);
 }
 
+// Since round 3 always 0 for a supported geometry (< 0: unsupported): the channels that do not fit in LDS live in the workspace,
+// the float map is only an output.  (Kept for callers written against the first version, where 1 meant "map_out required".)
 int emadapt_estep_needs_map(int H, int W, int C) {
     if (H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
     const long long HW = (long long)H * W;
     if (HW > (long long)kThreads * kMaxEPT || C > kMaxC) return EMADAPT_ERR_UNSUPPORTED;
     const int p_res = choose_p_res((int)((HW + 3) / 4 * 4), C);
     if (p_res < 0) return EMADAPT_ERR_UNSUPPORTED;
-    return p_res < C ? 1 : 0;
+    return 0;
 }
 
 int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label_kind, int64_t label_len,
@@ -862,7 +877,6 @@ int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label
     const int hwp = (int)((HW + 3) / 4 * 4);
     const int p_res = choose_p_res(hwp, C);
     if (p_res < 0) return EMADAPT_ERR_UNSUPPORTED;
-    if (p_res < C && !map_out) return EMADAPT_ERR_WORKSPACE;  // more classes may be present than fit in LDS
 
     float *gpart = static_cast<float *>(workspace);
     const double bytes = (double)B * HW * (C * 4.0 + 8.0) + (map_out ? (double)B * HW * C * 4.0 : 0.0);
@@ -877,6 +891,7 @@ int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label
     a.logits = logits; a.ldl = ldl; a.label = label; a.label_kind = label_kind; a.label_len = label_len;
     a.perms = perms; a.HW = (int)HW; a.C = C; a.suppress = suppress_others ? 1 : 0; a.num_iter = num_iter;
     a.margin = margin_others; a.k_bg = k_bg; a.k_fg = k_fg; a.gmax_part = gpart; a.map_out = map_out;
+    a.ovf = p_res < C ? reinterpret_cast<float *>(static_cast<char *>(workspace) + estep_ovf_offset()) : nullptr;
     a.labels_out = reinterpret_cast<long long *>(labels_out); a.p_res = p_res; a.hwp = hwp;
     a.full = (p_res >= C) ? 1 : 0;
     pairwise_program(a, (int)HW);

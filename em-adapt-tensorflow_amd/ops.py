@@ -396,8 +396,11 @@ def estep_device(logits, label, perms, num_classes, suppress_others=True, num_it
         labels_out = torch.empty((B, H, W), dtype=torch.int64, device=logits.device)
     hw = H * W
     k_bg, k_fg = int(hw * bg_p), int(hw * fg_p)  # estep.py:58-59
-    # the float map doubles as the home of present channels that do not fit in LDS
-    if map_out is None and (want_map or lib.emadapt_estep_needs_map(H, W, C)):
+    if lib.emadapt_estep_needs_map(H, W, C) < 0:
+        raise ValueError("E-step geometry %dx%dx%d is not supported (H*W <= 8192, C <= 256)" % (H, W, C))
+    if not want_map:
+        map_out = None   # only an output: the channels that do not fit in LDS live in the workspace
+    elif map_out is None:
         map_out = torch.empty((B, H, W, C), dtype=torch.float32, device=logits.device)
     nbytes = lib.emadapt_estep_workspace_bytes(B, H, W, C)
     ws = _WS.get(nbytes + 256, logits.device)

@@ -78,11 +78,12 @@ int emadapt_estep_host(float *map, int B, int H, int W, int C, const void *label
                        int64_t label_len, const int32_t *perms, int suppress_others, int num_iter,
                        float margin_others, int k_bg, int k_fg, int64_t *labels_out);
 
-/* Bytes of device workspace emadapt_estep needs. */
+/* Bytes of device workspace emadapt_estep needs: 256, plus B*C*roundup4(H*W) floats when H*W*C is too large for every class
+ * that may be present in an image to stay in LDS (513x513 / 41 classes: the other channels then live there, class-major). */
 size_t emadapt_estep_workspace_bytes(int B, int H, int W, int C);
 
-/* 1 when emadapt_estep needs a non-NULL map_out for this geometry (H*W*C too large for every class
- * that may be present to stay in LDS), 0 when map_out may be NULL, <0 for an unsupported geometry. */
+/* 0 for every supported geometry (map_out may always be NULL), <0 for an unsupported one.  The first version returned 1 when
+ * the float map doubled as workspace for the channels that do not fit in LDS; those now live in the workspace. */
 int emadapt_estep_needs_map(int H, int W, int C);
 
 /* Device E-step: replaces deeplab.py:109-124 (py_func(estep) + argmax) with no host round trip.
@@ -90,8 +91,6 @@ int emadapt_estep_needs_map(int H, int W, int C);
  *   label      per label_kind; label_len = elements per image for the pixel kinds
  *   perms      int32 [num_iter, C-1] on the device
  *   map_out    f32 [B,H,W,C] float map of estep.py:82, or NULL when only labels are wanted
- *              (required when more classes are present in an image than fit in LDS: the
- *              call then fails with EMADAPT_ERR_WORKSPACE if it is NULL)
  *   labels_out int64 [B,H,W]
  * One workgroup per image; present channels and the running max live in LDS. */
 int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label_kind,
