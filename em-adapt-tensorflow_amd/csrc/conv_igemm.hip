@@ -581,7 +581,9 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
         (void)choose_splits(a.M, a.N, a.K, 256, 256, 16, 256.0, 142e12, &t4);
         split4 = t4 < t3 * 0.98;
     }
-    int cfg = a.N <= 64 ? 1 : big ? (v2_ok(a, 16) ? 4 : 2) : split4 ? 4 : 3;
+    // (K <= 32 -- fc8's data gradient, K = 24 -- is one K step of any kernel: the launch is output traffic, and the small tiles
+    //  of variant 1, several workgroups per CU, keep it moving: 0.245 -> 0.208 ms, profiles/r03_fp32_experiments.txt)
+    int cfg = (a.N <= 64 || a.K <= 32) ? 1 : big ? (v2_ok(a, 16) ? 4 : 2) : split4 ? 4 : 3;
     // Variant 5 = the 256x256 kernel with the stream-K work split (igemm_v2.h): whenever the tile count is not a whole number
     // of rounds and every CU still gets a few dozen K steps.  N <= 1024 bounds the slab levels ([rows][N] each); the
     // N = 4096 layers keep the rows-of-whole-rounds + tail plan (8 % of their rows run on the 128x128 kernel).

@@ -46,7 +46,7 @@ FULL_SHAPES = [
     ("fc6", (16, 41, 41, 512, 4096, 4, 4), 5, 5),      # deeplab.py:92,145: 44.8 % of the MACs; stream-K over packed rows (the
                                                        # filter rows -6 / +6 lie outside the image for 6 of its 41 rows each)
     ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 4, 4),     # deeplab.py:95,147
-    ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 2),       # deeplab.py:95,149 (21 classes padded to 24: dgrad K = 24)
+    ("fc8", (16, 41, 41, 4096, 24, 1, 1), 1, 1),       # deeplab.py:95,149 (21 classes padded to 24: dgrad K = 24, one K step)
     ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 5, 5),   # 212 tiles of 256x256 on 256 CUs: stream-K pieces of 238.5 K steps
     ("conv5_2", (16, 41, 41, 512, 512, 3, 2), 5, 5),   # atrous rate 2 (deeplab.py:65): packed rows over 3 x 3 pixel classes
     ("conv3_2", (16, 81, 81, 256, 256, 3, 1), 5, 5),   # 411 tiles: 1.6 rounds -> stream-K

@@ -105,7 +105,7 @@ def test_launch_plans_at_the_benchmark_shapes():
         assert ops.conv_plan(16, 41, 41, 512, 4096, 4, 4)[:3] == (4, 24576, 1)     #   96 x 16 tiles = 6 rounds + a tail launch
     assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1)[:2] == (4, 24576)           # fc7 fwd
     assert ops.conv_plan(16, 41, 41, 4096, 4096, 1, 1, dgrad=True)[:2] == (4, 24576)
-    assert ops.conv_plan(16, 41, 41, 4096, 24, 1, 1, dgrad=True)[0] == 2           # fc8 dgrad (N = 4096, K = 24: round-1 kernel)
+    assert ops.conv_plan(16, 41, 41, 4096, 24, 1, 1, dgrad=True)[0] == 1           # fc8 dgrad (N = 4096, K = 24: one K step -> small tiles)
     p = ops.conv_plan(16, 41, 41, 512, 4096, 4, 4, dgrad=True)                     # fc6 dgrad (N = 512: 212 big tiles < 256 CUs,
     assert p[0] == 5 and p[1] == M and p[2] >= 2 and p[3] == 25                    #   K = 65536): stream-K over 5 x 5 pixel classes
     for batch in (2, 6, 8, 32):   # packed rows pay at every batch size (round 2's whole-tile classes: not below 12); the
