@@ -5,7 +5,7 @@ absent) importing the operators fails loudly with ``EmadaptLibraryError``.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_bool, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from ctypes import POINTER, c_bool, c_double, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_uint64, c_void_p
 
 from . import _build
 
@@ -72,6 +72,16 @@ PROTOTYPES = {
     "emadapt_conv_dgrad_x6": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_float, _vp, c_size_t, _vp]),
     "emadapt_conv_wgrad_x6_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "emadapt_conv_wgrad_x6": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_size_t, _vp]),
+    "emadapt_planes_bytes": (c_size_t, [c_longlong, c_int]),
+    "emadapt_split_planes": (c_int, [_vp, _vp, c_longlong, c_int, _vp]),
+    "emadapt_conv_x6p_supported": (c_int, [POINTER(ConvDesc), c_int]),
+    "emadapt_conv_x6p_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
+    "emadapt_conv_fwd_x6p_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "emadapt_conv_fwd_x6p": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_int, c_float, _vp, c_uint64, _vp, c_size_t, _vp]),
+    "emadapt_conv_dgrad_x6p_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "emadapt_conv_dgrad_x6p": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_float, _vp, c_size_t, _vp]),
+    "emadapt_conv_wgrad_x6p_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "emadapt_conv_wgrad_x6p": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_size_t, _vp]),
     "emadapt_maxpool_fwd_dt": (c_int, [_vp, c_int, c_int, c_int, c_int, c_int, c_int, _vp, _vp, _vp]),
     "emadapt_maxpool_bwd_dt": (c_int, [_vp, _vp, _vp, c_int, c_int, c_int, c_int, c_int, c_int, _vp, _vp]),
     "emadapt_bias_grad_dt": (c_int, [_vp, c_int, c_int64, c_int, _vp, _vp, c_size_t, _vp]),

@@ -1,0 +1,404 @@
+// bf16x6 on PRE-SPLIT operands ("plane images"): forward / data-gradient kernel, included by conv_x6p.hip.
+//
+// conv_x6.hip splits both fp32 operands into their three bf16 planes inside the loader waves -- once per tile, i.e. an
+// activation is split again by every N tile and every filter tap that reads it (7 vector-ALU instructions per MFMA at
+// 128x128 tiles) and stored to LDS through registers.  Here the split happens ONCE per tensor (split_planes_kernel, or the
+// epilogue that produces the tensor) into a plane image
+//     [row][k / 16][plane 0..2][16 x bf16]          (96 bytes per row and group of 16 k; a row is a pixel / a filter row)
+// and the GEMM kernel is built like the second-generation fp32 kernel (igemm_v2.h): tiles land in LDS by LDS-DMA exactly as
+// they lie in memory, nobody issues a vector-ALU instruction per element.
+//
+//   * 256 x 256 x 16 tiles, ONE workgroup of 8 waves per CU, every wave a 64 x 128 accumulator block (TM = 2, TN = 4: 48 MFMAs
+//     32x32x16 per K step from 18 ds_read_b128) AND 6 of the step's 48 DMA instructions -- no loader waves: with 72 fragment
+//     registers beside the 128 accumulators a wave needs more than the 168 registers a 12-wave workgroup would leave it.
+//   * LDS image of an operand's K step: [256 rows][96 B], dense (24 KB; ring of 3 stages x 2 operands = 144 KB).  A DMA
+//     instruction moves 64 consecutive 16-byte chunks of that image, i.e. 10 2/3 rows: lane -> (row, chunk) is a per-lane
+//     constant of the instruction, the row's pixel and its tap validity bits are looked up once per tile.
+//     (buffer_load_dwordx3 ... lds would give 8 whole rows per instruction, but it deposits lane l's 12 bytes at base + 16 l,
+//     not 12 l: scripts/dma_x3_lab.hip.)
+//   * bank conflicts: the 16 lanes of one ds_read_b128 group read the same 16-byte column of 16 rows 96 bytes apart -- only
+//     half of the banks -- so rows with bit 3 set store the two 16-byte halves of every plane swapped (the DMA lanes fetch
+//     them swapped, the fragment address XORs 16): conflict-free.
+//   * pipeline: a wave reads ALL fragments of step kt into registers, issues half of the step's MFMAs, waits for its own DMAs
+//     of step kt + 1, BARRIER, issues the DMAs of step kt + 3 into the buffer it has just finished reading, then the other half
+//     of the MFMAs: the matrix pipe has work queued on both sides of the barrier (no LDS round trip behind it), a DMA has two
+//     whole steps to land, and three buffers carry a fetch distance of three.
+//   * work split, packed rows, epilogues, stream-K fix-up: igemm_v2.h's, unchanged (same accumulator layout).
+// Requirements: Cx % 16 == 0, KH*KW <= 32, N % 4 == 0; plane images below 2 GiB.
+#pragma once
+#include <type_traits>
+
+#include "igemm_v2.h"
+
+namespace {
+
+typedef __bf16 xp_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int XP_ROWB = 96;                  // bytes of one row's K step (3 planes x 16 bf16), in memory and in LDS
+#ifdef XP_LAB_PAD128
+constexpr int XP_GB = 128;                   // (lab, timing only: groups padded to a 128-byte line in memory)
+#else
+constexpr int XP_GB = XP_ROWB;               // bytes from one group of 16 k to the next in memory
+#endif
+constexpr int XP_OPER = 256 * XP_ROWB;       // one operand's K step in LDS
+constexpr int XP_STAGE = 2 * XP_OPER;        // A + B
+constexpr int XP_NBUF = 3;
+constexpr int XP_WAVES = 8;
+constexpr int XP_IPW = XP_OPER / 1024 / XP_WAVES;   // DMA instructions per wave, operand and K step (3)
+constexpr size_t XP_LDS = (size_t)XP_NBUF * XP_STAGE;
+
+__device__ __forceinline__ void xp_dma(__amdgpu_buffer_rsrc_t r, char *lds_base, unsigned voffset, unsigned soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_t *)lds_base, 16, (int)voffset, (int)soffset, 0, 0);
+}
+
+// ABLM (diagnostic library only, tune "ablate"): parts of the K loop COMPILED out -- 1 no DMAs, 2 no fragment reads, 4 no waits /
+// barrier, 8 no MFMAs (results are garbage; scripts/x6p_ablate.py reads the time).
+template <bool SK, int ABLM = 0>
+__global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a) {
+    constexpr int BM = 256, BN = 256, BK = 16, NBUF = XP_NBUF, TM = 2, TN = 4;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+
+    // ---- work of this workgroup: igemm2_kernel's piece list (one (tile, K range) piece, or with SK a sequence of them)
+    const int nk_all = a.K / BK;
+    int tile_m = 0, tile_n = 0, kt0 = 0, nk = 0;
+    int lvl = -1;
+    int sk_u = 0, sk_end = 0, sk_units = 0, sk_v = 0;
+    {
+        const int ntile = a.tiles_m * a.tiles_n;
+        const int nblk = SK ? (int)gridDim.x : ntile * a.splits;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if constexpr (SK) {
+            sk_v = t;
+            sk_units = a.pk.n > 0 ? a.pk.run_u0[a.pk.nruns] : ntile * nk_all;
+            sk_u = __builtin_amdgcn_readfirstlane((int)sk_start(t, sk_units, nblk));
+            sk_end = __builtin_amdgcn_readfirstlane((int)sk_start(t + 1, sk_units, nblk));
+        } else {
+            const int split = t / ntile;
+            t -= split * ntile;
+            constexpr int GM = 8;
+            const int per_group = GM * a.tiles_n;
+            const int g = t / per_group;
+            const int first_m = g * GM;
+            const int gsz = (a.tiles_m - first_m < GM) ? (a.tiles_m - first_m) : GM;
+            const int in_g = t - g * per_group;
+            tile_m = first_m + in_g % gsz;
+            tile_n = in_g / gsz;
+            kt0 = (int)((long long)nk_all * split / a.splits);
+            nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
+            lvl = a.splits > 1 ? split : -1;
+        }
+    }
+    int run = 0;
+    int nk_tile = nk_all;
+    auto next_piece = [&]() -> bool {
+        if (sk_u >= sk_end) return false;
+        if (a.pk.n > 0) {
+            while (run + 1 < a.pk.nruns && sk_u >= a.pk.run_u0[run + 1]) run++;
+            nk_tile = (a.Cx / BK) * (int)a.pk.run_nkh[run] * (int)a.pk.run_nkw[run];
+            const int rel = sk_u - a.pk.run_u0[run];
+            const int t_in = __builtin_amdgcn_readfirstlane(rel / nk_tile);
+            kt0 = rel - t_in * nk_tile;
+            const int q = __builtin_amdgcn_readfirstlane(t_in / a.tiles_n);
+            tile_m = a.pk.run_tile0[run] + q;
+            tile_n = t_in - q * a.tiles_n;
+        } else {
+            const int t = __builtin_amdgcn_readfirstlane(sk_u / nk_tile);
+            kt0 = sk_u - t * nk_tile;
+            tile_m = __builtin_amdgcn_readfirstlane(t / a.tiles_n);
+            tile_n = t - tile_m * a.tiles_n;
+        }
+        const int left = sk_end - sk_u;
+        nk = (nk_tile - kt0 < left) ? nk_tile - kt0 : left;
+        lvl = nk == nk_tile ? -1 : sk_v - __builtin_amdgcn_readfirstlane(sk_owner((long long)(sk_u - kt0), sk_units, (int)gridDim.x));
+        sk_u += nk;
+        return true;
+    };
+    if constexpr (SK) {
+        if (!next_piece()) return;
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+
+    // ---- loader side: constants of the launch
+    // (the tap offset rides in the DMA's scalar operand, an UNSIGNED addend: the buffer starts `bias` bytes before the tensor)
+    const int rowb = a.Cx / 16 * XP_GB;   // bytes of a pixel / filter row in a plane image
+    int min_dh = a.sign * (0 - a.pad_h), min_dw = a.sign * (0 - a.pad_w);
+    {
+        const int KH = a.ntaps / a.KW;
+        const int dh1 = a.sign * ((KH - 1) * a.dil - a.pad_h), dw1 = a.sign * ((a.KW - 1) * a.dil - a.pad_w);
+        min_dh = dh1 < min_dh ? dh1 : min_dh;
+        min_dw = dw1 < min_dw ? dw1 : min_dw;
+    }
+    const int min_sp = min_dh * a.W + min_dw;
+    const unsigned bias = min_sp < 0 ? (unsigned)(-min_sp) * (unsigned)rowb : 0u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(a.x)) - bias, 0, (int)(a.x_bytes + bias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    constexpr unsigned kOOB = 0x80000000u;
+    // instruction j of this wave moves chunks [(wave * IPW + j) * 64, +64) of an operand's image: lane -> (row, chunk position);
+    // rows with bit 3 set hold the halves of every plane swapped
+    int ld_row[XP_IPW], ld_chunk[XP_IPW];
+#pragma unroll
+    for (int j = 0; j < XP_IPW; j++) {
+        const int q = (wave * XP_IPW + j) * 64 + lane;
+        ld_row[j] = q / 6;
+        ld_chunk[j] = (q - ld_row[j] * 6) ^ ((ld_row[j] >> 3) & 1);
+    }
+
+    // ---- consumer side: fragment addresses (bytes inside a stage); plane p is 32 bytes on, the wave's next 32 rows 3072
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int half = (lh ^ ((l31 >> 3) & 1)) * 16;
+    const int a_frag = (wm * 64 + l31) * XP_ROWB + half;
+    const int b_frag = XP_OPER + (wn * 128 + l31) * XP_ROWB + half;
+    f32x16 acc[TM][TN];
+    xp_bf16x8 av[3][TM], bv[3][TN];
+
+    do {   // one piece of work (SK: several)
+    const bool packed = SK && a.pk.n > 0;
+    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (packed: m0 is a GEMM row, a.pk.rowmap gives the pixel)
+    const int kh_first = packed ? a.pk.run_kh0[run] : 0, kw_first = packed ? a.pk.run_kw0[run] : 0;
+    const int nkw_t = packed ? a.pk.run_nkw[run] : a.KW;
+    const int ntaps_t = packed ? a.pk.run_nkh[run] * nkw_t : a.ntaps;
+    const unsigned magic_nt_t = packed ? (ntaps_t > 1 ? (unsigned)((0x100000000ULL + (unsigned)ntaps_t - 1) / (unsigned)ntaps_t) : 0u) : a.magic_nt;
+    const unsigned magic_nkw_t = packed ? (nkw_t > 1 ? (unsigned)((0x100000000ULL + (unsigned)nkw_t - 1) / (unsigned)nkw_t) : 0u) : a.magic_kw;
+    unsigned a_off[XP_IPW], a_bad[XP_IPW], b_off[XP_IPW];
+#pragma unroll
+    for (int j = 0; j < XP_IPW; j++) {
+        const int r = ld_row[j];
+        const int m = packed ? a.pk.rowmap[m0 + r] : (m0 + r < a.m_end ? m0 + r : -1);
+        if (m >= 0) {
+            const int t2 = m / a.W;
+            const int oh = t2 % a.H, ow = m - t2 * a.W;
+            a_off[j] = (unsigned)m * (unsigned)rowb + (unsigned)ld_chunk[j] * 16u;
+            unsigned rowbad = 0, colbad = 0;
+            const int KH = a.ntaps / a.KW;
+            for (int kh = 0; kh < KH; kh++) {
+                const int ih = oh + a.sign * (kh * a.dil - a.pad_h);
+                rowbad |= ((unsigned)ih < (unsigned)a.H ? 0u : 1u) << kh;
+            }
+            for (int kw = 0; kw < a.KW; kw++) {
+                const int iw = ow + a.sign * (kw * a.dil - a.pad_w);
+                colbad |= ((unsigned)iw < (unsigned)a.W ? 0u : 1u) << kw;
+            }
+            unsigned bad = 0;
+            const unsigned full = a.KW >= 32 ? 0xFFFFFFFFu : ((1u << a.KW) - 1u);
+            for (int kh = 0; kh < KH; kh++) bad |= (((rowbad >> kh) & 1u) ? full : colbad) << (kh * a.KW);
+            a_bad[j] = bad;
+        } else {
+            a_off[j] = 0;
+            a_bad[j] = 0xFFFFFFFFu;
+        }
+        const int n = n0 + r;
+        b_off[j] = ((unsigned)n * (unsigned)rowb + (unsigned)ld_chunk[j] * 16u) | (n < a.N ? 0u : kOOB);
+    }
+
+    // DMAs of K step kt (of this piece's tile) into ring buffer `buf`: this wave's 3 KB of each operand
+    int p_off = 0;
+    unsigned p_sw = 0, p_dead = 0;   // the pending filter part (step kt + 2 at the top of trip kt): ring buffer, scalar offset, dead bit
+    auto fill = [&](int buf, int kt, bool live, int parts) {
+        const unsigned chunk = __umulhi((unsigned)kt, magic_nt_t);
+        const unsigned tap_l = ntaps_t > 1 ? (unsigned)kt - chunk * (unsigned)ntaps_t : 0u;
+        const unsigned chunk_u = ntaps_t > 1 ? chunk : (unsigned)kt;
+        const unsigned khl = div_magic(tap_l, magic_nkw_t);
+        const unsigned kh = (unsigned)kh_first + khl;
+        const int kw = kw_first + (int)(tap_l - khl * (unsigned)nkw_t);
+        const unsigned tap_u = kh * (unsigned)a.KW + (unsigned)kw;
+        const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
+        const int dw = a.sign * (kw * a.dil - a.pad_w);
+        const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + chunk_u * (unsigned)XP_GB + bias));
+        const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tap_u * (unsigned)a.N * (unsigned)rowb + chunk_u * (unsigned)XP_GB));
+        const unsigned sh = 31u - (tap_u & 31u);   // moves this tap's "outside the image" bit to bit 31
+        const unsigned dead = live ? 0u : kOOB;    // (a step past the end of the piece: every lane out of range, zeros)
+        char *as = ldsb + buf * XP_STAGE + wave * (XP_IPW * 1024);
+#pragma unroll
+        for (int j = 0; j < XP_IPW; j++) xp_dma(xr, as + j * 1024, a_off[j] | ((a_bad[j] << sh) & kOOB) | dead, s_x);
+        if (parts & 2) {
+#pragma unroll
+            for (int j = 0; j < XP_IPW; j++) xp_dma(wr, as + XP_OPER + j * 1024, b_off[j] | dead, s_w);
+        } else {
+            p_off = buf * XP_STAGE;
+            p_sw = s_w;
+            p_dead = dead;
+        }
+    };
+    // Fragment reads and MFMAs, one instruction each; XP_SB pins the order they are written in (the schedule below IS the
+    // software pipeline: the compiler must not regroup it).
+#define XP_SB __builtin_amdgcn_sched_barrier(0);
+#define XP_RA0(P, I, BASE) av[P][I] = *reinterpret_cast<const xp_bf16x8 *>(ldsb + (BASE) + a_frag + (P) * 32 + (I) * (32 * XP_ROWB)); XP_SB
+#define XP_RB0(Q, J, BASE) bv[Q][J] = *reinterpret_cast<const xp_bf16x8 *>(ldsb + (BASE) + b_frag + (Q) * 32 + (J) * (32 * XP_ROWB)); XP_SB
+#define XP_RA(P, I, BASE) if constexpr (!(ABLM & 2)) { XP_RA0(P, I, BASE) }
+#define XP_RB(Q, J, BASE) if constexpr (!(ABLM & 2)) { XP_RB0(Q, J, BASE) }
+#define XP_MF(P, Q, I, J) if constexpr (!(ABLM & 8)) { acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[P][I], bv[Q][J], acc[I][J], 0, 0, 0); XP_SB }
+#define XP_DMA(R, DST, VOFF, SOFF) if constexpr (!(ABLM & 1)) { xp_dma(R, DST, VOFF, SOFF); XP_SB }
+#define XP_GROUP(P, Q) XP_MF(P, Q, 0, 0) XP_MF(P, Q, 0, 1) XP_MF(P, Q, 0, 2) XP_MF(P, Q, 0, 3) XP_MF(P, Q, 1, 0) XP_MF(P, Q, 1, 1) XP_MF(P, Q, 1, 2) XP_MF(P, Q, 1, 3)
+    // One K step = six groups of 8 MFMAs (plane pairs) in the cyclic order (0,2) (0,1) (0,0) | (1,0) (2,0) (1,1), the barrier
+    // after the third.  In that order every fragment's last use lies at least one group before its first use in the next
+    // step, so the next step's fragments are fetched INTO THE SAME REGISTERS while this step's MFMAs run: a0 / b2 right behind
+    // the barrier (dead since groups 3 / 1), b0 / a2 during group 6, b1 / a1 behind group 6 -- no wave ever waits for LDS in
+    // front of an MFMA, and the DMA instructions of step kt + 3 go out one by one between the MFMAs of group 5.  Both waves
+    // of a SIMD run this same schedule in step, so whatever a wave issues besides MFMAs must overlap ITS OWN MFMAs' execution.
+    // The body is branch-free: past the end of the piece the fetches read a buffer nobody needs (harmless) and the DMAs carry the
+    // out-of-range bit on every lane (they deposit zeros in a buffer nobody reads again) -- every step issues the same 6 DMAs, so
+    // the vmcnt bookkeeping is a constant, and the accumulators stay in place (with one body per case the register
+    // allocator moved them between bodies through out-of-place MFMAs and spilled).
+    // ONE body, the ring position a run-time scalar (two vector adds per step for the fragment addresses): unrolled over the ring,
+    // the allocator assigned the loop-carried fragments and accumulators differently in the three bodies and paid in copies.
+    //   u_off = byte offset of this step's ring buffer, NX that of the next step's
+    auto k_step = [&](int u_off, int NX, int kt) {
+        // scalars of the fill (step kt + 3 -> buffer U)
+        const unsigned ktf = (unsigned)(kt0 + kt + 3);
+        const unsigned chunk = __umulhi(ktf, magic_nt_t);
+        const unsigned tap_l = ntaps_t > 1 ? ktf - chunk * (unsigned)ntaps_t : 0u;
+        const unsigned chunk_u = ntaps_t > 1 ? chunk : ktf;
+        const unsigned khl = div_magic(tap_l, magic_nkw_t);
+        const unsigned kh = (unsigned)kh_first + khl;
+        const int kw = kw_first + (int)(tap_l - khl * (unsigned)nkw_t);
+        const unsigned tap_u = kh * (unsigned)a.KW + (unsigned)kw;
+        const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
+        const int dw = a.sign * (kw * a.dil - a.pad_w);
+        const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + chunk_u * (unsigned)XP_GB + bias));
+        const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tap_u * (unsigned)a.N * (unsigned)rowb + chunk_u * (unsigned)XP_GB));
+        const unsigned sh = 31u - (tap_u & 31u);
+        const unsigned dead = kt + 3 < nk ? 0u : kOOB;   // no such step: all lanes out of range
+        XP_SB
+        // first half: the filter part of step kt + 2 (pending from the previous trip) goes out, one DMA behind each group
+        {
+            char *bs = ldsb + p_off + XP_OPER + wave * (XP_IPW * 1024);
+            XP_GROUP(0, 2)
+            XP_DMA(wr, bs, b_off[0] | p_dead, p_sw)
+            XP_GROUP(0, 1)
+            XP_DMA(wr, bs + 1024, b_off[1] | p_dead, p_sw)
+            XP_GROUP(0, 0)
+            XP_DMA(wr, bs + 2048, b_off[2] | p_dead, p_sw)
+        }
+        if constexpr (!(ABLM & 4)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of this step has arrived (a1 was fetched last)
+            wait_vmcnt<2 * XP_IPW>();   // this wave's DMAs of step kt + 1 have landed (those of kt + 2 may be in flight)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        XP_SB
+        // second half: buffer u_off is free -- the activation part of step kt + 3, one DMA behind each group
+        char *as = ldsb + u_off + wave * (XP_IPW * 1024);
+        XP_MF(1, 0, 0, 0) XP_RA(0, 0, NX) XP_MF(1, 0, 0, 1) XP_RA(0, 1, NX) XP_MF(1, 0, 0, 2) XP_RB(2, 0, NX) XP_MF(1, 0, 0, 3) XP_RB(2, 1, NX)
+        XP_MF(1, 0, 1, 0) XP_RB(2, 2, NX) XP_MF(1, 0, 1, 1) XP_RB(2, 3, NX) XP_MF(1, 0, 1, 2) XP_MF(1, 0, 1, 3)
+        XP_DMA(xr, as, a_off[0] | ((a_bad[0] << sh) & kOOB) | dead, s_x)
+        XP_GROUP(2, 0)
+        XP_DMA(xr, as + 1024, a_off[1] | ((a_bad[1] << sh) & kOOB) | dead, s_x)
+        XP_MF(1, 1, 0, 0) XP_RB(0, 0, NX) XP_MF(1, 1, 0, 1) XP_RB(0, 1, NX) XP_MF(1, 1, 0, 2) XP_RB(0, 2, NX) XP_MF(1, 1, 0, 3) XP_RB(0, 3, NX)
+        XP_MF(1, 1, 1, 0) XP_RA(2, 0, NX) XP_MF(1, 1, 1, 1) XP_RA(2, 1, NX) XP_MF(1, 1, 1, 2) XP_MF(1, 1, 1, 3)
+        XP_DMA(xr, as + 2048, a_off[2] | ((a_bad[2] << sh) & kOOB) | dead, s_x)
+        XP_RB(1, 0, NX) XP_RB(1, 1, NX) XP_RB(1, 2, NX) XP_RB(1, 3, NX) XP_RA(1, 0, NX) XP_RA(1, 1, NX)
+        p_off = u_off;
+        p_sw = s_w;
+        p_dead = dead;
+    };
+
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    __syncthreads();   // the ring is free (SK: the previous piece's epilogue staged through it)
+    fill(0, kt0, true, 3);
+    fill(1, kt0 + 1, 1 < nk, 3);
+    fill(2, kt0 + 2, 2 < nk, 1);   // (its filter part goes out during step 0 like every later step's)
+    wait_vmcnt<3 * XP_IPW>();
+    __builtin_amdgcn_s_barrier();   // step 0 has landed
+    asm volatile("" ::: "memory");
+    XP_RA0(0, 0, 0) XP_RA0(0, 1, 0) XP_RB0(2, 0, 0) XP_RB0(2, 1, 0) XP_RB0(2, 2, 0) XP_RB0(2, 3, 0)
+    XP_RB0(1, 0, 0) XP_RB0(1, 1, 0) XP_RB0(1, 2, 0) XP_RB0(1, 3, 0) XP_RB0(0, 0, 0) XP_RB0(0, 1, 0) XP_RB0(0, 2, 0) XP_RB0(0, 3, 0)
+    XP_RA0(1, 0, 0) XP_RA0(1, 1, 0) XP_RA0(2, 0, 0) XP_RA0(2, 1, 0)
+    {
+        int u_off = 0;
+        for (int kt = 0; kt < nk; kt++) {
+            const int nx = u_off == (NBUF - 1) * XP_STAGE ? 0 : u_off + XP_STAGE;
+            k_step(u_off, nx, kt);
+            u_off = nx;
+        }
+    }
+    // the zero-depositing DMAs of the last steps are still in flight, and so may be the last fetches: drain both before
+    // the ring becomes the epilogue's staging area
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vmcnt<0>();
+    __syncthreads();
+#undef XP_SB
+#undef XP_RA0
+#undef XP_RB0
+#undef XP_RA
+#undef XP_RB
+#undef XP_MF
+#undef XP_DMA
+#undef XP_GROUP
+
+    float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+    int lane_e = tid & 63;
+    asm volatile("" : "+v"(lane_e));
+    float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (128 + 4));
+    static_assert(XP_WAVES * 16 * (128 + 4) * 4 <= XP_LDS, "epilogue slabs must fit in the ring");
+    // (after the last step's barrier nobody reads the ring and no DMA is in flight: the waves stage their accumulators through it)
+    if (packed)
+        store_acc_tile<TM, TN, 16, false, false, MapRows>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_, MapRows{a.pk.rowmap});
+    else
+        store_acc_tile<TM, TN, 16, false>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+    } while (SK && next_piece());
+}
+
+template <bool SK, int ABLM = 0>
+int launch_igemm_x6p(IgemmArgs &a, hipStream_t stream) {
+#ifdef EMADAPT_ABLATE_BUILD
+    if constexpr (ABLM == 0) {
+        switch (tune(TUNE_ABLATE)) {
+            case 1: return launch_igemm_x6p<SK, 1>(a, stream);
+            case 2: return launch_igemm_x6p<SK, 2>(a, stream);
+            case 3: return launch_igemm_x6p<SK, 3>(a, stream);
+            case 4: return launch_igemm_x6p<SK, 4>(a, stream);
+            case 7: return launch_igemm_x6p<SK, 7>(a, stream);
+            case 8: return launch_igemm_x6p<SK, 8>(a, stream);
+            case 9: return launch_igemm_x6p<SK, 9>(a, stream);
+            case 10: return launch_igemm_x6p<SK, 10>(a, stream);
+            case 12: return launch_igemm_x6p<SK, 12>(a, stream);
+            case 14: return launch_igemm_x6p<SK, 14>(a, stream);
+            default: break;
+        }
+    }
+#endif
+    static DynLdsAttr attr;
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_x6p_kernel<SK, ABLM>), XP_LDS);
+    if (rc) return rc;
+    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, 256);
+    a.tiles_n = (int)ceil_div(a.N, 256);
+    if constexpr (SK) {
+        const int nk_all = a.K / 16;
+        const long long tiles = (long long)a.tiles_m * a.tiles_n;
+        if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * 16 > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        const int G = a.pk.n > 0 ? streamk_grid_units(a.pk.run_u0[a.pk.nruns], a.splits) : streamk_grid(tiles, nk_all, a.splits);
+        const int levels = a.pk.n > 0 ? streamk_levels_packed(a, a.tiles_n, a.splits) : streamk_levels(tiles, nk_all, a.splits);
+        if (a.pk.n > 0) {
+            if (!a.pk.rowmap || a.m_begin != 0 || a.m_end != a.M) return EMADAPT_ERR_INVALID;
+            hipLaunchKernelGGL(rowmap_kernel, dim3((unsigned)a.tiles_m), dim3(256), 0, stream, a, const_cast<int *>(a.pk.rowmap));
+            rc = launch_status();
+            if (rc) return rc;
+        }
+        if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
+        hipLaunchKernelGGL((igemm_x6p_kernel<true, ABLM>), dim3((unsigned)G), dim3(XP_WAVES * 64), XP_LDS, stream, a);
+        rc = launch_status();
+        if (rc || levels == 0) return rc;
+        hipLaunchKernelGGL(streamk_fixup_kernel, dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, a, G, nk_all);
+        return launch_status();
+    } else {
+        const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;
+        if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((igemm_x6p_kernel<false, ABLM>), dim3((unsigned)nblk), dim3(XP_WAVES * 64), XP_LDS, stream, a);
+        rc = launch_status();
+        if (rc || a.splits <= 1) return rc;
+        return launch_splitk_epilogue(a, stream);
+    }
+}
+
+}  // namespace

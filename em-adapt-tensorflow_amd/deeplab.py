@@ -315,6 +315,15 @@ class ADAPT(Network):
             for layer, seg in self._segments.items():
                 kh, kw, cin_p, cout_p = seg["pshape"]
                 seg["wk32"] = self._flat["wk32"][seg["start"]:seg["start"] + seg["nw"]].view(kh * kw, cout_p, cin_p)
+            # plane images (csrc/conv_x6p.hip: 6 bytes per element) of the k-major image and of the HWIO master, for the
+            # layers whose channel counts are whole groups of 16
+            self._flat["wkp"] = torch.zeros(total * 6, dtype=torch.uint8, device=dev)
+            self._flat["wp6"] = torch.zeros(total * 6, dtype=torch.uint8, device=dev)
+            for layer, seg in self._segments.items():
+                kh, kw, cin_p, cout_p = seg["pshape"]
+                b0, b1 = seg["start"] * 6, (seg["start"] + seg["nw"]) * 6
+                seg["wkp"] = self._flat["wkp"][b0:b1] if cin_p % 16 == 0 else None
+                seg["wp6"] = self._flat["wp6"][b0:b1] if cout_p % 16 == 0 else None
             self._w16_seen = None
         if self.compute_dtype == "bf16":
             # bf16 filter images (include/emadapt.h, "bf16-compute variants"), one flat buffer per image kind
@@ -375,6 +384,23 @@ class ADAPT(Network):
                 bufs["idx"][op.name] = torch.empty((B, oh, ow, c), dtype=torch.uint8, device=dev)
             maxn = max(maxn, bufs["act"][op.name].numel())
             self.net[op.out_name] = bufs["act"][op.name]
+        if self.compute_dtype == "bf16x6":
+            # which convolutions run on the plane-image kernels (csrc/conv_x6p.hip), their input's plane image (kept from the
+            # forward pass for the filter gradient) and one scratch image for the gradient that enters a layer
+            xp, dyp_bytes = {}, 0
+            for op in self._plan:
+                if op.kind != "conv":
+                    continue
+                ih, iw = op.in_hw
+                d = ops.conv_desc(B, ih, iw, op.cin_p, op.cout_p, op.k, op.k, op.rate)
+                e = dict(d=d, fwd=op.seg["wkp"] is not None and ops.conv_x6p_supported(d, 0),
+                         dgrad=op.seg["wp6"] is not None and ops.conv_x6p_supported(d, 1), wgrad=ops.conv_x6p_supported(d, 2))
+                e["x"] = (torch.empty(B * ih * iw * op.cin_p * 6, dtype=torch.uint8, device=dev) if (e["fwd"] or e["wgrad"]) else None)
+                if e["dgrad"] or e["wgrad"]:
+                    dyp_bytes = max(dyp_bytes, B * ih * iw * op.cout_p * 6)
+                xp[op.name] = e
+            bufs["xp"] = xp
+            bufs["dyp"] = torch.empty(max(dyp_bytes, 16), dtype=torch.uint8, device=dev)
         bufs["gA"] = torch.empty(maxn, dtype=adt, device=dev)   # activation gradients ping-pong between these two
         bufs["gB"] = torch.empty(maxn, dtype=adt, device=dev)
         S1, S2 = self.out_hw
@@ -409,6 +435,10 @@ class ADAPT(Network):
                     ops.weights_to_bf16(op.w_pad, op.seg["wf16"], op.seg["wd16"])
                 else:
                     ops.filter_kmajor(op.w_pad, op.seg["wk32"])
+                    if op.seg["wkp"] is not None:
+                        ops.split_planes(op.seg["wk32"], out=op.seg["wkp"])
+                    if op.seg["wp6"] is not None:
+                        ops.split_planes(op.w_pad, out=op.seg["wp6"])
         self._w16_seen = ver
 
     def forward(self, images, keep_prob=1.0, drop_masks=None):
@@ -438,8 +468,15 @@ class ADAPT(Network):
                     ops.conv_fwd_bf16(x, op.seg["wf16"], (op.k, op.k), op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
                                       drop_mask=mask, drop_seed=seed, out=out)
                 elif x6:
-                    ops.conv_fwd_x6(x, op.seg["wk32"], (op.k, op.k), op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
-                                    drop_mask=mask, drop_seed=seed, out=out)
+                    e = bufs["xp"][op.name]
+                    if e["x"] is not None:
+                        ops.split_planes(x, out=e["x"])
+                    if e["fwd"]:
+                        ops.conv_fwd_x6p(e["x"], op.seg["wkp"], e["d"], op.b_pad, relu=op.relu, keep_prob=kp,
+                                         drop_mask=mask, drop_seed=seed, out=out)
+                    else:
+                        ops.conv_fwd_x6(x, op.seg["wk32"], (op.k, op.k), op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
+                                        drop_mask=mask, drop_seed=seed, out=out)
                 else:
                     ops.conv_fwd(x, op.w_pad, op.b_pad, op.rate, relu=op.relu, keep_prob=kp, drop_mask=mask,
                                  drop_seed=seed, out=out)
@@ -567,7 +604,13 @@ class ADAPT(Network):
                 if bf16:
                     ops.conv_wgrad_bf16(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
                 elif x6:
-                    ops.conv_wgrad_x6(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
+                    e = bufs["xp"][op.name]
+                    if e["wgrad"] or (e["dgrad"] and prev is not None):
+                        ops.split_planes(d, out=bufs["dyp"])
+                    if e["wgrad"]:
+                        ops.conv_wgrad_x6p(e["x"], bufs["dyp"], e["d"], out=op.gw_pad)
+                    else:
+                        ops.conv_wgrad_x6(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
                 else:
                     ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
                 ops.bias_grad(d, out=op.gb_pad)
@@ -587,7 +630,10 @@ class ADAPT(Network):
                 if bf16:
                     d = ops.conv_dgrad_bf16(d, op.seg["wd16"], (op.k, op.k), op.rate, gate=gate, gate_scale=scale, out=out)
                 elif x6:
-                    d = ops.conv_dgrad_x6(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
+                    if bufs["xp"][op.name]["dgrad"]:
+                        d = ops.conv_dgrad_x6p(bufs["dyp"], op.seg["wp6"], bufs["xp"][op.name]["d"], gate=gate, gate_scale=scale, out=out)
+                    else:
+                        d = ops.conv_dgrad_x6(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
                 else:
                     d = ops.conv_dgrad(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
             else:

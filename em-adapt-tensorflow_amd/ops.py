@@ -273,6 +273,68 @@ def conv_wgrad_x6(x, dy, KH, KW, dil=1, out=None):
     return dw
 
 
+# ---- bf16x6 on pre-split operands (csrc/conv_x6p.hip): plane images [rows][C/16][3][16] bf16, stored as uint8 tensors
+def split_planes(x, out=None):
+    """Plane image of an f32 tensor [..., C] (C % 16 == 0): x = p0 + p1 + p2 exactly, three bf16 planes, 6 bytes per element."""
+    _check(x, name="x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    nbytes = rows * C * 6
+    planes = out if out is not None else torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    _check(planes, torch.uint8, "out")
+    if planes.numel() < nbytes:
+        raise ValueError("out is too small for the plane image")
+    _lib.call("emadapt_split_planes", _p(x), _p(planes), rows, C, _stream())
+    return planes
+
+
+def conv_x6p_supported(d, kind):
+    """kind 0 forward, 1 data gradient, 2 filter gradient: does the plane-image kernel take this convolution?"""
+    return bool(_lib.load().emadapt_conv_x6p_supported(ctypes.byref(d), int(kind)))
+
+
+def conv_x6p_plan(d, dgrad=False):
+    plan = (ctypes.c_int * 5)()
+    _lib.call("emadapt_conv_x6p_plan", ctypes.byref(d), int(bool(dgrad)), plan)
+    return tuple(plan)
+
+
+def conv_fwd_x6p(xp, wkp, d, bias=None, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None):
+    """Forward convolution d from the plane images of x and of the k-major filter image [tap][Cout][Cin]."""
+    _check(xp, torch.uint8, "xp"); _check(wkp, torch.uint8, "wkp"); _check(bias, name="bias"); _check(drop_mask, torch.uint8, "drop_mask")
+    y = out if out is not None else torch.empty((d.B, d.H, d.W, d.Cout), dtype=torch.float32, device=xp.device)
+    _check(y, name="out")
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    nbytes = _lib.load().emadapt_conv_fwd_x6p_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, xp.device) if nbytes else None
+    _lib.call("emadapt_conv_fwd_x6p", ctypes.byref(d), _p(xp), _p(wkp), _p(bias), _p(y), epi, float(keep_prob),
+              _p(drop_mask), int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(ws), ws.numel() if ws is not None else 0, _stream())
+    return y
+
+
+def conv_dgrad_x6p(dyp, wp, d, gate=None, gate_scale=1.0, out=None):
+    """Data gradient of convolution d from the plane images of dy and of the HWIO filter."""
+    _check(dyp, torch.uint8, "dyp"); _check(wp, torch.uint8, "wp"); _check(gate, name="gate")
+    dx = out if out is not None else torch.empty((d.B, d.H, d.W, d.Cin), dtype=torch.float32, device=dyp.device)
+    _check(dx, name="out")
+    nbytes = _lib.load().emadapt_conv_dgrad_x6p_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, dyp.device) if nbytes else None
+    _lib.call("emadapt_conv_dgrad_x6p", ctypes.byref(d), _p(dyp), _p(wp), _p(dx), _p(gate), float(gate_scale), _p(ws),
+              ws.numel() if ws is not None else 0, _stream())
+    return dx
+
+
+def conv_wgrad_x6p(xp, dyp, d, out=None):
+    """Filter gradient of convolution d from the plane images of x and dy."""
+    _check(xp, torch.uint8, "xp"); _check(dyp, torch.uint8, "dyp")
+    dw = out if out is not None else torch.empty((d.KH, d.KW, d.Cin, d.Cout), dtype=torch.float32, device=xp.device)
+    _check(dw, name="out")
+    nbytes = _lib.load().emadapt_conv_wgrad_x6p_workspace_bytes(ctypes.byref(d))
+    ws = _WS.get(nbytes, xp.device)
+    _lib.call("emadapt_conv_wgrad_x6p", ctypes.byref(d), _p(xp), _p(dyp), _p(dw), _p(ws), ws.numel(), _stream())
+    return dw
+
+
 def bias_grad(dy, out=None):
     dt = _act(dy, "dy")
     N = dy.shape[-1]

@@ -219,6 +219,35 @@ size_t emadapt_conv_wgrad_x6_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_wgrad_x6(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, void *workspace,
                           size_t workspace_bytes, void *stream);
 
+/* "bf16x6" on PRE-SPLIT operands (csrc/conv_x6p.hip).  The split costs vector-ALU work per element; the entry points above do
+ * it inside the kernels, once per tile and filter tap.  Here it is done once per tensor into a PLANE IMAGE
+ *     [rows][C / 16][plane 0..2][16 x bf16]      (C % 16 == 0; 6 bytes per element; x = p0 + p1 + p2 exactly)
+ * and the kernels (256 x 256 tiles, LDS-DMA, one workgroup per CU) read plane images only: same arithmetic, same error bound,
+ * same epilogues / determinism as the x6 entry points, fp32 outputs.  Operands:
+ *   forward          planes of x [B*H*W][Cin]   and of the k-major filter image [KH*KW][Cout][Cin] (emadapt_filter_kmajor)
+ *   data gradient    planes of dy [B*H*W][Cout] and of the HWIO filter [KH*KW][Cin][Cout]
+ *   filter gradient  planes of x and of dy
+ * emadapt_conv_x6p_supported(d, kind) (kind 0 forward, 1 data gradient, 2 filter gradient) says whether a convolution is taken
+ * (channel counts in whole groups of 16, at least 256 output columns, a filter gradient's Cin a multiple of 256, plane images
+ * below 2 GiB); the others stay on the x6 entry points and return EMADAPT_ERR_UNSUPPORTED here.  Workspace: stream-K slab levels
+ * (+ the row table of packed rows) resp. split-M slabs, as for the fp32 kernels; EMADAPT_ERR_WORKSPACE when it is too small.
+ * emadapt_conv_x6p_plan: plan[0] rows of the first launch, [1] 1 = stream-K, [2] its slab levels, [3] pixel classes of packed
+ * rows (0 = off), [4] slab levels of the stream-K launch over the remaining rows (-1: a plain launch). */
+size_t emadapt_planes_bytes(long long rows, int C);
+int emadapt_split_planes(const float *x, void *planes, long long rows, int C, void *stream);
+int emadapt_conv_x6p_supported(const emadapt_conv_desc *d, int kind);
+int emadapt_conv_x6p_plan(const emadapt_conv_desc *d, int dgrad, int plan[5]);
+size_t emadapt_conv_fwd_x6p_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_fwd_x6p(const emadapt_conv_desc *d, const void *x_planes, const void *wk_planes, const float *bias,
+                         float *y, int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed,
+                         void *workspace, size_t workspace_bytes, void *stream);
+size_t emadapt_conv_dgrad_x6p_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_dgrad_x6p(const emadapt_conv_desc *d, const void *dy_planes, const void *w_planes, float *dx,
+                           const float *gate, float gate_scale, void *workspace, size_t workspace_bytes, void *stream);
+size_t emadapt_conv_wgrad_x6p_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_wgrad_x6p(const emadapt_conv_desc *d, const void *x_planes, const void *dy_planes, float *dw,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* The HBM-bound kernels of the step on either storage type (dtype = EMADAPT_DT_*; same semantics as the f32
  * entry points below, arithmetic in fp32 registers, results rounded to nearest-even when the output is bf16). */
 int emadapt_maxpool_fwd_dt(const void *x, int dtype, int B, int H, int W, int C, int stride, void *y, uint8_t *idx,
