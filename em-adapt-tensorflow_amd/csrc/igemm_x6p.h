@@ -146,7 +146,11 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
     for (int j = 0; j < XP_IPW; j++) {
         const int q = (wave * XP_IPW + j) * 64 + lane;
         ld_row[j] = q / 6;
+#ifdef XP_LAB_NOSWAP
+        ld_chunk[j] = (q - ld_row[j] * 6);   // (lab, timing only: lanes in ascending address order)
+#else
         ld_chunk[j] = (q - ld_row[j] * 6) ^ ((ld_row[j] >> 3) & 1);
+#endif
     }
 
     // ---- consumer side: fragment addresses (bytes inside a stage); plane p is 32 bytes on, the wave's next 32 rows 3072

@@ -50,6 +50,9 @@ __device__ __forceinline__ xp_bf16x8 wp_tr_frag(const char *lo_p) {
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// COMPACT: walk only the pixels inside the tap's box (a.skip).  The loaders' scalar arithmetic is branch-free: it runs between
+// the MFMAs of waves that have nobody else to issue them.
+template <bool COMPACT>
 __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
     constexpr int BMR = 16, NBUF = WP_NBUF, TK = 2, TN = 4;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
         tile_k = first_k + in_g % gsz;
         tile_n = in_g / gsz;
     }
-    if (a.skip) {   // tiles sorted by work, heaviest first (wgrad2_kernel)
+    if constexpr (COMPACT) {   // tiles sorted by work, heaviest first (wgrad2_kernel)
         const int per_k = a.tiles_n * a.splits;
         const int kr = (int)blockIdx.x / per_k, r = (int)blockIdx.x - kr * per_k;
         tile_k = a.korder[kr];
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
     const int tap_s = k0 / a.Cin;
     const int c0_s = k0 - tap_s * a.Cin;
     const int dh_s = (tap_s / a.KW) * a.dil - a.pad_h, dw_s = (tap_s % a.KW) * a.dil - a.pad_w;
-    const bool compact = a.skip != 0;
+    constexpr bool compact = COMPACT;
     int h0 = 0, w0 = 0, vw = a.W, pv = a.H * a.W;
     if (compact) {
         h0 = dh_s < 0 ? -dh_s : 0;
@@ -108,7 +111,6 @@ __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
     // ---- loader side
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.xp), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.dyp), 0, (int)a.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t nullr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.xp), 0, 0, 0x00020000);
     constexpr unsigned kOOB = 0x80000000u;
     const unsigned magic_pv = compact && pv > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)((0x100000000ULL + (unsigned)pv - 1) / (unsigned)pv)) : 0u;
     const unsigned magic_vw = compact && vw > 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)((0x100000000ULL + (unsigned)vw - 1) / (unsigned)vw)) : 0u;
@@ -118,48 +120,55 @@ __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
     const unsigned lc0 = (unsigned)lane * 16u, lc1 = lane < 32 ? 1024u + (unsigned)lane * 16u : (unsigned)(lane - 32) * 16u,
                    lc2 = 512u + (unsigned)lane * 16u;
     // dy: channels past N (a last, partial n tile) are out of range
+    // (kept apart from the byte offsets: a dead pixel's offset carries the bit too, and the sum of two would wrap into range)
     auto ybad = [&](unsigned lc) { return n0 + (int)(lc / XP_ROWB) * 16 < a.N ? 0u : kOOB; };
-    const unsigned yc0 = lc0 | ybad(lc0), yc1 = lc1 | ybad(lc1), yc2 = lc2 | ybad(lc2);
+    const unsigned yb0 = ybad(lc0), yb1 = ybad(lc1), yb2 = ybad(lc2);
     const bool second = lane >= 32;
 
-    // DMAs of reduction step st into ring buffer at byte offset `off`: this wave's pixels 2 wave, 2 wave + 1
-    auto fill = [&](int off, int st) {
-        unsigned sx[2], sy[2];
-        bool okx[2], live[2];
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            const int i = __builtin_amdgcn_readfirstlane(m_begin + st * BMR + 2 * wave + e);
-            live[e] = i < m_end;
-            int m, oh, ow;
-            if (compact) {
-                const unsigned img = div_magic((unsigned)i, magic_pv);
-                const unsigned r = (unsigned)i - img * (unsigned)pv;
-                const unsigned rh = div_magic(r, magic_vw);
-                oh = h0 + (int)rh;
-                ow = w0 + (int)(r - rh * (unsigned)vw);
-                m = ((int)img * a.H + oh) * a.W + ow;
-            } else {
-                m = i;
-                const unsigned t2 = div_magic((unsigned)m, a.magic_w);
-                ow = m - (int)t2 * a.W;
-                oh = (int)(t2 - div_magic(t2, a.magic_h) * (unsigned)a.H);
-            }
-            okx[e] = live[e] && (unsigned)(oh + dh_s) < (unsigned)a.H && (unsigned)(ow + dw_s) < (unsigned)a.W;
-            sx[e] = okx[e] ? (unsigned)(m + dh_s * a.W + dw_s) * (unsigned)xrow + (unsigned)(c0_s / 16 * XP_ROWB) : 0u;
-            sy[e] = live[e] ? (unsigned)m * (unsigned)yrow + (unsigned)(n0 / 16 * XP_ROWB) : 0u;
+    // n / d by multiply-high with d == 1 encoded as magic 0 -- as a select, not a branch
+    auto udiv = [](unsigned n, unsigned magic) { return __umulhi(n, magic) + (magic ? 0u : n); };
+    // pixel i of this split -> scalar byte offsets of its x block (at the tile's tap) and its dy block, each with the
+    // out-of-range bit where the pixel is past the end (resp. the tap outside the image)
+    auto pixel = [&](int i, unsigned &vx, unsigned &vy) {
+        const unsigned ui = (unsigned)i;
+        unsigned m, oh, ow;
+        if constexpr (COMPACT) {
+            const unsigned img = udiv(ui, magic_pv);
+            const unsigned r = ui - img * (unsigned)pv;
+            const unsigned rh = udiv(r, magic_vw);
+            oh = (unsigned)h0 + rh;
+            ow = (unsigned)w0 + (r - rh * (unsigned)vw);
+            m = (img * (unsigned)a.H + oh) * (unsigned)a.W + ow;
+        } else {
+            m = ui;
+            const unsigned t2 = udiv(m, a.magic_w);
+            ow = m - t2 * (unsigned)a.W;
+            oh = t2 - udiv(t2, a.magic_h) * (unsigned)a.H;
         }
-        char *xs = ldsb + off + wave * WP_PAIR;
-        char *ys = xs + WP_OPER;
-        // (the middle instruction serves both pixels: per-lane choice of the pixel's offset, out of range where that pixel is)
-        const unsigned vx1 = (second ? (okx[1] ? sx[1] : kOOB) : (okx[0] ? sx[0] : kOOB)) + lc1;
-        const unsigned vy1 = (second ? (live[1] ? sy[1] : kOOB) : (live[0] ? sy[0] : kOOB)) + yc1;
-        xp_dma(okx[0] ? xr : nullr, xs, lc0, sx[0]);
-        xp_dma(xr, xs + 1024, vx1, 0);
-        xp_dma(okx[1] ? xr : nullr, xs + 2048, lc2, sx[1]);
-        xp_dma(live[0] ? yr : nullr, ys, yc0, sy[0]);
-        xp_dma(yr, ys + 1024, vy1, 0);
-        xp_dma(live[1] ? yr : nullr, ys + 2048, yc2, sy[1]);
+        const bool live = i < m_end;
+        const bool ok = live & ((unsigned)((int)oh + dh_s) < (unsigned)a.H) & ((unsigned)((int)ow + dw_s) < (unsigned)a.W);
+        vx = ok ? (unsigned)((int)m + dh_s * a.W + dw_s) * (unsigned)xrow + (unsigned)(c0_s / 16 * XP_ROWB) : kOOB;
+        vy = live ? m * (unsigned)yrow + (unsigned)(n0 / 16 * XP_ROWB) : kOOB;
     };
+    // DMAs of reduction step st into the ring buffer at byte offset `off`: this wave's pixels 2 wave (first half) and 2 wave + 1
+    // (second half; the middle instruction of each operand serves both pixels, so it goes with the second)
+    unsigned vxa = 0, vya = 0;
+    auto fill_first = [&](int off, int st) {
+        pixel(__builtin_amdgcn_readfirstlane(m_begin + st * BMR + 2 * wave), vxa, vya);
+        char *xs = ldsb + off + wave * WP_PAIR;
+        xp_dma(xr, xs, vxa + lc0, 0);
+        xp_dma(yr, xs + WP_OPER, (vya + lc0) | yb0, 0);
+    };
+    auto fill_second = [&](int off, int st) {
+        unsigned vxb, vyb;
+        pixel(__builtin_amdgcn_readfirstlane(m_begin + st * BMR + 2 * wave + 1), vxb, vyb);
+        char *xs = ldsb + off + wave * WP_PAIR;
+        xp_dma(xr, xs + 1024, (second ? vxb : vxa) + lc1, 0);
+        xp_dma(xr, xs + 2048, vxb + lc2, 0);
+        xp_dma(yr, xs + WP_OPER + 1024, ((second ? vyb : vya) + lc1) | yb1, 0);
+        xp_dma(yr, xs + WP_OPER + 2048, (vyb + lc2) | yb2, 0);
+    };
+    auto fill = [&](int off, int st) { fill_first(off, st); fill_second(off, st); };
 
     // ---- consumer side: one fragment address per operand (bytes inside a stage)
     const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
@@ -193,9 +202,11 @@ __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
         WP_SB
         WP_MF(1, 0, 0, 0) WP_RA(0, 0, NX) WP_MF(1, 0, 0, 1) WP_RA(0, 1, NX) WP_MF(1, 0, 0, 2) WP_RB(2, 0, NX) WP_MF(1, 0, 0, 3) WP_RB(2, 1, NX)
         WP_MF(1, 0, 1, 0) WP_RB(2, 2, NX) WP_MF(1, 0, 1, 1) WP_RB(2, 3, NX) WP_MF(1, 0, 1, 2) WP_MF(1, 0, 1, 3)
-        fill(u_off, st + 3);   // (steps past the end: both pixels dead, zeros)
+        fill_first(u_off, st + 3);   // (steps past the end: both pixels dead, zeros)
         WP_SB
         WP_GROUP(2, 0)
+        fill_second(u_off, st + 3);
+        WP_SB
         WP_MF(1, 1, 0, 0) WP_RB(0, 0, NX) WP_MF(1, 1, 0, 1) WP_RB(0, 1, NX) WP_MF(1, 1, 0, 2) WP_RB(0, 2, NX) WP_MF(1, 1, 0, 3) WP_RB(0, 3, NX)
         WP_MF(1, 1, 1, 0) WP_RA(2, 0, NX) WP_MF(1, 1, 1, 1) WP_RA(2, 1, NX) WP_MF(1, 1, 1, 2) WP_MF(1, 1, 1, 3)
         WP_RB(1, 0, NX) WP_RB(1, 1, NX) WP_RB(1, 2, NX) WP_RB(1, 3, NX) WP_RA(1, 0, NX) WP_RA(1, 1, NX)
@@ -303,12 +314,19 @@ void wp_order_k_tiles(WgradXPArgs &a) {
 }
 
 int launch_wgrad_x6p(const WgradXPArgs &a, hipStream_t stream) {
-    static DynLdsAttr attr;
-    int rc = attr.ensure(reinterpret_cast<const void *>(&wgrad_x6p_kernel), WP_LDS);
-    if (rc) return rc;
     const long long nblk = (long long)a.tiles_k * a.tiles_n * a.splits;
     if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(wgrad_x6p_kernel, dim3((unsigned)nblk), dim3(512), WP_LDS, stream, a);
+    if (a.skip) {
+        static DynLdsAttr attr;
+        int rc = attr.ensure(reinterpret_cast<const void *>(&wgrad_x6p_kernel<true>), WP_LDS);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_x6p_kernel<true>, dim3((unsigned)nblk), dim3(512), WP_LDS, stream, a);
+    } else {
+        static DynLdsAttr attr;
+        int rc = attr.ensure(reinterpret_cast<const void *>(&wgrad_x6p_kernel<false>), WP_LDS);
+        if (rc) return rc;
+        hipLaunchKernelGGL(wgrad_x6p_kernel<false>, dim3((unsigned)nblk), dim3(512), WP_LDS, stream, a);
+    }
     return launch_status();
 }
 
