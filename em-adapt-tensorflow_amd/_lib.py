@@ -74,6 +74,8 @@ PROTOTYPES = {
     "emadapt_conv_wgrad_x6": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_size_t, _vp]),
     "emadapt_planes_bytes": (c_size_t, [c_longlong, c_int]),
     "emadapt_split_planes": (c_int, [_vp, _vp, c_longlong, c_int, _vp]),
+    "emadapt_filter_tiles_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "emadapt_filter_tiles": (c_int, [POINTER(ConvDesc), _vp, _vp, c_int, _vp]),
     "emadapt_conv_x6p_supported": (c_int, [POINTER(ConvDesc), c_int]),
     "emadapt_conv_x6p_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
     "emadapt_conv_fwd_x6p_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),

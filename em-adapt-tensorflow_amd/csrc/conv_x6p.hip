@@ -5,8 +5,8 @@
 // filter gradients whose 256-wide k tiles straddle taps) stay on conv_x6.hip's kernels: emadapt_conv_x6p_supported().
 //
 // Plane image of an fp32 tensor [rows][C], C % 16 == 0:   [rows][C / 16][plane 0..2][16 x bf16]    (6 bytes per element)
-//   forward:          activation planes [B*H*W][Cin]    x   filter planes of the k-major image [tap][Cout][Cin]
-//   data gradient:    dy planes [B*H*W][Cout]           x   filter planes of the HWIO master [tap][Cin][Cout]
+//   forward:          activation planes [B*H*W][Cin]    x   tiled filter planes, rows = Cout, k = Cin   (emadapt_filter_tiles)
+//   data gradient:    dy planes [B*H*W][Cout]           x   tiled filter planes, rows = Cin, k = Cout
 //   filter gradient:  activation planes, dy planes -> fp32 HWIO gradient
 #include <stdlib.h>
 
@@ -48,6 +48,39 @@ __global__ void __launch_bounds__(256) split_planes_kernel(const float4 *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Tiled plane image of a filter for igemm_x6p_kernel (see igemm_x6p.h): [tap][k / 16][row (zero rows up to a multiple of 256)]
+// [6 chunks], chunk position = (2 plane + half) ^ (bit 3 of the row).  DGRAD = false: rows = Cout, k = Cin (forward);
+// true: rows = Cin, k = Cout (data gradient).  One thread = 8 consecutive k of one row.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool DGRAD>
+__global__ void __launch_bounds__(256) filter_tiles_kernel(const float *__restrict__ w, uint4 *__restrict__ out, int Cin, int Cout,
+                                                           int taps, int rows_pad) {
+    const int rows = DGRAD ? Cin : Cout, kdim = DGRAD ? Cout : Cin;
+    const int G = kdim / 16;
+    const long long total = (long long)taps * G * rows_pad * 2;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int h = (int)(idx & 1);
+        long long t = idx >> 1;
+        const int row = (int)(t % rows_pad);
+        t /= rows_pad;
+        const int g = (int)(t % G), tap = (int)(t / G);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int k = g * 16 + h * 8 + e;
+            v[e] = row < rows ? (DGRAD ? w[((long long)tap * Cin + row) * Cout + k] : w[((long long)tap * Cin + k) * Cout + row]) : 0.f;
+        }
+        uint4 p0, p1, p2;
+        split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), p0, p1, p2);
+        const int par = (row >> 3) & 1;
+        uint4 *o = out + (((long long)tap * G + g) * rows_pad + row) * 6;
+        o[(0 + h) ^ par] = p0;
+        o[(2 + h) ^ par] = p1;
+        o[(4 + h) ^ par] = p2;
+    }
+}
+
 int launch_split_planes(const float *x, void *planes, long long elems, hipStream_t stream) {
     const long long n8 = elems / 8;
     if (n8 == 0) return EMADAPT_OK;
@@ -71,7 +104,7 @@ struct PlanXP {
 };
 
 bool xp_ok(const IgemmArgs &a) {
-    const long long plane_x = (long long)a.M * a.Cx * 6, plane_w = (long long)a.K * a.N * 6;
+    const long long plane_x = (long long)a.M * a.Cx * 6, plane_w = (long long)a.K * ceil_div(a.N, 256) * 256 * 6;
     const long long reach = ((long long)(a.ntaps / a.KW - 1) * a.dil * a.W + (long long)(a.KW - 1) * a.dil) * a.Cx * 6;
     return a.Cx % 16 == 0 && a.ntaps <= 32 && a.N % 4 == 0 && a.N >= 256 && plane_x + reach < (1LL << 31) && plane_w < (1LL << 31) &&
            (long long)a.M * a.N < (1LL << 40);
@@ -147,7 +180,7 @@ int dispatch_x6p(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStrea
 void fill_x6p(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
     fill_geometry(a, d, dgrad);
     a.x_bytes = (unsigned)((long long)a.M * (a.Cx / 16) * XP_GB);
-    a.w_bytes = (unsigned)((long long)a.K / 16 * a.N * XP_GB);
+    a.w_bytes = (unsigned)((long long)a.K / 16 * ceil_div(a.N, 256) * 256 * XP_ROWB);   // tiled filter image: rows padded to whole tiles
 }
 
 }  // namespace
@@ -161,6 +194,31 @@ int emadapt_split_planes(const float *x, void *planes, long long rows, int C, vo
     if (rows == 0) return EMADAPT_OK;
     if (!x || !planes || !aligned16(x) || !aligned16(planes)) return EMADAPT_ERR_INVALID;
     return launch_split_planes(x, planes, rows * C, as_stream(stream_));
+}
+
+size_t emadapt_filter_tiles_bytes(const emadapt_conv_desc *d, int dgrad) {
+    if (check_desc(d) != EMADAPT_OK) return 0;
+    const int rows = dgrad ? d->Cin : d->Cout, kdim = dgrad ? d->Cout : d->Cin;
+    if (kdim % 16 != 0) return 0;
+    return (size_t)d->KH * d->KW * (kdim / 16) * (size_t)(ceil_div(rows, 256) * 256) * XP_ROWB;
+}
+
+int emadapt_filter_tiles(const emadapt_conv_desc *d, const float *w, void *tiles, int dgrad, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!w || !tiles || !aligned16(w) || !aligned16(tiles)) return EMADAPT_ERR_INVALID;
+    const int rows = dgrad ? d->Cin : d->Cout, kdim = dgrad ? d->Cout : d->Cin;
+    if (kdim % 16 != 0) return EMADAPT_ERR_UNSUPPORTED;
+    const int rows_pad = (int)(ceil_div(rows, 256) * 256), taps = d->KH * d->KW;
+    long long g = ((long long)taps * (kdim / 16) * rows_pad * 2 + 255) / 256;
+    if (g > 16384) g = 16384;
+    if (dgrad)
+        hipLaunchKernelGGL(filter_tiles_kernel<true>, dim3((unsigned)g), dim3(256), 0, as_stream(stream_), w,
+                           reinterpret_cast<uint4 *>(tiles), d->Cin, d->Cout, taps, rows_pad);
+    else
+        hipLaunchKernelGGL(filter_tiles_kernel<false>, dim3((unsigned)g), dim3(256), 0, as_stream(stream_), w,
+                           reinterpret_cast<uint4 *>(tiles), d->Cin, d->Cout, taps, rows_pad);
+    return launch_status();
 }
 
 int emadapt_conv_x6p_supported(const emadapt_conv_desc *d, int kind) {

@@ -23,6 +23,11 @@
 //     of step kt + 1, BARRIER, issues the DMAs of step kt + 3 into the buffer it has just finished reading, then the other half
 //     of the MFMAs: the matrix pipe has work queued on both sides of the barrier (no LDS round trip behind it), a DMA has two
 //     whole steps to land, and three buffers carry a fetch distance of three.
+//   * the FILTER operand does not need the gather at all: its plane image is stored tile by tile in exactly the LDS order
+//         [tap][k / 16][row, padded with zero rows to a multiple of 256][6 chunks of 16 B, halves swapped where row bit 3 is set]
+//     (filter_tiles_kernel, once per optimizer step), so a K step's 256 filter rows are 24 contiguous KB and the filter DMAs are
+//     plain 1 KB copies -- half of the kernel's operand traffic at the DMA path's best rate (the activation side's 96-byte
+//     pieces run at about half of it: scripts/x6p_ablate.py).
 //   * work split, packed rows, epilogues, stream-K fix-up: igemm_v2.h's, unchanged (same accumulator layout).
 // Requirements: Cx % 16 == 0, KH*KW <= 32, N % 4 == 0; plane images below 2 GiB.
 #pragma once
@@ -125,7 +130,8 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
 
     // ---- loader side: constants of the launch
     // (the tap offset rides in the DMA's scalar operand, an UNSIGNED addend: the buffer starts `bias` bytes before the tensor)
-    const int rowb = a.Cx / 16 * XP_GB;   // bytes of a pixel / filter row in a plane image
+    const int rowb = a.Cx / 16 * XP_GB;   // bytes of a pixel in a plane image
+    const int n_pad = a.tiles_n * 256;     // filter rows per (tap, group of 16 k) in the tiled filter image
     int min_dh = a.sign * (0 - a.pad_h), min_dw = a.sign * (0 - a.pad_w);
     {
         const int KH = a.ntaps / a.KW;
@@ -196,8 +202,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
             a_off[j] = 0;
             a_bad[j] = 0xFFFFFFFFu;
         }
-        const int n = n0 + r;
-        b_off[j] = ((unsigned)n * (unsigned)rowb + (unsigned)ld_chunk[j] * 16u) | (n < a.N ? 0u : kOOB);
+        b_off[j] = (unsigned)((wave * XP_IPW + j) * 64 + lane) * 16u;   // the filter image is stored tile by tile in LDS order: plain copies
     }
 
     // DMAs of K step kt (of this piece's tile) into ring buffer `buf`: this wave's 3 KB of each operand
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
         const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
         const int dw = a.sign * (kw * a.dil - a.pad_w);
         const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + chunk_u * (unsigned)XP_GB + bias));
-        const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tap_u * (unsigned)a.N * (unsigned)rowb + chunk_u * (unsigned)XP_GB));
+        const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(((tap_u * (unsigned)(a.Cx / 16) + chunk_u) * (unsigned)n_pad + (unsigned)n0) * (unsigned)XP_ROWB));
         const unsigned sh = 31u - (tap_u & 31u);   // moves this tap's "outside the image" bit to bit 31
         const unsigned dead = live ? 0u : kOOB;    // (a step past the end of the piece: every lane out of range, zeros)
         char *as = ldsb + buf * XP_STAGE + wave * (XP_IPW * 1024);
@@ -265,7 +270,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
         const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
         const int dw = a.sign * (kw * a.dil - a.pad_w);
         const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + chunk_u * (unsigned)XP_GB + bias));
-        const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(tap_u * (unsigned)a.N * (unsigned)rowb + chunk_u * (unsigned)XP_GB));
+        const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(((tap_u * (unsigned)(a.Cx / 16) + chunk_u) * (unsigned)n_pad + (unsigned)n0) * (unsigned)XP_ROWB));
         const unsigned sh = 31u - (tap_u & 31u);
         const unsigned dead = kt + 3 < nk ? 0u : kOOB;   // no such step: all lanes out of range
         XP_SB

@@ -315,15 +315,13 @@ class ADAPT(Network):
             for layer, seg in self._segments.items():
                 kh, kw, cin_p, cout_p = seg["pshape"]
                 seg["wk32"] = self._flat["wk32"][seg["start"]:seg["start"] + seg["nw"]].view(kh * kw, cout_p, cin_p)
-            # plane images (csrc/conv_x6p.hip: 6 bytes per element) of the k-major image and of the HWIO master, for the
-            # layers whose channel counts are whole groups of 16
-            self._flat["wkp"] = torch.zeros(total * 6, dtype=torch.uint8, device=dev)
-            self._flat["wp6"] = torch.zeros(total * 6, dtype=torch.uint8, device=dev)
+            # tiled plane images (csrc/conv_x6p.hip, ops.filter_tiles) for the forward and the data-gradient kernel, for the
+            # layers whose reduction runs over whole groups of 16 channels
             for layer, seg in self._segments.items():
                 kh, kw, cin_p, cout_p = seg["pshape"]
-                b0, b1 = seg["start"] * 6, (seg["start"] + seg["nw"]) * 6
-                seg["wkp"] = self._flat["wkp"][b0:b1] if cin_p % 16 == 0 else None
-                seg["wp6"] = self._flat["wp6"][b0:b1] if cout_p % 16 == 0 else None
+                nf, nd = ops.filter_tiles_bytes(cin_p, cout_p, kh, kw, False), ops.filter_tiles_bytes(cin_p, cout_p, kh, kw, True)
+                seg["wkp"] = torch.zeros(nf, dtype=torch.uint8, device=dev) if nf else None
+                seg["wp6"] = torch.zeros(nd, dtype=torch.uint8, device=dev) if nd else None
             self._w16_seen = None
         if self.compute_dtype == "bf16":
             # bf16 filter images (include/emadapt.h, "bf16-compute variants"), one flat buffer per image kind
@@ -436,9 +434,9 @@ class ADAPT(Network):
                 else:
                     ops.filter_kmajor(op.w_pad, op.seg["wk32"])
                     if op.seg["wkp"] is not None:
-                        ops.split_planes(op.seg["wk32"], out=op.seg["wkp"])
+                        ops.filter_tiles(op.w_pad, False, out=op.seg["wkp"])
                     if op.seg["wp6"] is not None:
-                        ops.split_planes(op.w_pad, out=op.seg["wp6"])
+                        ops.filter_tiles(op.w_pad, True, out=op.seg["wp6"])
         self._w16_seen = ver
 
     def forward(self, images, keep_prob=1.0, drop_masks=None):

@@ -288,6 +288,28 @@ def split_planes(x, out=None):
     return planes
 
 
+def filter_tiles(w, dgrad=False, out=None):
+    """Tiled plane image of an HWIO filter for the plane-image forward (rows = Cout, k = Cin) or data-gradient (rows = Cin,
+    k = Cout) kernel: [tap][k / 16][rows padded to 256][96 B in LDS order] (csrc/igemm_x6p.h)."""
+    _check(w, name="w")
+    KH, KW, Cin, Cout = w.shape
+    d = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+    nbytes = _lib.load().emadapt_filter_tiles_bytes(ctypes.byref(d), int(bool(dgrad)))
+    if nbytes == 0:
+        raise ValueError("the reduction's channel count must be a whole number of groups of 16")
+    tiles = out if out is not None else torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+    _check(tiles, torch.uint8, "out")
+    if tiles.numel() < nbytes:
+        raise ValueError("out is too small for the tiled filter image")
+    _lib.call("emadapt_filter_tiles", ctypes.byref(d), _p(w), _p(tiles), int(bool(dgrad)), _stream())
+    return tiles
+
+
+def filter_tiles_bytes(Cin, Cout, KH, KW, dgrad=False):
+    d = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+    return int(_lib.load().emadapt_filter_tiles_bytes(ctypes.byref(d), int(bool(dgrad))))
+
+
 def conv_x6p_supported(d, kind):
     """kind 0 forward, 1 data gradient, 2 filter gradient: does the plane-image kernel take this convolution?"""
     return bool(_lib.load().emadapt_conv_x6p_supported(ctypes.byref(d), int(kind)))
@@ -300,7 +322,7 @@ def conv_x6p_plan(d, dgrad=False):
 
 
 def conv_fwd_x6p(xp, wkp, d, bias=None, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None):
-    """Forward convolution d from the plane images of x and of the k-major filter image [tap][Cout][Cin]."""
+    """Forward convolution d from the plane image of x and the tiled filter image filter_tiles(w)."""
     _check(xp, torch.uint8, "xp"); _check(wkp, torch.uint8, "wkp"); _check(bias, name="bias"); _check(drop_mask, torch.uint8, "drop_mask")
     y = out if out is not None else torch.empty((d.B, d.H, d.W, d.Cout), dtype=torch.float32, device=xp.device)
     _check(y, name="out")
@@ -313,7 +335,7 @@ def conv_fwd_x6p(xp, wkp, d, bias=None, relu=True, keep_prob=1.0, drop_mask=None
 
 
 def conv_dgrad_x6p(dyp, wp, d, gate=None, gate_scale=1.0, out=None):
-    """Data gradient of convolution d from the plane images of dy and of the HWIO filter."""
+    """Data gradient of convolution d from the plane image of dy and the tiled filter image filter_tiles(w, dgrad=True)."""
     _check(dyp, torch.uint8, "dyp"); _check(wp, torch.uint8, "wp"); _check(gate, name="gate")
     dx = out if out is not None else torch.empty((d.B, d.H, d.W, d.Cin), dtype=torch.float32, device=dyp.device)
     _check(dx, name="out")

@@ -24,4 +24,4 @@ for name, x, w in (("x fp32, w fp32", x0, w0), ("x bf16-exact, w bf16-exact", bf
     xg, wg = torch.tensor(x, device="cuda"), torch.tensor(w, device="cuda")
     print("%-28s native %s | x6 %s | planes %s" % (name, rel(ops.conv_fwd(xg, wg, None, 1).cpu(), y),
           rel(ops.conv_fwd_x6(xg, ops.filter_kmajor(wg), (k, k), None, 1).cpu(), y),
-          rel(ops.conv_fwd_x6p(ops.split_planes(xg), ops.split_planes(ops.filter_kmajor(wg)), d, None).cpu(), y)), flush=True)
+          rel(ops.conv_fwd_x6p(ops.split_planes(xg), ops.filter_tiles(wg), d, None).cpu(), y)), flush=True)

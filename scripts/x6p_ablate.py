@@ -16,7 +16,7 @@ x = torch.randn((B, H, H, Cin), device="cuda", generator=g).relu_()
 w = torch.randn((k, k, Cin, Cout), device="cuda", generator=g) * 0.05
 b = torch.randn((Cout,), device="cuda", generator=g)
 d = ops.conv_desc(B, H, H, Cin, Cout, k, k, rate)
-xp = ops.split_planes(x); wkp = ops.split_planes(ops.filter_kmajor(w))
+xp = ops.split_planes(x); wkp = ops.filter_tiles(w)
 if os.environ.get("XP_LAB_SO"):   # timing only: room for 8 bytes per element, contents irrelevant
     xp = torch.zeros((x.numel() * 8,), dtype=torch.uint8, device="cuda"); wkp = torch.zeros((w.numel() * 8,), dtype=torch.uint8, device="cuda")
 only = [int(v) for v in os.environ.get("XP_LAB_MASKS", "").split(",") if v]

@@ -53,7 +53,7 @@ for name in args.layers.split(","):
             if not ops.conv_x6p_supported(d, 0): print("%-8s fwd    not taken by the plane kernels" % name); continue
             ref = ops.conv_fwd(x, w, b, rate, relu=True)
             xp = ops.split_planes(x)
-            wkp = ops.split_planes(ops.filter_kmajor(w))
+            wkp = ops.filter_tiles(w)
             y = ops.conv_fwd_x6p(xp, wkp, d, b, relu=True)
             err = rel(y, ref)
             t = timed(lambda: ops.conv_fwd_x6p(xp, wkp, d, b, relu=True, out=y), args.iters)
@@ -66,7 +66,7 @@ for name in args.layers.split(","):
             gate = x
             ref = ops.conv_dgrad(dy, w, rate, gate=gate, gate_scale=1.0)
             dyp = ops.split_planes(dy)
-            wp = ops.split_planes(w)
+            wp = ops.filter_tiles(w, dgrad=True)
             dx = ops.conv_dgrad_x6p(dyp, wp, d, gate=gate, gate_scale=1.0)
             err = rel(dx, ref)
             t = timed(lambda: ops.conv_dgrad_x6p(dyp, wp, d, gate=gate, gate_scale=1.0, out=dx), args.iters)

@@ -71,6 +71,32 @@ def test_split_planes_is_exact_and_laid_out_as_documented(env):
         ops.split_planes(_t(torch, x[:, :40]))   # channel counts must be whole groups of 16
 
 
+def test_filter_tiles_layout(env):
+    """[tap][k / 16][row, zero rows up to a multiple of 256][6 chunks of 16 B]: chunk (2 plane + half) of a row sits at position
+    chunk ^ (bit 3 of the row) -- the LDS order of igemm_x6p_kernel's filter tile."""
+    ops, do, torch = env
+    rng = np.random.default_rng(4)
+    k, Cin, Cout = 3, 32, 40
+    w = rng.normal(0, 0.1, (k, k, Cin, Cout)).astype(np.float32)
+    for dgrad in (False, True):
+        rows, kdim = (Cin, Cout) if dgrad else (Cout, Cin)
+        if kdim % 16:
+            with pytest.raises(Exception):
+                ops.filter_tiles(_t(torch, w), dgrad=dgrad)
+            continue
+        got = ops.filter_tiles(_t(torch, w), dgrad=dgrad).cpu().numpy().view(np.uint16).reshape(k * k, kdim // 16, 256, 6, 8)
+        m = w.reshape(k * k, Cin, Cout)
+        m = m if dgrad else m.transpose(0, 2, 1)                       # [tap][row][k]
+        planes = planes_reference(m.reshape(-1, kdim)).reshape(k * k, rows, kdim // 16, 3, 2, 8)   # [tap][row][g][plane][half][8]
+        want = np.zeros((k * k, kdim // 16, 256, 6, 8), np.uint16)
+        for row in range(rows):
+            par = (row >> 3) & 1
+            for p in range(3):
+                for h in range(2):
+                    want[:, :, row, (2 * p + h) ^ par, :] = planes[:, row, :, p, h, :]
+        assert np.array_equal(got, want)
+
+
 # (B, H, W, Cin, Cout, k, dil): shapes at least one of the plane kernels takes
 SHAPES = [
     (2, 13, 11, 16, 256, 3, 1),
@@ -119,7 +145,7 @@ def test_plane_kernels_against_the_fp64_oracle(env, shape, plan):
     taken = [ops.conv_x6p_supported(d, kind) for kind in (0, 1, 2)]
     assert any(taken)
     if taken[0]:
-        xp, wkp = ops.split_planes(xg), ops.split_planes(ops.filter_kmajor(wg))
+        xp, wkp = ops.split_planes(xg), ops.filter_tiles(wg)
         assert _rel(ops.conv_fwd_x6p(xp, wkp, d, None).cpu(), (y - bt).detach()) < 2e-5
         assert _rel(ops.conv_fwd_x6p(xp, wkp, d, bg, relu=False).cpu(), y.detach()) < 2e-5
         got = ops.conv_fwd_x6p(xp, wkp, d, bg, relu=True)
@@ -130,9 +156,9 @@ def test_plane_kernels_against_the_fp64_oracle(env, shape, plan):
         assert _rel(ops.conv_fwd_x6p(xp, wkp, d, bg, relu=True, keep_prob=0.5, drop_mask=torch.tensor(mask, device="cuda:0")).cpu(), want) < 2e-5
     else:
         with pytest.raises(Exception):
-            ops.conv_fwd_x6p(ops.split_planes(xg), ops.split_planes(ops.filter_kmajor(wg)), d, None)
+            ops.conv_fwd_x6p(ops.split_planes(xg), ops.filter_tiles(wg), d, None)
     if taken[1]:
-        dyp, wp = ops.split_planes(dyg), ops.split_planes(wg)
+        dyp, wp = ops.split_planes(dyg), ops.filter_tiles(wg, dgrad=True)
         got = ops.conv_dgrad_x6p(dyp, wp, d)
         assert _rel(got.cpu(), xt.grad) < 2e-5
         assert torch.equal(got, ops.conv_dgrad_x6p(dyp, wp, d))
@@ -178,7 +204,7 @@ def test_whole_rounds_plus_tail_launch(env):
     w = rng.normal(0, 0.2, (1, 1, Cin, Cout)).astype(np.float32)
     want = x.reshape(-1, Cin).astype(np.float64) @ w.reshape(Cin, Cout).astype(np.float64)
     d = ops.conv_desc(B, H, W, Cin, Cout, 1, 1, 1)
-    xp, wkp = ops.split_planes(_t(torch, x)), ops.split_planes(ops.filter_kmajor(_t(torch, w)))
+    xp, wkp = ops.split_planes(_t(torch, x)), ops.filter_tiles(_t(torch, w))
     for cus in (5, 12, 0):
         ops.tune_set("plan_cus", cus)
         try:
@@ -215,8 +241,8 @@ def test_x6p_is_as_close_to_fp64_as_the_native_fp32_kernels(env):
         ops.tune_set("splitk", 0)
     assert ops.conv_x6p_plan(d)[1:3] == (0, 0) and ops.conv_x6p_plan(d, True)[1:3] == (0, 0)   # plain tiles: one accumulator per output
     pairs = [
-        ("fwd", native_fwd, ops.conv_fwd_x6p(xp, ops.split_planes(ops.filter_kmajor(wg)), d, None), y.detach().numpy()),
-        ("dgrad", native_dgrad, ops.conv_dgrad_x6p(dyp, ops.split_planes(wg), d), xt.grad.numpy()),
+        ("fwd", native_fwd, ops.conv_fwd_x6p(xp, ops.filter_tiles(wg), d, None), y.detach().numpy()),
+        ("dgrad", native_dgrad, ops.conv_dgrad_x6p(dyp, ops.filter_tiles(wg, dgrad=True), d), xt.grad.numpy()),
         ("wgrad", ops.conv_wgrad(xg, dyg, k, k, 1), ops.conv_wgrad_x6p(xp, dyp, d), wt.grad.numpy()),
     ]
     for name, native, planes, want in pairs:
@@ -246,11 +272,11 @@ def test_plane_kernels_at_the_benchmark_shapes(env, layer):
     def close(got, want, bar):
         return float((got - want).abs().max() / want.abs().max()) < bar
 
-    y = ops.conv_fwd_x6p(xp, ops.split_planes(ops.filter_kmajor(w)), d, b, relu=True)
+    y = ops.conv_fwd_x6p(xp, ops.filter_tiles(w), d, b, relu=True)
     assert close(y, ops.conv_fwd(x, w, b, rate, relu=True), 2e-5)
-    dx = ops.conv_dgrad_x6p(dyp, ops.split_planes(w), d, gate=x, gate_scale=2.0)
+    dx = ops.conv_dgrad_x6p(dyp, ops.filter_tiles(w, dgrad=True), d, gate=x, gate_scale=2.0)
     assert close(dx, ops.conv_dgrad(dy, w, rate, gate=x, gate_scale=2.0), 3e-5)
-    assert torch.equal(dx, ops.conv_dgrad_x6p(dyp, ops.split_planes(w), d, gate=x, gate_scale=2.0))
+    assert torch.equal(dx, ops.conv_dgrad_x6p(dyp, ops.filter_tiles(w, dgrad=True), d, gate=x, gate_scale=2.0))
     dw = ops.conv_wgrad_x6p(xp, dyp, d)
     assert close(dw, ops.conv_wgrad(x, dy, k, k, rate), 2e-5)
     del xp, dyp, y, dx, dw
@@ -313,10 +339,6 @@ def test_x6p_micro_step_matches_the_fp32_oracle_at_the_fp32_bars():
     torch.cuda.synchronize()
     seg = adapt._segments["fc7"]
     assert not torch.equal(before, seg["wkp"])
-    assert torch.equal(seg["wkp"], ops_split(seg["wk32"]))
-    assert torch.equal(seg["wp6"], ops_split(seg["w_pad"]))
-
-
-def ops_split(t):
     import em_adapt_tensorflow_amd.ops as ops
-    return ops.split_planes(t.contiguous())
+    assert torch.equal(seg["wkp"], ops.filter_tiles(seg["w_pad"].contiguous()))
+    assert torch.equal(seg["wp6"], ops.filter_tiles(seg["w_pad"].contiguous(), dgrad=True))
