@@ -472,6 +472,11 @@ class ADAPT(Network):
                     if e["fwd"]:
                         ops.conv_fwd_x6p(e["x"], op.seg["wkp"], e["d"], op.b_pad, relu=op.relu, keep_prob=kp,
                                          drop_mask=mask, drop_seed=seed, out=out)
+                    elif op.cout_p <= 64:
+                        # (64 or fewer output columns -- conv1_x, fc8: the native fp32 kernel's 256x64 tiles are the faster
+                        # fp32-grade kernel there, measured per layer: profiles/r03_x6_*)
+                        ops.conv_fwd(x, op.w_pad, op.b_pad, op.rate, relu=op.relu, keep_prob=kp, drop_mask=mask,
+                                     drop_seed=seed, out=out)
                     else:
                         ops.conv_fwd_x6(x, op.seg["wk32"], (op.k, op.k), op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
                                         drop_mask=mask, drop_seed=seed, out=out)
@@ -630,6 +635,8 @@ class ADAPT(Network):
                 elif x6:
                     if bufs["xp"][op.name]["dgrad"]:
                         d = ops.conv_dgrad_x6p(bufs["dyp"], op.seg["wp6"], bufs["xp"][op.name]["d"], gate=gate, gate_scale=scale, out=out)
+                    elif op.cin_p <= 64:
+                        d = ops.conv_dgrad(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
                     else:
                         d = ops.conv_dgrad_x6(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
                 else:
