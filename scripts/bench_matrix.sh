@@ -7,7 +7,7 @@ R=${1:-r02}
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/bench_matrix_$R.jsonl
 : > $O
-run() { python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | grep '"metric"' >> $O; }
+run() { python3 bench.py --no-alt --steps 8 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | grep '"metric"' >> $O; }
 run
 run --dtype bf16
 run --dtype bf16x6

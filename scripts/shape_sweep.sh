@@ -2,7 +2,7 @@
 # Smoke over batch sizes / input sizes / presets the launch plans are not tuned for: every line must end with a finite loss.
 # usage (GPU box): bash scripts/shape_sweep.sh
 cd "$GRAFT_REPO_ROOT"
-run() { echo -n "$* -> "; timeout -k 10 200 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof "$@" 2>&1 | python3 -c "
+run() { echo -n "$* -> "; timeout -k 10 200 python3 bench.py --no-alt --steps 2 --warmup 1 --no-cpu-baseline --no-prof "$@" 2>&1 | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
