@@ -224,9 +224,13 @@ int emadapt_conv_wgrad_x6(const emadapt_conv_desc *d, const float *x, const floa
  *     [rows][C / 16][plane 0..2][16 x bf16]      (C % 16 == 0; 6 bytes per element; x = p0 + p1 + p2 exactly)
  * and the kernels (256 x 256 tiles, LDS-DMA, one workgroup per CU) read plane images only: same arithmetic, same error bound,
  * same epilogues / determinism as the x6 entry points, fp32 outputs.  Operands:
- *   forward          planes of x [B*H*W][Cin]   and of the k-major filter image [KH*KW][Cout][Cin] (emadapt_filter_kmajor)
- *   data gradient    planes of dy [B*H*W][Cout] and of the HWIO filter [KH*KW][Cin][Cout]
+ *   forward          planes of x [B*H*W][Cin]   and the TILED plane image of the filter, rows = Cout, k = Cin
+ *   data gradient    planes of dy [B*H*W][Cout] and the tiled plane image of the filter, rows = Cin, k = Cout
  *   filter gradient  planes of x and of dy
+ * Tiled filter image (emadapt_filter_tiles(d, w_hwio, tiles, dgrad); emadapt_filter_tiles_bytes gives its size, 0 when the
+ * reduction's channel count is not a multiple of 16): [tap][k / 16][row, zero rows up to a multiple of 256][6 chunks of 16 B],
+ * chunk (2 plane + half) of a row at position chunk ^ (bit 3 of the row) -- a 256-row tile's K step is 24 contiguous KB in the
+ * order the kernel keeps it in LDS, so the filter side of the kernel is plain copies.  Refresh it when the weights change.
  * emadapt_conv_x6p_supported(d, kind) (kind 0 forward, 1 data gradient, 2 filter gradient) says whether a convolution is taken
  * (channel counts in whole groups of 16, at least 256 output columns, a filter gradient's Cin a multiple of 256, plane images
  * below 2 GiB); the others stay on the x6 entry points and return EMADAPT_ERR_UNSUPPORTED here.  Workspace: stream-K slab levels
@@ -235,14 +239,16 @@ int emadapt_conv_wgrad_x6(const emadapt_conv_desc *d, const float *x, const floa
  * rows (0 = off), [4] slab levels of the stream-K launch over the remaining rows (-1: a plain launch). */
 size_t emadapt_planes_bytes(long long rows, int C);
 int emadapt_split_planes(const float *x, void *planes, long long rows, int C, void *stream);
+size_t emadapt_filter_tiles_bytes(const emadapt_conv_desc *d, int dgrad);
+int emadapt_filter_tiles(const emadapt_conv_desc *d, const float *w, void *tiles, int dgrad, void *stream);
 int emadapt_conv_x6p_supported(const emadapt_conv_desc *d, int kind);
 int emadapt_conv_x6p_plan(const emadapt_conv_desc *d, int dgrad, int plan[5]);
 size_t emadapt_conv_fwd_x6p_workspace_bytes(const emadapt_conv_desc *d);
-int emadapt_conv_fwd_x6p(const emadapt_conv_desc *d, const void *x_planes, const void *wk_planes, const float *bias,
+int emadapt_conv_fwd_x6p(const emadapt_conv_desc *d, const void *x_planes, const void *w_tiles, const float *bias,
                          float *y, int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed,
                          void *workspace, size_t workspace_bytes, void *stream);
 size_t emadapt_conv_dgrad_x6p_workspace_bytes(const emadapt_conv_desc *d);
-int emadapt_conv_dgrad_x6p(const emadapt_conv_desc *d, const void *dy_planes, const void *w_planes, float *dx,
+int emadapt_conv_dgrad_x6p(const emadapt_conv_desc *d, const void *dy_planes, const void *w_tiles_dgrad, float *dx,
                            const float *gate, float gate_scale, void *workspace, size_t workspace_bytes, void *stream);
 size_t emadapt_conv_wgrad_x6p_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_wgrad_x6p(const emadapt_conv_desc *d, const void *x_planes, const void *dy_planes, float *dw,
