@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench lines of every BASELINE configuration that fits one GPU, un-profiled (gpurun -- bash scripts/bench_matrix.sh r02):
 # configs[1] fp32 (headline) / bf16 / bf16x6, LargeFOV preset, and configs[4] (513x513, 41 classes, 10 images) in both presets
-# and both arithmetics.  One JSON line per run -> gpurun_out/bench_matrix_<round>.jsonl
+# and all three arithmetics.  One JSON line per run -> gpurun_out/bench_matrix_<round>.jsonl
 set -e
 R=${1:-r02}
 cd "$GRAFT_REPO_ROOT"
@@ -13,10 +13,13 @@ run --dtype bf16
 run --dtype bf16x6
 run --preset largefov
 run --preset largefov --dtype bf16
+run --preset largefov --dtype bf16x6
 run --size 513 --classes 41 --batch 10
 run --size 513 --classes 41 --batch 10 --dtype bf16
+run --size 513 --classes 41 --batch 10 --dtype bf16x6
 run --size 513 --classes 41 --batch 10 --preset largefov
 run --size 513 --classes 41 --batch 10 --preset largefov --dtype bf16
+run --size 513 --classes 41 --batch 10 --preset largefov --dtype bf16x6
 python3 - <<PY
 import json
 for l in open("$O"):
