@@ -19,10 +19,9 @@
 //   * bank conflicts: the 16 lanes of one ds_read_b128 group read the same 16-byte column of 16 rows 96 bytes apart -- only
 //     half of the banks -- so rows with bit 3 set store the two 16-byte halves of every plane swapped (the DMA lanes fetch
 //     them swapped, the fragment address XORs 16): conflict-free.
-//   * pipeline: a wave reads ALL fragments of step kt into registers, issues half of the step's MFMAs, waits for its own DMAs
-//     of step kt + 1, BARRIER, issues the DMAs of step kt + 3 into the buffer it has just finished reading, then the other half
-//     of the MFMAs: the matrix pipe has work queued on both sides of the barrier (no LDS round trip behind it), a DMA has two
-//     whole steps to land, and three buffers carry a fetch distance of three.
+//   * pipeline (k_step below): the next step's fragments are fetched into the registers this step has finished with while its
+//     MFMAs run, the barrier sits in the middle of the step's MFMA stream (work queued on both sides of it, no LDS round trip
+//     behind it), and the DMAs of step kt + 2 leave as one burst in front of it.
 //   * the FILTER operand does not need the gather at all: its plane image is stored tile by tile in exactly the LDS order
 //         [tap][k / 16][row, padded with zero rows to a multiple of 256][6 chunks of 16 B, halves swapped where row bit 3 is set]
 //     (filter_tiles_kernel, once per optimizer step), so a K step's 256 filter rows are 24 contiguous KB and the filter DMAs are
@@ -57,7 +56,7 @@ __device__ __forceinline__ void xp_dma(__amdgpu_buffer_rsrc_t r, char *lds_base,
 }
 
 // ABLM (diagnostic library only, tune "ablate"): parts of the K loop COMPILED out -- 1 no DMAs, 2 no fragment reads, 4 no waits /
-// barrier, 8 no MFMAs (results are garbage; scripts/x6p_ablate.py reads the time).
+// barrier, 8 no MFMAs, 16 no barrier (waits stay), 32 no wait for the DMAs (results are garbage; scripts/x6p_ablate.py reads the time).
 template <bool SK, int ABLM = 0>
 __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a) {
     constexpr int BM = 256, BN = 256, BK = 16, NBUF = XP_NBUF, TM = 2, TN = 4;
@@ -206,9 +205,10 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
     }
 
     // DMAs of K step kt (of this piece's tile) into ring buffer `buf`: this wave's 3 KB of each operand
-    int p_off = 0;
-    unsigned p_sw = 0, p_dead = 0;   // the pending filter part (step kt + 2 at the top of trip kt): ring buffer, scalar offset, dead bit
-    auto fill = [&](int buf, int kt, bool live, int parts) {
+    // DMAs of K step kt (of this piece's tile) into the ring buffer at byte offset `off`: this wave's 3 KB of each operand.
+    // A step past the end of the piece (live = false) carries the out-of-range bit on every lane and deposits zeros: every
+    // step issues the same six instructions, so the vmcnt bookkeeping is a constant.
+    auto fill = [&](int off, int kt, bool live) {
         const unsigned chunk = __umulhi((unsigned)kt, magic_nt_t);
         const unsigned tap_l = ntaps_t > 1 ? (unsigned)kt - chunk * (unsigned)ntaps_t : 0u;
         const unsigned chunk_u = ntaps_t > 1 ? chunk : (unsigned)kt;
@@ -221,17 +221,13 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
         const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + chunk_u * (unsigned)XP_GB + bias));
         const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(((tap_u * (unsigned)(a.Cx / 16) + chunk_u) * (unsigned)n_pad + (unsigned)n0) * (unsigned)XP_ROWB));
         const unsigned sh = 31u - (tap_u & 31u);   // moves this tap's "outside the image" bit to bit 31
-        const unsigned dead = live ? 0u : kOOB;    // (a step past the end of the piece: every lane out of range, zeros)
-        char *as = ldsb + buf * XP_STAGE + wave * (XP_IPW * 1024);
+        const unsigned dead = live ? 0u : kOOB;
+        char *as = ldsb + off + wave * (XP_IPW * 1024);
+        if constexpr (!(ABLM & 1)) {
 #pragma unroll
-        for (int j = 0; j < XP_IPW; j++) xp_dma(xr, as + j * 1024, a_off[j] | ((a_bad[j] << sh) & kOOB) | dead, s_x);
-        if (parts & 2) {
+            for (int j = 0; j < XP_IPW; j++) xp_dma(xr, as + j * 1024, a_off[j] | ((a_bad[j] << sh) & kOOB) | dead, s_x);
 #pragma unroll
             for (int j = 0; j < XP_IPW; j++) xp_dma(wr, as + XP_OPER + j * 1024, b_off[j] | dead, s_w);
-        } else {
-            p_off = buf * XP_STAGE;
-            p_sw = s_w;
-            p_dead = dead;
         }
     };
     // Fragment reads and MFMAs, one instruction each; XP_SB pins the order they are written in (the schedule below IS the
@@ -242,69 +238,36 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
 #define XP_RA(P, I, BASE) if constexpr (!(ABLM & 2)) { XP_RA0(P, I, BASE) }
 #define XP_RB(Q, J, BASE) if constexpr (!(ABLM & 2)) { XP_RB0(Q, J, BASE) }
 #define XP_MF(P, Q, I, J) if constexpr (!(ABLM & 8)) { acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[P][I], bv[Q][J], acc[I][J], 0, 0, 0); XP_SB }
-#define XP_DMA(R, DST, VOFF, SOFF) if constexpr (!(ABLM & 1)) { xp_dma(R, DST, VOFF, SOFF); XP_SB }
 #define XP_GROUP(P, Q) XP_MF(P, Q, 0, 0) XP_MF(P, Q, 0, 1) XP_MF(P, Q, 0, 2) XP_MF(P, Q, 0, 3) XP_MF(P, Q, 1, 0) XP_MF(P, Q, 1, 1) XP_MF(P, Q, 1, 2) XP_MF(P, Q, 1, 3)
     // One K step = six groups of 8 MFMAs (plane pairs) in the cyclic order (0,2) (0,1) (0,0) | (1,0) (2,0) (1,1), the barrier
     // after the third.  In that order every fragment's last use lies at least one group before its first use in the next
     // step, so the next step's fragments are fetched INTO THE SAME REGISTERS while this step's MFMAs run: a0 / b2 right behind
     // the barrier (dead since groups 3 / 1), b0 / a2 during group 6, b1 / a1 behind group 6 -- no wave ever waits for LDS in
-    // front of an MFMA, and the DMA instructions of step kt + 3 go out one by one between the MFMAs of group 5.  Both waves
-    // of a SIMD run this same schedule in step, so whatever a wave issues besides MFMAs must overlap ITS OWN MFMAs' execution.
-    // The body is branch-free: past the end of the piece the fetches read a buffer nobody needs (harmless) and the DMAs carry the
-    // out-of-range bit on every lane (they deposit zeros in a buffer nobody reads again) -- every step issues the same 6 DMAs, so
-    // the vmcnt bookkeeping is a constant, and the accumulators stay in place (with one body per case the register
-    // allocator moved them between bodies through out-of-place MFMAs and spilled).
-    // ONE body, the ring position a run-time scalar (two vector adds per step for the fragment addresses): unrolled over the ring,
-    // the allocator assigned the loop-carried fragments and accumulators differently in the three bodies and paid in copies.
-    //   u_off = byte offset of this step's ring buffer, NX that of the next step's
-    auto k_step = [&](int u_off, int NX, int kt) {
-        // scalars of the fill (step kt + 3 -> buffer U)
-        const unsigned ktf = (unsigned)(kt0 + kt + 3);
-        const unsigned chunk = __umulhi(ktf, magic_nt_t);
-        const unsigned tap_l = ntaps_t > 1 ? ktf - chunk * (unsigned)ntaps_t : 0u;
-        const unsigned chunk_u = ntaps_t > 1 ? chunk : ktf;
-        const unsigned khl = div_magic(tap_l, magic_nkw_t);
-        const unsigned kh = (unsigned)kh_first + khl;
-        const int kw = kw_first + (int)(tap_l - khl * (unsigned)nkw_t);
-        const unsigned tap_u = kh * (unsigned)a.KW + (unsigned)kw;
-        const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
-        const int dw = a.sign * (kw * a.dil - a.pad_w);
-        const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + chunk_u * (unsigned)XP_GB + bias));
-        const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(((tap_u * (unsigned)(a.Cx / 16) + chunk_u) * (unsigned)n_pad + (unsigned)n0) * (unsigned)XP_ROWB));
-        const unsigned sh = 31u - (tap_u & 31u);
-        const unsigned dead = kt + 3 < nk ? 0u : kOOB;   // no such step: all lanes out of range
+    // front of an MFMA.  The six DMAs of step kt + 2 go out as ONE burst behind group 3, in front of the waits and the barrier
+    // (into the buffer of step kt - 1, free since the previous barrier): what a wave loses waiting for the address unit it would
+    // have spent waiting at the barrier anyway.  Measured against the alternatives in one process (profiles/r03_x6p_ablation.txt:
+    // one DMA per group, bursts behind the barrier at fetch distance 3, issue staggered over the waves): 4-11 % faster.
+    // ONE branch-free body, the ring position a run-time scalar: with a body per case (or per ring position) the register allocator
+    // moved the loop-carried accumulators between bodies through out-of-place MFMAs and spilled.
+    //   u_off / NX / PV = byte offsets of the ring buffers of steps kt, kt + 1 and kt - 1 (= kt + 2)
+    auto k_step = [&](int u_off, int NX, int PV, int kt) {
         XP_SB
-        // first half: the filter part of step kt + 2 (pending from the previous trip) goes out, one DMA behind each group
-        {
-            char *bs = ldsb + p_off + XP_OPER + wave * (XP_IPW * 1024);
-            XP_GROUP(0, 2)
-            XP_DMA(wr, bs, b_off[0] | p_dead, p_sw)
-            XP_GROUP(0, 1)
-            XP_DMA(wr, bs + 1024, b_off[1] | p_dead, p_sw)
-            XP_GROUP(0, 0)
-            XP_DMA(wr, bs + 2048, b_off[2] | p_dead, p_sw)
-        }
+        XP_GROUP(0, 2) XP_GROUP(0, 1) XP_GROUP(0, 0)
+        fill(PV, kt0 + kt + 2, kt + 2 < nk);
+        XP_SB
         if constexpr (!(ABLM & 4)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of this step has arrived (a1 was fetched last)
-            wait_vmcnt<2 * XP_IPW>();   // this wave's DMAs of step kt + 1 have landed (those of kt + 2 may be in flight)
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(ABLM & 32)) wait_vmcnt<2 * XP_IPW>();   // this wave's DMAs of step kt + 1 have landed (those of kt + 2 just left)
+            if constexpr (!(ABLM & 16)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
         XP_SB
-        // second half: buffer u_off is free -- the activation part of step kt + 3, one DMA behind each group
-        char *as = ldsb + u_off + wave * (XP_IPW * 1024);
         XP_MF(1, 0, 0, 0) XP_RA(0, 0, NX) XP_MF(1, 0, 0, 1) XP_RA(0, 1, NX) XP_MF(1, 0, 0, 2) XP_RB(2, 0, NX) XP_MF(1, 0, 0, 3) XP_RB(2, 1, NX)
         XP_MF(1, 0, 1, 0) XP_RB(2, 2, NX) XP_MF(1, 0, 1, 1) XP_RB(2, 3, NX) XP_MF(1, 0, 1, 2) XP_MF(1, 0, 1, 3)
-        XP_DMA(xr, as, a_off[0] | ((a_bad[0] << sh) & kOOB) | dead, s_x)
         XP_GROUP(2, 0)
-        XP_DMA(xr, as + 1024, a_off[1] | ((a_bad[1] << sh) & kOOB) | dead, s_x)
         XP_MF(1, 1, 0, 0) XP_RB(0, 0, NX) XP_MF(1, 1, 0, 1) XP_RB(0, 1, NX) XP_MF(1, 1, 0, 2) XP_RB(0, 2, NX) XP_MF(1, 1, 0, 3) XP_RB(0, 3, NX)
         XP_MF(1, 1, 1, 0) XP_RA(2, 0, NX) XP_MF(1, 1, 1, 1) XP_RA(2, 1, NX) XP_MF(1, 1, 1, 2) XP_MF(1, 1, 1, 3)
-        XP_DMA(xr, as + 2048, a_off[2] | ((a_bad[2] << sh) & kOOB) | dead, s_x)
         XP_RB(1, 0, NX) XP_RB(1, 1, NX) XP_RB(1, 2, NX) XP_RB(1, 3, NX) XP_RA(1, 0, NX) XP_RA(1, 1, NX)
-        p_off = u_off;
-        p_sw = s_w;
-        p_dead = dead;
     };
 
 #pragma unroll
@@ -314,20 +277,20 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     __syncthreads();   // the ring is free (SK: the previous piece's epilogue staged through it)
-    fill(0, kt0, true, 3);
-    fill(1, kt0 + 1, 1 < nk, 3);
-    fill(2, kt0 + 2, 2 < nk, 1);   // (its filter part goes out during step 0 like every later step's)
-    wait_vmcnt<3 * XP_IPW>();
+    fill(0, kt0, true);
+    fill(XP_STAGE, kt0 + 1, 1 < nk);
+    wait_vmcnt<2 * XP_IPW>();
     __builtin_amdgcn_s_barrier();   // step 0 has landed
     asm volatile("" ::: "memory");
     XP_RA0(0, 0, 0) XP_RA0(0, 1, 0) XP_RB0(2, 0, 0) XP_RB0(2, 1, 0) XP_RB0(2, 2, 0) XP_RB0(2, 3, 0)
     XP_RB0(1, 0, 0) XP_RB0(1, 1, 0) XP_RB0(1, 2, 0) XP_RB0(1, 3, 0) XP_RB0(0, 0, 0) XP_RB0(0, 1, 0) XP_RB0(0, 2, 0) XP_RB0(0, 3, 0)
     XP_RA0(1, 0, 0) XP_RA0(1, 1, 0) XP_RA0(2, 0, 0) XP_RA0(2, 1, 0)
     {
-        int u_off = 0;
+        int u_off = 0, pv = (NBUF - 1) * XP_STAGE;
         for (int kt = 0; kt < nk; kt++) {
             const int nx = u_off == (NBUF - 1) * XP_STAGE ? 0 : u_off + XP_STAGE;
-            k_step(u_off, nx, kt);
+            k_step(u_off, nx, pv, kt);
+            pv = u_off;
             u_off = nx;
         }
     }
@@ -342,7 +305,6 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
 #undef XP_RA
 #undef XP_RB
 #undef XP_MF
-#undef XP_DMA
 #undef XP_GROUP
 
     float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
@@ -373,6 +335,9 @@ int launch_igemm_x6p(IgemmArgs &a, hipStream_t stream) {
             case 10: return launch_igemm_x6p<SK, 10>(a, stream);
             case 12: return launch_igemm_x6p<SK, 12>(a, stream);
             case 14: return launch_igemm_x6p<SK, 14>(a, stream);
+            case 16: return launch_igemm_x6p<SK, 16>(a, stream);
+            case 32: return launch_igemm_x6p<SK, 32>(a, stream);
+            case 48: return launch_igemm_x6p<SK, 48>(a, stream);
             default: break;
         }
     }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Plane-image bf16x6 forward kernel (csrc/igemm_x6p.h) with parts of its K loop COMPILED out (diagnostic library,
 -DEMADAPT_ABLATE_BUILD; results are garbage, only the time is read): what the DMAs, the fragment reads, the barrier and the
-MFMAs cost alone and together.  tune "ablate": 1 no DMAs, 2 no fragment reads, 4 no waits / barrier, 8 no MFMAs."""
+MFMAs cost alone and together.  tune "ablate": 1 no DMAs, 2 no fragment reads, 4 no waits / barrier, 8 no MFMAs, 16 no barrier, 32 no DMA wait."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +25,8 @@ flop = 2.0 * B * H * H * k * k * Cin * Cout
 def call(): ops.conv_fwd_x6p(xp, wkp, d, b, relu=True, out=y)
 for name, v in (("everything", 0), ("no DMAs", 1), ("no fragment reads", 2), ("no waits / barrier", 4), ("no MFMAs", 8),
                 ("no DMAs, no reads", 3), ("MFMAs alone (no DMAs, reads, barrier)", 7), ("no MFMAs, no DMAs (reads + barrier)", 9),
-                ("no MFMAs, no reads (DMAs + barrier)", 10), ("no MFMAs, no barrier", 12), ("DMAs alone (no reads, barrier, MFMAs)", 14)):
+                ("no MFMAs, no reads (DMAs + barrier)", 10), ("no MFMAs, no barrier", 12), ("DMAs alone (no reads, barrier, MFMAs)", 14),
+                ("no barrier (waits stay)", 16), ("no wait for the DMAs (barrier stays)", 32), ("neither barrier nor DMA wait (fragment wait stays)", 48)):
     if only and v not in only: continue
     ops.tune_set("ablate", v)
     call(); torch.cuda.synchronize()
