@@ -246,3 +246,65 @@ def test_stream_k_plans_and_their_workspace_are_consistent():
                 else:
                     assert ws == (main_s * M * N * 4 if main_s > 1 else 0)
     assert {1, 3, 4, 5} <= seen, seen
+
+
+def test_plane_kernel_plans_sizes_and_shape_rules_need_no_device():
+    """Host side of the bf16x6 plane-image kernels (csrc/conv_x6p.hip): which convolutions they take, their launch plans with
+    the workspace each asks for, and the sizes of the plane / tiled filter images."""
+    import ctypes
+    from em_adapt_tensorflow_amd import _lib, ops
+    lib = _lib.load()
+    # plane image: 6 bytes per element; tiled filter image: rows padded to whole 256-row tiles, reduction in groups of 16
+    assert lib.emadapt_planes_bytes(26896, 512) == 26896 * 512 * 6
+    assert ops.filter_tiles_bytes(512, 4096, 4, 4) == 16 * (512 // 16) * 4096 * 96            # fc6 forward: rows = Cout
+    assert ops.filter_tiles_bytes(512, 4096, 4, 4, dgrad=True) == 16 * (4096 // 16) * 512 * 96  # data gradient: rows = Cin
+    assert ops.filter_tiles_bytes(4096, 24, 1, 1) == (4096 // 16) * 256 * 96                  # fc8: 24 rows in one padded tile
+    assert ops.filter_tiles_bytes(4096, 24, 1, 1, dgrad=True) == 0                            # k = 24 is not a whole group of 16
+    # which layers of the benchmark network (batch 16, 321 x 321) run on the plane kernels: (forward, data gradient, filter gradient)
+    taken = lambda *s: tuple(ops.conv_x6p_supported(ops.conv_desc(*s), kind) for kind in (0, 1, 2))
+    assert taken(16, 321, 321, 4, 64, 3, 3, 1) == (False, False, False)     # conv1_1
+    assert taken(16, 161, 161, 128, 128, 3, 3, 1) == (False, False, False)  # conv2_2: 128 output columns stay on conv_x6.hip
+    assert taken(16, 81, 81, 128, 256, 3, 3, 1) == (True, False, False)     # conv3_1: dgrad has 128 columns, wgrad needs Cin % 256 == 0
+    assert taken(16, 81, 81, 256, 256, 3, 3, 1) == (True, True, True)       # conv3_2
+    assert taken(16, 41, 41, 512, 512, 3, 3, 2) == (True, True, True)       # conv5_x
+    assert taken(16, 41, 41, 512, 4096, 4, 4, 4) == (True, True, True)      # fc6
+    assert taken(16, 41, 41, 4096, 4096, 1, 1, 1) == (True, True, True)     # fc7
+    assert taken(16, 41, 41, 4096, 24, 1, 1, 1) == (False, False, False)    # fc8
+    M = 16 * 41 * 41
+    # plans: (rows of the first launch, stream-K?, its slab levels, pixel classes of packed rows, tail slab levels / -1 plain)
+    assert ops.conv_x6p_plan(ops.conv_desc(16, 41, 41, 4096, 4096, 1, 1, 1)) == (24576, 0, 0, 0, 3)   # fc7: 6 whole rounds + stream-K tail
+    assert ops.conv_x6p_plan(ops.conv_desc(16, 41, 41, 512, 4096, 4, 4, 4))[:2] == (M, 1)             # fc6: stream-K over packed rows
+    assert ops.conv_x6p_plan(ops.conv_desc(16, 41, 41, 512, 4096, 4, 4, 4))[3] == 25
+    assert ops.conv_x6p_plan(ops.conv_desc(16, 41, 41, 512, 512, 3, 3, 2))[3] == 9                    # conv5_x: 3 x 3 pixel classes
+    assert ops.conv_x6p_plan(ops.conv_desc(16, 41, 41, 512, 512, 3, 3, 1)) == (M, 1, 3, 0, 0)         # conv4_x: 212 tiles, stream-K
+    lib.emadapt_conv_fwd_x6p_workspace_bytes.restype = ctypes.c_size_t
+    lib.emadapt_conv_dgrad_x6p_workspace_bytes.restype = ctypes.c_size_t
+    rng = np.random.default_rng(1)
+    kinds = set()
+    for _ in range(200):
+        B, H, W = int(rng.integers(1, 17)), int(rng.integers(5, 90)), int(rng.integers(5, 90))
+        Cin, Cout = int(rng.choice([16, 64, 256, 512, 1024])), int(rng.choice([48, 256, 320, 512, 2048, 4096]))
+        k, dil = int(rng.choice([1, 3, 4])), int(rng.choice([1, 2, 4]))
+        Mx = B * H * W
+        with ops.tuned(plan_cus=int(rng.choice([0, 3, 7, 64, 256]))):
+            for dgrad in (False, True):
+                d = ops.conv_desc(B, H, W, Cin, Cout, k, k, dil)
+                ws = (lib.emadapt_conv_dgrad_x6p_workspace_bytes if dgrad else lib.emadapt_conv_fwd_x6p_workspace_bytes)(ctypes.byref(d))
+                if not ops.conv_x6p_supported(d, int(dgrad)):
+                    assert ws == 0
+                    continue
+                N = Cin if dgrad else Cout
+                rows, sk, levels, classes, tail = ops.conv_x6p_plan(d, dgrad)
+                table = -(-Mx // 256) * 256 * 4 if classes else 0
+                if sk:
+                    kinds.add("packed" if classes else "stream-k")
+                    assert rows == Mx and levels != 1 and ws == levels * Mx * N * 4 + table
+                else:
+                    assert classes == 0 and levels == 0 and 0 < rows <= Mx
+                    if rows < Mx:
+                        kinds.add("tail")
+                        assert rows % 256 == 0 and N > 1024 and tail != 1 and ws == max(tail, 0) * (Mx - rows) * N * 4
+                    else:
+                        kinds.add("plain")
+                        assert ws == 0
+    assert kinds == {"plain", "stream-k", "packed", "tail"}, kinds
