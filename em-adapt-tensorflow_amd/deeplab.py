@@ -79,6 +79,7 @@ class ADAPT(Network):
         self.act_dtype = torch.bfloat16 if act == "bf16" else torch.float32
         self._cpad = 8 if act == "bf16" else 4   # channel padding of the buffers (16-byte vectors)
         self._w16_seen = None
+        self._plane_fwd = {}   # bf16x6: layer -> its forward pass runs on the plane-image kernel (decided per batch size in _alloc)
         self._plan = []
         self._shapes = {}
         self._dry = False
@@ -315,13 +316,17 @@ class ADAPT(Network):
             for layer, seg in self._segments.items():
                 kh, kw, cin_p, cout_p = seg["pshape"]
                 seg["wk32"] = self._flat["wk32"][seg["start"]:seg["start"] + seg["nw"]].view(kh * kw, cout_p, cin_p)
-            # tiled plane images (csrc/conv_x6p.hip, ops.filter_tiles) for the forward and the data-gradient kernel, for the
-            # layers whose reduction runs over whole groups of 16 channels
+            # tiled plane images (csrc/conv_x6p.hip, ops.filter_tiles) for the forward and the data-gradient kernel of the layers
+            # the plane kernels can take: a reduction over whole groups of 16 channels and at least 256 output columns
+            # (emadapt_conv_x6p_supported's channel rules; its size limits are checked per batch in _alloc).  "kmajor": the layer's
+            # forward pass runs on conv_x6.hip's kernel and needs the k-contiguous f32 image (64 or fewer output columns: native).
             for layer, seg in self._segments.items():
                 kh, kw, cin_p, cout_p = seg["pshape"]
-                nf, nd = ops.filter_tiles_bytes(cin_p, cout_p, kh, kw, False), ops.filter_tiles_bytes(cin_p, cout_p, kh, kw, True)
+                nf = ops.filter_tiles_bytes(cin_p, cout_p, kh, kw, False) if cout_p >= 256 else 0
+                nd = ops.filter_tiles_bytes(cin_p, cout_p, kh, kw, True) if cin_p >= 256 else 0
                 seg["wkp"] = torch.zeros(nf, dtype=torch.uint8, device=dev) if nf else None
                 seg["wp6"] = torch.zeros(nd, dtype=torch.uint8, device=dev) if nd else None
+                seg["kmajor"] = seg["wkp"] is None and cout_p > 64
             self._w16_seen = None
         if self.compute_dtype == "bf16":
             # bf16 filter images (include/emadapt.h, "bf16-compute variants"), one flat buffer per image kind
@@ -398,6 +403,10 @@ class ADAPT(Network):
                     dyp_bytes = max(dyp_bytes, B * ih * iw * op.cout_p * 6)
                 xp[op.name] = e
             bufs["xp"] = xp
+            plane_fwd = {name: e["fwd"] for name, e in xp.items()}
+            if plane_fwd != self._plane_fwd:   # (first batch, or a batch size that changes which layers the plane kernels take)
+                self._plane_fwd = plane_fwd
+                self._w16_seen = None
             bufs["dyp"] = torch.empty(max(dyp_bytes, 16), dtype=torch.uint8, device=dev)
         bufs["gA"] = torch.empty(maxn, dtype=adt, device=dev)   # activation gradients ping-pong between these two
         bufs["gB"] = torch.empty(maxn, dtype=adt, device=dev)
@@ -432,7 +441,8 @@ class ADAPT(Network):
                 if self.compute_dtype == "bf16":
                     ops.weights_to_bf16(op.w_pad, op.seg["wf16"], op.seg["wd16"])
                 else:
-                    ops.filter_kmajor(op.w_pad, op.seg["wk32"])
+                    if op.seg["kmajor"] or not self._plane_fwd.get(op.name, True):
+                        ops.filter_kmajor(op.w_pad, op.seg["wk32"])
                     if op.seg["wkp"] is not None:
                         ops.filter_tiles(op.w_pad, False, out=op.seg["wkp"])
                     if op.seg["wp6"] is not None:
@@ -442,11 +452,11 @@ class ADAPT(Network):
     def forward(self, images, keep_prob=1.0, drop_masks=None):
         """The conv stack (deeplab.py:35-49). images [B,H,W,3]; returns the fc8 logits view [B,S,S,C]."""
         images = self._to_dev(images)
-        self.refresh_bf16_weights()
         bf16 = self.compute_dtype == "bf16"
         x6 = self.compute_dtype == "bf16x6"
         B = images.shape[0]
         bufs = self._alloc(B)
+        self.refresh_bf16_weights()
         self.net["input"] = images
         self.net["drop_probe"] = keep_prob
         if images.shape[3] == bufs["x4"].shape[3]:
