@@ -105,7 +105,8 @@ struct PlanXP {
 
 bool xp_ok(const IgemmArgs &a) {
     const long long plane_x = (long long)a.M * a.Cx * 6, plane_w = (long long)a.K * ceil_div(a.N, 256) * 256 * 6;
-    const long long reach = ((long long)(a.ntaps / a.KW - 1) * a.dil * a.W + (long long)(a.KW - 1) * a.dil) * a.Cx * 6;
+    // (per-lane offset + scalar offset must stay below bit 31, the out-of-range flag: image + the taps' reach + one pixel row)
+    const long long reach = ((long long)(a.ntaps / a.KW - 1) * a.dil * a.W + (long long)(a.KW - 1) * a.dil + 1) * a.Cx * 6;
     return a.Cx % 16 == 0 && a.ntaps <= 32 && a.N % 4 == 0 && a.N >= 256 && plane_x + reach < (1LL << 31) && plane_w < (1LL << 31) &&
            (long long)a.M * a.N < (1LL << 40);
 }
