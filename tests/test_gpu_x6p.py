@@ -342,3 +342,39 @@ def test_x6p_micro_step_matches_the_fp32_oracle_at_the_fp32_bars():
     import em_adapt_tensorflow_amd.ops as ops
     assert torch.equal(seg["wkp"], ops.filter_tiles(seg["w_pad"].contiguous()))
     assert torch.equal(seg["wp6"], ops.filter_tiles(seg["w_pad"].contiguous(), dgrad=True))
+
+
+def test_full_size_single_image_bf16x6():
+    """BASELINE config 1 (one 321x321 image, 21 classes, the network as written) with compute_dtype bf16x6: conv3_1 .. fc7 run on
+    the plane kernels at their real channel counts (K up to 65536), logits within north_star's 1e-3 of the fp32 CPU oracle, label
+    map identical (mirrors tests/test_gpu_model.py::test_full_size_single_image_config1)."""
+    import torch
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from oracle import deeplab_oracle as do
+    from oracle import estep_oracle as eo
+    adapt = ADAPT({"input_size": (321, 321), "category_num": 21, "width": 64, "preset": "ref", "accum_num": 1, "batch_size": 1,
+                   "compute_dtype": "bf16x6"})
+    adapt.build()
+    oracle = do.DeepLabOracle(category_num=21, preset="ref", width=64, dtype=torch.float32)
+    params = do.init_params(oracle.specs, seed=11, he=True)
+    for layer, (w, b) in params.items():
+        adapt.weights[layer][0].copy_(torch.tensor(w).to(adapt.device))
+        adapt.weights[layer][1].copy_(torch.tensor(b).to(adapt.device))
+    images, labels = do.synthetic_batch(1, 321, 21, seed=0)
+    images = (images / 50.0).astype(np.float32)
+    logits = adapt.forward(images, 1.0).cpu().numpy()
+    engaged = adapt._bufs["xp"]
+    for layer in ("conv3_2", "conv4_2", "conv5_3", "fc6", "fc7"):
+        assert engaged[layer]["fwd"] and engaged[layer]["dgrad"] and engaged[layer]["wgrad"], layer
+    assert engaged["conv3_1"]["fwd"] and not engaged["conv3_1"]["wgrad"] and not engaged["conv2_2"]["fwd"]
+    want = oracle.forward(oracle.tensors(params, requires_grad=False), images)["output"].numpy()
+    assert logits.shape == (1, 41, 41, 21)
+    assert _rel(logits, want) < 1e-3
+    perms = eo.draw_perms(5, 21, seed=3)
+    adapt.pre_train(1e-3, 1e-5, 0.9, 1)
+    adapt.micro_step(images, labels, keep_prob=1.0, perms=perms)
+    adapt.apply_update()
+    torch.cuda.synchronize()
+    want_labels, _ = oracle.estep_labels(logits, labels, perms)
+    assert np.array_equal(adapt.net["e_argmax"].cpu().numpy(), want_labels)
+    assert np.isfinite(float(adapt.loss["norm"].cpu()))
