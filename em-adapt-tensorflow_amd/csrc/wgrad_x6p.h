@@ -191,22 +191,21 @@ __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
 #define WP_MF(P, Q, I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[P][I], bv[Q][J], acc[I][J], 0, 0, 0); WP_SB
 #define WP_GROUP(P, Q) WP_MF(P, Q, 0, 0) WP_MF(P, Q, 0, 1) WP_MF(P, Q, 0, 2) WP_MF(P, Q, 0, 3) WP_MF(P, Q, 1, 0) WP_MF(P, Q, 1, 1) WP_MF(P, Q, 1, 2) WP_MF(P, Q, 1, 3)
     // the software pipeline of igemm_x6p_kernel: six groups (0,2) (0,1) (0,0) | (1,0) (2,0) (1,1), barrier after the third, the next
-    // step's fragments fetched into the registers this step has finished with, the DMAs of step st + 3 behind the barrier
-    auto k_step = [&](int u_off, int NX, int st) {
+    // step's fragments fetched into the registers this step has finished with, the DMAs of step st + 2 as one burst in front of
+    // the barrier (into the buffer of step st - 1)
+    auto k_step = [&](int NX, int PV, int st) {
         WP_SB
         WP_GROUP(0, 2) WP_GROUP(0, 1) WP_GROUP(0, 0)
+        fill(PV, st + 2);   // (steps past the end: both pixels dead, zeros)
+        WP_SB
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_vmcnt<6>();   // this wave's DMAs of step st + 1 have landed (those of st + 2 may be in flight)
+        wait_vmcnt<6>();   // this wave's DMAs of step st + 1 have landed (those of st + 2 just left)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         WP_SB
         WP_MF(1, 0, 0, 0) WP_RA(0, 0, NX) WP_MF(1, 0, 0, 1) WP_RA(0, 1, NX) WP_MF(1, 0, 0, 2) WP_RB(2, 0, NX) WP_MF(1, 0, 0, 3) WP_RB(2, 1, NX)
         WP_MF(1, 0, 1, 0) WP_RB(2, 2, NX) WP_MF(1, 0, 1, 1) WP_RB(2, 3, NX) WP_MF(1, 0, 1, 2) WP_MF(1, 0, 1, 3)
-        fill_first(u_off, st + 3);   // (steps past the end: both pixels dead, zeros)
-        WP_SB
         WP_GROUP(2, 0)
-        fill_second(u_off, st + 3);
-        WP_SB
         WP_MF(1, 1, 0, 0) WP_RB(0, 0, NX) WP_MF(1, 1, 0, 1) WP_RB(0, 1, NX) WP_MF(1, 1, 0, 2) WP_RB(0, 2, NX) WP_MF(1, 1, 0, 3) WP_RB(0, 3, NX)
         WP_MF(1, 1, 1, 0) WP_RA(2, 0, NX) WP_MF(1, 1, 1, 1) WP_RA(2, 1, NX) WP_MF(1, 1, 1, 2) WP_MF(1, 1, 1, 3)
         WP_RB(1, 0, NX) WP_RB(1, 1, NX) WP_RB(1, 2, NX) WP_RB(1, 3, NX) WP_RA(1, 0, NX) WP_RA(1, 1, NX)
@@ -215,17 +214,17 @@ __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
     if (nsteps > 0) {
         fill(0, 0);
         fill(WP_STAGE, 1);
-        fill(2 * WP_STAGE, 2);
-        wait_vmcnt<12>();
+        wait_vmcnt<6>();
         __builtin_amdgcn_s_barrier();   // step 0 has landed
         asm volatile("" ::: "memory");
         WP_RA(0, 0, 0) WP_RA(0, 1, 0) WP_RB(2, 0, 0) WP_RB(2, 1, 0) WP_RB(2, 2, 0) WP_RB(2, 3, 0)
         WP_RB(1, 0, 0) WP_RB(1, 1, 0) WP_RB(1, 2, 0) WP_RB(1, 3, 0) WP_RB(0, 0, 0) WP_RB(0, 1, 0) WP_RB(0, 2, 0) WP_RB(0, 3, 0)
         WP_RA(1, 0, 0) WP_RA(1, 1, 0) WP_RA(2, 0, 0) WP_RA(2, 1, 0)
-        int u_off = 0;
+        int u_off = 0, pv = (NBUF - 1) * WP_STAGE;
         for (int st = 0; st < nsteps; st++) {
             const int nx = u_off == (NBUF - 1) * WP_STAGE ? 0 : u_off + WP_STAGE;
-            k_step(u_off, nx, st);
+            k_step(nx, pv, st);
+            pv = u_off;
             u_off = nx;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
