@@ -2,8 +2,7 @@
 //
 // conv_x6.hip splits both fp32 operands into their three bf16 planes inside the loader waves -- once per tile, i.e. an
 // activation is split again by every N tile and every filter tap that reads it (7 vector-ALU instructions per MFMA at
-// 128x128 tiles) and stored to LDS through registers.  Here the split happens ONCE per tensor (split_planes_kernel, or the
-// epilogue that produces the tensor) into a plane image
+// 128x128 tiles) and stored to LDS through registers.  Here the split happens ONCE per tensor (split_planes_kernel) into a plane image
 //     [row][k / 16][plane 0..2][16 x bf16]          (96 bytes per row and group of 16 k; a row is a pixel / a filter row)
 // and the GEMM kernel is built like the second-generation fp32 kernel (igemm_v2.h): tiles land in LDS by LDS-DMA exactly as
 // they lie in memory, nobody issues a vector-ALU instruction per element.
@@ -30,8 +29,6 @@
 //   * work split, packed rows, epilogues, stream-K fix-up: igemm_v2.h's, unchanged (same accumulator layout).
 // Requirements: Cx % 16 == 0, KH*KW <= 32, N % 4 == 0; plane images below 2 GiB.
 #pragma once
-#include <type_traits>
-
 #include "igemm_v2.h"
 
 namespace {
