@@ -77,6 +77,7 @@ PROTOTYPES = {
     "emadapt_filter_tiles_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "emadapt_filter_tiles": (c_int, [POINTER(ConvDesc), _vp, _vp, c_int, _vp]),
     "emadapt_conv_x6p_supported": (c_int, [POINTER(ConvDesc), c_int]),
+    "emadapt_conv_x6p_pays": (c_int, [POINTER(ConvDesc), c_int]),
     "emadapt_conv_x6p_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
     "emadapt_conv_fwd_x6p_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "emadapt_conv_fwd_x6p": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_int, c_float, _vp, c_uint64, _vp, c_size_t, _vp]),

@@ -230,6 +230,22 @@ int emadapt_conv_x6p_supported(const emadapt_conv_desc *d, int kind) {
     return xp_ok(a) ? 1 : 0;
 }
 
+// Advice for a host that has both kernel families: does the plane kernel have enough work to fill the part?  One workgroup per
+// CU and 256 x 256 tiles need either stream-K's >= 32 K steps per CU or whole rounds of tiles; a single image's conv4_x (14 tiles
+// of 288 steps) would run on 14 CUs -- conv_x6.hip's 128 x 128 split-K launches are the better fp32-grade choice there.
+int emadapt_conv_x6p_pays(const emadapt_conv_desc *d, int kind) {
+    if (!emadapt_conv_x6p_supported(d, kind) || d->B == 0) return 0;
+    const int cus = plan_cus();
+    if (kind == 2) {
+        const PlanWP p = plan_wgrad_x6p(d);
+        return (long long)p.tiles_k * p.tiles_n * p.splits * 2 >= cus ? 1 : 0;
+    }
+    IgemmArgs a;
+    fill_x6p(a, d, kind == 1);
+    const long long t = ceil_div(a.M, 256) * ceil_div(a.N, 256);
+    return t * (a.K / 16) >= 32LL * cus ? 1 : 0;
+}
+
 size_t emadapt_conv_fwd_x6p_workspace_bytes(const emadapt_conv_desc *d) {
     if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
     IgemmArgs a;

@@ -396,8 +396,11 @@ class ADAPT(Network):
                     continue
                 ih, iw = op.in_hw
                 d = ops.conv_desc(B, ih, iw, op.cin_p, op.cout_p, op.k, op.k, op.rate)
-                e = dict(d=d, fwd=op.seg["wkp"] is not None and ops.conv_x6p_supported(d, 0),
-                         dgrad=op.seg["wp6"] is not None and ops.conv_x6p_supported(d, 1), wgrad=ops.conv_x6p_supported(d, 2))
+                # config "x6_planes": "auto" (default) = where the plane kernel has enough work to fill the part at this batch
+                # size, "always" = wherever it can run (the parity tests drive it on small shapes this way)
+                take = ops.conv_x6p_supported if self.config.get("x6_planes", "auto") == "always" else ops.conv_x6p_pays
+                e = dict(d=d, fwd=op.seg["wkp"] is not None and take(d, 0), dgrad=op.seg["wp6"] is not None and take(d, 1),
+                         wgrad=take(d, 2))
                 e["x"] = (torch.empty(B * ih * iw * op.cin_p * 6, dtype=torch.uint8, device=dev) if (e["fwd"] or e["wgrad"]) else None)
                 if e["dgrad"] or e["wgrad"]:
                     dyp_bytes = max(dyp_bytes, B * ih * iw * op.cout_p * 6)

@@ -315,6 +315,11 @@ def conv_x6p_supported(d, kind):
     return bool(_lib.load().emadapt_conv_x6p_supported(ctypes.byref(d), int(kind)))
 
 
+def conv_x6p_pays(d, kind):
+    """conv_x6p_supported and enough work for one 256 x 256 workgroup per CU (a host with both kernel families asks this)."""
+    return bool(_lib.load().emadapt_conv_x6p_pays(ctypes.byref(d), int(kind)))
+
+
 def conv_x6p_plan(d, dgrad=False):
     plan = (ctypes.c_int * 5)()
     _lib.call("emadapt_conv_x6p_plan", ctypes.byref(d), int(bool(dgrad)), plan)

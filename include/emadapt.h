@@ -242,6 +242,7 @@ int emadapt_split_planes(const float *x, void *planes, long long rows, int C, vo
 size_t emadapt_filter_tiles_bytes(const emadapt_conv_desc *d, int dgrad);
 int emadapt_filter_tiles(const emadapt_conv_desc *d, const float *w, void *tiles, int dgrad, void *stream);
 int emadapt_conv_x6p_supported(const emadapt_conv_desc *d, int kind);
+int emadapt_conv_x6p_pays(const emadapt_conv_desc *d, int kind);   /* supported AND enough work to fill the part (else: the x6 entry points) */
 int emadapt_conv_x6p_plan(const emadapt_conv_desc *d, int dgrad, int plan[5]);
 size_t emadapt_conv_fwd_x6p_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_fwd_x6p(const emadapt_conv_desc *d, const void *x_planes, const void *w_tiles, const float *bias,

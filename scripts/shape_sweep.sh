@@ -20,3 +20,11 @@ run --batch 16 --width 32
 run --batch 2 --size 129 --width 48 --classes 5
 run --batch 3 --dtype bf16
 run --batch 32 --dtype bf16
+run --batch 1 --dtype bf16x6
+run --batch 3 --dtype bf16x6
+run --batch 7 --dtype bf16x6
+run --batch 32 --dtype bf16x6
+run --batch 5 --size 257 --classes 21 --dtype bf16x6
+run --batch 16 --width 32 --dtype bf16x6
+run --batch 2 --size 129 --width 48 --classes 5 --dtype bf16x6
+run --batch 1 --size 513 --classes 41 --preset largefov --dtype bf16x6

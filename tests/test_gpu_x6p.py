@@ -296,7 +296,7 @@ def test_x6p_micro_step_matches_the_fp32_oracle_at_the_fp32_bars():
     from oracle import estep_oracle as eo
     B, width, size, C = 2, 32, 65, 5
     adapt = ADAPT({"input_size": (size, size), "category_num": C, "width": width, "accum_num": 1, "batch_size": B,
-                   "compute_dtype": "bf16x6"})
+                   "compute_dtype": "bf16x6", "x6_planes": "always"})
     adapt.build()
     oracle = do.DeepLabOracle(category_num=C, width=width, dtype=torch.float64)
     params = do.init_params(oracle.specs, seed=12, he=True)
@@ -353,7 +353,7 @@ def test_full_size_single_image_bf16x6():
     from oracle import deeplab_oracle as do
     from oracle import estep_oracle as eo
     adapt = ADAPT({"input_size": (321, 321), "category_num": 21, "width": 64, "preset": "ref", "accum_num": 1, "batch_size": 1,
-                   "compute_dtype": "bf16x6"})
+                   "compute_dtype": "bf16x6", "x6_planes": "always"})
     adapt.build()
     oracle = do.DeepLabOracle(category_num=21, preset="ref", width=64, dtype=torch.float32)
     params = do.init_params(oracle.specs, seed=11, he=True)

@@ -270,6 +270,12 @@ def test_plane_kernel_plans_sizes_and_shape_rules_need_no_device():
     assert taken(16, 41, 41, 512, 4096, 4, 4, 4) == (True, True, True)      # fc6
     assert taken(16, 41, 41, 4096, 4096, 1, 1, 1) == (True, True, True)     # fc7
     assert taken(16, 41, 41, 4096, 24, 1, 1, 1) == (False, False, False)    # fc8
+    # ... and where they have enough work to fill 256 CUs (a host with both kernel families asks this: one image's conv4_x is
+    # 14 tiles of 288 K steps -- the split-K launches of conv_x6.hip are the better choice there)
+    pays = lambda *s: tuple(ops.conv_x6p_pays(ops.conv_desc(*s), kind) for kind in (0, 1, 2))
+    assert pays(16, 41, 41, 512, 512, 3, 3, 1) == (True, True, True) and pays(1, 41, 41, 512, 512, 3, 3, 1) == (False, False, True)
+    assert pays(1, 41, 41, 4096, 4096, 1, 1, 1) == (True, True, True) and pays(1, 81, 81, 256, 256, 3, 3, 1)[:2] == (False, False)
+    assert pays(16, 41, 41, 4096, 24, 1, 1, 1) == (False, False, False)
     M = 16 * 41 * 41
     # plans: (rows of the first launch, stream-K?, its slab levels, pixel classes of packed rows, tail slab levels / -1 plain)
     assert ops.conv_x6p_plan(ops.conv_desc(16, 41, 41, 4096, 4096, 1, 1, 1)) == (24576, 0, 0, 0, 3)   # fc7: 6 whole rounds + stream-K tail
