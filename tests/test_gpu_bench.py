@@ -1,0 +1,47 @@
+"""bench.py's contract on a small workload: ONE JSON line on stdout carrying the driver's keys, the roofline and cpu_baseline
+objects and (for the default fp32 arithmetic on one GPU) the bf16x6 side measurement.  Run as a child process, like the driver
+does."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "65", "--classes", "5", "--width", "16", "--batch", "2",
+                        "--steps", "3", "--warmup", "1", "--cpu-batch", "1", "--cpu-steps", "1"] + list(flags),
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_default_line_has_every_contract_key():
+    d = _run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "images/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "fp32" and d["data"] == "synthetic"
+    assert abs(d["value"] - 2 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3          # value = images / timed seconds
+    assert isinstance(d["config"]["workload"], str) and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "traffic" in r and r["launches"] > 0 and r["avg_launch_ms"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "images/s" and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
+    x = d["bf16x6"]                                                                        # the fp32-grade fast path, beside the headline
+    assert x["unit"] == "images/s" and x["value"] > 0 and x["peak"] == 419.4 and abs(x["final_loss"] - d["final_loss"]) < 1e-3
+
+
+def test_other_arithmetics_and_no_alt():
+    d = _run("--dtype", "bf16x6", "--no-cpu-baseline")
+    assert d["dtype"] == "bf16x6" and d["roofline"]["peak"] == 419.4 and "bf16x6" not in d and "cpu_baseline" not in d
+    d = _run("--no-alt", "--no-cpu-baseline", "--no-prof")
+    assert d["dtype"] == "fp32" and "bf16x6" not in d and "roofline" not in d
