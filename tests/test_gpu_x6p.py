@@ -378,3 +378,38 @@ def test_full_size_single_image_bf16x6():
     want_labels, _ = oracle.estep_labels(logits, labels, perms)
     assert np.array_equal(adapt.net["e_argmax"].cpu().numpy(), want_labels)
     assert np.isfinite(float(adapt.loss["norm"].cpu()))
+
+
+def test_full_size_config5_bf16x6():
+    """BASELINE config 5 (513x513, 41 classes, fc6 3x3 rate 12 -> 1024) with compute_dtype bf16x6: the rate-12 gather over packed
+    rows on 65x65 maps, logits within 1e-3 of the fp32 CPU oracle, label map identical (mirrors test_full_size_config5)."""
+    import torch
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from oracle import deeplab_oracle as do
+    from oracle import estep_oracle as eo
+    C, size = 41, 513
+    adapt = ADAPT({"input_size": (size, size), "category_num": C, "width": 64, "preset": "largefov", "accum_num": 1, "batch_size": 1,
+                   "compute_dtype": "bf16x6", "x6_planes": "always"})
+    adapt.build()
+    oracle = do.DeepLabOracle(category_num=C, preset="largefov", width=64, dtype=torch.float32)
+    params = do.init_params(oracle.specs, seed=11, he=True)
+    for layer, (w, b) in params.items():
+        adapt.weights[layer][0].copy_(torch.tensor(w).to(adapt.device))
+        adapt.weights[layer][1].copy_(torch.tensor(b).to(adapt.device))
+    images, labels = do.synthetic_batch(1, size, C, seed=4)
+    images = (images / 50.0).astype(np.float32)
+    logits = adapt.forward(images, 1.0).cpu().numpy()
+    engaged = adapt._bufs["xp"]
+    assert engaged["fc6"]["fwd"] and engaged["fc6"]["dgrad"] and engaged["fc6"]["wgrad"] and engaged["fc7"]["fwd"]
+    want = oracle.forward(oracle.tensors(params, requires_grad=False), images)["output"].numpy()
+    assert logits.shape == (1, 65, 65, C)
+    assert _rel(logits, want) < 1e-3
+    perms = eo.draw_perms(5, C, seed=6)
+    adapt.pre_train(1e-3, 1e-5, 0.9, 1)
+    adapt.micro_step(images, labels, keep_prob=1.0, perms=perms)
+    adapt.apply_update()
+    torch.cuda.synchronize()
+    want_labels, _ = oracle.estep_labels(logits, labels, perms)
+    got = adapt.net["e_argmax"].cpu().numpy()
+    assert np.array_equal(got, want_labels)
+    assert len(np.unique(got)) >= 2 and np.isfinite(float(adapt.loss["norm"].cpu()))
