@@ -397,11 +397,15 @@ class ADAPT(Network):
                 ih, iw = op.in_hw
                 d = ops.conv_desc(B, ih, iw, op.cin_p, op.cout_p, op.k, op.k, op.rate)
                 # config "x6_planes": "auto" (default) = where the plane kernel has enough work to fill the part at this batch
-                # size, "always" = wherever it can run (the parity tests drive it on small shapes this way)
+                # size, "always" = wherever it can run and the six-MFMA kernels for every other GEMM with more than 64 columns,
+                # however small (the parity tests drive them on small shapes this way)
                 take = ops.conv_x6p_supported if self.config.get("x6_planes", "auto") == "always" else ops.conv_x6p_pays
                 e = dict(d=d, fwd=op.seg["wkp"] is not None and take(d, 0), dgrad=op.seg["wp6"] is not None and take(d, 1),
                          wgrad=take(d, 2))
                 e["x"] = (torch.empty(B * ih * iw * op.cin_p * 6, dtype=torch.uint8, device=dev) if (e["fwd"] or e["wgrad"]) else None)
+                # a GEMM below 3 GFLOP (small maps / narrow nets; at the benchmark shapes none) is launch- and tail-bound: the native
+                # fp32 kernels' split-K plans are the faster fp32-grade choice there (scripts/shape_sweep.sh)
+                e["small"] = (2.0 * B * ih * iw * op.k * op.k * op.cin_p * op.cout_p < 3e9 and self.config.get("x6_planes", "auto") != "always")
                 if e["dgrad"] or e["wgrad"]:
                     dyp_bytes = max(dyp_bytes, B * ih * iw * op.cout_p * 6)
                 xp[op.name] = e
@@ -485,7 +489,7 @@ class ADAPT(Network):
                     if e["fwd"]:
                         ops.conv_fwd_x6p(e["x"], op.seg["wkp"], e["d"], op.b_pad, relu=op.relu, keep_prob=kp,
                                          drop_mask=mask, drop_seed=seed, out=out)
-                    elif op.cout_p <= 64:
+                    elif op.cout_p <= 64 or e["small"]:
                         # (64 or fewer output columns -- conv1_x, fc8: the native fp32 kernel's 256x64 tiles are the faster
                         # fp32-grade kernel there, measured per layer: profiles/r03_x6_*)
                         ops.conv_fwd(x, op.w_pad, op.b_pad, op.rate, relu=op.relu, keep_prob=kp, drop_mask=mask,
@@ -625,6 +629,8 @@ class ADAPT(Network):
                         ops.split_planes(d, out=bufs["dyp"])
                     if e["wgrad"]:
                         ops.conv_wgrad_x6p(e["x"], bufs["dyp"], e["d"], out=op.gw_pad)
+                    elif e["small"]:
+                        ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
                     else:
                         ops.conv_wgrad_x6(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
                 else:
@@ -648,7 +654,7 @@ class ADAPT(Network):
                 elif x6:
                     if bufs["xp"][op.name]["dgrad"]:
                         d = ops.conv_dgrad_x6p(bufs["dyp"], op.seg["wp6"], bufs["xp"][op.name]["d"], gate=gate, gate_scale=scale, out=out)
-                    elif op.cin_p <= 64:
+                    elif op.cin_p <= 64 or bufs["xp"][op.name]["small"]:
                         d = ops.conv_dgrad(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
                     else:
                         d = ops.conv_dgrad_x6(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)

@@ -123,7 +123,7 @@ def test_x6_micro_step_matches_the_fp32_oracle_at_the_fp32_bars():
     from oracle import estep_oracle as eo
     B, width, size, C = 2, 8, 65, 5
     adapt = ADAPT({"input_size": (size, size), "category_num": C, "width": width, "accum_num": 1, "batch_size": B,
-                   "compute_dtype": "bf16x6"})
+                   "compute_dtype": "bf16x6", "x6_planes": "always"})   # (at this size "auto" would hand every GEMM to the native kernels)
     adapt.build()
     oracle = do.DeepLabOracle(category_num=C, width=width, dtype=torch.float64)
     params = do.init_params(oracle.specs, seed=11, he=True)
