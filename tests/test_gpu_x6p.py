@@ -413,3 +413,14 @@ def test_full_size_config5_bf16x6():
     got = adapt.net["e_argmax"].cpu().numpy()
     assert np.array_equal(got, want_labels)
     assert len(np.unique(got)) >= 2 and np.isfinite(float(adapt.loss["norm"].cpu()))
+
+
+def test_differential_fuzz_against_the_native_kernels():
+    """80 random shapes / filters / dilations / launch layouts / epilogues (scripts/x6p_fuzz.py, fixed seed): the plane kernels
+    against the native fp32 kernels at 3e-5 of the tensor's maximum."""
+    import importlib.util, os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "x6p_fuzz.py")
+    spec = importlib.util.spec_from_file_location("x6p_fuzz", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(80, 7) == 0
