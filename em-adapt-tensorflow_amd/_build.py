@@ -73,7 +73,7 @@ def build(force=False, jobs=None, verbose=True, ablate=False):
                     os.remove(o)
             srcs = sources()
             jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) // 2))
-            extra = ("-DEMADAPT_ABLATE_BUILD",) + tuple(os.environ.get("EMADAPT_LAB_CXXFLAGS", "").split()) if ablate else ()
+            extra = ("-DEMADAPT_ABLATE_BUILD",) + tuple(os.environ.get("EMADAPT_LAB_CXXFLAGS", "").split()) if ablate else ()   # (lab flags: diagnostic build only)
             with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
                 objs = list(ex.map(lambda src: _compile(src, obj_dir, extra), srcs))
             tmp = "%s.tmp.%d" % (lib_path, os.getpid())

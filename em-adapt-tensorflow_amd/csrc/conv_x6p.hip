@@ -180,7 +180,7 @@ int dispatch_x6p(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStrea
 
 void fill_x6p(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
     fill_geometry(a, d, dgrad);
-    a.x_bytes = (unsigned)((long long)a.M * (a.Cx / 16) * XP_GB);
+    a.x_bytes = (unsigned)((long long)a.M * (a.Cx / 16) * XP_ROWB);
     a.w_bytes = (unsigned)((long long)a.K / 16 * ceil_div(a.N, 256) * 256 * XP_ROWB);   // tiled filter image: rows padded to whole tiles
 }
 

@@ -36,11 +36,6 @@ namespace {
 typedef __bf16 xp_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int XP_ROWB = 96;                  // bytes of one row's K step (3 planes x 16 bf16), in memory and in LDS
-#ifdef XP_LAB_PAD128
-constexpr int XP_GB = 128;                   // (lab, timing only: groups padded to a 128-byte line in memory)
-#else
-constexpr int XP_GB = XP_ROWB;               // bytes from one group of 16 k to the next in memory
-#endif
 constexpr int XP_OPER = 256 * XP_ROWB;       // one operand's K step in LDS
 constexpr int XP_STAGE = 2 * XP_OPER;        // A + B
 constexpr int XP_NBUF = 3;
@@ -126,7 +121,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
 
     // ---- loader side: constants of the launch
     // (the tap offset rides in the DMA's scalar operand, an UNSIGNED addend: the buffer starts `bias` bytes before the tensor)
-    const int rowb = a.Cx / 16 * XP_GB;   // bytes of a pixel in a plane image
+    const int rowb = a.Cx / 16 * XP_ROWB;   // bytes of a pixel in a plane image
     const int n_pad = a.tiles_n * 256;     // filter rows per (tap, group of 16 k) in the tiled filter image
     int min_dh = a.sign * (0 - a.pad_h), min_dw = a.sign * (0 - a.pad_w);
     {
@@ -148,11 +143,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
     for (int j = 0; j < XP_IPW; j++) {
         const int q = (wave * XP_IPW + j) * 64 + lane;
         ld_row[j] = q / 6;
-#ifdef XP_LAB_NOSWAP
-        ld_chunk[j] = (q - ld_row[j] * 6);   // (lab, timing only: lanes in ascending address order)
-#else
         ld_chunk[j] = (q - ld_row[j] * 6) ^ ((ld_row[j] >> 3) & 1);
-#endif
     }
 
     // ---- consumer side: fragment addresses (bytes inside a stage); plane p is 32 bytes on, the wave's next 32 rows 3072
@@ -215,7 +206,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
         const unsigned tap_u = kh * (unsigned)a.KW + (unsigned)kw;
         const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
         const int dw = a.sign * (kw * a.dil - a.pad_w);
-        const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + chunk_u * (unsigned)XP_GB + bias));
+        const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + chunk_u * (unsigned)XP_ROWB + bias));
         const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(((tap_u * (unsigned)(a.Cx / 16) + chunk_u) * (unsigned)n_pad + (unsigned)n0) * (unsigned)XP_ROWB));
         const unsigned sh = 31u - (tap_u & 31u);   // moves this tap's "outside the image" bit to bit 31
         const unsigned dead = live ? 0u : kOOB;

@@ -6,7 +6,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from em_adapt_tensorflow_amd import _build, _lib
-_lib._bind(os.environ.get("XP_LAB_SO", _build.ABLATE_LIB_PATH))   # (XP_LAB_SO: a lab build, e.g. groups padded to 128 bytes)
+_lib._bind(os.environ.get("XP_LAB_SO", _build.ABLATE_LIB_PATH))   # (XP_LAB_SO: another diagnostic build; also switches to all-zero operands)
 from em_adapt_tensorflow_amd import ops
 layer = sys.argv[1] if len(sys.argv) > 1 else "fc7"
 H, Cin, Cout, k, rate = {"fc7": (41, 4096, 4096, 1, 1), "conv4_2": (41, 512, 512, 3, 1), "fc6": (41, 512, 4096, 4, 4)}[layer]
