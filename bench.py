@@ -10,9 +10,12 @@ BASELINE.json configs[1]: 321x321x3 inputs, batch 16, 21 classes, fp32, the netw
 reference (fc6 4x4 rate 4 -> 4096; `--preset largefov` selects the 3x3 rate-12 variant).  Inputs, labels,
 dropout and the E-step visiting orders are resident in HBM before the timed region starts.
 
-For N > 1 the driver launches this file with torch.distributed.run, one rank per GPU (RCCL); every rank
-keeps batch 16 (weak scaling) and the value is the whole-job images/s with the time taken as the MAX over
-ranks between two barriers.
+For N > 1 there is one rank per GPU (RCCL); every rank keeps batch 16 (weak scaling) and the value is the whole-job
+images/s with the time taken as the MAX over ranks between two barriers.  Either a launcher provides the ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment), or -- when `--gpus N` arrives with no
+WORLD_SIZE in the environment -- this file is its own launcher: before it touches the GPU it starts N fresh worker
+processes of itself, relays rank 0's line and exits non-zero if any worker did (`launch_workers`).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the dominant kernel class (conv implicit-GEMM fwd / dgrad / wgrad) timed live with HIP events
@@ -78,6 +81,8 @@ def parse():
                          "the library) = each bucket as soon as it is complete.  E.g. conv2_2 holds everything back until the "
                          "~6.5 ms of many-small-workgroup kernels at the end of backward (dist.py); compare the two by "
                          "allreduce.exposed_ms_per_step and the step time on a multi-GPU node")
+    ap.add_argument("--launch-timeout", type=float, default=0.0,
+                    help="N > 1 started without a launcher: seconds after which the workers are ended (0 = no limit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the data-parallel flow on a single GPU)")
     return ap.parse_args()
@@ -163,19 +168,113 @@ def cpu_baseline(args):
     }
 
 
+def launch_workers(n, worker_cmd, timeout=None, env=None, out=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes (one rank per GPU), relay rank 0's
+    stdout (the one JSON line), return 0 only if every worker did.  Runs BEFORE anything in this process touches the GPU:
+    the parent imports neither torch nor the HIP library, so the children are ordinary fork+exec of a GPU-free process.
+    When a worker fails the others are ended (exact PIDs, SIGTERM then SIGKILL) and its exit code is returned.
+
+    worker_cmd -- argv of one worker; RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR / MASTER_PORT are
+                  supplied through the environment exactly as torch.distributed.run would.
+    """
+    import signal
+    import socket
+    import subprocess
+    import threading
+
+    out = out or sys.stdout
+    base = dict(os.environ if env is None else env)
+    if "MASTER_PORT" not in base:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:   # a free port of the loopback interface
+            s.bind(("127.0.0.1", 0))
+            base["MASTER_PORT"] = str(s.getsockname()[1])
+    base["MASTER_ADDR"] = base.get("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts
+    base.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    procs = []
+    try:
+        for r in range(n):
+            e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                     GROUP_RANK="0", ROLE_RANK=str(r), EMADAPT_BENCH_WORKER="1")
+            # rank 0's stdout is the job's stdout (relayed line by line); the other ranks may only talk on stderr
+            procs.append(subprocess.Popen(list(worker_cmd), env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                          stderr=None, text=(r == 0) or None))
+    except OSError:
+        for p in procs:
+            p.kill()
+        raise
+
+    def relay(pipe):
+        for line in pipe:
+            out.write(line)
+            out.flush()
+
+    t = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    t.start()
+    stop = []   # the launcher itself told to stop (the driver's own time limit): take the workers along
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            old_handlers[sig] = signal.signal(sig, lambda signum, frame: stop.append(signum))
+    deadline = None if not timeout else time.monotonic() + timeout
+    rc, failed = 0, None
+    live = set(range(n))
+    while live and failed is None:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0:
+                failed, rc = r, (c if c > 0 else 128 - c)
+                break
+        if deadline is not None and time.monotonic() > deadline and live:
+            failed, rc = min(live), 124
+        if stop and live and failed is None:
+            failed, rc = min(live), 128 + stop[0]
+        if live and failed is None:
+            time.sleep(0.05)
+    if failed is not None:
+        print("bench.py: %s; ending the %d worker(s) still running" % (
+            "launcher received signal %d" % stop[0] if stop else "rank %d %s" % (
+                failed, "timed out" if rc == 124 else "exited with code %d" % rc), sum(procs[r].poll() is None for r in live)),
+            file=sys.stderr)
+        for r in live:
+            if procs[r].poll() is None:
+                procs[r].send_signal(signal.SIGTERM)
+        t_kill = time.monotonic() + 10
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    for sig, h in old_handlers.items():
+        signal.signal(sig, h)
+    t.join(timeout=5)
+    return rc
+
+
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # started without a launcher (the driver's `python bench.py --gpus N`): be the launcher.  Nothing above this line,
+        # and nothing in launch_workers, imports torch or loads the HIP library.
+        raise SystemExit(launch_workers(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                        timeout=args.launch_timeout or None))
     import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or args.force_dist
     if args.gpus != world and rank == 0 and distributed:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-    if args.gpus > 1 and not distributed:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.backend == "nccl" and distributed and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        # fail fast and say why (device_count() does not initialise the GPU): RCCL wants one device per rank
+        raise SystemExit("bench.py --gpus %d --backend nccl needs %d GPUs, %d visible (one rank per GPU; to rehearse the "
+                         "data-parallel flow on fewer GPUs use --backend gloo)" % (world, world, torch.cuda.device_count()))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (the product path has no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -241,9 +340,11 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
+        t_local = time.perf_counter()   # when THIS rank's GPU was done (per-rank spread in the line; `value` uses the fenced time)
         if distributed:
             dist.barrier()
         torch.cuda.synchronize(device)
+        return t_local
 
     for i in range(args.warmup):
         step(i)
@@ -262,7 +363,7 @@ def main():
             ops.prof_enable(i % every == 0)
             prof_steps += i % every == 0
         step(args.warmup + i)
-    fence()
+    t_local = fence()
     dt = time.perf_counter() - t0
     prof = None
     if not args.no_prof:
@@ -270,8 +371,14 @@ def main():
         prof = ops.prof_collect()
         ops.prof_reset()
     gs_stats = adapt._gradsync.stats() if adapt._gradsync is not None else None
+    rank_ms = [(t_local - t0) / max(args.steps, 1) * 1e3]
     if distributed:
         from em_adapt_tensorflow_amd.dist import all_reduce_max
+        # the communicator's own size, not argv's: what the collectives really ran over
+        world = dist.get_world_size()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_ms[0])
+        rank_ms = [float(x) for x in gathered]
         dt = all_reduce_max(dt, device)
         if gs_stats is not None and gs_stats["exposed_ms"] is not None:
             gs_stats["exposed_ms_max_over_ranks"] = all_reduce_max(gs_stats["exposed_ms"], device)
@@ -291,6 +398,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms, 3),
+            "ms_per_step_ranks": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "n": len(rank_ms)},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

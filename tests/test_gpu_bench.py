@@ -45,3 +45,33 @@ def test_other_arithmetics_and_no_alt():
     assert d["dtype"] == "bf16x6" and d["roofline"]["peak"] == 419.4 and "bf16x6" not in d and "cpu_baseline" not in d
     d = _run("--no-alt", "--no-cpu-baseline", "--no-prof")
     assert d["dtype"] == "fp32" and "bf16x6" not in d and "roofline" not in d
+
+
+def test_gpus_2_launches_itself_and_prints_one_line():
+    """The driver's command for N > 1 is `python bench.py --gpus N` with no launcher around it: bench.py starts the N ranks
+    itself (fresh processes, before anything touches the GPU).  Two gloo ranks share this box's one GPU here; on a multi-GPU
+    node the default backend is RCCL with one rank per GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--size", "65", "--classes", "5",
+                        "--width", "16", "--batch", "2", "--steps", "3", "--warmup", "1", "--launch-timeout", "500"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["allreduce"]["ranks"] == 2 and d["allreduce"]["backend"].startswith("gloo")
+    r = d["ms_per_step_ranks"]
+    assert r["n"] == 2 and 0 < r["min"] <= r["max"] <= d["ms_per_step"] * 1.001
+    assert abs(d["value"] - 4 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3          # whole-job images / timed seconds
+    assert "cpu_baseline" not in d                                                          # N = 1 only
+
+
+def test_gpus_2_rccl_on_one_gpu_fails_fast_with_a_reason():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the RCCL job would run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--launch-timeout", "300"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=400, text=True)
+    assert p.returncode != 0 and p.stdout.strip() == "" and "needs 2 GPUs, 1 visible" in p.stderr
