@@ -425,7 +425,9 @@ def main():
             dom = max(conv, key=lambda k: conv[k]["ms"])
             d = conv[dom]
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+            tf_exec = d["flops_executed"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
             all_flops = sum(v["flops"] for v in conv.values())
+            all_exec = sum(v["flops_executed"] for v in conv.values())
             all_ms = sum(v["ms"] for v in conv.values())
             peak = {"fp32": PEAK_FP32_MATRIX_TFLOPS, "bf16": PEAK_BF16_MATRIX_TFLOPS,
                     "bf16x6": round(PEAK_BF16_MATRIX_TFLOPS / 6, 1)}[args.dtype]
@@ -436,14 +438,25 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": round(tf / peak, 4),
+                # MFMA utilisation proper: the FLOPs the launches ISSUED (the library's count: algorithmic minus the products
+                # with a dilated filter's zero padding that the kernels skip) / time / peak.  `frac` is what the caller gets
+                # (SURVEY 8d's algorithmic FLOPs), `frac_executed` how busy the matrix pipe was; both never above 1 together
+                "frac_executed": round(tf_exec / peak, 4),
+                "achieved_executed": round(tf_exec, 2),
+                "executed_over_algorithmic": round(d["flops_executed"] / d["flops"], 4) if d["flops"] > 0 else None,
                 "traffic": None,   # filled below from the committed PMC passes when they cover this workload
+                "algorithmic_bytes": round(d["bytes"] / max(d["launches"], 1)),   # per launch: every operand and the output once
+                "traffic_over_algorithmic": None,
                 "launches": d["launches"],
                 "timed_steps_with_events": "%d of %d (every %d%s)" % (prof_steps, args.steps, every, "th" if every > 3 else ""),
                 "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
                 "flop_per_launch": d["flops"] / max(d["launches"], 1),
-                "flop_accounting": "algorithmic (2*M*K*N per launch, zero-padding products included: SURVEY 8d); the fp32 kernels "
-                                   "skip the padding of dilated filters (~5.5 % of the ref preset's products)",
+                "flop_accounting": "frac / achieved / flop_per_launch: algorithmic (2*M*K*N per launch, zero-padding products "
+                                   "included: SURVEY 8d); frac_executed / achieved_executed: the products the kernels really "
+                                   "issue (packed pixel classes and per-tap pixel boxes skip a dilated filter's padding)",
                 "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None,
+                "all_conv_tflops_executed": round(all_exec / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None,
+                "all_conv_frac_executed": round(all_exec / (all_ms * 1e-3) / 1e12 / peak, 4) if all_ms > 0 else None,
                 "step_tflops": round(fb_flops * args.batch / (ms * 1e-3) / 1e12, 2),
             }
             # HBM (L2-miss) bytes per launch of the dominant class: PMC counters need their own rocprofv3 passes
@@ -460,6 +473,8 @@ def main():
                     calls = d["launches"] / max(prof_steps, 1)
                     out["roofline"]["traffic"] = round((per_step["read_bytes"] + per_step["write_bytes"]) / max(calls, 1))
                     out["roofline"]["traffic_unit"] = "bytes per launch (HBM-side reads + writes, %s)" % os.path.relpath(tpath, here)
+                    if d["bytes"] > 0:
+                        out["roofline"]["traffic_over_algorithmic"] = round(out["roofline"]["traffic"] / (d["bytes"] / d["launches"]), 2)
                     break
                 except (OSError, KeyError, ValueError):
                     continue

@@ -116,6 +116,9 @@ PROTOTYPES = {
     "emadapt_prof_enable": (None, [c_int]),
     "emadapt_prof_reset": (None, []),
     "emadapt_prof_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "emadapt_conv_executed_fraction": (c_int, [POINTER(ConvDesc), c_int, c_int, POINTER(c_double)]),
+    "emadapt_conv_bf16_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
+    "emadapt_prof_collect2": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
 }
 
 _LIB = None

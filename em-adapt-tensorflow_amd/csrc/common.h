@@ -34,12 +34,30 @@ inline int launch_status() {
 struct ProfScope {
     ProfScope(int kind, double flops, double bytes, hipStream_t stream);
     ~ProfScope();
+    // FLOPs the launch really issues when that is less than the algorithmic count given to the constructor (kernels that
+    // skip the products with a dilated filter's zero padding): fraction of the algorithmic FLOPs, 1.0 by default
+    void executed_fraction(double f);
     int kind_;
     hipStream_t stream_;
     void *rec_;
 };
 
 constexpr int kWave = 64;
+
+// Filter gradient with pixel skipping: (pixel, tap) pairs at which the tap reads inside the image / all of them.
+inline double taps_inside_fraction(int H, int W, int KH, int KW, int dil, int pad_h, int pad_w) {
+    double walked = 0.0;
+    for (int tap = 0; tap < KH * KW; tap++) {
+        const int dh = (tap / KW) * dil - pad_h, dw = (tap % KW) * dil - pad_w;
+        const int vh = H - (dh < 0 ? -dh : dh), vw = W - (dw < 0 ? -dw : dw);
+        walked += (double)(vh > 0 ? vh : 0) * (vw > 0 ? vw : 0);
+    }
+    return walked / ((double)KH * KW * H * W);
+}
+// executed / algorithmic FLOPs of the launches a conv entry makes for this shape (host arithmetic only)
+double exec_fraction_fp32(const emadapt_conv_desc *d, int kind);   // conv_igemm.hip (kind 0 / 1), conv_wgrad.hip (kind 2)
+double exec_fraction_fp32_wgrad(const emadapt_conv_desc *d);
+double exec_fraction_x6p(const emadapt_conv_desc *d, int kind);    // conv_x6p.hip
 
 // Division by a launch-time constant d as one v_mul_hi_u32: magic = ceil(2^32 / d) gives n / d exactly while
 // n * d < 2^32 (checked on the host for every quantity divided this way); d == 1 is encoded as magic 0 (identity).

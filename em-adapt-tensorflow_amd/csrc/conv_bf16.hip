@@ -758,6 +758,24 @@ int emadapt_weights_to_bf16(const emadapt_conv_desc *d, const float *w, void *w_
     return launch_status();
 }
 
+int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]) {
+    if (!plan || kind < 0 || kind > 2) return EMADAPT_ERR_INVALID;
+    int rc = kind == 2 ? check_desc_wgrad(d) : check_desc(d);
+    if (rc) return rc;
+    if (kind == 2) {
+        const PlanW p = make_plan_bf16(d);
+        plan[0] = p.bko; plan[1] = p.bn; plan[2] = p.splits;
+        return EMADAPT_OK;
+    }
+    IgemmArgs a;
+    int Cxp;
+    fill_geometry_bf16(a, Cxp, d, kind == 1);
+    const PlanG p = plan_bf16(a);
+    plan[0] = plan[1] = p.big ? 256 : 128;
+    plan[2] = p.splits;
+    return EMADAPT_OK;
+}
+
 size_t emadapt_conv_fwd_bf16_workspace_bytes(const emadapt_conv_desc *d) {
     if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
     IgemmArgs a;
@@ -795,7 +813,8 @@ int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype
     a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
     a.epi = epilogue; a.scale = 1.f; set_keep(a, keep_prob); a.seed = drop_seed;
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N, 0.0, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N,
+                   (double)a.M * a.Cx * (x_dtype ? 2 : 4) + 2.0 * a.ntaps * a.Cx * a.N + (double)a.M * a.N * (y_dtype ? 2 : 4), stream);
     return dispatch_igemm_bf16_dt(a, Cxp, x_dtype, y_dtype, workspace, workspace_bytes, stream);
 }
 
@@ -815,7 +834,8 @@ int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const void *dy, int dy_d
     a.bias = nullptr; a.gate = static_cast<const float *>(gate); a.mask = nullptr;
     a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; set_keep(a, 1.f); a.seed = 0;
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N, 0.0, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)(a.ntaps * a.Cx) * a.N,
+                   (double)a.M * a.Cx * (dy_dtype ? 2 : 4) + 2.0 * a.ntaps * a.Cx * a.N + (double)a.M * a.N * (dx_dtype ? 2 : 4) * (gate ? 2.0 : 1.0), stream);
     return dispatch_igemm_bf16_dt(a, Cxp, dy_dtype, dx_dtype, workspace, workspace_bytes, stream);
 }
 
@@ -853,7 +873,7 @@ int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dty
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * (x_dtype ? 2 : 4));
     a.y_bytes = (unsigned)((long long)a.M * d->Cout * (dy_dtype ? 2 : 4));
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
-    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, (double)a.x_bytes + (double)a.y_bytes + 4.0 * a.K * a.N, stream);
     rc = x_dtype ? (dy_dtype ? launch_wgrad_bf16_plan<true, true>(p, a, stream) : launch_wgrad_bf16_plan<true, false>(p, a, stream))
                  : (dy_dtype ? launch_wgrad_bf16_plan<false, true>(p, a, stream) : launch_wgrad_bf16_plan<false, false>(p, a, stream));
     if (rc) return rc;

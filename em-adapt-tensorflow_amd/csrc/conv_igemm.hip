@@ -680,7 +680,7 @@ int launch_variant(int cfg, IgemmArgs &a, hipStream_t stream) {
 }
 
 template <bool BT>
-int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream, ProfScope &prof) {
 #ifdef EMADAPT_ABLATE_BUILD
     a.ablate = tune(TUNE_ABLATE);
 #else
@@ -697,7 +697,9 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
     a.pk.rowmap = nullptr;
     if (p.cfg == 5) {
         if (p.bands) {
-            if (!build_row_pack(a, (int)ceil_div(a.N, 256))) return EMADAPT_ERR_INVALID;   // (the plan was made from the same geometry)
+            double exec = 1.0;
+            if (!build_row_pack(a, (int)ceil_div(a.N, 256), &exec)) return EMADAPT_ERR_INVALID;   // (the plan was made from the same geometry)
+            prof.executed_fraction(exec);
             a.pk.rowmap = reinterpret_cast<const int *>(static_cast<char *>(workspace) + (size_t)p.main_splits * a.M * a.N * sizeof(float));
         }
         a.m_begin = 0;
@@ -730,6 +732,17 @@ namespace emadapt {
 // SAME padding of a stride-1 (dilated) convolution: TF pads (dilated_k - 1)/2 before, the rest after
 // (nn_ops._with_space_to_batch_base_paddings): 3x3 rate r -> r; 4x4 rate 4 -> 6 (taps -6,-2,+2,+6).
 int conv_pad_before(int k, int dil) { return ((k - 1) * dil) / 2; }
+
+double exec_fraction_fp32(const emadapt_conv_desc *d, int kind) {
+    if (kind == 2) return exec_fraction_fp32_wgrad(d);
+    if (check_desc(d) != EMADAPT_OK || d->B == 0) return 1.0;
+    IgemmArgs a;
+    fill_geometry(a, d, kind == 1);
+    const LaunchPlan p = plan_launches(a);
+    double e = 1.0;
+    if (p.cfg == 5 && p.bands && build_row_pack(a, (int)ceil_div(a.N, 256), &e)) return e;
+    return 1.0;
+}
 }  // namespace emadapt
 
 
@@ -763,6 +776,12 @@ int emadapt_conv_plan(const emadapt_conv_desc *d, int dgrad, int plan[4]) {
     return EMADAPT_OK;
 }
 
+int emadapt_conv_executed_fraction(const emadapt_conv_desc *d, int kind, int arithmetic, double *fraction) {
+    if (!d || !fraction || kind < 0 || kind > 2 || arithmetic < 0 || arithmetic > 2) return EMADAPT_ERR_INVALID;
+    *fraction = arithmetic == 0 ? exec_fraction_fp32(d, kind) : arithmetic == 2 ? exec_fraction_x6p(d, kind) : 1.0;
+    return EMADAPT_OK;
+}
+
 int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w, const float *bias, float *y,
                      int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed, void *workspace,
                      size_t workspace_bytes, void *stream_) {
@@ -780,8 +799,8 @@ int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w,
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
     a.epi = epilogue; a.scale = 1.f; set_keep(a, keep_prob); a.seed = drop_seed;
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    return dispatch_igemm<false>(a, workspace, workspace_bytes, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 4.0 * ((double)a.M * a.Cx + (double)a.K * a.N + (double)a.M * a.N), stream);   // bytes: every operand once
+    return dispatch_igemm<false>(a, workspace, workspace_bytes, stream, prof);
 }
 
 int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float *w, float *dx, const float *gate,
@@ -796,8 +815,8 @@ int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float 
     a.x = dy; a.w = w; a.y = dx; a.bias = nullptr; a.gate = gate; a.mask = nullptr;
     a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; set_keep(a, 1.f); a.seed = 0;
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    return dispatch_igemm<true>(a, workspace, workspace_bytes, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 4.0 * ((double)a.M * a.Cx + (double)a.K * a.N + (double)a.M * a.N * (gate ? 2.0 : 1.0)), stream);
+    return dispatch_igemm<true>(a, workspace, workspace_bytes, stream, prof);
 }
 
 }  // extern "C"

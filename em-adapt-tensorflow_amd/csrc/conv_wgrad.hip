@@ -558,6 +558,18 @@ int launch_wgrad2(const WgradArgs &a, hipStream_t stream) {
 
 }  // namespace
 
+namespace emadapt {
+double exec_fraction_fp32_wgrad(const emadapt_conv_desc *d) {
+    if (check_desc(d) != EMADAPT_OK || d->B == 0) return 1.0;
+    const Plan p = make_plan(d);
+    const long long M = (long long)d->B * d->H * d->W;
+    const bool ut = d->Cin % 256 == 0 && tune(TUNE_FP32_LOADER) != 1;
+    const bool skip = ut && d->KH * d->KW > 1 && tune(TUNE_FP32_LOADER) != 2 && M * d->H * d->W < (1LL << 32) && p.tiles_k <= 256;
+    if (!skip || p.gen != 2) return 1.0;
+    return taps_inside_fraction(d->H, d->W, d->KH, d->KW, d->dil, conv_pad_before(d->KH, d->dil), conv_pad_before(d->KW, d->dil));
+}
+}  // namespace emadapt
+
 extern "C" {
 
 size_t emadapt_conv_wgrad_workspace_bytes(const emadapt_conv_desc *d) {
@@ -592,12 +604,15 @@ int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *
     a.tiles_k = p.tiles_k; a.tiles_n = p.tiles_n; a.splits = p.splits; a.rows_per_split = p.rows_per_split;
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
-    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 4.0 * ((double)a.M * d->Cin + (double)a.M * a.N + (double)a.K * a.N), stream);
     const bool ut = d->Cin % 256 == 0 && tune(TUNE_FP32_LOADER) != 1;   // a 256-wide k tile lies inside one tap
     // skip the pixels at which a tile's tap is outside the image (fp32_loader = 2 keeps the dense walk: tests, A/B); the
     // compact index is divided by multiply-high: exact while pixels x box size < 2^32
     a.skip = ut && a.ntaps > 1 && tune(TUNE_FP32_LOADER) != 2 && (long long)a.M * d->H * d->W < (1LL << 32) && p.tiles_k <= 256;
-    if (a.skip) order_k_tiles(a);
+    if (a.skip) {
+        order_k_tiles(a);
+        if (p.gen == 2) prof.executed_fraction(taps_inside_fraction(d->H, d->W, d->KH, d->KW, d->dil, a.pad_h, a.pad_w));
+    }
     rc = p.gen == 2 ? (ut ? launch_wgrad2<true>(a, stream) : launch_wgrad2<false>(a, stream)) : (p.bn == 64) ? launch_wgrad<64>(a, stream) : launch_wgrad<128>(a, stream);
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);

@@ -582,7 +582,7 @@ int emadapt_conv_fwd_x6(const emadapt_conv_desc *d, const float *x, const float 
     a.x = x; a.w = w_kmajor; a.y = y; a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
     a.epi = epilogue; a.scale = 1.f; set_keep(a, keep_prob); a.seed = drop_seed;
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 4.0 * ((double)a.M * a.Cx + (double)a.K * a.N + (double)a.M * a.N), stream);
     return dispatch_igemm_x6(a, workspace, workspace_bytes, stream);
 }
 
@@ -598,7 +598,7 @@ int emadapt_conv_dgrad_x6(const emadapt_conv_desc *d, const float *dy, const flo
     a.x = dy; a.w = w; a.y = dx; a.bias = nullptr; a.gate = gate; a.mask = nullptr;
     a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; set_keep(a, 1.f); a.seed = 0;
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 4.0 * ((double)a.M * a.Cx + (double)a.K * a.N + (double)a.M * a.N), stream);
     return dispatch_igemm_x6(a, workspace, workspace_bytes, stream);
 }
 
@@ -632,7 +632,7 @@ int emadapt_conv_wgrad_x6(const emadapt_conv_desc *d, const float *x, const floa
     a.tiles_k = p.tiles_k; a.tiles_n = p.tiles_n; a.splits = p.splits; a.rows_per_split = p.rows_per_split;
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
-    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 4.0 * ((double)a.M * d->Cin + (double)a.M * a.N + (double)a.K * a.N), stream);
     rc = p.bko == 256 ? launch_wgrad_x6<256, 128>(a, stream)
        : p.bn == 64  ? launch_wgrad_x6<128, 64>(a, stream)
                      : launch_wgrad_x6<128, 128>(a, stream);

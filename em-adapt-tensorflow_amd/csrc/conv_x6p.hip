@@ -148,7 +148,7 @@ size_t xp_workspace_bytes(const IgemmArgs &a) {
     return b;
 }
 
-int dispatch_x6p(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+int dispatch_x6p(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream, ProfScope &prof) {
     const PlanXP p = plan_x6p(a);
     if (xp_workspace_bytes(a) > 0 && (!workspace || workspace_bytes < xp_workspace_bytes(a))) return EMADAPT_ERR_WORKSPACE;
     a.ablate = 0;
@@ -159,7 +159,9 @@ int dispatch_x6p(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStrea
     a.m_end = p.main_rows;
     if (p.main_sk) {
         if (p.bands) {
-            if (!build_row_pack(a, (int)ceil_div(a.N, 256))) return EMADAPT_ERR_INVALID;
+            double exec = 1.0;
+            if (!build_row_pack(a, (int)ceil_div(a.N, 256), &exec)) return EMADAPT_ERR_INVALID;
+            prof.executed_fraction(exec);
             a.pk.rowmap = reinterpret_cast<const int *>(static_cast<char *>(workspace) + (size_t)p.main_levels * a.M * a.N * sizeof(float));
         }
         a.splits = plan_cus();
@@ -185,6 +187,24 @@ void fill_x6p(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
 }
 
 }  // namespace
+
+namespace emadapt {
+// (for the layers the plane kernels take: emadapt_conv_x6p_supported / _pays; the others run elsewhere and skip nothing)
+double exec_fraction_x6p(const emadapt_conv_desc *d, int kind) {
+    if (check_desc(d) != EMADAPT_OK || d->B == 0) return 1.0;
+    if (kind == 2) {
+        if (!wp_ok(d) || d->KH * d->KW <= 1 || tune(TUNE_FP32_LOADER) == 2) return 1.0;
+        return taps_inside_fraction(d->H, d->W, d->KH, d->KW, d->dil, conv_pad_before(d->KH, d->dil), conv_pad_before(d->KW, d->dil));
+    }
+    IgemmArgs a;
+    fill_x6p(a, d, kind == 1);
+    if (!xp_ok(a)) return 1.0;
+    const PlanXP p = plan_x6p(a);
+    double e = 1.0;
+    if (p.main_sk && p.bands && build_row_pack(a, (int)ceil_div(a.N, 256), &e)) return e;
+    return 1.0;
+}
+}  // namespace emadapt
 
 extern "C" {
 
@@ -291,8 +311,8 @@ int emadapt_conv_fwd_x6p(const emadapt_conv_desc *d, const void *x_planes, const
     a.gate = nullptr; a.mask = drop_mask;
     a.epi = epilogue; a.scale = 1.f; set_keep(a, keep_prob); a.seed = drop_seed;
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    return dispatch_x6p(a, workspace, workspace_bytes, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N, 6.0 * ((double)a.M * a.Cx + (double)a.K * a.N) + 4.0 * a.M * a.N, stream);   // plane images 6 B / element
+    return dispatch_x6p(a, workspace, workspace_bytes, stream, prof);
 }
 
 int emadapt_conv_dgrad_x6p(const emadapt_conv_desc *d, const void *dy_planes, const void *w_planes, float *dx, const float *gate,
@@ -309,8 +329,8 @@ int emadapt_conv_dgrad_x6p(const emadapt_conv_desc *d, const void *dy_planes, co
     a.gate = gate; a.mask = nullptr;
     a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; set_keep(a, 1.f); a.seed = 0;
     hipStream_t stream = as_stream(stream_);
-    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
-    return dispatch_x6p(a, workspace, workspace_bytes, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N, 6.0 * ((double)a.M * a.Cx + (double)a.K * a.N) + 4.0 * a.M * a.N * (gate ? 2.0 : 1.0), stream);
+    return dispatch_x6p(a, workspace, workspace_bytes, stream, prof);
 }
 
 size_t emadapt_conv_wgrad_x6p_workspace_bytes(const emadapt_conv_desc *d) {
@@ -347,7 +367,8 @@ int emadapt_conv_wgrad_x6p(const emadapt_conv_desc *d, const void *x_planes, con
     // skip the pixels at which a tile's tap is outside the image (fp32_loader = 2 keeps the dense walk: tests, A/B)
     a.skip = a.ntaps > 1 && tune(TUNE_FP32_LOADER) != 2;
     if (a.skip) wp_order_k_tiles(a);
-    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 0.0, stream);
+    ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 6.0 * ((double)a.M * d->Cin + (double)a.M * a.N) + 4.0 * a.K * a.N, stream);
+    if (a.skip) prof.executed_fraction(taps_inside_fraction(d->H, d->W, d->KH, d->KW, d->dil, a.pad_h, a.pad_w));
     rc = launch_wgrad_x6p(a, stream);
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);

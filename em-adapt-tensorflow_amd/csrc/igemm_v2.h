@@ -641,7 +641,7 @@ inline int bands_1d(int size, int K, int dil, int pad, int sign, Band1D *out, in
 // 2.1 % of its forward / data-gradient time; the rate-1 layers' 2.7 % buy 1.6 / 0.5 % -- inside the noise of the step).
 // tiles_n = N tiles of the launch (a unit is one K step of one tile).
 constexpr int kPackMinSavingPct = 5;
-inline bool build_row_pack(IgemmArgs &a, int tiles_n) {
+inline bool build_row_pack(IgemmArgs &a, int tiles_n, double *exec_frac = nullptr) {
     RowPack &pk = a.pk;
     pk.n = 0;
     pk.nruns = 0;
@@ -706,6 +706,7 @@ inline bool build_row_pack(IgemmArgs &a, int tiles_n) {
     if (cost * 100 > dense * (100 - min_saving)) return false;
     pk.nruns = nruns;
     pk.n = n;
+    if (exec_frac) *exec_frac = (double)cost / (double)dense;   // (tile row, tap) pairs walked / all of them
     return true;
 }
 

@@ -14,7 +14,7 @@ thread_local int g_last_hip_error = 0;
 namespace {
 struct ProfRec {
     int kind;
-    double flops, bytes;
+    double flops, bytes, flops_exec;
     hipEvent_t start, stop;
 };
 std::mutex g_prof_mu;
@@ -60,9 +60,14 @@ ProfScope::ProfScope(int kind, double flops, double bytes, hipStream_t stream)
     }
     r->kind = kind;
     r->flops = flops;
+    r->flops_exec = flops;
     r->bytes = bytes;
     (void)hipEventRecord(r->start, stream);
     rec_ = r;
+}
+
+void ProfScope::executed_fraction(double f) {
+    if (rec_) static_cast<ProfRec *>(rec_)->flops_exec = static_cast<ProfRec *>(rec_)->flops * f;
 }
 
 ProfScope::~ProfScope() {
@@ -79,7 +84,7 @@ using namespace emadapt;
 
 extern "C" {
 
-int emadapt_version(void) { return 100; /* 0.1.0 */ }
+int emadapt_version(void) { return EMADAPT_ABI_VERSION; }
 
 const char *emadapt_strerror(int code) {
     switch (code) {
@@ -134,10 +139,17 @@ void emadapt_prof_reset(void) {
 
 int emadapt_prof_collect(int64_t launches[EMADAPT_K_COUNT], double ms[EMADAPT_K_COUNT],
                          double flops[EMADAPT_K_COUNT], double bytes[EMADAPT_K_COUNT]) {
+    return emadapt_prof_collect2(launches, ms, flops, bytes, nullptr);
+}
+
+int emadapt_prof_collect2(int64_t launches[EMADAPT_K_COUNT], double ms[EMADAPT_K_COUNT], double flops[EMADAPT_K_COUNT],
+                          double bytes[EMADAPT_K_COUNT], double flops_executed[EMADAPT_K_COUNT]) {
+    if (!launches || !ms || !flops || !bytes) return EMADAPT_ERR_INVALID;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int k = 0; k < EMADAPT_K_COUNT; k++) {
         launches[k] = 0;
         ms[k] = flops[k] = bytes[k] = 0.0;
+        if (flops_executed) flops_executed[k] = 0.0;
     }
     for (ProfRec *r : g_prof_recs) {
         EMADAPT_HIP_TRY(hipEventSynchronize(r->stop));
@@ -148,6 +160,7 @@ int emadapt_prof_collect(int64_t launches[EMADAPT_K_COUNT], double ms[EMADAPT_K_
         ms[k] += t;
         flops[k] += r->flops;
         bytes[k] += r->bytes;
+        if (flops_executed) flops_executed[k] += r->flops_exec;
     }
     return EMADAPT_OK;
 }

@@ -552,6 +552,24 @@ def conv_plan(B, H, W, Cin, Cout, k, dil=1, dgrad=False):
     return tuple(out)
 
 
+def conv_bf16_plan(B, H, W, Cin, Cout, k, dil=1, kind="fwd"):
+    """(tile rows, tile columns, split factor) of the bf16 launch for this shape."""
+    d = conv_desc(B, H, W, Cin, Cout, k, k, dil)
+    out = (ctypes.c_int * 3)()
+    _lib.call("emadapt_conv_bf16_plan", ctypes.byref(d), {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind], out)
+    return tuple(out)
+
+
+def conv_executed_fraction(B, H, W, Cin, Cout, k, dil=1, kind="fwd", arithmetic="fp32"):
+    """Executed / algorithmic FLOPs of the launch(es) for this shape: < 1 where the kernels skip a dilated filter's padding
+    (host arithmetic only, no GPU needed)."""
+    d = conv_desc(B, H, W, Cin, Cout, k, k, dil)
+    f = ctypes.c_double(1.0)
+    _lib.call("emadapt_conv_executed_fraction", ctypes.byref(d), {"fwd": 0, "dgrad": 1, "wgrad": 2}[kind],
+              {"fp32": 0, "bf16": 1, "bf16x6": 2}[arithmetic], ctypes.byref(f))
+    return f.value
+
+
 def tune_set(key, value):
     """Force a launch-plan choice (include/emadapt.h "Launch-plan overrides"); 0 restores the automatic plan."""
     _lib.call("emadapt_tune_set", key.encode(), int(value))
@@ -591,12 +609,15 @@ def prof_reset():
 
 
 def prof_collect():
-    """{kernel class: dict(launches, ms, flops, bytes)} accumulated since the last reset."""
+    """{kernel class: dict(launches, ms, flops, flops_executed, bytes)} accumulated since the last reset.  flops = algorithmic
+    (2*M*K*N); flops_executed = what the launches issued (less where a kernel skips a dilated filter's padding)."""
     n = len(_lib.K_NAMES)
     launches = (ctypes.c_int64 * n)()
     ms = (ctypes.c_double * n)()
     flops = (ctypes.c_double * n)()
     nbytes = (ctypes.c_double * n)()
-    _lib.call("emadapt_prof_collect", launches, ms, flops, nbytes)
-    return {name: dict(launches=int(launches[i]), ms=float(ms[i]), flops=float(flops[i]), bytes=float(nbytes[i]))
+    fexec = (ctypes.c_double * n)()
+    _lib.call("emadapt_prof_collect2", launches, ms, flops, nbytes, fexec)
+    return {name: dict(launches=int(launches[i]), ms=float(ms[i]), flops=float(flops[i]), flops_executed=float(fexec[i]),
+                       bytes=float(nbytes[i]))
             for i, name in enumerate(_lib.K_NAMES)}

@@ -31,7 +31,16 @@ extern "C" {
 #define EMADAPT_ERR_WORKSPACE (-4)   /* workspace too small                                      */
 #define EMADAPT_ERR_NODEVICE (-5)    /* no usable gfx950 device                                  */
 
-int emadapt_version(void);                 /* 10000*major + 100*minor + patch */
+/* ABI history (emadapt_version() returns the library's EMADAPT_ABI_VERSION; 10000*major + 100*minor + patch):
+ *   100  rounds 1-2.
+ *   200  round 3 changed the E-step workspace contract WITHOUT a bump (advisor finding, fixed here): for geometries whose
+ *        channels do not fit in LDS (65x65x41) emadapt_estep_workspace_bytes() grew by B*C*H*W floats (class-major home of the
+ *        non-resident channels) and emadapt_estep() returns EMADAPT_ERR_WORKSPACE below that; map_out is output only and
+ *        emadapt_estep_needs_map() is 0 for every supported geometry.  A caller written against 100 that sized its workspace
+ *        by the constant it knew must re-query emadapt_estep_workspace_bytes().  Added: emadapt_prof_collect2 (executed
+ *        FLOPs), emadapt_conv_*: tensors of 2 GiB and more (batch-sliced launches). */
+#define EMADAPT_ABI_VERSION 200
+int emadapt_version(void);
 const char *emadapt_strerror(int code);
 int emadapt_last_hip_error(void);          /* hipError_t of the last failing HIP call on this thread */
 int emadapt_device_count(void);            /* does not initialise a context */
@@ -199,6 +208,10 @@ int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const void *dy, int dy_d
 size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
                             float *dw, void *workspace, size_t workspace_bytes, void *stream);
+/* The plan a bf16 launch will take for this shape (kind 0 forward, 1 data gradient, 2 filter gradient): plan[0] x plan[1] = the
+ * output tile (forward / data gradient: pixels x channels, 256 x 256 or 128 x 128; filter gradient: filter rows x columns),
+ * plan[2] = split-K / split-M factor.  The parity tests assert through it that the benchmark shapes run the big tiles.  (ABI 200) */
+int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]);
 
 /* ---- fp32-grade GEMMs on the bf16 matrix pipe ("bf16x6", opt-in).  Every fp32 operand is split exactly into
  * three bf16 pieces (x = p0 + p1 + p2: 8+8+8 mantissa bits) and each product is formed from the six piece pairs
@@ -349,6 +362,11 @@ int emadapt_tune_set(const char *key, int value);
  * workspace behind the slab levels -- else 0). */
 int emadapt_conv_plan(const emadapt_conv_desc *d, int dgrad, int plan[4]);
 int emadapt_tune_get(const char *key, int *value);
+/* Executed / algorithmic FLOPs of the launches a conv entry makes for this shape (host arithmetic, no device needed): kind 0
+ * forward, 1 data gradient, 2 filter gradient; arithmetic 0 = fp32 kernels, 1 = bf16 (always 1.0: the dense reduction),
+ * 2 = the bf16x6 plane kernels.  < 1 where the launch skips the products with a dilated filter's zero padding; what
+ * emadapt_prof_collect2 accumulates per launch.  (ABI 200) */
+int emadapt_conv_executed_fraction(const emadapt_conv_desc *d, int kind, int arithmetic, double *fraction);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement support (bench.py): per-kernel HIP-event timing on the launch stream.
@@ -366,6 +384,12 @@ void emadapt_prof_reset(void);
  * algorithmic FLOPs (conv classes) and algorithmic bytes (the others). */
 int emadapt_prof_collect(int64_t launches[EMADAPT_K_COUNT], double ms[EMADAPT_K_COUNT],
                          double flops[EMADAPT_K_COUNT], double bytes[EMADAPT_K_COUNT]);
+/* The same, plus per class the FLOPs the launches really ISSUED (flops_executed, may be NULL): the fp32 and bf16x6 kernels skip
+ * the products of a dilated filter's taps with the zero padding (packed pixel classes in forward / data gradient, per-tap pixel
+ * boxes in the filter gradient), so executed <= algorithmic; equal for every kernel that walks the dense reduction.  MFMA
+ * utilisation is executed FLOPs / time / peak; algorithmic FLOPs / time is the throughput the caller sees.  (ABI 101) */
+int emadapt_prof_collect2(int64_t launches[EMADAPT_K_COUNT], double ms[EMADAPT_K_COUNT], double flops[EMADAPT_K_COUNT],
+                          double bytes[EMADAPT_K_COUNT], double flops_executed[EMADAPT_K_COUNT]);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,7 @@ def load(path):
         key = int(r["Dispatch_Id"])
         d = by.setdefault(key, {"name": short(r["Kernel_Name"]), "ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
         d[r["Counter_Name"]] = float(r["Counter_Value"])
-    return list(by.values())
+    return [by[k] for k in sorted(by)]   # dispatch order (the file is not always in it)
 
 
 out = ["# rocprofv3 --pmc passes over `bench.py --steps 1 --warmup 1` (kernel-trace + counters only; one run per counter set).",
@@ -77,39 +77,45 @@ for name, a in agg.items():
             rd / 1e9, wr / 1e9, (rd + wr) / 1e9 / max(n, 1), 100 * hit))
 open("%s/%s_pmc_conv_kernels.txt" % (DST, R), "w").write("\n".join(out) + "\n")
 
-# HBM bytes per step and kernel class (bench.py's roofline.traffic): the class of a launch is in its name for the fp32
-# kernels (BT = true -> data gradient); the bf16 forward and data-gradient launches share one symbol and are told apart
-# by position (forward launches come first: one per conv layer = as many as there are filter-gradient launches).
+# HBM bytes per step and kernel class (bench.py's roofline.traffic).  The class of a launch comes from its position in the
+# step (scripts/kernel_classes.py: forward launches precede the first filter-gradient launch), cross-checked against the BT
+# template argument of the fp32 kernels read by position.
 import json
 
-
-def classes_of(rows):
-    nw = sum(1 for r in rows if "wgrad" in r["name"])
-    out, seen_bf16 = [], 0
-    for r in rows:
-        n = r["name"]
-        if "wgrad" in n:
-            out.append("igemm_wgrad")
-        elif "igemm_bf16" in n:
-            out.append("igemm_fwd" if seen_bf16 < nw else "igemm_dgrad")
-            seen_bf16 += 1
-        else:
-            out.append("igemm_dgrad" if re.search(r"true>", n) else "igemm_fwd")
-    return out
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_classes import classes_by_order, conv_kernel  # noqa: E402
 
 
-traffic = {c: {"read_bytes": 0.0, "write_bytes": 0.0} for c in ("igemm_fwd", "igemm_dgrad", "igemm_wgrad")}
+def full_rows(path):
+    by = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        d = by.setdefault(int(r["Dispatch_Id"]), {"full": r["Kernel_Name"], "name": short(r["Kernel_Name"])})
+        d[r["Counter_Name"]] = float(r["Counter_Value"])
+    return [by[k] for k in sorted(by)]   # dispatch order = launch order
+
+
+traffic = {c: {"read_bytes": 0.0, "write_bytes": 0.0, "launches": 0} for c in ("igemm_fwd", "igemm_dgrad", "igemm_wgrad")}
+per_kernel = collections.OrderedDict()
 for sub, counter, key, mult in (("pmc_fetch", "FETCH_SIZE", "read_bytes", 2 * 1024.0), ("pmc_write", "WRITE_SIZE", "write_bytes", 1024.0)):
-    rows = load(newest("%s/%s/runc/*_counter_collection.csv" % (SRC, sub)))
-    conv = [r for r in rows if re.search(r"igemm|wgrad", r["name"]) and "splitk" not in r["name"]]
-    conv = conv[len(conv) // 2:]
-    for r, c in zip(conv, classes_of(conv)):
+    rows = [r for r in full_rows(newest("%s/%s/runc/*_counter_collection.csv" % (SRC, sub))) if conv_kernel(r["full"]) is not None]
+    assert len(rows) % 2 == 0, "expected two identical steps (--warmup 1 --steps 1)"
+    conv = rows[len(rows) // 2:]   # the second (timed) step
+    for r, c in zip(conv, classes_by_order([r["full"] for r in conv])):
         traffic[c][key] += r.get(counter, 0.0) * mult
+        traffic[c]["launches"] += key == "read_bytes"
+        k = per_kernel.setdefault(r["name"], {"read_bytes": 0.0, "write_bytes": 0.0, "by_class": {}})
+        k[key] += r.get(counter, 0.0) * mult
+        kc = k["by_class"].setdefault(c, {"read_bytes": 0.0, "write_bytes": 0.0})
+        kc[key] += r.get(counter, 0.0) * mult
 line = json.load(open(SRC + "/bench_line.json"))
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/make_profiles.sh over bench.py --steps 1 --warmup 1; "
                      "read = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md), write = WRITE_SIZE KiB; "
-                     "L2-miss (fabric) traffic, Infinity-Cache hits included",
+                     "L2-miss (fabric) traffic, Infinity-Cache hits included; class of a launch = its position in the step "
+                     "(scripts/kernel_classes.py)",
            "dtype": line["dtype"], "workload": line["config"]["workload"], "key": line["config"].get("workload_key"),
-           "per_step": traffic},
+           "per_step": traffic, "per_kernel": per_kernel},
           open("%s/%s_traffic.json" % (DST, R), "w"), indent=1)
 print("\n".join(out))
+for c, t in traffic.items():
+    print("%-12s %3d launches  read %.2f GB  write %.2f GB  per launch %.3f GB" % (
+        c, t["launches"], t["read_bytes"] / 1e9, t["write_bytes"] / 1e9, (t["read_bytes"] + t["write_bytes"]) / 1e9 / max(t["launches"], 1)))

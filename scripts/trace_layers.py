@@ -5,11 +5,20 @@ launch is followed by its 128x128 tail launch for the rows of the partial last r
 algorithmic TFLOP/s and the fraction of the matrix peak (157.3 TFLOP/s fp32; 2516.6 TFLOP/s dense bf16 when the trace
 holds the bf16 kernels, a sixth of that for the bf16x6 kernels).
 
+Two fractions per line: `alg%` = algorithmic FLOPs (2*M*K*N, padding products included: SURVEY 8d) / time / peak -- the
+throughput a caller sees, above 100 % where a kernel skips the products with a dilated filter's zero padding -- and `exe%` =
+the FLOPs the launch really issued (emadapt_conv_executed_fraction, the library's own host arithmetic) / time / peak: MFMA
+utilisation, never above 100 %.
+
 usage: scripts/trace_layers.py <kernel_trace.csv> [batch] [size] [classes] [preset]
 """
 import csv
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from em_adapt_tensorflow_amd import ops  # noqa: E402  (host-side plan arithmetic only: works without a GPU)
 
 PEAK = 157.3e12  # replaced by the bf16 peak in main() when the trace holds bf16 kernels
 
@@ -71,33 +80,52 @@ def main():
     per_step = len(L) * 3 - 1  # conv1_1 has no dgrad
     last = groups[-per_step:]
     fwd, bwd = last[:len(L)], last[len(L):]
-    tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
+    tot = {"fwd": [0, 0, 0], "dgrad": [0, 0, 0], "wgrad": [0, 0, 0]}
+    arith = "bf16x6" if PEAK == 2516.6e12 / 6 else "bf16" if PEAK == 2516.6e12 else "fp32"
+    dil_of = {"fc6": 4 if preset == "ref" else 12, "conv5_1": 2, "conv5_2": 2, "conv5_3": 2}
 
-    def show(kind, name, g, flops):
+    def executed(kind, name, g, h, k, cin, cout):
+        """Executed / algorithmic FLOPs of this logical launch: the library's plan arithmetic for the kernel family that ran it
+        (only the second-generation fp32 kernels and the bf16x6 plane kernels skip anything)."""
+        names = " ".join(r["Kernel_Name"] for r in g)
+        if arith == "bf16" or (arith == "bf16x6" and "_x6p_kernel" not in names):
+            return 1.0
+        if arith == "fp32" and not re.search(r"igemm2_kernel|wgrad2_kernel", names):
+            return 1.0
+        cin_p, cout_p = -(-cin // 4) * 4, -(-cout // 4) * 4   # (conv1_1's 3 channels / fc8's classes are padded in the buffers)
+        return ops.conv_executed_fraction(B, h, h, cin_p, cout_p, k, dil_of.get(name, 1), kind, arith)
+
+    def show(kind, name, g, flops, frac):
         ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in g)
         tf = flops / ns * 1e9
         tot[kind][0] += ns
         tot[kind][1] += flops
+        tot[kind][2] += flops * frac
         kn = " + ".join(short(r["Kernel_Name"]) for r in g)
         wg = "+".join(str(int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])) for r in g)
-        print("%-6s %-8s %9.3f ms  %6.1f TF  %5.1f%%  wgs %-10s %s" % (kind, name, ns / 1e6, tf / 1e12, 100 * tf / PEAK, wg, kn))
+        print("%-6s %-8s %9.3f ms  %6.1f TF  alg %5.1f%%  exe %5.1f%%  wgs %-10s %s" % (
+            kind, name, ns / 1e6, tf / 1e12, 100 * tf / PEAK, 100 * tf * frac / PEAK, wg, kn))
 
     for (name, h, k, cin, cout), g in zip(L, fwd):
-        show("fwd", name, g, 2.0 * B * h * h * k * k * cin * cout)
+        show("fwd", name, g, 2.0 * B * h * h * k * k * cin * cout, executed("fwd", name, g, h, k, cin, cout))
     i = 0
     for (name, h, k, cin, cout) in reversed(L):
         fl = 2.0 * B * h * h * k * k * cin * cout
-        show("wgrad", name, bwd[i], fl)
+        show("wgrad", name, bwd[i], fl, executed("wgrad", name, bwd[i], h, k, cin, cout))
         i += 1
         if name != "conv1_1":
-            show("dgrad", name, bwd[i], fl)
+            show("dgrad", name, bwd[i], fl, executed("dgrad", name, bwd[i], h, k, cin, cout))
             i += 1
-    for k, (ns, fl) in tot.items():
-        print("TOTAL %-6s %8.3f ms  %6.1f TF  %5.1f%%" % (k, ns / 1e6, fl / ns * 1e9 / 1e12, 100 * fl / ns * 1e9 / PEAK))
+    for k, (ns, fl, fe) in tot.items():
+        print("TOTAL %-6s %8.3f ms  %6.1f TF  alg %5.1f%%  exe %5.1f%%" % (
+            k, ns / 1e6, fl / ns * 1e9 / 1e12, 100 * fl / ns * 1e9 / PEAK, 100 * fe / ns * 1e9 / PEAK))
     ns = sum(v[0] for v in tot.values())
     fl = sum(v[1] for v in tot.values())
-    print("TOTAL conv   %8.3f ms  %6.1f TF  %5.1f%%   (ideal at peak: %.1f ms)" % (ns / 1e6, fl / ns * 1e9 / 1e12,
-                                                                                100 * fl / ns * 1e9 / PEAK, fl / PEAK * 1e3))
+    fe = sum(v[2] for v in tot.values())
+    print("TOTAL conv   %8.3f ms  %6.1f TF  alg %5.1f%%  exe %5.1f%%   (ideal at peak: %.1f ms algorithmic, %.1f ms executed; "
+          "%.1f %% of the products are skipped padding)" % (ns / 1e6, fl / ns * 1e9 / 1e12, 100 * fl / ns * 1e9 / PEAK,
+                                                           100 * fe / ns * 1e9 / PEAK, fl / PEAK * 1e3, fe / PEAK * 1e3,
+                                                           100 * (1 - fe / fl)))
 
 
 if __name__ == "__main__":

@@ -52,7 +52,7 @@ def test_reference_e_step_signature_is_bindable(lib):
 
 
 def test_version_and_errors(lib):
-    assert lib.emadapt_version() >= 100
+    assert lib.emadapt_version() >= 200
     assert lib.emadapt_strerror(0) == b"ok"
     assert b"workspace" in lib.emadapt_strerror(-4)
     assert lib.emadapt_estep_needs_map(41, 41, 21) == 0   # 321x321 / 21 classes: everything fits in LDS

@@ -1,0 +1,138 @@
+"""Whole-model parity at the workloads BASELINE.json's configs name, literally: configs[1] = 16 images of 321x321, 21 classes,
+the network as the reference builds it (deeplab.py:35-107; batch = deeplab.py:288 scaled to 16 per GPU), one micro-step
+(deeplab.py:265-270: forward, E-step, backward, accumulate) in fp32 against the fp32 CPU oracle, and the same step with bf16
+conv operands (configs[2] / [3] per-GPU arithmetic) against the oracle's bf16 arithmetic model.  The other model-level tests run
+a single full-size image or narrow nets; the launch plans (stream-K pieces, packed pixel classes, whole rounds of 256x256 tiles,
+split-M filter gradients) are functions of the batch, so this is the only place the benchmark's own launches meet an oracle end
+to end.
+
+Bars: logits within 1e-3 of the tensor's max (north_star) AND element-wise within 1e-3 relative on every logit whose magnitude
+is above 1 % of the max (the max-norm alone says nothing about small logits); the 16 label maps bit-identical to the oracle
+E-step on the same logits; loss 1e-4; fc8 / fc6 / conv1_1 gradients (the two ends and the largest layer) 2e-4 of max.
+bf16: logits 1e-2, gradients 8e-2 relative L2 (the bars of test_gpu_bf16.py, argued in DESIGN 4.3), label maps identical.
+The CPU oracle needs ~10 s per step at this size on the GPU box's host cores."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+B, SIZE, C = 16, 321, 21
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from oracle import deeplab_oracle as do
+    from oracle import estep_oracle as eo
+    torch.set_num_threads(max(1, min(64, len(os.sched_getaffinity(0)))))
+    images, labels = do.synthetic_batch(B, SIZE, C, seed=0)       # rectangles of foreground classes + void border
+    images = (images / 50.0).astype(np.float32)
+    rng = np.random.default_rng(1)
+    masks = {l: (rng.random((B, 41, 41, 4096)) < 0.5).astype(np.uint8) for l in ("fc6", "fc7")}
+    perms = eo.draw_perms(5, C, seed=3)
+    return dict(ADAPT=ADAPT, do=do, eo=eo, torch=torch, images=images, labels=labels, masks=masks, perms=perms)
+
+
+def _rel(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def _l2(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+
+
+def _elementwise(got, want, floor=0.01):
+    """max |got - want| / |want| over the elements with |want| > floor * max|want|."""
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    big = np.abs(want) > floor * np.abs(want).max()
+    assert big.mean() > 0.5, "the bar must constrain most of the tensor (%.2f)" % big.mean()
+    return float((np.abs(got - want)[big] / np.abs(want)[big]).max())
+
+
+def _build(e, compute_dtype):
+    torch, do = e["torch"], e["do"]
+    adapt = e["ADAPT"]({"input_size": (SIZE, SIZE), "category_num": C, "width": 64, "preset": "ref", "accum_num": 1,
+                        "batch_size": B, "compute_dtype": compute_dtype})
+    adapt.build()
+    kw = dict(compute_dtype="bf16", act_dtype="bf16") if compute_dtype == "bf16" else {}
+    oracle = do.DeepLabOracle(category_num=C, preset="ref", width=64, dtype=torch.float32, **kw)
+    params = do.init_params(oracle.specs, seed=11, he=True)
+    for layer, (w, b) in params.items():
+        adapt.weights[layer][0].copy_(torch.tensor(w).to(adapt.device))
+        adapt.weights[layer][1].copy_(torch.tensor(b).to(adapt.device))
+    adapt.pre_train(base_lr=1e-3, weight_decay=1e-5, momentum=0.9, batch_size=B)
+    return adapt, oracle, params
+
+
+def _grads(adapt, layer):
+    seg = adapt._segments[layer]
+    s, nw = seg["start"], seg["nw"]
+    kh, kw, cin, cout = seg["shape"]
+    w = adapt._flat["accum"][s:s + nw].view(seg["pshape"])[:, :, :cin, :cout].cpu().numpy()
+    b = adapt._flat["accum"][s + nw:s + nw + cout].cpu().numpy()
+    return w, b
+
+
+def test_config2_fp32_batch16_micro_step_against_the_fp32_oracle(env):
+    e = env
+    torch = e["torch"]
+    adapt, oracle, params = _build(e, "fp32")
+    # the plans under test are the benchmark's: stream-K over packed rows for fc6, whole rounds of 256x256 tiles for fc7
+    from em_adapt_tensorflow_amd import ops
+    assert ops.conv_plan(B, 41, 41, 512, 4096, 4, 4)[0] == 5 and ops.conv_plan(B, 41, 41, 4096, 4096, 1, 1)[0] == 4
+
+    logits = adapt.forward(e["images"], keep_prob=0.5, drop_masks=e["masks"]).cpu().numpy()
+    assert logits.shape == (B, 41, 41, C)
+    adapt.micro_step(e["images"], e["labels"], keep_prob=0.5, perms=e["perms"], drop_masks=e["masks"])
+    torch.cuda.synchronize()
+    got_labels = adapt.net["e_argmax"].cpu().numpy()
+    want_labels, _ = oracle.estep_labels(logits, e["labels"], e["perms"])
+    assert got_labels.shape == (B, 41, 41) and np.array_equal(got_labels, want_labels)       # 16 label maps, bit-identical
+    assert len(np.unique(got_labels)) >= 3
+
+    ref = oracle.micro_step(params, e["images"], e["labels"], e["perms"], weight_decay=1e-5, keep_prob=0.5, masks=e["masks"],
+                            labels_override=want_labels)
+    r_max, r_el = _rel(logits, ref["logits"]), _elementwise(logits, ref["logits"])
+    print("fp32 B=16 logits: max-norm %.2e, element-wise (|want| > 1%% of max) %.2e" % (r_max, r_el))
+    assert r_max < 1e-3 and r_el < 1e-3
+    assert abs(float(adapt.loss["norm"].cpu()) - ref["loss_norm"]) / abs(ref["loss_norm"]) < 1e-4
+    for layer in ("fc8", "fc6", "conv1_1"):
+        gw, gb = _grads(adapt, layer)
+        dw, db = ref["grads"][layer]
+        print("fp32 B=16 %s: dw %.2e db %.2e" % (layer, _rel(gw, dw), _rel(gb, db)))
+        assert _rel(gw, dw) < 2e-4 and _rel(gb, db) < 2e-4, layer
+
+
+def test_config3_bf16_batch16_micro_step_against_the_bf16_arithmetic_model(env):
+    e = env
+    torch = e["torch"]
+    adapt, oracle, params = _build(e, "bf16")
+    from em_adapt_tensorflow_amd import ops
+    assert ops.conv_bf16_plan(B, 41, 41, 4096, 4096, 1, 1)[0] == 256 and ops.conv_bf16_plan(B, 41, 41, 512, 4096, 4, 4, "dgrad")[0] == 256
+
+    logits = adapt.forward(e["images"], keep_prob=0.5, drop_masks=e["masks"]).cpu().numpy()
+    adapt.micro_step(e["images"], e["labels"], keep_prob=0.5, perms=e["perms"], drop_masks=e["masks"])
+    torch.cuda.synchronize()
+    got_labels = adapt.net["e_argmax"].cpu().numpy()
+    want_labels, _ = oracle.estep_labels(logits, e["labels"], e["perms"])
+    assert np.array_equal(got_labels, want_labels)
+
+    ref = oracle.micro_step(params, e["images"], e["labels"], e["perms"], weight_decay=1e-5, keep_prob=0.5, masks=e["masks"],
+                            labels_override=want_labels)
+    print("bf16 B=16 logits: max-norm %.2e" % _rel(logits, ref["logits"]))
+    assert _rel(logits, ref["logits"]) < 1e-2
+    assert abs(float(adapt.loss["norm"].cpu()) - ref["loss_norm"]) / abs(ref["loss_norm"]) < 5e-3
+    for layer in ("fc8", "fc6", "conv1_1"):
+        gw, gb = _grads(adapt, layer)
+        dw, db = ref["grads"][layer]
+        print("bf16 B=16 %s: dw %.2e db %.2e (relative L2)" % (layer, _l2(gw, dw), _l2(gb, db)))
+        assert _l2(gw, dw) < 8e-2 and _l2(gb, db) < 8e-2, layer

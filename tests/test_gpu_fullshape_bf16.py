@@ -1,0 +1,101 @@
+"""GPU parity of the bf16 conv kernels AT THE BENCHMARK SHAPES of BASELINE configs[2] / [3] (16 images per GPU, bf16 operands,
+fp32 accumulation): fc6, fc7, conv4_2, conv3_2 -- the 256x256x64 one-workgroup-per-CU launches (1696 workgroups for fc6 / fc7) --
+and conv1_2 (12,881 workgroups of 128x128) run forward with the model's epilogues (bias + ReLU [+ dropout mask]:
+deeplab.py:58-59,92-100), data gradient with the ReLU / dropout gate and filter gradient, against the fp64 oracle evaluated on
+the SAME bf16-rounded operands (products of bf16 numbers are exact in fp32, so only the fp32 summation order differs: 2e-5 of the
+tensor's max magnitude), in both storage types (bf16-stored tensors must give bit-identical sums to f32-stored tensors holding the
+same values; a bf16 output is the f32 output rounded once), repeatable bit for bit, with the launch plan asserted
+(emadapt_conv_bf16_plan).  The small-shape file (test_gpu_bf16.py) never reaches these grids."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import em_adapt_tensorflow_amd.ops as ops
+    from oracle import deeplab_oracle as do
+    torch.set_num_threads(max(1, min(64, len(os.sched_getaffinity(0)))))
+    return ops, do, torch
+
+
+def _rel(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+# name, (B, H, W, Cin, Cout, k, dil), tile of forward / data gradient, tile of the filter gradient, dropout
+FULL = [
+    ("fc6", (16, 41, 41, 512, 4096, 4, 4), 256, (256, 256), True),      # deeplab.py:92,145
+    ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 256, (256, 256), True),     # deeplab.py:95,147
+    ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 256, (256, 256), False),
+    ("conv3_2", (16, 81, 81, 256, 256, 3, 1), 256, (256, 256), False),
+    ("conv1_2", (16, 321, 321, 64, 64, 3, 1), 128, (128, 64), False),   # 12,881 workgroups; 1.65 M pixels
+]
+
+
+@pytest.mark.parametrize("name,shape,tile,wtile,drop", FULL, ids=[f[0] for f in FULL])
+def test_bf16_benchmark_shape_against_fp64_oracle_on_rounded_operands(env, name, shape, tile, wtile, drop):
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    pf, pd, pw = (ops.conv_bf16_plan(B, H, W, Cin, Cout, k, dil, kind) for kind in ("fwd", "dgrad", "wgrad"))
+    assert pf[0] == tile and pd[0] == tile and pw[:2] == wtile, (pf, pd, pw)
+    if name == "fc6":
+        assert pd[2] > 1, pd          # 212 tiles of a 65536-long reduction: split-K slabs
+
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    fan_in = k * k * Cin
+    # operands ARE bf16 values (what the model stores): post-ReLU input, He filters, unit gradients
+    x = torch.randn((B, H, W, Cin), generator=g).clamp_(min=0).bfloat16()
+    w = (torch.randn((k, k, Cin, Cout), generator=g) * float(np.sqrt(2.0 / fan_in))).float()
+    b = (torch.randn((Cout,), generator=g) * 0.1).float()
+    dy = torch.randn((B, H, W, Cout), generator=g).bfloat16()
+    mask = (torch.rand((B, H, W, Cout), generator=g) < 0.5).to(torch.uint8) if drop else None
+
+    # fp64 oracle on the rounded operands
+    xr = x.double().requires_grad_(True)
+    wr = w.bfloat16().double().requires_grad_(True)
+    y_lin = do.conv_same(xr, wr, b.double(), dil)
+    y_lin.backward(dy.double())
+    want_y = torch.relu(y_lin.detach())
+    scale = 2.0 if drop else 1.0
+    if drop:
+        want_y = want_y * scale * mask.double()
+    want_dx = torch.where(x.double() > 0, xr.grad * scale, torch.zeros((), dtype=torch.float64))
+    want_dw = wr.grad
+    del y_lin
+
+    dev = "cuda:0"
+    xg, wg, bg, dyg = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    mg = mask.to(dev) if drop else None
+    wf, wd = ops.weights_to_bf16(wg)
+    kw = dict(relu=True, keep_prob=0.5 if drop else 1.0, drop_mask=mg)
+
+    # forward: bf16-stored input -> f32 output
+    y1 = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, **kw)
+    assert _rel(y1.cpu(), want_y) < 2e-5
+    assert torch.equal(y1, ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, **kw)), "forward must repeat bitwise"
+    assert torch.equal(y1, ops.conv_fwd_bf16(xg.float(), wf, (k, k), bg, dil, **kw)), "f32-stored input: the same sums"
+    assert torch.equal(ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, out_dtype=torch.bfloat16, **kw), y1.bfloat16())
+    del y1
+
+    # data gradient with the ReLU (x dropout scale) gate of the layer below
+    dx1 = ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg.float(), gate_scale=scale)
+    assert _rel(dx1.cpu(), want_dx) < 2e-5
+    assert torch.equal(dx1, ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg.float(), gate_scale=scale))
+    assert torch.equal(dx1, ops.conv_dgrad_bf16(dyg.float(), wd, (k, k), dil, gate=xg.float(), gate_scale=scale))
+    assert torch.equal(ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg, gate_scale=scale), dx1.bfloat16())   # bf16 gate -> bf16 dx
+    del dx1
+
+    # filter gradient
+    dw1 = ops.conv_wgrad_bf16(xg, dyg, k, k, dil)
+    assert _rel(dw1.cpu(), want_dw) < 2e-5
+    assert torch.equal(dw1, ops.conv_wgrad_bf16(xg, dyg, k, k, dil)), "filter gradient must repeat bitwise"
+    assert torch.equal(dw1, ops.conv_wgrad_bf16(xg.float(), dyg.float(), k, k, dil))
