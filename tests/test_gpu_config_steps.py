@@ -7,10 +7,15 @@ split-M filter gradients) are functions of the batch, so this is the only place 
 to end.
 
 Bars: logits within 1e-3 of the tensor's max (north_star) AND element-wise within 1e-3 relative on every logit whose magnitude
-is above 1 % of the max (the max-norm alone says nothing about small logits); the 16 label maps bit-identical to the oracle
-E-step on the same logits; loss 1e-4; fc8 / fc6 / conv1_1 gradients (the two ends and the largest layer) 2e-4 of max.
-bf16: logits 1e-2, gradients 8e-2 relative L2 (the bars of test_gpu_bf16.py, argued in DESIGN 4.3), label maps identical.
-The CPU oracle needs ~10 s per step at this size on the GPU box's host cores."""
+is above 1 % of the max (the max-norm alone says nothing about small logits), against the fp64 AND the fp32 CPU oracle; the 16
+label maps bit-identical to the oracle E-step on the same logits; loss 1e-4.  Gradients of fc8 / fc6 / conv1_1 (the two ends and
+the largest layer): measured here (scripts/b16_grad_margins.py, profiles/r04_b16_margins.txt), two fp32 evaluations of this
+graph at this size differ by 1.5e-7 (fc8) ... 3e-4 (fc6) ... 7e-4 (conv1_1) of the tensor's max whichever pair is taken -- GPU vs
+fp64 oracle, fp32 CPU oracle vs fp64 oracle -- because 110 M ReLU gates and 20 M max-pool arg-maxes sit on fp32-rounded
+pre-activations and a handful of them flip.  So the bar on a gradient is relative to what fp32 arithmetic itself does to this
+graph: the GPU must be within 1.5 x the fp32 CPU oracle's own distance from the fp64 oracle (floor 2e-4, the small-model bar),
+and within 1e-3 outright.  bf16: logits 1e-2, gradients 8e-2 relative L2 (the bars of test_gpu_bf16.py, argued in DESIGN 4.3),
+label maps identical.  The CPU oracles need ~12 s (fp32) and ~40 s (fp64) per step at this size on the GPU box's host cores."""
 import os
 
 import numpy as np
@@ -99,17 +104,21 @@ def test_config2_fp32_batch16_micro_step_against_the_fp32_oracle(env):
     assert got_labels.shape == (B, 41, 41) and np.array_equal(got_labels, want_labels)       # 16 label maps, bit-identical
     assert len(np.unique(got_labels)) >= 3
 
-    ref = oracle.micro_step(params, e["images"], e["labels"], e["perms"], weight_decay=1e-5, keep_prob=0.5, masks=e["masks"],
-                            labels_override=want_labels)
-    r_max, r_el = _rel(logits, ref["logits"]), _elementwise(logits, ref["logits"])
-    print("fp32 B=16 logits: max-norm %.2e, element-wise (|want| > 1%% of max) %.2e" % (r_max, r_el))
-    assert r_max < 1e-3 and r_el < 1e-3
-    assert abs(float(adapt.loss["norm"].cpu()) - ref["loss_norm"]) / abs(ref["loss_norm"]) < 1e-4
+    kw = dict(weight_decay=1e-5, keep_prob=0.5, masks=e["masks"], labels_override=want_labels)
+    ref32 = oracle.micro_step(params, e["images"], e["labels"], e["perms"], **kw)
+    oracle64 = e["do"].DeepLabOracle(category_num=C, preset="ref", width=64, dtype=torch.float64)
+    ref64 = oracle64.micro_step(params, e["images"], e["labels"], e["perms"], **kw)
+    for name, ref in (("fp64", ref64), ("fp32", ref32)):
+        r_max, r_el = _rel(logits, ref["logits"]), _elementwise(logits, ref["logits"])
+        print("fp32 B=16 logits vs %s oracle: max-norm %.2e, element-wise (|want| > 1%% of max) %.2e" % (name, r_max, r_el))
+        assert r_max < 1e-3 and r_el < 1e-3
+        assert abs(float(adapt.loss["norm"].cpu()) - ref["loss_norm"]) / abs(ref["loss_norm"]) < 1e-4
     for layer in ("fc8", "fc6", "conv1_1"):
-        gw, gb = _grads(adapt, layer)
-        dw, db = ref["grads"][layer]
-        print("fp32 B=16 %s: dw %.2e db %.2e" % (layer, _rel(gw, dw), _rel(gb, db)))
-        assert _rel(gw, dw) < 2e-4 and _rel(gb, db) < 2e-4, layer
+        for i, what in enumerate(("dw", "db")):
+            got, want, cpu32 = _grads(adapt, layer)[i], ref64["grads"][layer][i], ref32["grads"][layer][i]
+            gpu_err, fp32_err = _rel(got, want), _rel(cpu32, want)
+            print("fp32 B=16 %s %s: GPU vs fp64 %.2e; fp32 CPU oracle vs fp64 %.2e" % (layer, what, gpu_err, fp32_err))
+            assert gpu_err < max(2e-4, 1.5 * fp32_err) and gpu_err < 1e-3, (layer, what)
 
 
 def test_config3_bf16_batch16_micro_step_against_the_bf16_arithmetic_model(env):
