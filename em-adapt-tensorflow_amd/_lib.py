@@ -118,6 +118,13 @@ PROTOTYPES = {
     "emadapt_prof_collect": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "emadapt_conv_executed_fraction": (c_int, [POINTER(ConvDesc), c_int, c_int, POINTER(c_double)]),
     "emadapt_conv_bf16_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
+    "emadapt_conv_bf16t_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "emadapt_filter_tiles_bf16_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "emadapt_filter_tiles_bf16": (c_int, [POINTER(ConvDesc), _vp, _vp, c_int, _vp]),
+    "emadapt_conv_bf16t_workspace_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
+    "emadapt_conv_bf16t_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
+    "emadapt_conv_fwd_bf16t": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_int, c_int, c_float, _vp, c_uint64, _vp, c_size_t, _vp]),
+    "emadapt_conv_dgrad_bf16t": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, c_int, _vp, c_float, _vp, c_size_t, _vp]),
     "emadapt_prof_collect2": (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
 }
 

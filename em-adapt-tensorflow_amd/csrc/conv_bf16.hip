@@ -138,6 +138,12 @@ __global__ void __launch_bounds__(256) splitk_epilogue_t_kernel(IgemmArgs a) {
     }
 }
 
+}  // namespace
+
+#include "igemm_b16t.h"   // the LDS-DMA kernel for bf16-stored activations (uses epilogue_t / cvt4 / splitk_epilogue_t_kernel above)
+
+namespace {
+
 // Storage types: XBF = the gathered activation (x, or dy for the data gradient) is bf16 in memory (Cx % 8 == 0; 16-byte
 // loads carry 8 channels and go to LDS unconverted); YBF = the output (and the gate of the data gradient) is bf16.
 // ABLM: diagnostic builds only (scripts/bf16_ablate.py) -- parts of the kernel compiled out; 0 in every shipped instantiation.
@@ -733,6 +739,90 @@ int launch_wgrad_bf16_plan(const PlanW &p, const WgradBf16Args &a, hipStream_t s
                         : launch_wgrad_bf16<128, 128, 64, XBF, DBF>(a, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA kernel (igemm_b16t.h): launch plan.  One workgroup per CU: whole rounds of tiles run as plain tiles; whatever is not a
+// whole number of rounds runs stream-K (N <= 1024: the whole launch; wider outputs: the rows of the partial last round only, so
+// the slab levels stay small).
+// ------------------------------------------------------------------------------------------------------------------
+struct PlanBT {
+    int main_rows;     // rows of the first launch
+    int main_sk;       // 1: stream-K
+    int main_levels;   // its slab levels
+    int tail_levels;   // rows [main_rows, M): a stream-K launch with this many slab levels (-1: a plain launch)
+};
+
+void fill_b16t(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
+    fill_geometry(a, d, dgrad);
+    a.x_bytes = (unsigned)((long long)a.M * a.Cx * 2);
+    a.w_bytes = (unsigned)((long long)a.K / BT_BK * ceil_div(a.N, 256) * 256 * BT_ROWB);   // tiled filter image: rows padded to whole tiles
+}
+
+bool bt_ok(const emadapt_conv_desc *d, bool dgrad, int y_bf16) {
+    if (check_desc(d) != EMADAPT_OK) return false;
+    const long long M = (long long)d->B * d->H * d->W;
+    const int Cx = dgrad ? d->Cout : d->Cin, N = dgrad ? d->Cin : d->Cout;
+    const int ntaps = d->KH * d->KW;
+    const long long img_x = M * Cx * 2, img_w = (long long)ntaps * (Cx / BT_BK) * ceil_div(N, 256) * 256 * BT_ROWB;
+    // (per-lane offset + scalar offset must stay below bit 31, the out-of-range flag: image + the taps' reach + one pixel row)
+    const long long reach = ((long long)(d->KH - 1) * d->dil * d->W + (long long)(d->KW - 1) * d->dil + 1) * Cx * 2;
+    return Cx % BT_BK == 0 && ntaps <= 32 && N % (y_bf16 ? 8 : 4) == 0 && img_x + reach < (1LL << 31) && img_w < (1LL << 31) &&
+           M * N < (1LL << 40);
+}
+
+PlanBT plan_b16t(const IgemmArgs &a) {
+    const int cus = plan_cus();
+    PlanBT p = {a.M, 0, 0, 0};
+    const long long tn = ceil_div(a.N, 256), tm = ceil_div(a.M, 256), t = tm * tn;
+    const int nk = a.K / BT_BK;
+    if (t % cus == 0 || t * nk / cus < 16) return p;   // whole rounds, or too little work per CU to cut into pieces
+    if (a.N <= 1024 || t < cus) {
+        p.main_sk = 1;
+        p.main_levels = streamk_levels(t, nk, cus);
+        return p;
+    }
+    const long long tm_full = (t / cus) * cus / tn;
+    if (tm_full >= 1 && tm_full < tm) {
+        p.main_rows = (int)(tm_full * 256);
+        const long long tail_tiles = (tm - tm_full) * tn;
+        p.tail_levels = tail_tiles * nk / cus >= 16 ? streamk_levels(tail_tiles, nk, cus) : -1;
+    }
+    return p;
+}
+
+size_t bt_workspace_bytes(const IgemmArgs &a) {
+    const PlanBT p = plan_b16t(a);
+    size_t b = (size_t)p.main_levels * p.main_rows * a.N * sizeof(float);
+    if (p.main_rows < a.M && p.tail_levels > 0) b += (size_t)p.tail_levels * (a.M - p.main_rows) * a.N * sizeof(float);
+    return b;
+}
+
+template <bool YBF>
+int dispatch_b16t(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    const PlanBT p = plan_b16t(a);
+    if (bt_workspace_bytes(a) > 0 && (!workspace || workspace_bytes < bt_workspace_bytes(a))) return EMADAPT_ERR_WORKSPACE;
+    a.ablate = 0;
+    a.tap_inner = 1;
+    a.pk.n = 0;
+    a.pk.rowmap = nullptr;
+    a.m_begin = 0;
+    a.m_end = p.main_rows;
+    if (p.main_sk) {
+        a.splits = plan_cus();
+        a.slab = p.main_levels > 0 ? static_cast<float *>(workspace) : nullptr;
+        return launch_igemm_b16t<true, YBF>(a, stream);
+    }
+    a.splits = 1;
+    a.slab = nullptr;
+    int rc = launch_igemm_b16t<false, YBF>(a, stream);
+    if (rc || p.main_rows >= a.M) return rc;
+    a.m_begin = p.main_rows;
+    a.m_end = a.M;
+    if (p.tail_levels < 0) return launch_igemm_b16t<false, YBF>(a, stream);
+    a.splits = plan_cus();
+    a.slab = p.tail_levels > 0 ? static_cast<float *>(workspace) : nullptr;
+    return launch_igemm_b16t<true, YBF>(a, stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -879,6 +969,97 @@ int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dty
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
     return rc;
+}
+
+/* ---- LDS-DMA kernel on bf16-stored activations and a TILED filter image (igemm_b16t.h) ---- */
+int emadapt_conv_bf16t_supported(const emadapt_conv_desc *d, int kind, int y_dtype) {
+    if (kind < 0 || kind > 1 || (y_dtype & ~1)) return 0;
+    return bt_ok(d, kind == 1, y_dtype) ? 1 : 0;
+}
+
+size_t emadapt_filter_tiles_bf16_bytes(const emadapt_conv_desc *d, int dgrad) {
+    if (check_desc(d) != EMADAPT_OK) return 0;
+    const int rows = dgrad ? d->Cin : d->Cout, kdim = dgrad ? d->Cout : d->Cin;
+    if (kdim % BT_BK != 0) return 0;
+    return (size_t)d->KH * d->KW * (kdim / BT_BK) * (size_t)(ceil_div(rows, 256) * 256) * BT_ROWB;
+}
+
+int emadapt_filter_tiles_bf16(const emadapt_conv_desc *d, const float *w, void *tiles, int dgrad, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!w || !tiles || !aligned16(w) || !aligned16(tiles)) return EMADAPT_ERR_INVALID;
+    const int rows = dgrad ? d->Cin : d->Cout, kdim = dgrad ? d->Cout : d->Cin;
+    if (kdim % BT_BK != 0) return EMADAPT_ERR_UNSUPPORTED;
+    const int rows_pad = (int)(ceil_div(rows, 256) * 256), taps = d->KH * d->KW;
+    long long g = ((long long)taps * (kdim / BT_BK) * rows_pad * 4 + 255) / 256;
+    if (g > 16384) g = 16384;
+    if (dgrad)
+        hipLaunchKernelGGL(filter_tiles_b16_kernel<true>, dim3((unsigned)g), dim3(256), 0, as_stream(stream_), w,
+                           reinterpret_cast<uint4 *>(tiles), d->Cin, d->Cout, kdim, taps, rows_pad);
+    else
+        hipLaunchKernelGGL(filter_tiles_b16_kernel<false>, dim3((unsigned)g), dim3(256), 0, as_stream(stream_), w,
+                           reinterpret_cast<uint4 *>(tiles), d->Cin, d->Cout, kdim, taps, rows_pad);
+    return launch_status();
+}
+
+size_t emadapt_conv_bf16t_workspace_bytes(const emadapt_conv_desc *d, int kind) {
+    if (kind < 0 || kind > 1 || !bt_ok(d, kind == 1, 0) || d->B == 0) return 0;
+    IgemmArgs a;
+    fill_b16t(a, d, kind == 1);
+    return bt_workspace_bytes(a);
+}
+
+int emadapt_conv_bf16t_plan(const emadapt_conv_desc *d, int kind, int plan[4]) {
+    if (!plan || kind < 0 || kind > 1) return EMADAPT_ERR_INVALID;
+    if (!bt_ok(d, kind == 1, 0)) return EMADAPT_ERR_UNSUPPORTED;
+    IgemmArgs a;
+    fill_b16t(a, d, kind == 1);
+    const PlanBT p = plan_b16t(a);
+    plan[0] = p.main_rows; plan[1] = p.main_sk; plan[2] = p.main_levels; plan[3] = p.tail_levels;
+    return EMADAPT_OK;
+}
+
+int emadapt_conv_fwd_bf16t(const emadapt_conv_desc *d, const void *x_bf16, const void *w_tiles, const float *bias, void *y,
+                           int y_dtype, int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed,
+                           void *workspace, size_t workspace_bytes, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!x_bf16 || !w_tiles || !y || (y_dtype & ~1)) return EMADAPT_ERR_INVALID;
+    if (epilogue < EMADAPT_EPI_NONE || epilogue > EMADAPT_EPI_BIAS_RELU) return EMADAPT_ERR_INVALID;
+    if (epilogue != EMADAPT_EPI_NONE && !bias) return EMADAPT_ERR_INVALID;
+    if (!(keep_prob > 0.f) || keep_prob > 1.f) return EMADAPT_ERR_INVALID;
+    if (keep_prob < 1.f && epilogue != EMADAPT_EPI_BIAS_RELU) return EMADAPT_ERR_INVALID;
+    if (!aligned16(x_bf16) || !aligned16(w_tiles) || !aligned16(y) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
+    if (!bt_ok(d, false, y_dtype)) return EMADAPT_ERR_UNSUPPORTED;
+    if (d->B == 0) return EMADAPT_OK;
+    IgemmArgs a;
+    fill_b16t(a, d, false);
+    a.x = static_cast<const float *>(x_bf16); a.w = static_cast<const float *>(w_tiles); a.y = static_cast<float *>(y);
+    a.bias = bias; a.gate = nullptr; a.mask = drop_mask;
+    a.epi = epilogue; a.scale = 1.f; set_keep(a, keep_prob); a.seed = drop_seed;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_IGEMM_FWD, 2.0 * a.M * (double)a.K * a.N,
+                   2.0 * ((double)a.M * a.Cx + (double)a.K * a.N) + (double)a.M * a.N * (y_dtype ? 2 : 4), stream);
+    return y_dtype ? dispatch_b16t<true>(a, workspace, workspace_bytes, stream) : dispatch_b16t<false>(a, workspace, workspace_bytes, stream);
+}
+
+int emadapt_conv_dgrad_bf16t(const emadapt_conv_desc *d, const void *dy_bf16, const void *w_tiles, void *dx, int dx_dtype,
+                             const void *gate, float gate_scale, void *workspace, size_t workspace_bytes, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!dy_bf16 || !w_tiles || !dx || (dx_dtype & ~1)) return EMADAPT_ERR_INVALID;
+    if (!aligned16(dy_bf16) || !aligned16(w_tiles) || !aligned16(dx) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
+    if (!bt_ok(d, true, dx_dtype)) return EMADAPT_ERR_UNSUPPORTED;
+    if (d->B == 0) return EMADAPT_OK;
+    IgemmArgs a;
+    fill_b16t(a, d, true);
+    a.x = static_cast<const float *>(dy_bf16); a.w = static_cast<const float *>(w_tiles); a.y = static_cast<float *>(dx);
+    a.bias = nullptr; a.gate = static_cast<const float *>(gate); a.mask = nullptr;
+    a.epi = EMADAPT_EPI_NONE; a.scale = gate_scale; set_keep(a, 1.f); a.seed = 0;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_IGEMM_DGRAD, 2.0 * a.M * (double)a.K * a.N,
+                   2.0 * ((double)a.M * a.Cx + (double)a.K * a.N) + (double)a.M * a.N * (dx_dtype ? 2 : 4) * (gate ? 2.0 : 1.0), stream);
+    return dx_dtype ? dispatch_b16t<true>(a, workspace, workspace_bytes, stream) : dispatch_b16t<false>(a, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,358 @@
+// bf16 forward / data-gradient kernel on LDS-DMA ("b16t": bf16 operands, Tiled filter image), included by conv_bf16.hip.
+//
+// Round 1-3's bf16 kernel (igemm_bf16_kernel) moves its operands global -> registers -> LDS with four producer waves beside
+// eight MFMA waves and sits at 43-55 % of the dense bf16 matrix rate: producers alone and consumers alone each need ~55 % of
+// the kernel's time and overlap by a fifth (profiles/r03_bf16_ablation.txt) -- the ds_write_b128 path (13 cycles of
+// VGPR -> LDS transfer per KB), the producers' issue slots and 192 registers of staging are all spent on bytes that need no
+// arithmetic.  This kernel is the plane-image kernel of the bf16x6 path (igemm_x6p.h) with ONE plane: a bf16 NHWC activation
+// already IS an image whose K-step slices are contiguous runs of a row, so the tiles land in LDS by LDS-DMA exactly as they lie
+// in memory and no wave issues a vector instruction per element.
+//
+//   * 256 x 256 x 32 tiles, ONE workgroup of 8 waves per CU, every wave a 64 x 128 accumulator block (TM = 2, TN = 4: 16 MFMAs
+//     32x32x16 per K step from 12 ds_read_b128) and 4 of the step's 32 DMA instructions; no loader waves.
+//   * LDS image of an operand's K step: [256 rows][64 B] dense (16 KB); ring of 4 stages x 2 operands = 128 KB, fetched 3 steps
+//     ahead.  (K steps of 64 -- 128-byte row pieces, a whole cache line -- allow only two 64 KB stages: round 2 measured that
+//     form at the mercy of the DMA latency.)  A DMA instruction moves 64 consecutive 16-byte slots = 16 rows.
+//   * bank conflicts: the 16 lanes of a ds_read_b128 group read one 16-byte column of 16 rows 64 bytes apart -- a quarter of the
+//     banks -- so slot s of row r holds the row's chunk s ^ ((r >> 2) & 3) (the DMA lanes fetch the chunks in that order, the
+//     fragment address applies the same XOR): the four row quads of a group land on four different slot columns.
+//   * the FILTER is stored tile by tile in exactly that LDS order (filter_tiles_b16_kernel, once per optimizer step):
+//         [tap][k / 32][row, zero rows up to a multiple of 256][4 slots of 16 B, swizzled]
+//     so a K step's 256 filter rows are 16 contiguous KB and the filter DMAs are plain 1 KB copies.
+//   * pipeline (k_step): two groups of 8 MFMAs per step (k 0..15, k 16..31).  The barrier sits between them; behind it the
+//     fragments of the NEXT step's first group are fetched into the registers the first group has just finished with, one read
+//     behind each MFMA of the second group, and the next step's second group is fetched behind the step's last MFMA (in flight
+//     while the next first group runs).  The four DMAs of step kt + 3 leave as one burst in front of the barrier, into the
+//     stage of step kt - 1 (free since the previous barrier).
+//   * work split: plain tiles (XCD-aware order, optional split-K into slab levels) or stream-K (SK: the K steps of all tiles cut
+//     into one piece per CU; partial tiles go to slab levels and streamk_fixup_t_kernel adds them in workgroup order).
+// Requirements: activations stored bf16 (x_dtype = EMADAPT_DT_BF16), Cx % 32 == 0, KH*KW <= 32, N % 8 == 0 for bf16 outputs,
+// images below 2 GiB.
+#pragma once
+#include "igemm_v2.h"
+
+namespace {
+
+typedef __bf16 bt_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BT_BK = 32;
+constexpr int BT_ROWB = 2 * BT_BK;             // bytes of one row's K step, in memory and in LDS
+constexpr int BT_OPER = 256 * BT_ROWB;         // one operand's K step in LDS (16 KB)
+constexpr int BT_STAGE = 2 * BT_OPER;          // A + B
+constexpr int BT_NBUF = 4;
+constexpr int BT_WAVES = 8;
+constexpr int BT_IPW = BT_OPER / 1024 / BT_WAVES;   // DMA instructions per wave, operand and K step (2)
+constexpr size_t BT_LDS = (size_t)BT_NBUF * BT_STAGE;
+
+// ------------------------------------------------------------------------------------------------------------------
+// Tiled bf16 image of a filter: [tap][k / 32][row (zero rows up to a multiple of 256)][4 slots], slot s of row r = the row's
+// k chunk s ^ ((r >> 2) & 3) (8 bf16 each).  DGRAD = false: rows = Cout, k = Cin (forward); true: rows = Cin, k = Cout (data
+// gradient; k beyond the real channel count reads zero).  One thread = one 16-byte slot.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool DGRAD>
+__global__ void __launch_bounds__(256) filter_tiles_b16_kernel(const float *__restrict__ w, uint4 *__restrict__ out, int Cin, int Cout,
+                                                               int kpad, int taps, int rows_pad) {
+    const int rows = DGRAD ? Cin : Cout, kdim = DGRAD ? Cout : Cin;
+    const int G = kpad / BT_BK;
+    const long long total = (long long)taps * G * rows_pad * 4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int slot = (int)(idx & 3);
+        long long t = idx >> 2;
+        const int row = (int)(t % rows_pad);
+        t /= rows_pad;
+        const int g = (int)(t % G), tap = (int)(t / G);
+        const int chunk = slot ^ ((row >> 2) & 3);
+        bt_bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int k = g * BT_BK + chunk * 8 + e;
+            const float f = (row < rows && k < kdim) ? (DGRAD ? w[((long long)tap * Cin + row) * Cout + k] : w[((long long)tap * Cin + k) * Cout + row]) : 0.f;
+            v[e] = (__bf16)f;
+        }
+        out[idx] = *reinterpret_cast<uint4 *>(&v);
+    }
+}
+
+// Stream-K second stage for bf16-storage outputs (igemm_v2.h's streamk_fixup_kernel is the f32 one): the tiles that more than one
+// workgroup worked on.  One block = 16 rows of one 256 x 256 tile.
+template <bool YBF>
+__global__ void __launch_bounds__(256) streamk_fixup_t_kernel(IgemmArgs a, int G, int nk_all) {
+    const int t = blockIdx.x >> 4, part = blockIdx.x & 15;
+    const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
+    const long long U = (long long)a.tiles_m * a.tiles_n * nk_all, u0 = (long long)t * nk_all;
+    const int vf = sk_owner(u0, U, G), vl = sk_owner(u0 + nk_all - 1, U, G);
+    const int cnt = vl - vf + 1;
+    if (cnt <= 1) return;
+    const long long mn = (long long)(a.m_end - a.m_begin) * a.N;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int idx = it * 256 + threadIdx.x;
+        const int r = part * 16 + (idx >> 6);
+        const int row = a.m_begin + tile_m * 256 + r;
+        const int col = tile_n * 256 + (idx & 63) * 4;
+        if (row >= a.m_end || col >= a.N) continue;
+        const long long o = (long long)row * a.N + col;
+        const float *sp = a.slab + (o - (long long)a.m_begin * a.N);
+        float4 v = *reinterpret_cast<const float4 *>(sp);
+        for (int l = 1; l < cnt; l++) {
+            const float4 u = *reinterpret_cast<const float4 *>(sp + l * mn);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        v.x = epilogue_t<YBF>(a, v.x, col + 0, o + 0);
+        v.y = epilogue_t<YBF>(a, v.y, col + 1, o + 1);
+        v.z = epilogue_t<YBF>(a, v.z, col + 2, o + 2);
+        v.w = epilogue_t<YBF>(a, v.w, col + 3, o + 3);
+        if constexpr (YBF) *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(a.y) + o) = cvt4(v);
+        else *reinterpret_cast<float4 *>(a.y + o) = v;
+    }
+}
+
+template <bool SK, bool YBF>
+__global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs a) {
+    constexpr int BM = 256, BN = 256, BK = BT_BK, NBUF = BT_NBUF, TM = 2, TN = 4;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+
+    // ---- work of this workgroup: one (tile, K range) piece, or with SK a sequence of them
+    const int nk_all = a.K / BK;
+    int tile_m = 0, tile_n = 0, kt0 = 0, nk = 0;
+    int lvl = -1;
+    int sk_u = 0, sk_end = 0, sk_units = 0, sk_v = 0;
+    {
+        const int ntile = a.tiles_m * a.tiles_n;
+        const int nblk = SK ? (int)gridDim.x : ntile * a.splits;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if constexpr (SK) {
+            sk_v = t;
+            sk_units = ntile * nk_all;
+            sk_u = __builtin_amdgcn_readfirstlane((int)sk_start(t, sk_units, nblk));
+            sk_end = __builtin_amdgcn_readfirstlane((int)sk_start(t + 1, sk_units, nblk));
+        } else {
+            const int split = t / ntile;
+            t -= split * ntile;
+            constexpr int GM = 8;
+            const int per_group = GM * a.tiles_n;
+            const int g = t / per_group;
+            const int first_m = g * GM;
+            const int gsz = (a.tiles_m - first_m < GM) ? (a.tiles_m - first_m) : GM;
+            const int in_g = t - g * per_group;
+            tile_m = first_m + in_g % gsz;
+            tile_n = in_g / gsz;
+            kt0 = (int)((long long)nk_all * split / a.splits);
+            nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
+            lvl = a.splits > 1 ? split : -1;
+        }
+    }
+    auto next_piece = [&]() -> bool {
+        if (sk_u >= sk_end) return false;
+        const int t = __builtin_amdgcn_readfirstlane(sk_u / nk_all);
+        kt0 = sk_u - t * nk_all;
+        tile_m = __builtin_amdgcn_readfirstlane(t / a.tiles_n);
+        tile_n = t - tile_m * a.tiles_n;
+        const int left = sk_end - sk_u;
+        nk = (nk_all - kt0 < left) ? nk_all - kt0 : left;
+        lvl = nk == nk_all ? -1 : sk_v - __builtin_amdgcn_readfirstlane(sk_owner((long long)(sk_u - kt0), sk_units, (int)gridDim.x));
+        sk_u += nk;
+        return true;
+    };
+    if constexpr (SK) {
+        if (!next_piece()) return;
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+
+    // ---- loader side: constants of the launch
+    // (the tap offset rides in the DMA's scalar operand, an UNSIGNED addend: the buffer starts `bias` bytes before the tensor)
+    const int rowb = a.Cx * 2;             // bytes of a pixel
+    const int n_pad = a.tiles_n * 256;     // filter rows per (tap, group of 32 k) in the tiled filter image
+    const int cgroups = a.Cx / BK;
+    int min_dh = a.sign * (0 - a.pad_h), min_dw = a.sign * (0 - a.pad_w);
+    {
+        const int KH = a.ntaps / a.KW;
+        const int dh1 = a.sign * ((KH - 1) * a.dil - a.pad_h), dw1 = a.sign * ((a.KW - 1) * a.dil - a.pad_w);
+        min_dh = dh1 < min_dh ? dh1 : min_dh;
+        min_dw = dw1 < min_dw ? dw1 : min_dw;
+    }
+    const int min_sp = min_dh * a.W + min_dw;
+    const unsigned bias = min_sp < 0 ? (unsigned)(-min_sp) * (unsigned)rowb : 0u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(a.x)) - bias, 0, (int)(a.x_bytes + bias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    constexpr unsigned kOOB = 0x80000000u;
+    // instruction j of this wave moves slots [(wave * IPW + j) * 64, +64) of an operand's image: lane -> (row, slot)
+    int ld_row[BT_IPW], ld_chunk[BT_IPW];
+#pragma unroll
+    for (int j = 0; j < BT_IPW; j++) {
+        const int q = (wave * BT_IPW + j) * 64 + lane;
+        ld_row[j] = q >> 2;
+        ld_chunk[j] = (q & 3) ^ ((ld_row[j] >> 2) & 3);
+    }
+
+    // ---- consumer side: fragment addresses (bytes inside a stage).  Lane (l31, lh) reads k 8 lh .. 8 lh + 7 of group g from
+    // row l31: chunk 2 g + lh, stored at slot (2 g + lh) ^ ((l31 >> 2) & 3); the wave's next 32 rows are 2048 bytes on
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int sw = (l31 >> 2) & 3;
+    int a_frag[2], b_frag[2];
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        a_frag[g] = (wm * 64 + l31) * BT_ROWB + (((2 * g + lh) ^ sw) << 4);
+        b_frag[g] = BT_OPER + (wn * 128 + l31) * BT_ROWB + (((2 * g + lh) ^ sw) << 4);
+    }
+    f32x16 acc[TM][TN];
+    bt_bf16x8 av[2][TM], bv[2][TN];
+
+    do {   // one piece of work (SK: several)
+    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
+    unsigned a_off[BT_IPW], a_bad[BT_IPW], b_off[BT_IPW];
+#pragma unroll
+    for (int j = 0; j < BT_IPW; j++) {
+        const int r = ld_row[j];
+        const int m = m0 + r < a.m_end ? m0 + r : -1;
+        if (m >= 0) {
+            const int t2 = m / a.W;
+            const int oh = t2 % a.H, ow = m - t2 * a.W;
+            a_off[j] = (unsigned)m * (unsigned)rowb + (unsigned)ld_chunk[j] * 16u;
+            unsigned rowbad = 0, colbad = 0;
+            const int KH = a.ntaps / a.KW;
+            for (int kh = 0; kh < KH; kh++) {
+                const int ih = oh + a.sign * (kh * a.dil - a.pad_h);
+                rowbad |= ((unsigned)ih < (unsigned)a.H ? 0u : 1u) << kh;
+            }
+            for (int kw = 0; kw < a.KW; kw++) {
+                const int iw = ow + a.sign * (kw * a.dil - a.pad_w);
+                colbad |= ((unsigned)iw < (unsigned)a.W ? 0u : 1u) << kw;
+            }
+            unsigned bad = 0;
+            const unsigned full = a.KW >= 32 ? 0xFFFFFFFFu : ((1u << a.KW) - 1u);
+            for (int kh = 0; kh < KH; kh++) bad |= (((rowbad >> kh) & 1u) ? full : colbad) << (kh * a.KW);
+            a_bad[j] = bad;
+        } else {
+            a_off[j] = 0;
+            a_bad[j] = 0xFFFFFFFFu;
+        }
+        b_off[j] = (unsigned)((wave * BT_IPW + j) * 64 + lane) * 16u;   // the filter image is stored in LDS order: plain copies
+    }
+
+    // DMAs of K step kt (of this piece's tile) into the ring buffer at byte offset `off`: this wave's 2 KB of each operand.
+    // K order = (channel group, tap).  A step past the end of the piece (live = false) carries the out-of-range bit on every
+    // lane and deposits zeros: every step issues the same four instructions, so the vmcnt bookkeeping is a constant.
+    auto fill = [&](int off, int kt, bool live) {
+        const unsigned chunk = __umulhi((unsigned)kt, a.magic_nt);
+        const unsigned tap = a.ntaps > 1 ? (unsigned)kt - chunk * (unsigned)a.ntaps : 0u;
+        const unsigned chunk_u = a.ntaps > 1 ? chunk : (unsigned)kt;
+        const unsigned kh = div_magic(tap, a.magic_kw);
+        const int kw = (int)(tap - kh * (unsigned)a.KW);
+        const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
+        const int dw = a.sign * (kw * a.dil - a.pad_w);
+        const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + chunk_u * (unsigned)BT_ROWB + bias));
+        const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(((tap * (unsigned)cgroups + chunk_u) * (unsigned)n_pad + (unsigned)n0) * (unsigned)BT_ROWB));
+        const unsigned sh = 31u - (tap & 31u);   // moves this tap's "outside the image" bit to bit 31
+        const unsigned dead = live ? 0u : kOOB;
+        char *as = ldsb + off + wave * (BT_IPW * 1024);
+#pragma unroll
+        for (int j = 0; j < BT_IPW; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t *)(as + j * 1024), 16, (int)(a_off[j] | ((a_bad[j] << sh) & kOOB) | dead), (int)s_x, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BT_IPW; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_t *)(as + BT_OPER + j * 1024), 16, (int)(b_off[j] | dead), (int)s_w, 0, 0);
+    };
+#define BT_SB __builtin_amdgcn_sched_barrier(0);
+#define BT_RA(G, I, BASE) av[G][I] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BASE) + a_frag[G] + (I) * (32 * BT_ROWB)); BT_SB
+#define BT_RB(G, J, BASE) bv[G][J] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BASE) + b_frag[G] + (J) * (32 * BT_ROWB)); BT_SB
+#define BT_MF(G, I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[G][I], bv[G][J], acc[I][J], 0, 0, 0); BT_SB
+    //   NX / PV = byte offsets of the ring buffers of steps kt + 1 and kt - 1 (= kt + 3)
+    auto k_step = [&](int NX, int PV, int kt) {
+        BT_SB
+        BT_MF(0, 0, 0) BT_MF(0, 0, 1) BT_MF(0, 0, 2) BT_MF(0, 0, 3) BT_MF(0, 1, 0) BT_MF(0, 1, 1) BT_MF(0, 1, 2) BT_MF(0, 1, 3)
+        fill(PV, kt0 + kt + 3, kt + 3 < nk);
+        BT_SB
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of this step has arrived
+        wait_vmcnt<2 * 2 * BT_IPW>();                          // this wave's DMAs of step kt + 1 have landed (kt + 2, kt + 3 in flight)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        BT_SB
+        BT_MF(1, 0, 0) BT_RA(0, 0, NX) BT_MF(1, 0, 1) BT_RA(0, 1, NX) BT_MF(1, 0, 2) BT_RB(0, 0, NX) BT_MF(1, 0, 3) BT_RB(0, 1, NX)
+        BT_MF(1, 1, 0) BT_RB(0, 2, NX) BT_MF(1, 1, 1) BT_RB(0, 3, NX) BT_MF(1, 1, 2) BT_MF(1, 1, 3)
+        BT_RB(1, 0, NX) BT_RB(1, 1, NX) BT_RB(1, 2, NX) BT_RB(1, 3, NX) BT_RA(1, 0, NX) BT_RA(1, 1, NX)
+    };
+
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    __syncthreads();   // the ring is free (SK: the previous piece's epilogue staged through it)
+    fill(0, kt0, true);
+    fill(BT_STAGE, kt0 + 1, 1 < nk);
+    fill(2 * BT_STAGE, kt0 + 2, 2 < nk);
+    wait_vmcnt<2 * 2 * BT_IPW>();
+    __builtin_amdgcn_s_barrier();   // step 0 has landed
+    asm volatile("" ::: "memory");
+    BT_RA(0, 0, 0) BT_RA(0, 1, 0) BT_RB(0, 0, 0) BT_RB(0, 1, 0) BT_RB(0, 2, 0) BT_RB(0, 3, 0)
+    BT_RB(1, 0, 0) BT_RB(1, 1, 0) BT_RB(1, 2, 0) BT_RB(1, 3, 0) BT_RA(1, 0, 0) BT_RA(1, 1, 0)
+    {
+        int u_off = 0, pv = (NBUF - 1) * BT_STAGE;
+        for (int kt = 0; kt < nk; kt++) {
+            const int nx = u_off == (NBUF - 1) * BT_STAGE ? 0 : u_off + BT_STAGE;
+            k_step(nx, pv, kt);
+            pv = u_off;
+            u_off = nx;
+        }
+    }
+    // the zero-depositing DMAs of the last steps are still in flight, and so may be the last fetches: drain both before
+    // the ring becomes the epilogue's staging area
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vmcnt<0>();
+    __syncthreads();
+#undef BT_SB
+#undef BT_RA
+#undef BT_RB
+#undef BT_MF
+
+    float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+    int lane_e = tid & 63;
+    asm volatile("" : "+v"(lane_e));
+    float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (128 + 4));
+    static_assert(BT_WAVES * 16 * (128 + 4) * 4 <= BT_LDS, "epilogue slabs must fit in the ring");
+    store_acc_tile<TM, TN, 16, YBF>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+    } while (SK && next_piece());
+}
+
+// a.splits: SK = false -> split-K factor (>= 1; > 1 needs a.slab); SK = true -> number of workgroups (CUs), a.slab for the levels
+template <bool SK, bool YBF>
+int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
+    static DynLdsAttr attr;
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16t_kernel<SK, YBF>), BT_LDS);
+    if (rc) return rc;
+    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, 256);
+    a.tiles_n = (int)ceil_div(a.N, 256);
+    const int nk_all = a.K / BT_BK;
+    const long long tiles = (long long)a.tiles_m * a.tiles_n;
+    if constexpr (SK) {
+        if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * 16 > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        const int G = streamk_grid(tiles, nk_all, a.splits);
+        const int levels = streamk_levels(tiles, nk_all, a.splits);
+        if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
+        hipLaunchKernelGGL((igemm_b16t_kernel<true, YBF>), dim3((unsigned)G), dim3(BT_WAVES * 64), BT_LDS, stream, a);
+        rc = launch_status();
+        if (rc || levels == 0) return rc;
+        hipLaunchKernelGGL(streamk_fixup_t_kernel<YBF>, dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, a, G, nk_all);
+        return launch_status();
+    } else {
+        const long long nblk = tiles * a.splits;
+        if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF>), dim3((unsigned)nblk), dim3(BT_WAVES * 64), BT_LDS, stream, a);
+        rc = launch_status();
+        if (rc || a.splits <= 1) return rc;
+        long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(splitk_epilogue_t_kernel<YBF>, dim3((unsigned)g), dim3(256), 0, stream, a);
+        return launch_status();
+    }
+}
+
+}  // namespace

@@ -211,6 +211,75 @@ def conv_wgrad_bf16(x, dy, KH, KW, dil=1, out=None):
     return dw
 
 
+# ---- bf16 forward / data gradient on LDS-DMA with a tiled filter image (include/emadapt.h "bf16 ... on LDS-DMA")
+def conv_bf16t_supported(d, kind, out_bf16=True):
+    return bool(_lib.load().emadapt_conv_bf16t_supported(ctypes.byref(d), {"fwd": 0, "dgrad": 1}[kind], 1 if out_bf16 else 0))
+
+
+def conv_bf16t_plan(B, H, W, Cin, Cout, k, dil=1, kind="fwd"):
+    """(rows of the first launch, 1 = stream-K, its slab levels, slab levels of the launch over the remaining rows / -1)."""
+    d = conv_desc(B, H, W, Cin, Cout, k, k, dil)
+    out = (ctypes.c_int * 4)()
+    _lib.call("emadapt_conv_bf16t_plan", ctypes.byref(d), {"fwd": 0, "dgrad": 1}[kind], out)
+    return tuple(out)
+
+
+def filter_tiles_bf16(w, dgrad=False, out=None):
+    """Tiled bf16 image of an f32 HWIO filter for conv_fwd_bf16t (dgrad=False) / conv_dgrad_bf16t (dgrad=True)."""
+    _check(w, name="w")
+    KH, KW, Cin, Cout = w.shape
+    d = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+    n = _lib.load().emadapt_filter_tiles_bf16_bytes(ctypes.byref(d), int(bool(dgrad)))
+    if n == 0:
+        raise ValueError("no tiled bf16 image for a filter with %d reduction channels (multiple of 32 needed)" % (Cout if dgrad else Cin))
+    t = out if out is not None else torch.empty(n // 2, dtype=torch.bfloat16, device=w.device)
+    _check(t, torch.bfloat16, "out")
+    if t.numel() * 2 != n:
+        raise ValueError("out has the wrong size")
+    _lib.call("emadapt_filter_tiles_bf16", ctypes.byref(d), _p(w), _p(t), int(bool(dgrad)), _stream())
+    return t
+
+
+def conv_fwd_bf16t(x, wt, ksize, Cout, bias=None, dil=1, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None,
+                   out_dtype=None):
+    """conv_fwd_bf16 on the LDS-DMA kernel: x stored bf16, wt = filter_tiles_bf16(w); output bf16 unless out / out_dtype say f32."""
+    _check(x, torch.bfloat16, "x"); _check(wt, torch.bfloat16, "wt"); _check(bias, name="bias"); _check(drop_mask, torch.uint8, "drop_mask")
+    B, H, W, Cin = x.shape
+    KH, KW = ksize
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    if wt.numel() * 2 != _lib.load().emadapt_filter_tiles_bf16_bytes(ctypes.byref(d), 0):
+        raise ValueError("tiled filter image does not match the convolution")
+    y = out if out is not None else torch.empty((B, H, W, Cout), dtype=out_dtype or torch.bfloat16, device=x.device)
+    ydt = _act(y, "out")
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    nbytes = _lib.load().emadapt_conv_bf16t_workspace_bytes(ctypes.byref(d), 0)
+    ws = _WS.get(nbytes, x.device) if nbytes else None
+    _lib.call("emadapt_conv_fwd_bf16t", ctypes.byref(d), _p(x), _p(wt), _p(bias), _p(y), ydt, epi, float(keep_prob), _p(drop_mask),
+              int(drop_seed) & 0xFFFFFFFFFFFFFFFF, _p(ws), ws.numel() if ws is not None else 0, _stream())
+    return y
+
+
+def conv_dgrad_bf16t(dy, wt, ksize, Cin, dil=1, gate=None, gate_scale=1.0, out=None, out_dtype=None):
+    """conv_dgrad_bf16 on the LDS-DMA kernel: dy stored bf16, wt = filter_tiles_bf16(w, dgrad=True); dx and the gate share a type."""
+    _check(dy, torch.bfloat16, "dy"); _check(wt, torch.bfloat16, "wt"); gdt = _act(gate, "gate")
+    B, H, W, Cout = dy.shape
+    KH, KW = ksize
+    d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
+    if wt.numel() * 2 != _lib.load().emadapt_filter_tiles_bf16_bytes(ctypes.byref(d), 1):
+        raise ValueError("tiled filter image does not match the convolution")
+    if out is None:
+        out_dtype = out_dtype or (gate.dtype if gate is not None else torch.bfloat16)
+    dx = out if out is not None else torch.empty((B, H, W, Cin), dtype=out_dtype, device=dy.device)
+    xdt = _act(dx, "out")
+    if gate is not None and gdt != xdt:
+        raise TypeError("gate and dx must have the same storage type")
+    nbytes = _lib.load().emadapt_conv_bf16t_workspace_bytes(ctypes.byref(d), 1)
+    ws = _WS.get(nbytes, dy.device) if nbytes else None
+    _lib.call("emadapt_conv_dgrad_bf16t", ctypes.byref(d), _p(dy), _p(wt), _p(dx), xdt, _p(gate), float(gate_scale),
+              _p(ws), ws.numel() if ws is not None else 0, _stream())
+    return dx
+
+
 # ---- fp32-grade GEMMs on the bf16 matrix pipe (include/emadapt.h "bf16x6"): all tensors f32
 def filter_kmajor(w, out=None):
     """k-contiguous f32 image [KH*KW, Cout, Cin] of the HWIO filter (what conv_fwd_x6 reads)."""

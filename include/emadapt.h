@@ -213,6 +213,27 @@ int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dty
  * plan[2] = split-K / split-M factor.  The parity tests assert through it that the benchmark shapes run the big tiles.  (ABI 200) */
 int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]);
 
+/* ---- bf16 forward / data gradient on LDS-DMA (round 4; csrc/igemm_b16t.h).  For bf16-STORED activations whose gathered channel
+ * count is a multiple of 32 (every layer from conv1_2 on; kind 0: Cin % 32 == 0, kind 1: Cout % 32 == 0) the operand tiles go
+ * global -> LDS by DMA, no producer wavefronts, with the filter pre-tiled in LDS order:
+ *     tiled image  [tap][k / 32][row, zero rows up to a multiple of 256][4 x 16 B, slot s of row r = k chunk s ^ ((r >> 2) & 3)]
+ *     dgrad = 0: rows = Cout, k = Cin;  dgrad = 1: rows = Cin, k = Cout     (emadapt_filter_tiles_bf16, once per optimizer step)
+ * Same arithmetic as emadapt_conv_fwd_bf16 / _dgrad_bf16 (bf16 operands rounded RNE, exact products, fp32 sums; the K order of
+ * the sum differs), same epilogues, bitwise reproducible.  y_dtype / dx_dtype: EMADAPT_DT_*; the gate has dx's storage type.
+ * emadapt_conv_bf16t_supported: 1 when the shape qualifies.  emadapt_conv_bf16t_plan: plan[0] rows of the first launch (whole
+ * rounds of 256 x 256 tiles on the CUs), [1] 1 = that launch is stream-K, [2] its slab levels, [3] slab levels of the stream-K
+ * launch over the remaining rows (-1: plain tiles; 0 with plan[0] == M: there is none).  (ABI 200) */
+int emadapt_conv_bf16t_supported(const emadapt_conv_desc *d, int kind, int y_dtype);
+size_t emadapt_filter_tiles_bf16_bytes(const emadapt_conv_desc *d, int dgrad);
+int emadapt_filter_tiles_bf16(const emadapt_conv_desc *d, const float *w, void *tiles, int dgrad, void *stream);
+size_t emadapt_conv_bf16t_workspace_bytes(const emadapt_conv_desc *d, int kind);
+int emadapt_conv_bf16t_plan(const emadapt_conv_desc *d, int kind, int plan[4]);
+int emadapt_conv_fwd_bf16t(const emadapt_conv_desc *d, const void *x_bf16, const void *w_tiles, const float *bias, void *y,
+                           int y_dtype, int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed,
+                           void *workspace, size_t workspace_bytes, void *stream);
+int emadapt_conv_dgrad_bf16t(const emadapt_conv_desc *d, const void *dy_bf16, const void *w_tiles, void *dx, int dx_dtype,
+                             const void *gate, float gate_scale, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- fp32-grade GEMMs on the bf16 matrix pipe ("bf16x6", opt-in).  Every fp32 operand is split exactly into
  * three bf16 pieces (x = p0 + p1 + p2: 8+8+8 mantissa bits) and each product is formed from the six piece pairs
  * that matter (the dropped ones are below 2^-25 of the product), accumulated in fp32 by
