@@ -107,7 +107,9 @@ __global__ void __launch_bounds__(256) streamk_fixup_t_kernel(IgemmArgs a, int G
     }
 }
 
-template <bool SK, bool YBF>
+// ABLM (diagnostic library only, tune "ablate"): parts of the K loop COMPILED out -- 1 no DMAs, 2 no fragment reads, 4 no waits /
+// barrier, 8 no MFMAs, 16 no barrier (waits stay); results are garbage, scripts/bf16t_ablate.py reads the time.
+template <bool SK, bool YBF, int ABLM = 0>
 __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs a) {
     constexpr int BM = 256, BN = 256, BK = BT_BK, NBUF = BT_NBUF, TM = 2, TN = 4;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
@@ -163,6 +165,7 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
+    const bool late = wave >= 4;   // (the SIMD partner of wave w is wave w + 4)
 
     // ---- loader side: constants of the launch
     // (the tap offset rides in the DMA's scalar operand, an UNSIGNED addend: the buffer starts `bias` bytes before the tensor)
@@ -252,6 +255,7 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
         const unsigned sh = 31u - (tap & 31u);   // moves this tap's "outside the image" bit to bit 31
         const unsigned dead = live ? 0u : kOOB;
         char *as = ldsb + off + wave * (BT_IPW * 1024);
+        if constexpr (ABLM & 1) return;
 #pragma unroll
         for (int j = 0; j < BT_IPW; j++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t *)(as + j * 1024), 16, (int)(a_off[j] | ((a_bad[j] << sh) & kOOB) | dead), (int)s_x, 0, 0);
@@ -260,19 +264,28 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_t *)(as + BT_OPER + j * 1024), 16, (int)(b_off[j] | dead), (int)s_w, 0, 0);
     };
 #define BT_SB __builtin_amdgcn_sched_barrier(0);
-#define BT_RA(G, I, BASE) av[G][I] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BASE) + a_frag[G] + (I) * (32 * BT_ROWB)); BT_SB
-#define BT_RB(G, J, BASE) bv[G][J] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BASE) + b_frag[G] + (J) * (32 * BT_ROWB)); BT_SB
-#define BT_MF(G, I, J) acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[G][I], bv[G][J], acc[I][J], 0, 0, 0); BT_SB
+#define BT_RA0(G, I, BASE) av[G][I] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BASE) + a_frag[G] + (I) * (32 * BT_ROWB)); BT_SB
+#define BT_RB0(G, J, BASE) bv[G][J] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BASE) + b_frag[G] + (J) * (32 * BT_ROWB)); BT_SB
+#define BT_RA(G, I, BASE) if constexpr (!(ABLM & 2)) { BT_RA0(G, I, BASE) }
+#define BT_RB(G, J, BASE) if constexpr (!(ABLM & 2)) { BT_RB0(G, J, BASE) }
+#define BT_MF(G, I, J) if constexpr (!(ABLM & 8)) { acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[G][I], bv[G][J], acc[I][J], 0, 0, 0); BT_SB }
     //   NX / PV = byte offsets of the ring buffers of steps kt + 1 and kt - 1 (= kt + 3)
     auto k_step = [&](int NX, int PV, int kt) {
         BT_SB
         BT_MF(0, 0, 0) BT_MF(0, 0, 1) BT_MF(0, 0, 2) BT_MF(0, 0, 3) BT_MF(0, 1, 0) BT_MF(0, 1, 1) BT_MF(0, 1, 2) BT_MF(0, 1, 3)
-        fill(PV, kt0 + kt + 3, kt + 3 < nk);
+        // The two waves of a SIMD (w and w + 4) run the same program between the same barriers; issued at the same point, their
+        // DMA bursts (~100 cycles of address-unit wait per instruction) would idle the SIMD's matrix pipe together.  Waves 0-3
+        // issue theirs in FRONT of the barrier, waves 4-7 BEHIND it: each half's burst runs beside the other half's 16 MFMAs.
+        if (!late) fill(PV, kt0 + kt + 3, kt + 3 < nk);
         BT_SB
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of this step has arrived
-        wait_vmcnt<2 * 2 * BT_IPW>();                          // this wave's DMAs of step kt + 1 have landed (kt + 2, kt + 3 in flight)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if constexpr (!(ABLM & 4)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of this step has arrived
+            // this wave's DMAs of step kt + 1 have landed (in flight: kt + 2 and, for waves 0-3, kt + 3)
+            if (late) wait_vmcnt<2 * BT_IPW>(); else wait_vmcnt<2 * 2 * BT_IPW>();
+            if constexpr (!(ABLM & 16)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if (late) fill(PV, kt0 + kt + 3, kt + 3 < nk);
         BT_SB
         BT_MF(1, 0, 0) BT_RA(0, 0, NX) BT_MF(1, 0, 1) BT_RA(0, 1, NX) BT_MF(1, 0, 2) BT_RB(0, 0, NX) BT_MF(1, 0, 3) BT_RB(0, 1, NX)
         BT_MF(1, 1, 0) BT_RB(0, 2, NX) BT_MF(1, 1, 1) BT_RB(0, 3, NX) BT_MF(1, 1, 2) BT_MF(1, 1, 3)
@@ -292,8 +305,8 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
     wait_vmcnt<2 * 2 * BT_IPW>();
     __builtin_amdgcn_s_barrier();   // step 0 has landed
     asm volatile("" ::: "memory");
-    BT_RA(0, 0, 0) BT_RA(0, 1, 0) BT_RB(0, 0, 0) BT_RB(0, 1, 0) BT_RB(0, 2, 0) BT_RB(0, 3, 0)
-    BT_RB(1, 0, 0) BT_RB(1, 1, 0) BT_RB(1, 2, 0) BT_RB(1, 3, 0) BT_RA(1, 0, 0) BT_RA(1, 1, 0)
+    BT_RA0(0, 0, 0) BT_RA0(0, 1, 0) BT_RB0(0, 0, 0) BT_RB0(0, 1, 0) BT_RB0(0, 2, 0) BT_RB0(0, 3, 0)
+    BT_RB0(1, 0, 0) BT_RB0(1, 1, 0) BT_RB0(1, 2, 0) BT_RB0(1, 3, 0) BT_RA0(1, 0, 0) BT_RA0(1, 1, 0)
     {
         int u_off = 0, pv = (NBUF - 1) * BT_STAGE;
         for (int kt = 0; kt < nk; kt++) {
@@ -311,6 +324,8 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
 #undef BT_SB
 #undef BT_RA
 #undef BT_RB
+#undef BT_RA0
+#undef BT_RB0
 #undef BT_MF
 
     float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
@@ -323,10 +338,21 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
 }
 
 // a.splits: SK = false -> split-K factor (>= 1; > 1 needs a.slab); SK = true -> number of workgroups (CUs), a.slab for the levels
-template <bool SK, bool YBF>
+template <bool SK, bool YBF, int ABLM = 0>
 int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
+#ifdef EMADAPT_ABLATE_BUILD
+    if constexpr (ABLM == 0 && YBF) {
+        switch (tune(TUNE_ABLATE)) {
+#define EMADAPT_ABL_CASE(m) case m: return launch_igemm_b16t<SK, YBF, m>(a, stream);
+            EMADAPT_ABL_CASE(1) EMADAPT_ABL_CASE(2) EMADAPT_ABL_CASE(3) EMADAPT_ABL_CASE(4) EMADAPT_ABL_CASE(7) EMADAPT_ABL_CASE(8)
+            EMADAPT_ABL_CASE(9) EMADAPT_ABL_CASE(10) EMADAPT_ABL_CASE(14) EMADAPT_ABL_CASE(16)
+#undef EMADAPT_ABL_CASE
+            default: break;
+        }
+    }
+#endif
     static DynLdsAttr attr;
-    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16t_kernel<SK, YBF>), BT_LDS);
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16t_kernel<SK, YBF, ABLM>), BT_LDS);
     if (rc) return rc;
     a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, 256);
     a.tiles_n = (int)ceil_div(a.N, 256);
@@ -337,7 +363,7 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
         const int G = streamk_grid(tiles, nk_all, a.splits);
         const int levels = streamk_levels(tiles, nk_all, a.splits);
         if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
-        hipLaunchKernelGGL((igemm_b16t_kernel<true, YBF>), dim3((unsigned)G), dim3(BT_WAVES * 64), BT_LDS, stream, a);
+        hipLaunchKernelGGL((igemm_b16t_kernel<true, YBF, ABLM>), dim3((unsigned)G), dim3(BT_WAVES * 64), BT_LDS, stream, a);
         rc = launch_status();
         if (rc || levels == 0) return rc;
         hipLaunchKernelGGL(streamk_fixup_t_kernel<YBF>, dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, a, G, nk_all);
@@ -345,7 +371,7 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
     } else {
         const long long nblk = tiles * a.splits;
         if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF>), dim3((unsigned)nblk), dim3(BT_WAVES * 64), BT_LDS, stream, a);
+        hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF, ABLM>), dim3((unsigned)nblk), dim3(BT_WAVES * 64), BT_LDS, stream, a);
         rc = launch_status();
         if (rc || a.splits <= 1) return rc;
         long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;

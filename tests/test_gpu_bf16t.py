@@ -1,0 +1,136 @@
+"""GPU parity of the LDS-DMA bf16 forward / data-gradient kernel (csrc/igemm_b16t.h; BASELINE configs[2] / [3] arithmetic: bf16
+operands, fp32 accumulation) through the C ABI: the tiled filter image bit for bit against a NumPy restatement of its layout, then
+forward (bias / ReLU / dropout mask) and data gradient (plain / gated) against the fp64 oracle evaluated on the same bf16-rounded
+operands (2e-5: only the fp32 summation order differs), bf16 outputs = the f32 outputs rounded once, every result repeatable bit
+for bit, in every launch layout -- plain tiles, stream-K with slab levels, whole rounds + stream-K tail -- forced onto small
+awkward shapes by shrinking `plan_cus`; and at the benchmark shapes against the round-1 bf16 kernel."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import em_adapt_tensorflow_amd.ops as ops
+    from oracle import deeplab_oracle as do
+    return ops, do, torch
+
+
+def _rel(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def _tiles_ref(w, dgrad):
+    """[tap][k / 32][rows padded to 256][4 slots x 8], slot s of row r = k chunk s ^ ((r >> 2) & 3); bf16 bit patterns."""
+    import torch
+    KH, KW, Cin, Cout = w.shape
+    wb = torch.tensor(w).bfloat16().view(torch.int16).numpy().reshape(KH * KW, Cin, Cout)
+    m = wb.transpose(0, 1, 2) if dgrad else wb.transpose(0, 2, 1)        # [tap][row][k]
+    taps, rows, kdim = m.shape
+    rp = -(-rows // 256) * 256
+    out = np.zeros((taps, kdim // 32, rp, 4, 8), np.int16)
+    for r in range(rows):
+        for s in range(4):
+            c = s ^ ((r >> 2) & 3)
+            out[:, :, r, s, :] = m[:, r, :].reshape(taps, kdim // 32, 4, 8)[:, :, c, :]
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 32, 40), (1, 1, 64, 264), (4, 4, 96, 8), (3, 3, 64, 32)])
+def test_tiled_filter_image_layout(env, shape):
+    ops, do, torch = env
+    rng = np.random.default_rng(sum(shape))
+    w = rng.normal(0, 1, shape).astype(np.float32)
+    wg = torch.tensor(w, device="cuda:0")
+    got = ops.filter_tiles_bf16(wg).view(torch.int16).cpu().numpy()
+    assert np.array_equal(got, _tiles_ref(w, False))
+    if shape[3] % 32 == 0:
+        got = ops.filter_tiles_bf16(wg, dgrad=True).view(torch.int16).cpu().numpy()
+        assert np.array_equal(got, _tiles_ref(w, True))
+
+
+# (B, H, W, Cin, Cout, k, dil), plan_cus: M / N tails, several taps and dilations, K of 1 .. 144 steps, Cout not a multiple of 32
+SMALL = [
+    ((1, 7, 9, 32, 8, 3, 1), 256),
+    ((2, 13, 11, 64, 40, 3, 2), 256),
+    ((2, 19, 17, 32, 264, 1, 1), 3),       # two N tiles; 3 "CUs": stream-K pieces across tiles
+    ((3, 21, 20, 96, 520, 3, 1), 4),       # 6 x 3 tiles on 4 CUs
+    ((1, 41, 41, 64, 1032, 1, 1), 2),      # N > 1024: whole rounds as plain tiles + a stream-K tail
+    ((2, 16, 16, 128, 256, 4, 4), 5),      # 4x4 rate 4 (fc6's filter), 16 taps
+    ((1, 25, 25, 32, 48, 3, 12), 256),     # rate 12 reaches far outside the map
+    ((2, 30, 18, 160, 288, 3, 1), 7),
+]
+
+
+@pytest.mark.parametrize("shape,cus", SMALL)
+def test_b16t_small_shapes_every_layout(env, shape, cus):
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    rng = np.random.default_rng(hash(shape) % (1 << 31))
+    x = torch.tensor(rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)).bfloat16()
+    w = torch.tensor(rng.normal(0, 0.2, (k, k, Cin, Cout)).astype(np.float32))
+    b = torch.tensor(rng.normal(0, 0.5, (Cout,)).astype(np.float32))
+    mask = torch.tensor((rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8))
+    xr = x.double().requires_grad_(True)
+    wr = w.bfloat16().double()
+    y = do.conv_same(xr, wr, b.double(), dil)
+    xg, wg, bg, mg = x.cuda(), w.cuda(), b.cuda(), mask.cuda()
+    wt = ops.filter_tiles_bf16(wg)
+    with ops.tuned(plan_cus=cus):
+        plan = ops.conv_bf16t_plan(B, H, W, Cin, Cout, k, dil)
+        got = ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=False, out_dtype=torch.float32)
+        assert _rel(got.cpu(), y.detach()) < 2e-5, plan
+        assert torch.equal(got, ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=False, out_dtype=torch.float32)), plan
+        assert _rel(ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, None, dil, out_dtype=torch.float32).cpu(), (y - b.double()).detach()) < 2e-5
+        want = torch.relu(y.detach()) * 2.0 * mask.double()
+        got = ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg, out_dtype=torch.float32)
+        assert _rel(got.cpu(), want) < 2e-5, plan
+        if Cout % 8 == 0:
+            assert torch.equal(ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg), got.bfloat16())
+        # same sums as the round-1 kernel up to the order of the K steps
+        wf, _ = ops.weights_to_bf16(wg, want_dgrad=False)
+        old = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=True, keep_prob=0.5, drop_mask=mg)
+        assert _rel(got.cpu(), old.cpu()) < 2e-5
+    if Cout % 32 == 0:                       # data gradient: the roles of Cin / Cout swap
+        dy = torch.tensor(rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)).bfloat16()
+        gate = torch.tensor(rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)).bfloat16()
+        y.backward(dy.double())
+        dyg, gg = dy.cuda(), gate.cuda()
+        wtd = ops.filter_tiles_bf16(wg, dgrad=True)
+        with ops.tuned(plan_cus=cus):
+            plan = ops.conv_bf16t_plan(B, H, W, Cin, Cout, k, dil, "dgrad")
+            got = ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, out_dtype=torch.float32)
+            assert _rel(got.cpu(), xr.grad) < 2e-5, plan
+            want = torch.where(gate.double() > 0, xr.grad * 2.0, torch.zeros((), dtype=torch.float64))
+            g32 = ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=gg.float(), gate_scale=2.0)
+            assert g32.dtype == torch.float32 and _rel(g32.cpu(), want) < 2e-5, plan
+            assert torch.equal(g32, ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=gg.float(), gate_scale=2.0))
+            assert torch.equal(ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=gg, gate_scale=2.0), g32.bfloat16())
+
+
+def test_b16t_layout_coverage_of_the_small_shapes(env):
+    """The forced layouts above really are the three kinds the benchmark uses."""
+    ops, do, torch = env
+    kinds = set()
+    for shape, cus in SMALL:
+        with ops.tuned(plan_cus=cus):
+            B, H, W, Cin, Cout, k, dil = shape
+            rows, sk, lv, tail = ops.conv_bf16t_plan(B, H, W, Cin, Cout, k, dil)
+            kinds.add("sk%d" % min(lv, 2) if sk else ("plain" if rows == B * H * W else "rounds+tail%d" % min(tail, 1)))
+    assert {"plain", "sk2"} <= kinds and any(k.startswith("rounds+tail") for k in kinds), kinds
+
+
+def test_unsupported_shapes_are_refused(env):
+    ops, do, torch = env
+    x = torch.zeros((1, 8, 8, 24), dtype=torch.bfloat16, device="cuda:0")
+    d = ops.conv_desc(1, 8, 8, 24, 32, 3, 3, 1)
+    assert not ops.conv_bf16t_supported(d, "fwd") and ops.conv_bf16t_supported(d, "dgrad")
+    with pytest.raises(ValueError):
+        ops.filter_tiles_bf16(torch.zeros((3, 3, 24, 32), device="cuda:0"))
+    with pytest.raises(TypeError):
+        ops.conv_fwd_bf16t(x.float(), torch.zeros(8, dtype=torch.bfloat16, device="cuda:0"), (3, 3), 32)
