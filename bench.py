@@ -81,6 +81,15 @@ def parse():
                          "the library) = each bucket as soon as it is complete.  E.g. conv2_2 holds everything back until the "
                          "~6.5 ms of many-small-workgroup kernels at the end of backward (dist.py); compare the two by "
                          "allreduce.exposed_ms_per_step and the step time on a multi-GPU node")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1: payload of the gradient exchange.  bf16 (configs[2] / [3]: the ~7 ms bf16 backward pass cannot "
+                         "hide 260 MB) halves the bytes on every link; contributions are rounded once, ACCUMULATED IN FP32 by the "
+                         "shard's owner, the sum rounded once; master weights / accumulators / Momentum stay fp32.  Implies "
+                         "--allreduce-algo direct")
+    ap.add_argument("--allreduce-algo", default="auto", choices=["auto", "allreduce", "direct"],
+                    help="N > 1: allreduce = one RCCL all-reduce per bucket (ring: one xGMI link's bandwidth per step); direct = "
+                         "reduce-scatter + all-gather as two all-to-all steps, every rank talking to all 7 peers at once, on a side "
+                         "stream (dist.py); auto = allreduce for fp32 payloads, direct for bf16")
     ap.add_argument("--launch-timeout", type=float, default=0.0,
                     help="N > 1 started without a launcher: seconds after which the workers are ended (0 = no limit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
@@ -317,7 +326,9 @@ def main():
     cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
            "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb,
-           "allreduce_release_at": None if args.release_at == "none" else args.release_at}
+           "allreduce_release_at": None if args.release_at == "none" else args.release_at, "grad_dtype": args.grad_dtype}
+    if args.allreduce_algo != "auto":
+        cfg["allreduce_algo"] = args.allreduce_algo
     for kv in filter(None, args.tune.split(",")):
         ops.tune_set(kv.split("=")[0], int(kv.split("=")[1]))
     data = SyntheticData(dict(cfg, seed=0, unique_batches=2))   # SyntheticData mixes the rank into its seed
@@ -492,6 +503,8 @@ def main():
                 "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""),
                 "ranks": gs_stats["world_size"],
                 "bytes_per_update": gs_stats["bytes_per_update"],
+                "algo": gs_stats["algo"], "grad_dtype": gs_stats["payload"],
+                "wire_bytes_per_rank_per_update": gs_stats["wire_bytes_per_update"],
                 "buckets": gs_stats["buckets"],
                 "bucket_mb": args.bucket_mb,
                 "release_at": args.release_at,

@@ -580,8 +580,12 @@ class ADAPT(Network):
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
                 (torch.distributed.get_world_size() > 1 or self.config.get("force_gradsync", False)):
             from .dist import GradSync
+            # config "allreduce_algo": "allreduce" (RCCL's own) | "direct" (reduce-scatter + all-gather as two all-to-all steps over
+            # all xGMI links, on a side stream); "grad_dtype": "fp32" | "bf16" payload (bf16 needs "direct"; dist.py)
+            grad_dtype = str(self.config.get("grad_dtype", "fp32"))
+            algo = str(self.config.get("allreduce_algo", "direct" if grad_dtype == "bf16" else "allreduce"))
             self._gradsync = GradSync(self._flat["accum"], [(s["start"], s["end"]) for s in self._bucket_order()],
-                                      bucket_bytes=int(self.config.get("bucket_mb", 32)) << 20)
+                                      bucket_bytes=int(self.config.get("bucket_mb", 32)) << 20, algo=algo, payload=grad_dtype)
 
     def _bucket_order(self):
         return [self._segments[op.name] for op in reversed(self._plan) if op.kind == "conv"]

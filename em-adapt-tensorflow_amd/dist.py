@@ -26,6 +26,23 @@ bench.py reports ``allreduce.exposed_ms_per_step`` for whichever is selected (``
 
 Timing is OFF by default (a long training run must not pile up HIP events); bench.py and the tests switch it on, and the
 record kept is bounded.
+
+Two exchange algorithms (round 4), both leaving the SUM over ranks in the fp32 accumulator, identical on every rank:
+
+* ``algo="allreduce"`` (default): one ``dist.all_reduce`` per fp32 bucket -- RCCL's ring / tree, whose per-step bandwidth is that
+  of ONE xGMI link (~153 GB/s per direction of the seven a GPU has).
+* ``algo="direct"``: reduce-scatter and all-gather written out as two all-to-all steps, so every rank talks to all its peers at
+  once, one xGMI link each ("Distributed communication backend"): rank j owns shard j of a bucket; (1)
+  ``all_to_all_single`` sends shard j of the local gradients to rank j; (2) rank j adds the W contributions IN FP32, IN RANK
+  ORDER (deterministic; each element is summed exactly once, by its owner, so all ranks end up with the same bits); (3)
+  ``all_gather_into_tensor`` returns the summed shards.  The work runs on a SIDE stream (comm + the cast / sum kernels), ordered
+  behind the point of the compute stream at which the bucket became final; ``wait()`` makes the compute stream wait for it.
+
+``payload="bf16"`` (``direct`` only; BASELINE configs[2] / [3], whose bf16 backward pass -- ~7 ms -- cannot hide 260 MB per
+update): both all-to-all steps carry bf16, halving the bytes on every link: the exchanged gradient is
+``bf16(sum_r fp32(bf16(g_r)))`` -- contributions rounded once (RNE), accumulated in fp32, the sum rounded once.  Master weights,
+the accumulator and Momentum stay fp32 (deeplab.py:202-205 semantics on a gradient with ~3 significant digits: the same precision
+class as the bf16 backward pass that produced it).
 """
 import collections
 
@@ -34,15 +51,26 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, flat, segments, bucket_bytes=64 << 20, group=None):
+    def __init__(self, flat, segments, bucket_bytes=64 << 20, group=None, algo="allreduce", payload="fp32"):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("torch.distributed is not initialised")
+        if algo not in ("allreduce", "direct") or payload not in ("fp32", "bf16"):
+            raise ValueError("algo must be 'allreduce' or 'direct', payload 'fp32' or 'bf16' (got %r, %r)" % (algo, payload))
+        if payload == "bf16" and algo != "direct":
+            raise ValueError("the bf16 gradient payload accumulates in fp32 on arrival: it needs algo='direct' (a ring all-reduce "
+                             "of bf16 would round the running sum at every hop)")
+        if not flat.dtype.is_floating_point or (payload == "bf16" and flat.dtype != torch.float32):
+            raise TypeError("the accumulator must be a floating-point buffer (fp32 for the bf16 payload)")
         self.flat = flat
         self.group = group
+        self.algo = algo
+        self.payload = payload
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.total = max(e for _, e in segments)
         per = max(int(bucket_bytes) // flat.element_size(), 1)
+        if algo == "direct":   # shards of equal size: bucket boundaries on multiples of the world size
+            per = max(per // self.world_size, 1) * self.world_size
         # bucket boundaries are multiples of `per`, clipped to the used extent of the flat buffer
         self.buckets = [(s, min(s + per, self.total)) for s in range(0, self.total, per)]
         self._next_bucket = 0
@@ -57,6 +85,51 @@ class GradSync:
         # per update: (backward-start, [launch events], wait-start, [after-bucket events]); the last `keep` updates only
         self._ev = collections.deque(maxlen=256)
         self._cur = None
+        # direct exchange: staging sized for the largest bucket (padded to whole shards), a side stream for CUDA tensors
+        self._side = None
+        self._side_used = False
+        if algo == "direct":
+            W = self.world_size
+            pdt = torch.bfloat16 if payload == "bf16" else flat.dtype   # ("fp32" = the accumulator's own type)
+            n = max(-(-(e - s) // W) * W for s, e in self.buckets)
+            self._send = torch.zeros(n, dtype=pdt, device=flat.device)
+            self._recv = torch.empty(n, dtype=pdt, device=flat.device)
+            self._shard = torch.empty(n // W, dtype=flat.dtype, device=flat.device)
+            self._shard_p = torch.empty(n // W, dtype=pdt, device=flat.device) if payload == "bf16" else self._shard
+            self._gath = torch.empty(n, dtype=pdt, device=flat.device)
+            if flat.is_cuda:
+                self._side = torch.cuda.Stream(device=flat.device)
+        self.wire_bytes_per_update = self._wire_bytes()
+
+    def _wire_bytes(self):
+        """Bytes one rank SENDS per update (what its xGMI links carry): ring all-reduce 2 (W-1)/W x payload; direct: two
+        all-to-all steps of (W-1)/W x payload each."""
+        W = self.world_size
+        el = 2 if self.payload == "bf16" else self.flat.element_size()
+        return int(2 * (W - 1) / W * self.total * el)
+
+    def _exchange_direct(self, s, e):
+        """flat[s:e] <- sum over ranks, by shard owners (see the module docstring).  Runs on the current stream."""
+        W = self.world_size
+        n = e - s
+        npad = -(-n // W) * W
+        sh = npad // W
+        send, recv, gath = self._send[:npad], self._recv[:npad], self._gath[:npad]
+        send[:n].copy_(self.flat[s:e])           # fp32 -> payload type (bf16: round to nearest even)
+        if npad > n:
+            send[n:].zero_()
+        dist.all_to_all_single(recv, send, group=self.group)
+        acc = self._shard[:sh]
+        acc.copy_(recv[:sh])                     # contribution of rank 0, then 1, 2, ... : fixed order, fp32 adds
+        for r in range(1, W):
+            acc.add_(recv[r * sh:(r + 1) * sh])
+        if self.payload == "bf16":
+            out = self._shard_p[:sh]
+            out.copy_(acc)                       # the sum, rounded once
+        else:
+            out = acc
+        dist.all_gather_into_tensor(gath, out, group=self.group)
+        self.flat[s:e].copy_(gath[:n])
 
     def _event(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -91,7 +164,16 @@ class GradSync:
             view = self.flat[s:e]
             if self.timing and self.trace:
                 self._cur["launch"].append(self._event())
-            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.algo == "direct":
+                if self._side is not None:   # behind the point at which this bucket became final, beside the rest of backward
+                    self._side.wait_stream(torch.cuda.current_stream(self.flat.device))
+                    with torch.cuda.stream(self._side):
+                        self._exchange_direct(s, e)
+                    self._side_used = True
+                else:
+                    self._exchange_direct(s, e)
+            else:
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.launched_bytes += view.numel() * view.element_size()
             self._next_bucket += 1
 
@@ -107,6 +189,9 @@ class GradSync:
             w.wait()   # the compute stream waits for the collective; the host does not block
             if self.timing and self.trace and self._cur is not None:
                 self._cur["done"].append(self._event())
+        if self._side_used:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._side)
+            self._side_used = False
         if self.timing and self._cur is not None:
             self._cur["wait1"] = self._event()
             self._ev.append(self._cur)
@@ -121,7 +206,8 @@ class GradSync:
         bucket count, and -- with `trace` on -- for the last update the offset of every bucket's launch from the start of
         the gradient exchange window and the stall observed when it was joined (ms)."""
         out = dict(updates=len(self._ev), world_size=self.world_size, buckets=len(self.buckets),
-                   bytes_per_update=self.total * self.flat.element_size(), exposed_ms=None, backward_window_ms=None)
+                   bytes_per_update=self.total * self.flat.element_size(), algo=self.algo, payload=self.payload,
+                   wire_bytes_per_update=self.wire_bytes_per_update, exposed_ms=None, backward_window_ms=None)
         if self._ev:
             torch.cuda.synchronize(self.flat.device)
             out["exposed_ms"] = sum(e["wait0"].elapsed_time(e["wait1"]) for e in self._ev) / len(self._ev)

@@ -133,3 +133,66 @@ def test_data_parallel_equals_global_batch(tmp_path):
     mp.spawn(_dp_equivalence_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     err = float(open(tmp_path / "err.txt").read())
     assert err < 1e-9, err
+
+
+def _direct_worker(rank, world, port, out_dir):
+    """algo="direct" (reduce-scatter + all-gather as two all-to-all steps, fp32 accumulation by the shard's owner, in rank order)
+    with the fp32 and the bf16 payload; bucket sizes that are not multiples of the world size (padding lanes)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from em_adapt_tensorflow_amd.dist import GradSync
+
+    segs = [(0, 1088), (1088, 1088 + 4163), (5251, 5251 + 321)]
+    total = segs[-1][1]
+    rng = np.random.default_rng(200 + rank)
+    mine = torch.tensor((rng.normal(0, 1, total) * np.exp(rng.normal(0, 3, total))).astype(np.float32))   # wide dynamic range
+    with pytest.raises(ValueError):
+        GradSync(mine.clone(), segs, algo="allreduce", payload="bf16")   # a bf16 ring would round the running sum at every hop
+    for payload in ("fp32", "bf16"):
+        flat = mine.clone()
+        gs = GradSync(flat, segs, bucket_bytes=2048 * 4, algo="direct", payload=payload)
+        assert all((e - s) % world == 0 for s, e in gs.buckets[:-1])
+        el = 2 if payload == "bf16" else 4
+        assert gs.wire_bytes_per_update == int(2 * (world - 1) / world * total * el)
+        gs.hold()
+        gs.segment_ready(*segs[0])
+        assert gs._next_bucket == 0
+        gs.release()
+        for s, e in segs[1:]:
+            gs.segment_ready(s, e)
+        gs.wait()
+        assert gs.launched_bytes == total * 4 and gs.stats()["payload"] == payload
+        np.save(os.path.join(out_dir, "%s_%d.npy" % (payload, rank)), flat.numpy())
+        flat.copy_(mine)                     # a second update re-uses the object and its staging buffers
+        for s, e in segs:
+            gs.segment_ready(s, e)
+        gs.wait()
+        assert np.array_equal(flat.numpy(), np.load(os.path.join(out_dir, "%s_%d.npy" % (payload, rank))))
+    np.save(os.path.join(out_dir, "mine%d.npy" % rank), mine.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_exchange_and_bf16_payload(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_direct_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mine = [torch.tensor(np.load(tmp_path / ("mine%d.npy" % r))) for r in range(world)]
+    # fp32 payload: contributions added in rank order, in fp32, by one owner -- every rank holds the same bits
+    want32 = mine[0].clone()
+    for m in mine[1:]:
+        want32 += m
+    # bf16 payload: bf16(sum_r fp32(bf16(g_r))), the sum in fp32 in rank order
+    acc = mine[0].bfloat16().float()
+    for m in mine[1:]:
+        acc += m.bfloat16().float()
+    want16 = acc.bfloat16().float()
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ("fp32_%d.npy" % r)), want32.numpy()), r
+        assert np.array_equal(np.load(tmp_path / ("bf16_%d.npy" % r)), want16.numpy()), r      # exact, hence identical on all ranks
+    # and the bf16 exchange equals the fp32 exchange to bf16 rounding: one rounding per contribution + one of the sum
+    bound = sum(m.abs() for m in mine) * 2.0 ** -8 + want32.abs() * 2.0 ** -8
+    assert bool(((want16 - want32).abs() <= bound).all())
+    assert float((want16 - want32).abs().max()) > 0            # (it IS a different number)
