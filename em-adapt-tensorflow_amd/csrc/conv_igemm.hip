@@ -749,6 +749,11 @@ double exec_fraction_fp32(const emadapt_conv_desc *d, int kind) {
 extern "C" {
 
 size_t emadapt_conv_fwd_workspace_bytes(const emadapt_conv_desc *d) {
+    if (d && d->B > 0 && check_desc(d) == EMADAPT_ERR_UNSUPPORTED && slice_batch(d, false) > 0) {   // batch-sliced launch: the largest slice
+        emadapt_conv_desc s = *d;
+        s.B = slice_batch(d, false);
+        return s.B < d->B ? emadapt_conv_fwd_workspace_bytes(&s) : 0;
+    }
     if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
     IgemmArgs a;
     fill_geometry(a, d, false);
@@ -756,6 +761,11 @@ size_t emadapt_conv_fwd_workspace_bytes(const emadapt_conv_desc *d) {
 }
 
 size_t emadapt_conv_dgrad_workspace_bytes(const emadapt_conv_desc *d) {
+    if (d && d->B > 0 && check_desc(d) == EMADAPT_ERR_UNSUPPORTED && slice_batch(d, false) > 0) {
+        emadapt_conv_desc s = *d;
+        s.B = slice_batch(d, false);
+        return s.B < d->B ? emadapt_conv_dgrad_workspace_bytes(&s) : 0;
+    }
     if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
     IgemmArgs a;
     fill_geometry(a, d, true);
@@ -786,6 +796,22 @@ int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w,
                      int epilogue, float keep_prob, const uint8_t *drop_mask, uint64_t drop_seed, void *workspace,
                      size_t workspace_bytes, void *stream_) {
     int rc = check_desc(d);
+    if (rc == EMADAPT_ERR_UNSUPPORTED && x && y) {   // a tensor of 2 GiB or more: slices of whole images (igemm_common.h slice_batch)
+        const int bs = slice_batch(d, false);
+        if (bs > 0 && bs < d->B) {
+            const long long hw = (long long)d->H * d->W;
+            for (int b0 = 0, s = 0; b0 < d->B; b0 += bs, s++) {
+                emadapt_conv_desc dd = *d;
+                dd.B = d->B - b0 < bs ? d->B - b0 : bs;
+                // (the built-in dropout stream is a function of (seed, element index in the launch): every slice draws from a seed of its own)
+                rc = emadapt_conv_fwd(&dd, x + b0 * hw * d->Cin, w, bias, y + b0 * hw * d->Cout, epilogue, keep_prob,
+                                      drop_mask ? drop_mask + b0 * hw * d->Cout : nullptr, drop_seed + 0x9E3779B97F4A7C15ULL * (uint64_t)s,
+                                      workspace, workspace_bytes, stream_);
+                if (rc) return rc;
+            }
+            return EMADAPT_OK;
+        }
+    }
     if (rc) return rc;
     if (!x || !w || !y) return EMADAPT_ERR_INVALID;
     if (epilogue < EMADAPT_EPI_NONE || epilogue > EMADAPT_EPI_BIAS_RELU) return EMADAPT_ERR_INVALID;
@@ -806,6 +832,20 @@ int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w,
 int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float *w, float *dx, const float *gate,
                        float gate_scale, void *workspace, size_t workspace_bytes, void *stream_) {
     int rc = check_desc(d);
+    if (rc == EMADAPT_ERR_UNSUPPORTED && dy && dx) {   // a tensor of 2 GiB or more: slices of whole images
+        const int bs = slice_batch(d, false);
+        if (bs > 0 && bs < d->B) {
+            const long long hw = (long long)d->H * d->W;
+            for (int b0 = 0; b0 < d->B; b0 += bs) {
+                emadapt_conv_desc dd = *d;
+                dd.B = d->B - b0 < bs ? d->B - b0 : bs;
+                rc = emadapt_conv_dgrad(&dd, dy + b0 * hw * d->Cout, w, dx + b0 * hw * d->Cin, gate ? gate + b0 * hw * d->Cin : nullptr,
+                                        gate_scale, workspace, workspace_bytes, stream_);
+                if (rc) return rc;
+            }
+            return EMADAPT_OK;
+        }
+    }
     if (rc) return rc;
     if (!dy || !w || !dx) return EMADAPT_ERR_INVALID;
     if (!aligned16(dy) || !aligned16(w) || !aligned16(dx) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;

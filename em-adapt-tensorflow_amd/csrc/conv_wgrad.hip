@@ -572,7 +572,33 @@ double exec_fraction_fp32_wgrad(const emadapt_conv_desc *d) {
 
 extern "C" {
 
+// Images per launch when the tensors are too large for one (igemm_common.h slice_batch, with this file's check_desc)
+static int slice_batch(const emadapt_conv_desc *d, bool) {
+    if (!d || d->B <= 0) return 0;
+    emadapt_conv_desc one = *d;
+    one.B = 1;
+    if (check_desc(&one) != EMADAPT_OK) return 0;
+    const long long hw = (long long)d->H * d->W, cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
+    long long b = ((1LL << 30) - 1) / hw;
+    const long long b2 = ((1LL << 31) - 1) / (hw * cmax * 4), b3 = ((1LL << 32) - 1) / (hw * (d->W > d->H ? d->W : d->H));
+    b = b2 < b ? b2 : b;
+    b = b3 < b ? b3 : b;
+    return b < 1 ? 0 : (int)(b < d->B ? b : d->B);
+}
+
+// batch-sliced filter gradient (tensors of 2 GiB and more): workspace = [one slice's own workspace][slices x KN floats]
+static size_t wgrad_slice_ws(const emadapt_conv_desc *d, int bs) {
+    emadapt_conv_desc s = *d;
+    s.B = bs;
+    return (emadapt_conv_wgrad_workspace_bytes(&s) + 255) & ~(size_t)255;
+}
+
 size_t emadapt_conv_wgrad_workspace_bytes(const emadapt_conv_desc *d) {
+    if (d && d->B > 0 && check_desc(d) == EMADAPT_ERR_UNSUPPORTED) {
+        const int bs = slice_batch(d, true);
+        if (bs > 0 && bs < d->B)
+            return wgrad_slice_ws(d, bs) + (size_t)ceil_div(d->B, bs) * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+    }
     if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
     const Plan p = make_plan(d);
     if (p.splits <= 1) return 0;
@@ -582,6 +608,24 @@ size_t emadapt_conv_wgrad_workspace_bytes(const emadapt_conv_desc *d) {
 int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, void *workspace,
                        size_t workspace_bytes, void *stream_) {
     int rc = check_desc(d);
+    if (rc == EMADAPT_ERR_UNSUPPORTED && x && dy && dw) {   // a tensor of 2 GiB or more: per-slice gradients, added in slice order
+        const int bs = slice_batch(d, true);
+        if (bs > 0 && bs < d->B) {
+            if (!workspace || workspace_bytes < emadapt_conv_wgrad_workspace_bytes(d) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+                return EMADAPT_ERR_WORKSPACE;
+            const long long hw = (long long)d->H * d->W, KN = (long long)d->KH * d->KW * d->Cin * d->Cout;
+            const size_t ws_slice = wgrad_slice_ws(d, bs);
+            float *parts = reinterpret_cast<float *>(static_cast<char *>(workspace) + ws_slice);
+            int s = 0;
+            for (int b0 = 0; b0 < d->B; b0 += bs, s++) {
+                emadapt_conv_desc dd = *d;
+                dd.B = d->B - b0 < bs ? d->B - b0 : bs;
+                rc = emadapt_conv_wgrad(&dd, x + b0 * hw * d->Cin, dy + b0 * hw * d->Cout, parts + (long long)s * KN, workspace, ws_slice, stream_);
+                if (rc) return rc;
+            }
+            return launch_slab_sum(parts, s, KN, dw, as_stream(stream_));
+        }
+    }
     if (rc) return rc;
     if (!x || !dy || !dw) return EMADAPT_ERR_INVALID;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dw) |

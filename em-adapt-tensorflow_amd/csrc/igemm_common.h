@@ -345,6 +345,27 @@ int check_desc(const emadapt_conv_desc *d) {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Tensors of 2 GiB and more (513x513 inputs at batch 32: conv1's 2.16 GB activations): the kernels address an operand with
+// 32-bit byte offsets, so the fp32 entries cut such a launch into slices of whole images, each slice a launch of its own on
+// bumped base pointers (images are independent in forward and data gradient; the filter gradient adds the slices' results).
+// Returns the images per slice (== d->B when the whole batch is one launch), 0 when not even one image fits.
+inline int slice_batch(const emadapt_conv_desc *d, bool wgrad) {
+    if (!d || d->B <= 0) return 0;
+    emadapt_conv_desc one = *d;
+    one.B = 1;
+    if (check_desc(&one) != EMADAPT_OK) return 0;
+    const long long hw = (long long)d->H * d->W, cmax = d->Cin > d->Cout ? d->Cin : d->Cout;
+    long long b = ((1LL << 30) - 1) / hw;
+    const long long b2 = ((1LL << 31) - 1) / (hw * cmax * 4);
+    b = b2 < b ? b2 : b;
+    if (wgrad) {
+        const long long b3 = ((1LL << 32) - 1) / (hw * (d->W > d->H ? d->W : d->H));   // magic-division range of the pixel index
+        b = b3 < b ? b3 : b;
+    }
+    if (b < 1) return 0;
+    return (int)(b < d->B ? b : d->B);
+}
+
 // geometry shared by the launch and the workspace query
 void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
     a.H = d->H; a.W = d->W; a.KW = d->KW; a.dil = d->dil; a.sign = dgrad ? -1 : 1;

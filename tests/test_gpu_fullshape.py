@@ -376,3 +376,36 @@ def test_one_wide_filters_and_one_pixel_wide_maps(env):
         for gen in (0, 2):
             with ops.tuned(wgrad_gen=gen):
                 assert _rel(ops.conv_wgrad(xg, dyg, kh, kw, dil).cpu(), wt.grad) < 2e-5, (case, gen)
+
+
+def test_tensors_of_2_gib_and_more_run_as_batch_slices(env):
+    """513x513 inputs at batch 32 put conv1's activations (2.16 GB) past the 32-bit byte offsets the kernels address an operand
+    with (config 5 "as memory allows" was capped at batch 31 by offsets, not by the 288 GB).  The fp32 entries now cut
+    such a launch into slices of whole images (csrc/igemm_common.h slice_batch; the filter gradient adds the slices' results in
+    slice order).  A synthetic layer whose OUTPUT is 2.16 GB (129 x 256 x 256 x 64 fp32: slices of 127 + 2 images): forward with
+    bias + ReLU, gated data gradient and filter gradient against the fp32 CPU oracle over every image."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k = 129, 256, 256, 32, 64, 3
+    assert B * H * W * Cout * 4 >= 2 ** 31 > (B - 2) * H * W * Cout * 4
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    x = torch.randn((B, H, W, Cin), device="cuda:0", generator=g).clamp_(min=0)
+    w = torch.randn((k, k, Cin, Cout), device="cuda:0", generator=g) * float(np.sqrt(2.0 / (k * k * Cin)))
+    b = torch.randn((Cout,), device="cuda:0", generator=g) * 0.1
+    dy = torch.randn((B, H, W, Cout), device="cuda:0", generator=g)
+    y = ops.conv_fwd(x, w, b, 1, relu=True)
+    dx = ops.conv_dgrad(dy, w, 1, gate=x)
+    dw = ops.conv_wgrad(x, dy, k, k, 1)
+    assert torch.equal(dw, ops.conv_wgrad(x, dy, k, k, 1)), "sliced filter gradient must repeat bitwise"
+    # oracle, image by image (the CPU tensors of the whole batch would be 2 x 2 GB of autograd state)
+    wt = w.cpu().requires_grad_(True)
+    bt = b.cpu()
+    worst_y = worst_dx = 0.0
+    for b0 in range(0, B, 16):
+        xs = x[b0:b0 + 16].cpu().requires_grad_(True)
+        ys = do.conv_same(xs, wt, bt, 1)
+        ys.backward(dy[b0:b0 + 16].cpu())
+        worst_y = max(worst_y, _rel(y[b0:b0 + 16].cpu().numpy(), torch.relu(ys).detach().numpy()))
+        want_dx = np.where(xs.detach().numpy() > 0, xs.grad.numpy(), 0)
+        worst_dx = max(worst_dx, _rel(dx[b0:b0 + 16].cpu().numpy(), want_dx))
+    assert worst_y < 1e-4 and worst_dx < 1e-4, (worst_y, worst_dx)
+    assert _rel(dw.cpu().numpy(), wt.grad.numpy()) < 1e-4
