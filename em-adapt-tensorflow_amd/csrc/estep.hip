@@ -102,6 +102,10 @@ struct EstepArgs {
     const float *gmax_part;   // [kGmaxBlocks] per-block maxima of estep_gmax_kernel
     float *map_out;
     float *ovf;       // [B][C][hwp] class-major home of the channels that are not LDS-resident (workspace; used when p_res < C)
+    float *mxbuf;     // [B][hwp] per-pixel maxima after the suppress step, written by estep_prep_kernel (p_res < C only)
+    float *part_v;    // [B][hwp] / [B][hwp] / [B]: labels-only runs of an overflow geometry -- the E-step kernel leaves the argmax over
+    int *part_i;      //   its LDS-resident classes (value + shift, class) and the image's shift; estep_finish_kernel completes it
+    float *shiftbuf;  //   over the class images in the workspace, on the whole chip
     long long *labels_out;
     int p_res;  // present-channel slots resident in LDS
     int hwp;    // HW rounded up to a multiple of 4 (LDS row pitch)
@@ -332,8 +336,152 @@ __device__ unsigned radix_select(const unsigned (&key)[EPT], int k, const Lds &l
     return (prefix << 10) | (SEL_ABL(32) ? 0u : hist_locate<8>(h2, kk, lane));
 }
 
+// Overflow geometries (65 x 65 x 41: only 7 of the 41 class images fit in LDS beside the bookkeeping), step (ii) of estep.py:46-55
+// for the whole batch ON THE WHOLE CHIP (round 4): one thread per pixel reads its logits row, forms the row minimum over
+// (present ? x : x + global max), replaces the absent classes above it, and writes EVERY class image class-major into the
+// workspace plus the pixel's maximum.  Rounds 2-3 did this inside the E-step kernel, i.e. on B of the 256 CUs: a workgroup moved
+// its 2.2 MB (two passes over the rows + the class-major images) at the ~30 GB/s one CU gets out of 4-byte-per-lane accesses --
+// 65-87 of the kernel's 210-236 us at B = 10.  Spread over 17 workgroups per image it is a few microseconds, and the E-step
+// kernel's phase 2 shrinks to copying the resident class images into LDS.
+__global__ void __launch_bounds__(256) estep_prep_kernel(EstepArgs a) {
+    __shared__ int present[kMaxC];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int HW = a.HW, C = a.C, hwp = a.hwp;
+    for (int c = tid; c < C; c += 256) present[c] = 0;
+    __syncthreads();
+    if (a.label_kind == EMADAPT_LABEL_MULTIHOT) {      // image-level label set (estep.py:35-44), as in estep_kernel
+        const unsigned char *mh = static_cast<const unsigned char *>(a.label) + (size_t)b * C;
+        for (int c = tid; c < C; c += 256)
+            if (mh[c]) present[c] = 1;
+    } else if (a.label_kind == EMADAPT_LABEL_F32) {
+        const float *lab = static_cast<const float *>(a.label) + (size_t)b * a.label_len;
+        for (long long i = tid; i < a.label_len; i += 256) {
+            const int v = (int)(unsigned char)(int)lab[i];
+            if (v < C) present[v] = 1;
+        }
+    } else {
+        const int *lab = static_cast<const int *>(a.label) + (size_t)b * a.label_len;
+        for (long long i = tid; i < a.label_len; i += 256) {
+            const int v = (int)(unsigned char)lab[i];
+            if (v < C) present[v] = 1;
+        }
+    }
+    float gmax = 0.f;
+    const bool suppress = a.suppress != 0;
+    if (suppress) {
+        float g = a.gmax_part[tid & 63];
+        for (int o = 32; o > 0; o >>= 1) g = fmaxf(g, __shfl_xor(g, o));
+        gmax = g;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    const int ic = i < HW ? i : HW - 1;
+    const float *row = a.logits + ((size_t)b * HW + ic) * a.ldl;
+    float *out = a.ovf + (size_t)b * C * hwp + ic;
+    float m = FLT_MAX, mxv = 0.f;
+    if ((a.ldl & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0) {
+        const int nq = (C + 3) >> 2;
+        if (suppress)
+            for (int q = 0; q < nq; q++) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + 4 * q);
+                const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (4 * q + k < C) {
+                        const float t = present[4 * q + k] ? x[k] : x[k] + gmax;
+                        m = (t < m) ? t : m;
+                    }
+            }
+        for (int q = 0; q < nq; q++) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + 4 * q);   // (second touch of a row the thread has just read)
+            float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = 4 * q + k;
+                if (c < C) {
+                    if (suppress && !present[c] && x[k] > m) x[k] = m - a.margin;
+                    mxv = (c == 0 || x[k] > mxv) ? x[k] : mxv;
+                    if (i < HW) out[(size_t)c * hwp] = x[k];    // consecutive lanes -> consecutive pixels: coalesced
+                }
+            }
+        }
+    } else {
+        if (suppress)
+            for (int c = 0; c < C; c++) {
+                const float t = present[c] ? row[c] : row[c] + gmax;
+                m = (t < m) ? t : m;
+            }
+        for (int c = 0; c < C; c++) {
+            float x = row[c];
+            if (suppress && !present[c] && x > m) x = m - a.margin;
+            mxv = (c == 0 || x > mxv) ? x : mxv;
+            if (i < HW) out[(size_t)c * hwp] = x;
+        }
+    }
+    if (i < HW) a.mxbuf[(size_t)b * hwp + i] = mxv;
+}
+
+// Second half of the argmax of an overflow geometry (labels-only runs; see the end of estep_kernel): one thread per pixel walks the
+// class images that were NOT LDS-resident in estep_kernel -- absent classes and the present classes beyond the p_res-th -- in class
+// order, on value + shift (the fp32 sum the reference compares, estep.py:81-82 + deeplab.py:123), and merges with the partial
+// result: the larger value, on a tie the lower class.  Which classes were resident is recomputed from the label set (slots are
+// handed out in ascending class order, estep_kernel).
+__global__ void __launch_bounds__(256) estep_finish_kernel(EstepArgs a) {
+    __shared__ int present[kMaxC];
+    __shared__ int nonres[kMaxC];
+    __shared__ int n_nonres;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int HW = a.HW, C = a.C, hwp = a.hwp;
+    for (int c = tid; c < C; c += 256) present[c] = 0;
+    __syncthreads();
+    if (a.label_kind == EMADAPT_LABEL_MULTIHOT) {
+        const unsigned char *mh = static_cast<const unsigned char *>(a.label) + (size_t)b * C;
+        for (int c = tid; c < C; c += 256)
+            if (mh[c]) present[c] = 1;
+    } else if (a.label_kind == EMADAPT_LABEL_F32) {
+        const float *lab = static_cast<const float *>(a.label) + (size_t)b * a.label_len;
+        for (long long i = tid; i < a.label_len; i += 256) {
+            const int v = (int)(unsigned char)(int)lab[i];
+            if (v < C) present[v] = 1;
+        }
+    } else {
+        const int *lab = static_cast<const int *>(a.label) + (size_t)b * a.label_len;
+        for (long long i = tid; i < a.label_len; i += 256) {
+            const int v = (int)(unsigned char)lab[i];
+            if (v < C) present[v] = 1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int P = 0, n = 0;
+        for (int c = 0; c < C; c++) {
+            const bool res = present[c] && P < a.p_res;
+            P += present[c] ? 1 : 0;
+            if (!res) nonres[n++] = c;
+        }
+        n_nonres = n;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= HW) return;
+    const float shift = a.shiftbuf[b];
+    const float *img = a.ovf + (size_t)b * C * hwp + i;
+    int best = -1;
+    float bv = 0.f;
+    const int n = n_nonres;
+    for (int k = 0; k < n; k++) {     // consecutive lanes -> consecutive pixels of one class image: coalesced
+        const int c = nonres[k];
+        const float v = img[(size_t)c * hwp] + shift;
+        if (best < 0 || v > bv) { bv = v; best = c; }
+    }
+    const float pv = a.part_v[(size_t)b * hwp + i];
+    const int pi = a.part_i[(size_t)b * hwp + i];
+    if (pi >= 0 && (best < 0 || pv > bv || (pv == bv && pi < best))) best = pi;
+    a.labels_out[(size_t)b * HW + i] = best;
+}
+
 template <int EPT>
-__global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
+__global__ void __launch_bounds__(kThreads, 2) estep_kernel(EstepArgs a) {   // (LDS admits one workgroup per CU: 2 waves per SIMD, 256 registers)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Lds l = carve(smem, a.hwp, a.p_res);
     const int tid = threadIdx.x;
@@ -476,94 +624,25 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
             const int i = tid + e * kThreads;
             if (i < HW) l.mx[i] = mxv[e];
         }
-    } else if ((a.ldl & 3) == 0 && (reinterpret_cast<uintptr_t>(a.logits) & 15) == 0) {
-        // ---- suppress absent classes (estep.py:46-55), per-pixel max, present channels -> LDS: the logits come from HBM.
-        // Quads of classes outside, the thread's pixels inside: EPT independent 16-byte loads in flight (a thread walking its
-        // pixels one after the other, one dependent scalar load per class, took 210 us at 65 x 65 x 41).
-        const int nq = (C + 3) >> 2;
-        const float *rowp[EPT];
-        bool ok[EPT];
-#pragma unroll
-        for (int e = 0; e < EPT; e++) {
-            const int i = tid + e * kThreads;
-            ok[e] = i < HW;
-            rowp[e] = a.logits + ((size_t)b * HW + (ok[e] ? i : HW - 1)) * a.ldl;
+    } else {
+        // ---- overflow geometry: estep_prep_kernel has suppressed the absent classes (estep.py:46-55) and left EVERY class image
+        // class-major in the workspace plus the per-pixel maxima; what remains here is to bring the resident classes into LDS
+        // (coalesced 16-byte copies) and the maxima into l.mx.
+        const int n4 = hwp >> 2;
+        for (int c = 0; c < C; c++) {
+            const int sl = __builtin_amdgcn_readfirstlane(l.slot[c]);
+            if (sl < 0 || sl >= p_res) continue;
+            const float4 *src = reinterpret_cast<const float4 *>(a.ovf + ((size_t)b * C + c) * hwp);
+            float4 *dst = reinterpret_cast<float4 *>(l.chan + (size_t)sl * hwp);
+#pragma unroll 4
+            for (int g = tid; g < n4; g += kThreads) dst[g] = src[g];
         }
-        float m[EPT], mxv[EPT];
-#pragma unroll
-        for (int e = 0; e < EPT; e++) { m[e] = FLT_MAX; mxv[e] = 0.f; }
-        if (suppress) {
-            for (int q = 0; q < nq; q++) {
-                float4 v[EPT];
-#pragma unroll
-                for (int e = 0; e < EPT; e++) v[e] = *reinterpret_cast<const float4 *>(rowp[e] + 4 * q);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int c = 4 * q + k;
-                    if (c >= C) break;
-                    const bool present = __builtin_amdgcn_readfirstlane(l.slot[c]) >= 0;
-#pragma unroll
-                    for (int e = 0; e < EPT; e++) {
-                        const float x = k == 0 ? v[e].x : k == 1 ? v[e].y : k == 2 ? v[e].z : v[e].w;
-                        const float t = present ? x : x + gmax;
-                        m[e] = (t < m[e]) ? t : m[e];
-                    }
-                }
-            }
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(a.mxbuf + (size_t)b * hwp);
+            float4 *dst = reinterpret_cast<float4 *>(l.mx);
+            for (int g = tid; g < n4; g += kThreads) dst[g] = src[g];
         }
-        for (int q = 0; q < nq; q++) {
-            float4 v[EPT];
-#pragma unroll
-            for (int e = 0; e < EPT; e++) v[e] = *reinterpret_cast<const float4 *>(rowp[e] + 4 * q);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int c = 4 * q + k;
-                if (c >= C) break;
-                const int sl = __builtin_amdgcn_readfirstlane(l.slot[c]);
-#pragma unroll
-                for (int e = 0; e < EPT; e++) {
-                    float x = k == 0 ? v[e].x : k == 1 ? v[e].y : k == 2 ? v[e].z : v[e].w;
-                    if (suppress && sl < 0 && x > m[e]) x = m[e] - a.margin;
-                    mxv[e] = (c == 0 || x > mxv[e]) ? x : mxv[e];
-                    if (ok[e]) {
-                        const int i = tid + e * kThreads;
-                        if (sl >= 0 && sl < p_res) l.chan[(size_t)sl * hwp + i] = x;
-                        else a.ovf[((size_t)b * C + c) * hwp + i] = x;   // consecutive lanes -> consecutive pixels: coalesced
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPT; e++)
-            if (ok[e]) l.mx[tid + e * kThreads] = mxv[e];
-    } else
-    // (row pitch not a multiple of four floats: one pixel after the other, scalar loads)
-#pragma unroll 1
-    for (int e = 0; e < EPT; e++) {
-        const int i = tid + e * kThreads;
-        if (i < HW) {
-            const size_t row = (size_t)b * HW + i;
-            const float *p = a.logits + row * a.ldl;
-            float m = FLT_MAX;
-            if (suppress) {
-                for (int c = 0; c < C; c++) {
-                    const float v = p[c];
-                    const float t = (l.slot[c] >= 0) ? v : v + gmax;
-                    m = (t < m) ? t : m;
-                }
-            }
-            const float repl = m - a.margin;
-            float mxv = 0.f;
-            for (int c = 0; c < C; c++) {
-                float v = p[c];
-                const int s = l.slot[c];
-                if (suppress && s < 0 && v > m) v = repl;
-                mxv = (c == 0 || v > mxv) ? v : mxv;
-                if (s >= 0 && s < p_res) l.chan[(size_t)s * hwp + i] = v;
-                else a.ovf[((size_t)b * C + c) * hwp + i] = v;
-            }
-            l.mx[i] = mxv;
-        }
+        __syncthreads();
     }
 #pragma unroll
     for (int e = 0; e < EPT; e++) {  // running max of the thread's own pixels -> registers
@@ -699,6 +778,37 @@ __global__ void __launch_bounds__(kThreads) estep_kernel(EstepArgs a) {
             const int i = tid + e * kThreads;
             ok[e] = i < HW;
             pi[e] = ok[e] ? i : HW - 1;
+        }
+        if (!a.map_out) {
+            // Labels only (the training step).  34 of the 41 class images live in the workspace, and ONE CU reads them at ~30 GB/s
+            // (32 of the kernel's 172 us at 65 x 65 x 41).  So this kernel only takes the argmax over its LDS-resident classes
+            // (deeplab.py:123 on value + shift; slots ascend with the class, so the first maximum is the lowest class) and leaves
+            // (value, class) per pixel and the image's shift; estep_finish_kernel completes the argmax over the other classes on the
+            // whole chip: max of the two partial maxima, the lower class on a tie -- the same label as one pass in class order.
+            int best[EPT];
+            float bv[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) { best[e] = -1; bv[e] = 0.f; }
+            for (int c = 0; c < C; c++) {
+                const int sl = __builtin_amdgcn_readfirstlane(l.slot[c]);
+                if (sl < 0 || sl >= p_res) continue;
+                const float *ch = l.chan + (size_t)sl * hwp;
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const float v = ch[min(tid + e * kThreads, HW - 1)] + shift;
+                    if (best[e] < 0 || v > bv[e]) { bv[e] = v; best[e] = c; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int i = tid + e * kThreads;
+                if (i < HW) {
+                    a.part_v[(size_t)b * hwp + i] = bv[e];
+                    a.part_i[(size_t)b * hwp + i] = best[e];
+                }
+            }
+            if (tid == 0) a.shiftbuf[b] = shift;
+            return;
         }
         for (int c = 0; c < C; c++) {
             const int sl = __builtin_amdgcn_readfirstlane(l.slot[c]);
@@ -844,7 +954,8 @@ size_t emadapt_estep_workspace_bytes(int B, int H, int W, int C) {
     const int hwp = (int)((HW + 3) / 4 * 4);
     const int p_res = choose_p_res(hwp, C);
     if (p_res < 0 || p_res >= C) return estep_ovf_offset();
-    return estep_ovf_offset() + (size_t)B * C * hwp * sizeof(float);
+    // class images + per-pixel maxima + the partial argmax (value, class) + the images' shifts (round 4)
+    return estep_ovf_offset() + (size_t)B * (C + 3) * hwp * sizeof(float) + align_up((size_t)B * sizeof(float), 16);
 }
 
 // Since round 3 always 0 for a supported geometry (< 0: unsupported): the channels that do not fit in LDS live in the workspace,
@@ -892,9 +1003,18 @@ int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label
     a.perms = perms; a.HW = (int)HW; a.C = C; a.suppress = suppress_others ? 1 : 0; a.num_iter = num_iter;
     a.margin = margin_others; a.k_bg = k_bg; a.k_fg = k_fg; a.gmax_part = gpart; a.map_out = map_out;
     a.ovf = p_res < C ? reinterpret_cast<float *>(static_cast<char *>(workspace) + estep_ovf_offset()) : nullptr;
+    a.mxbuf = a.ovf ? a.ovf + (size_t)B * C * hwp : nullptr;
+    a.part_v = a.ovf ? a.mxbuf + (size_t)B * hwp : nullptr;
+    a.part_i = a.ovf ? reinterpret_cast<int *>(a.part_v + (size_t)B * hwp) : nullptr;
+    a.shiftbuf = a.ovf ? a.part_v + 2 * (size_t)B * hwp : nullptr;
     a.labels_out = reinterpret_cast<long long *>(labels_out); a.p_res = p_res; a.hwp = hwp;
     a.full = (p_res >= C) ? 1 : 0;
     pairwise_program(a, (int)HW);
+    if (!a.full) {   // overflow geometry: the suppress step for the whole batch, on the whole chip
+        hipLaunchKernelGGL(estep_prep_kernel, dim3((unsigned)ceil_div(HW, 256), (unsigned)B), dim3(256), 0, stream, a);
+        int rc = launch_status();
+        if (rc) return rc;
+    }
 #ifdef EMADAPT_ABLATE_BUILD
     a.stop_after = tune(TUNE_ESTEP_STOP);
 #else
@@ -902,10 +1022,15 @@ int emadapt_estep(const float *logits, int64_t ldl, const void *label, int label
 #endif
     const size_t lds = align_up(lds_bytes(hwp, p_res), 16);
     const int ept = (int)ceil_div(HW, kThreads);
-    if (ept <= 1) return launch_estep<1>(a, B, lds, stream);
-    if (ept <= 4) return launch_estep<4>(a, B, lds, stream);   // 41x41 = 1681 (321x321 input)
-    if (ept <= 9) return launch_estep<9>(a, B, lds, stream);   // 65x65 = 4225 (513x513 input)
-    return launch_estep<16>(a, B, lds, stream);
+    int rc;
+    if (ept <= 1) rc = launch_estep<1>(a, B, lds, stream);
+    else if (ept <= 4) rc = launch_estep<4>(a, B, lds, stream);   // 41x41 = 1681 (321x321 input)
+    else if (ept <= 9) rc = launch_estep<9>(a, B, lds, stream);   // 65x65 = 4225 (513x513 input)
+    else rc = launch_estep<16>(a, B, lds, stream);
+    if (rc || a.full || a.map_out || a.stop_after) return rc;
+    // overflow geometry, labels only: the argmax over the class images in the workspace, on the whole chip
+    hipLaunchKernelGGL(estep_finish_kernel, dim3((unsigned)ceil_div(HW, 256), (unsigned)B), dim3(256), 0, stream, a);
+    return launch_status();
 }
 
 int emadapt_resize_nearest(const float *in, int B, int H, int W, float *out, int oh, int ow, void *stream_) {

@@ -57,7 +57,7 @@ def test_version_and_errors(lib):
     assert b"workspace" in lib.emadapt_strerror(-4)
     assert lib.emadapt_estep_needs_map(41, 41, 21) == 0   # 321x321 / 21 classes: everything fits in LDS
     assert lib.emadapt_estep_needs_map(65, 65, 41) == 0   # 513x513 / 41 classes: the overflow lives in the workspace
-    assert lib.emadapt_estep_workspace_bytes(10, 65, 65, 41) == 256 + 10 * 41 * 4228 * 4
+    assert lib.emadapt_estep_workspace_bytes(10, 65, 65, 41) == 256 + 10 * (41 + 3) * 4228 * 4 + 48   # class images, maxima, partial argmax, shifts
     assert lib.emadapt_estep_workspace_bytes(16, 41, 41, 21) == 256
     assert lib.emadapt_estep_needs_map(200, 200, 21) == -2
     assert lib.emadapt_estep_workspace_bytes(16, 41, 41, 21) >= 16
