@@ -57,6 +57,9 @@ def parse():
                     help="arithmetic of the conv inner products: fp32 = native fp32 MFMA (BASELINE configs[1], the "
                          "headline); bf16 = bf16 operands with fp32 accumulation (configs[2]/[3]); bf16x6 = fp32-grade "
                          "results from six bf16 MFMAs per product over the exact 3-way bf16 split of both fp32 operands")
+    ap.add_argument("--x6-planes", default="auto", choices=["auto", "always"],
+                    help="bf16x6: auto = the plane-image kernels where they have enough work to fill the part at this batch size (small "
+                         "/ narrow workloads then run on the native fp32 kernels); always = wherever they can run (tests)")
     ap.add_argument("--tune", default="", help="launch-plan overrides for A/B runs, e.g. fp32_loader=2,plan_cus=256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="images per CPU-baseline step (BASELINE.md section 4: 16)")
@@ -326,7 +329,7 @@ def main():
     cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
            "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb,
-           "allreduce_release_at": None if args.release_at == "none" else args.release_at, "grad_dtype": args.grad_dtype}
+           "allreduce_release_at": None if args.release_at == "none" else args.release_at, "grad_dtype": args.grad_dtype, "x6_planes": args.x6_planes}
     if args.allreduce_algo != "auto":
         cfg["allreduce_algo"] = args.allreduce_algo
     for kv in filter(None, args.tune.split(",")):

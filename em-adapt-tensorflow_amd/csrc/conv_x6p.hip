@@ -1,8 +1,11 @@
 // bf16x6 on pre-split operands (compute_dtype = "bf16x6"): plane images, the 256x256 LDS-DMA kernels that read them, and
 // their C entry points.  Arithmetic and error bound are conv_x6.hip's (x = p0 + p1 + p2 exactly, six bf16 MFMAs per product
 // accumulated in fp32); what changes is WHERE the split happens -- once per tensor instead of once per tile and tap -- and with
-// it the kernel structure (igemm_x6p.h).  Shapes these kernels do not take (channel counts that are not multiples of 16, N < 128,
-// filter gradients whose 256-wide k tiles straddle taps) stay on conv_x6.hip's kernels: emadapt_conv_x6p_supported().
+// it the kernel structure (igemm_x6p.h).  Shapes these kernels do not take stay on conv_x6.hip's kernels; the rules, per kind,
+// exactly as xp_ok (below) and wp_ok (wgrad_x6p.h) implement them and emadapt_conv_x6p_supported() reports them:
+//   forward / data gradient: reduction channels (Cin resp. Cout) % 16 == 0, N (Cout resp. Cin) >= 256 and % 4 == 0, <= 32 taps;
+//   filter gradient:         Cin % 256 == 0 (a 256-wide k tile inside one tap), Cout >= 128 and % 16 == 0, taps x Cin / 256 <= 256;
+//   all:                     plane images below 2 GiB.
 //
 // Plane image of an fp32 tensor [rows][C], C % 16 == 0:   [rows][C / 16][plane 0..2][16 x bf16]    (6 bytes per element)
 //   forward:          activation planes [B*H*W][Cin]    x   tiled filter planes, rows = Cout, k = Cin   (emadapt_filter_tiles)

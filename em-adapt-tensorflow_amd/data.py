@@ -66,8 +66,9 @@ class SyntheticData:
         labels = torch.as_tensor(synthetic_labels(rng, batch_size, self.h, self.w, self.category_num)).to(self.device)
         return images, labels
 
-    def next_batch(self, category="train", batch_size=None, epoches=-1):
-        """Endless iterator over (images f32 [B,H,W,3], labels f32 [B,H,W,1]), resident on the device."""
+    def next_batch(self, category="train", batch_size=None, epoches=-1, start_epoch=None):
+        """Endless iterator over (images f32 [B,H,W,3], labels f32 [B,H,W,1]), resident on the device (start_epoch: accepted for
+        the dataset class's signature; a synthetic source has no epochs)."""
         batch_size = batch_size or self.config.get("batch_size", 1)
         pool = [self.make_batch(batch_size, i) for i in range(self.unique_batches)]
         i = 0
@@ -179,7 +180,7 @@ class dataset:
         return data_f, data_len
 
     def reset_info(self):
-        self.info = {"epoch": {}, "index": {}, "perm": {}}
+        self.info = {"epoch": {}, "index": {}, "perm": {}, "next_epoch": {}}
         for category in self.categorys:
             self.info["epoch"][category] = 0
             self.info["index"][category] = 0
@@ -234,8 +235,11 @@ class dataset:
         do_flip = bool(flip) and bool(self.rng.uniform() < 0.5)
         return image_preprocess(img, label, (self.h, self.w), scale=scale, flip=do_flip, device=self.device)
 
-    def sample_order(self, category=None, batch_size=None, epoches=-1):
-        """Iterator over (epoch, position, sample indices) of this rank's batches.  One permutation per epoch, shared
+    def sample_order(self, category=None, batch_size=None, epoches=-1, start_epoch=0):
+        """Iterator over (epoch, position, sample indices) of this rank's batches, `epoches` epochs from `start_epoch` on (the
+        order of an epoch is a function of (seed, category, epoch) alone, so a resumed run that passes the epoch it stopped in --
+        config "start_epoch", or a second train() call on the same object, which continues behind the epochs already handed out
+        -- does not replay epoch 0, 1, ...: advisor finding, round 3).  One permutation per epoch, shared
         by all ranks (``epoch_perm``: a function of seed, category and epoch); a global batch is ``batch_size * world`` consecutive entries of it and rank r
         takes entries [r*batch_size, (r+1)*batch_size) -- ranks never see the same sample within an epoch.  With one
         rank a short final batch is yielded as is (tf.data ``batch``); with several ranks the ragged remainder of an
@@ -248,8 +252,9 @@ class dataset:
         if n == 0 or (self.world > 1 and n < gb):
             raise ValueError("category %r holds %d samples: fewer than one global batch of %d x %d ranks" % (
                 category, n, batch_size, self.world))
-        ep = 0
-        while epoches < 0 or ep < epoches:
+        ep = int(start_epoch)
+        last = ep + epoches
+        while epoches < 0 or ep < last:
             perm = self.epoch_perm(category, ep)
             self.info["perm"][category] = perm
             stop = n if self.world == 1 else (n // gb) * gb
@@ -257,9 +262,13 @@ class dataset:
                 yield ep, s, perm[s + self.rank * batch_size:s + (self.rank + 1) * batch_size]
             ep += 1
 
-    def next_batch(self, category=None, batch_size=None, epoches=-1):
+    def next_batch(self, category=None, batch_size=None, epoches=-1, start_epoch=None):
+        """dataset.next_batch.  start_epoch = None continues behind the epochs this object has already handed out for the
+        category (0 for a fresh object); an integer starts there (resuming a run: ADAPT.train passes config "start_epoch")."""
         import concurrent.futures
         category = category or self.default_category
+        if start_epoch is None:
+            start_epoch = self.info["next_epoch"].get(category, 0)
         batch_size = batch_size or self.config.get("batch_size", 1)
         files = self.data_f[category]
         train = category == "train"
@@ -268,7 +277,7 @@ class dataset:
             def submit(idx):
                 return [pool.submit(self._decode, files["img"][i], files["label"][i]) for i in idx]
 
-            it = self.sample_order(category, batch_size, epoches)
+            it = self.sample_order(category, batch_size, epoches, start_epoch)
             nxt = next(it, None)
             pending = submit(nxt[2]) if nxt else None
             while nxt is not None:
@@ -284,4 +293,6 @@ class dataset:
                     labs.append(y)
                 self.info["epoch"][category] = ep
                 self.info["index"][category] = s + len(idx) * self.world
+                # a later iterator over this category starts behind the last epoch this one has drawn from
+                self.info["next_epoch"][category] = ep + 1
                 yield torch.stack(imgs), torch.stack(labs), [files["id"][i] for i in idx]

@@ -80,6 +80,7 @@ class ADAPT(Network):
         self._cpad = 8 if act == "bf16" else 4   # channel padding of the buffers (16-byte vectors)
         self._w16_seen = None
         self._plane_fwd = {}   # bf16x6: layer -> its forward pass runs on the plane-image kernel (decided per batch size in _alloc)
+        self._plane_dgrad = {}  # ... and its data gradient
         self._plan = []
         self._shapes = {}
         self._dry = False
@@ -322,11 +323,12 @@ class ADAPT(Network):
             # forward pass runs on conv_x6.hip's kernel and needs the k-contiguous f32 image (64 or fewer output columns: native).
             for layer, seg in self._segments.items():
                 kh, kw, cin_p, cout_p = seg["pshape"]
-                nf = ops.filter_tiles_bytes(cin_p, cout_p, kh, kw, False) if cout_p >= 256 else 0
-                nd = ops.filter_tiles_bytes(cin_p, cout_p, kh, kw, True) if cin_p >= 256 else 0
-                seg["wkp"] = torch.zeros(nf, dtype=torch.uint8, device=dev) if nf else None
-                seg["wp6"] = torch.zeros(nd, dtype=torch.uint8, device=dev) if nd else None
-                seg["kmajor"] = seg["wkp"] is None and cout_p > 64
+                # (the images are ALLOCATED in _alloc, for the layers that take the plane kernels at the batch size in use, and
+                # refreshed for those alone: by the channel rule alone the ref preset carried ~600 MB of images and rebuilt them
+                # after every optimizer step even at batch 1, where no plane kernel runs -- advisor finding, round 3)
+                seg["can_wkp"], seg["can_wp6"] = cout_p >= 256, cin_p >= 256
+                seg["wkp"] = seg["wp6"] = None
+                seg["kmajor"] = not seg["can_wkp"] and cout_p > 64
             self._w16_seen = None
         if self.compute_dtype == "bf16":
             # bf16 filter images (include/emadapt.h, "bf16-compute variants"), one flat buffer per image kind
@@ -400,8 +402,11 @@ class ADAPT(Network):
                 # size, "always" = wherever it can run and the six-MFMA kernels for every other GEMM with more than 64 columns,
                 # however small (the parity tests drive them on small shapes this way)
                 take = ops.conv_x6p_supported if self.config.get("x6_planes", "auto") == "always" else ops.conv_x6p_pays
-                e = dict(d=d, fwd=op.seg["wkp"] is not None and take(d, 0), dgrad=op.seg["wp6"] is not None and take(d, 1),
-                         wgrad=take(d, 2))
+                e = dict(d=d, fwd=op.seg["can_wkp"] and take(d, 0), dgrad=op.seg["can_wp6"] and take(d, 1), wgrad=take(d, 2))
+                for key, flag, dg in (("wkp", e["fwd"], False), ("wp6", e["dgrad"], True)):
+                    if flag and op.seg[key] is None:
+                        kh, kw, cin_p, cout_p = op.seg["pshape"]
+                        op.seg[key] = torch.zeros(ops.filter_tiles_bytes(cin_p, cout_p, kh, kw, dg), dtype=torch.uint8, device=dev)
                 e["x"] = (torch.empty(B * ih * iw * op.cin_p * 6, dtype=torch.uint8, device=dev) if (e["fwd"] or e["wgrad"]) else None)
                 # a GEMM below 3 GFLOP (small maps / narrow nets; at the benchmark shapes none) is launch- and tail-bound: the native
                 # fp32 kernels' split-K plans are the faster fp32-grade choice there (scripts/shape_sweep.sh)
@@ -411,8 +416,9 @@ class ADAPT(Network):
                 xp[op.name] = e
             bufs["xp"] = xp
             plane_fwd = {name: e["fwd"] for name, e in xp.items()}
-            if plane_fwd != self._plane_fwd:   # (first batch, or a batch size that changes which layers the plane kernels take)
-                self._plane_fwd = plane_fwd
+            plane_dgrad = {name: e["dgrad"] for name, e in xp.items()}
+            if plane_fwd != self._plane_fwd or plane_dgrad != self._plane_dgrad:   # (first batch, or a batch size that changes which layers the plane kernels take)
+                self._plane_fwd, self._plane_dgrad = plane_fwd, plane_dgrad
                 self._w16_seen = None
             bufs["dyp"] = torch.empty(max(dyp_bytes, 16), dtype=torch.uint8, device=dev)
         bufs["gA"] = torch.empty(maxn, dtype=adt, device=dev)   # activation gradients ping-pong between these two
@@ -450,14 +456,16 @@ class ADAPT(Network):
                 else:
                     if op.seg["kmajor"] or not self._plane_fwd.get(op.name, True):
                         ops.filter_kmajor(op.w_pad, op.seg["wk32"])
-                    if op.seg["wkp"] is not None:
+                    if self._plane_fwd.get(op.name, False):
                         ops.filter_tiles(op.w_pad, False, out=op.seg["wkp"])
-                    if op.seg["wp6"] is not None:
+                    if self._plane_dgrad.get(op.name, False):
                         ops.filter_tiles(op.w_pad, True, out=op.seg["wp6"])
         self._w16_seen = ver
 
-    def forward(self, images, keep_prob=1.0, drop_masks=None):
-        """The conv stack (deeplab.py:35-49). images [B,H,W,3]; returns the fc8 logits view [B,S,S,C]."""
+    def forward(self, images, keep_prob=1.0, drop_masks=None, for_backward=False):
+        """The conv stack (deeplab.py:35-49). images [B,H,W,3]; returns the fc8 logits view [B,S,S,C].  for_backward: the pass is
+        followed by backward() (micro_step): bf16x6 then also splits the inputs of the layers whose FILTER GRADIENT alone runs on
+        the plane kernels; an inference pass skips that work."""
         images = self._to_dev(images)
         bf16 = self.compute_dtype == "bf16"
         x6 = self.compute_dtype == "bf16x6"
@@ -484,7 +492,7 @@ class ADAPT(Network):
                                       drop_mask=mask, drop_seed=seed, out=out)
                 elif x6:
                     e = bufs["xp"][op.name]
-                    if e["x"] is not None:
+                    if e["x"] is not None and (e["fwd"] or for_backward):
                         ops.split_planes(x, out=e["x"])
                     if e["fwd"]:
                         ops.conv_fwd_x6p(e["x"], op.seg["wkp"], e["d"], op.b_pad, relu=op.relu, keep_prob=kp,
@@ -674,7 +682,7 @@ class ADAPT(Network):
 
     def micro_step(self, images, labels, keep_prob=0.5, perms=None, drop_masks=None):
         """sess.run(net["accum_gradient_accum"], feed) of deeplab.py:267: fwd + E-step + bwd + accumulate."""
-        self.forward(images, keep_prob, drop_masks)
+        self.forward(images, keep_prob, drop_masks, for_backward=True)
         self.run_estep(labels, perms)
         dl = self._ce(want_grad=True)
         last = (self._micro % self.accum_num) == self.accum_num - 1
@@ -719,7 +727,9 @@ class ADAPT(Network):
         rank, world = dist_rank_world(self.config)
         if rank != 0:
             log = lambda *a, **k: None  # noqa: E731
-        train_iter = self.data.next_batch(category="train", batch_size=batch_size, epoches=-1)
+        # (config "start_epoch": the epoch a resumed run continues in; None = behind the epochs this data object has handed out)
+        train_iter = self.data.next_batch(category="train", batch_size=batch_size, epoches=-1,
+                                          start_epoch=self.config.get("start_epoch", None))
         self.config.setdefault("batch_size", batch_size)
         self.build()
         self.pre_train(base_lr, weight_decay, momentum, batch_size,

@@ -266,8 +266,9 @@ int emadapt_conv_wgrad_x6(const emadapt_conv_desc *d, const float *x, const floa
  * chunk (2 plane + half) of a row at position chunk ^ (bit 3 of the row) -- a 256-row tile's K step is 24 contiguous KB in the
  * order the kernel keeps it in LDS, so the filter side of the kernel is plain copies.  Refresh it when the weights change.
  * emadapt_conv_x6p_supported(d, kind) (kind 0 forward, 1 data gradient, 2 filter gradient) says whether a convolution is taken
- * (channel counts in whole groups of 16, at least 256 output columns, a filter gradient's Cin a multiple of 256, plane images
- * below 2 GiB); the others stay on the x6 entry points and return EMADAPT_ERR_UNSUPPORTED here.  Workspace: stream-K slab levels
+ * -- forward / data gradient: reduction channels (Cin resp. Cout) in whole groups of 16 and at least 256 output columns (Cout
+ * resp. Cin; a multiple of 4), at most 32 taps; filter gradient: Cin a multiple of 256, Cout >= 128 and a multiple of 16; all:
+ * plane images below 2 GiB -- the others stay on the x6 entry points and return EMADAPT_ERR_UNSUPPORTED here.  Workspace: stream-K slab levels
  * (+ the row table of packed rows) resp. split-M slabs, as for the fp32 kernels; EMADAPT_ERR_WORKSPACE when it is too small.
  * emadapt_conv_x6p_plan: plan[0] rows of the first launch, [1] 1 = stream-K, [2] its slab levels, [3] pixel classes of packed
  * rows (0 = off), [4] slab levels of the stream-K launch over the remaining rows (-1: a plain launch). */

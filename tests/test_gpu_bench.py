@@ -41,7 +41,8 @@ def test_default_line_has_every_contract_key():
 
 
 def test_other_arithmetics_and_no_alt():
-    d = _run("--dtype", "bf16x6", "--no-cpu-baseline")
+    # (--x6-planes always: at this size and width the automatic plan would leave every layer to the native fp32 kernels)
+    d = _run("--dtype", "bf16x6", "--no-cpu-baseline", "--x6-planes", "always", "--width", "32")
     assert d["dtype"] == "bf16x6" and d["roofline"]["peak"] == 419.4 and "bf16x6" not in d and "cpu_baseline" not in d
     d = _run("--no-alt", "--no-cpu-baseline", "--no-prof")
     assert d["dtype"] == "fp32" and "bf16x6" not in d and "roofline" not in d

@@ -150,8 +150,9 @@ def test_random_large_batches_against_c_oracle(pkg):
 
 def test_every_pixels_per_thread_variant_against_c_oracle(pkg):
     """The kernel is instantiated for 1 / 4 / 9 / 16 pixels per thread (512 threads per image); 41 x 41 and 65 x 65 take the
-    middle two.  Here the smallest and the largest, each with every class LDS-resident and with the LDS overflowing (the float
-    map then doubles as workspace), label maps and float maps bit for bit against the C restatement of estep.py:33-84."""
+    middle two.  Here the smallest and the largest, each with every class LDS-resident and with the LDS overflowing (the class
+    images that do not fit live class-major in the workspace, written by estep_prep_kernel; labels-only calls finish their argmax in
+    estep_finish_kernel), label maps and float maps bit for bit against the C restatement of estep.py:33-84."""
     est, ops, torch = pkg
     from oracle import estep_oracle as eo
     from oracle import estep_oracle_c as eoc

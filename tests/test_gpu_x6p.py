@@ -424,3 +424,28 @@ def test_differential_fuzz_against_the_native_kernels():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(80, 7) == 0
+
+
+def test_filter_plane_images_exist_only_for_the_layers_that_use_them():
+    """The tiled filter images (2 x 6 bytes per weight) are allocated and refreshed for the layers whose forward / data gradient
+    really runs on the plane kernels at the batch size in use, not for every layer the channel rule would allow (advisor finding,
+    round 3: ~600 MB rebuilt per optimizer step at batch 1, where no plane kernel runs)."""
+    import torch
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from oracle import deeplab_oracle as do
+    images, labels = do.synthetic_batch(1, 65, 5, seed=1)
+    for mode, expect_any in (("auto", False), ("always", True)):
+        a = ADAPT({"input_size": (65, 65), "category_num": 5, "width": 32, "batch_size": 1, "accum_num": 1, "compute_dtype": "bf16x6",
+                   "x6_planes": mode})
+        a.build()
+        a.pre_train(1e-3, 1e-5, 0.9, 1)
+        a.micro_step((images / 50).astype(np.float32), labels, keep_prob=1.0)
+        a.apply_update()
+        a.forward((images / 50).astype(np.float32), 1.0)          # inference pass: refreshes the images in use, splits no wgrad-only input
+        torch.cuda.synchronize()
+        xp = a._bufs["xp"]
+        for name, seg in a._segments.items():
+            assert (seg["wkp"] is not None) == xp[name]["fwd"], (mode, name)
+            assert (seg["wp6"] is not None) == xp[name]["dgrad"], (mode, name)
+        assert any(e["fwd"] or e["dgrad"] for e in xp.values()) == expect_any, mode
+        assert np.isfinite(float(a.loss["norm"].cpu()))

@@ -188,6 +188,30 @@ def test_dataset_epoch_order_is_stateless_and_small_sets_fail_loudly(tmp_path):
         next(small.sample_order("train", 3))
 
 
+def test_resumed_runs_continue_in_their_epoch(tmp_path):
+    """A resumed run (config "start_epoch") or a second pass over the same data object must not replay epoch 0, 1, ...: the order
+    of an epoch is a function of (seed, category, epoch), and sample_order starts where it is told to (advisor finding, round 3)."""
+    ds = _list_only_dataset(tmp_path, 12, seed=3)
+    full = list(ds.sample_order("train", 4, epoches=4))
+    tail = list(ds.sample_order("train", 4, epoches=2, start_epoch=2))
+    assert [e for e, _, _ in tail] == [2, 2, 2, 3, 3, 3]
+    for (e0, s0, i0), (e1, s1, i1) in zip(full[6:], tail):
+        assert (e0, s0) == (e1, s1) and np.array_equal(i0, i1)
+    assert not np.array_equal(full[0][2], tail[0][2])                 # (epoch 2 is not epoch 0)
+    # next_batch without start_epoch continues behind what this object has handed out (decode / preprocess stubbed out)
+    ds._decode = lambda img_f, label_f: (None, None)
+    ds.image_preprocess = lambda img, lab, random_scale=False, flip=False: (__import__("torch").zeros(1), __import__("torch").zeros(1))
+    first = ds.next_batch("train", 4, epoches=1)
+    ids_a = [ids for _, _, ids in first]
+    assert ds.info["next_epoch"]["train"] == 1
+    second = ds.next_batch("train", 4, epoches=1)
+    ids_b = [ids for _, _, ids in second]
+    assert ds.info["epoch"]["train"] == 1 and ds.info["next_epoch"]["train"] == 2
+    assert sorted(sum(ids_a, [])) == sorted(sum(ids_b, [])) and ids_a != ids_b     # same samples, epoch 1's order
+    again = [ids for _, _, ids in ds.next_batch("train", 4, epoches=1, start_epoch=0)]
+    assert again == ids_a
+
+
 def test_synthetic_data_differs_per_rank():
     from em_adapt_tensorflow_amd.data import SyntheticData
     cfg = {"input_size": (33, 33), "category_num": 21, "device": "cpu", "seed": 0}
