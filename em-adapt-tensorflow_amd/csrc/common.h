@@ -80,6 +80,8 @@ enum TuneKey {
                        //    launch's products (0 = the default, 5)
     TUNE_ESTEP_STOP,   // diagnostic builds only (-DEMADAPT_ABLATE_BUILD): leave the E-step kernel after phase n
     TUNE_ABLATE,       // diagnostic builds only: ablation bit mask of the fp32 igemm kernel
+    TUNE_RASTER_GM,    // M tiles per group of the plain-tile launches' XCD-aware order (0 = the default, 8): the workgroups resident on
+                       //    one XCD cover GM M-tiles x the N-tiles that fit (scripts/raster_sweep.py measures the L2 hit rate and the time)
     TUNE_COUNT
 };
 int tune(TuneKey key);

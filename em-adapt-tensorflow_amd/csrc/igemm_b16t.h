@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
         } else {
             const int split = t / ntile;
             t -= split * ntile;
-            constexpr int GM = 8;
+            const int GM = a.gm;
             const int per_group = GM * a.tiles_n;
             const int g = t / per_group;
             const int first_m = g * GM;

@@ -76,6 +76,7 @@ struct IgemmArgs {
     unsigned magic_nt;   // ceil(2^32/ntaps)
     RowPack pk;          // stream-K launches that skip padding (pk.n > 0)
     unsigned magic_w;    // ceil(2^32 / W)
+    int gm;      // M tiles per group of the plain-tile order (tune "raster_gm", default 8)
     int ablate;  // diagnostic builds only (tune "ablate"): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
 };
 
@@ -376,6 +377,7 @@ void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
     a.x_bytes = (unsigned)((long long)a.M * a.Cx * 4); a.w_bytes = (unsigned)((long long)a.K * a.N * 4);
     a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
     a.magic_w = magic_u32(a.W); a.pk.n = 0; a.pk.rowmap = nullptr;
+    a.gm = tune(TUNE_RASTER_GM) > 0 ? tune(TUNE_RASTER_GM) : 8;
 }
 
 }  // namespace

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
         } else {
             const int split = t / ntile;
             t -= split * ntile;
-            constexpr int GM = 8;
+            const int GM = a.gm;
             const int per_group = GM * a.tiles_n;
             const int g = t / per_group;
             const int first_m = g * GM;
