@@ -769,12 +769,19 @@ bool bt_ok(const emadapt_conv_desc *d, bool dgrad, int y_bf16) {
            M * N < (1LL << 40);
 }
 
+// The kernel variant: igemm_b16t_kernel (64-byte activation pieces) by default; tune "bf16_tile" = 64 selects igemm_b16w_kernel
+// (128-byte pieces, work cut in double steps of 64 channels) where the gathered channel count allows it.  Measured
+// (profiles/r04_bf16t_ablation.txt): the wide pieces raise the operand stream's own rate by 8 % (0.578 -> 0.530 ms alone) and
+// the kernel's by nothing -- what the two streams lose is their overlap, on random operands, to the power cap.
+bool bt_wide(const IgemmArgs &a) { return tune(TUNE_BF16_TILE) == 64 && a.Cx % 64 == 0; }
+
 PlanBT plan_b16t(const IgemmArgs &a) {
     const int cus = plan_cus();
     PlanBT p = {a.M, 0, 0, 0};
     const long long tn = ceil_div(a.N, 256), tm = ceil_div(a.M, 256), t = tm * tn;
-    const int nk = a.K / BT_BK;
-    if (t % cus == 0 || t * nk / cus < 16) return p;   // whole rounds, or too little work per CU to cut into pieces
+    const int bk = bt_wide(a) ? 64 : BT_BK;
+    const int nk = a.K / bk;
+    if (t % cus == 0 || t * nk * bk / cus < 16 * BT_BK) return p;   // whole rounds, or too little work per CU to cut into pieces
     if (a.N <= 1024 || t < cus) {
         p.main_sk = 1;
         p.main_levels = streamk_levels(t, nk, cus);
@@ -784,7 +791,7 @@ PlanBT plan_b16t(const IgemmArgs &a) {
     if (tm_full >= 1 && tm_full < tm) {
         p.main_rows = (int)(tm_full * 256);
         const long long tail_tiles = (tm - tm_full) * tn;
-        p.tail_levels = tail_tiles * nk / cus >= 16 ? streamk_levels(tail_tiles, nk, cus) : -1;
+        p.tail_levels = tail_tiles * nk * bk / cus >= 16 * BT_BK ? streamk_levels(tail_tiles, nk, cus) : -1;
     }
     return p;
 }
@@ -794,6 +801,11 @@ size_t bt_workspace_bytes(const IgemmArgs &a) {
     size_t b = (size_t)p.main_levels * p.main_rows * a.N * sizeof(float);
     if (p.main_rows < a.M && p.tail_levels > 0) b += (size_t)p.tail_levels * (a.M - p.main_rows) * a.N * sizeof(float);
     return b;
+}
+
+template <bool SK, bool YBF>
+int launch_bt(IgemmArgs &a, hipStream_t stream) {
+    return bt_wide(a) ? launch_igemm_b16w<SK, YBF>(a, stream) : launch_igemm_b16t<SK, YBF>(a, stream);
 }
 
 template <bool YBF>
@@ -809,18 +821,18 @@ int dispatch_b16t(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStre
     if (p.main_sk) {
         a.splits = plan_cus();
         a.slab = p.main_levels > 0 ? static_cast<float *>(workspace) : nullptr;
-        return launch_igemm_b16t<true, YBF>(a, stream);
+        return launch_bt<true, YBF>(a, stream);
     }
     a.splits = 1;
     a.slab = nullptr;
-    int rc = launch_igemm_b16t<false, YBF>(a, stream);
+    int rc = launch_bt<false, YBF>(a, stream);
     if (rc || p.main_rows >= a.M) return rc;
     a.m_begin = p.main_rows;
     a.m_end = a.M;
-    if (p.tail_levels < 0) return launch_igemm_b16t<false, YBF>(a, stream);
+    if (p.tail_levels < 0) return launch_bt<false, YBF>(a, stream);
     a.splits = plan_cus();
     a.slab = p.tail_levels > 0 ? static_cast<float *>(workspace) : nullptr;
-    return launch_igemm_b16t<true, YBF>(a, stream);
+    return launch_bt<true, YBF>(a, stream);
 }
 
 }  // namespace

@@ -337,6 +337,277 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
     } while (SK && next_piece());
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// "Wide A" variant (igemm_b16w_kernel): the activation side fetched in 128-BYTE pieces.
+//
+// What caps igemm_b16t_kernel is the delivery rate of its operand stream (profiles/r04_bf16t_ablation.txt: the DMAs alone run at
+// 47 GB/s per CU = 62 % of the matrix rate): a K step of 32 channels is a 64-byte piece of a pixel's row, half a cache line per
+// lane group -- every line crosses L2 -> L1 twice, a K step apart, and a 64-lane instruction spans 16 lines instead of 8.  The
+// filter side has no such problem (its image is stored in LDS order: contiguous KBs).  Here the ACTIVATION ring holds DOUBLE steps:
+//     A slot = [256 rows][128 B] = 64 channels of one tap (32 KB; ring of 3)          B slot = [256 rows][64 B] as before (ring of 4)
+// 96 + 64 = 160 KB, all of the LDS.  The K order becomes (channel pair-group of 64, tap, half); a unit of work is a double step
+// (stream-K and split-K cut at multiples of 64 channels: Cx % 64 == 0), and inside it the two half steps run igemm_b16t_kernel's
+// schedule unchanged (barrier per half step, fragments of the next half step prefetched behind it): the A fragments of half h come
+// from the 64-byte half h of the 128-byte rows.  An A slot is filled every other half step (4 DMA instructions per wave, 8 whole
+// rows each), a B slot every half step (2 instructions).  Swizzle of the 128-byte rows: slot s (of 8) of row r holds chunk
+// s ^ f(r), f(r) = ((r >> 1) & 3) | (((r >> 4) & 1) << 2) -- the 16 rows of a ds_read_b128 lane group ({0-3, 12-15, 20-27} and
+// {4-11, 16-19, 28-31} mod 32) then hit 16 different 16-byte columns of the two 128-byte halves of a bank row.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BW_AROW = 128;
+constexpr int BW_ASLOT = 256 * BW_AROW;          // 32 KB
+constexpr int BW_NA = 3, BW_NB = 4;
+constexpr int BW_BBASE = BW_NA * BW_ASLOT;       // the B ring behind the A ring
+constexpr int BW_AIPW = BW_ASLOT / 1024 / BT_WAVES;   // 4 DMA instructions per wave and A slot
+constexpr size_t BW_LDS = (size_t)BW_BBASE + (size_t)BW_NB * BT_OPER;
+static_assert(BW_LDS == 160 * 1024, "the two rings fill the LDS");
+
+template <bool SK, bool YBF, int ABLM = 0>
+__global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16w_kernel(IgemmArgs a) {
+    constexpr int BM = 256, BN = 256, TM = 2, TN = 4;
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];
+
+    // ---- work of this workgroup, in DOUBLE steps (64 channels of one tap)
+    const int nk_all = a.K / 64;
+    int tile_m = 0, tile_n = 0, kt0 = 0, nk = 0;
+    int lvl = -1;
+    int sk_u = 0, sk_end = 0, sk_units = 0, sk_v = 0;
+    {
+        const int ntile = a.tiles_m * a.tiles_n;
+        const int nblk = SK ? (int)gridDim.x : ntile * a.splits;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if constexpr (SK) {
+            sk_v = t;
+            sk_units = ntile * nk_all;
+            sk_u = __builtin_amdgcn_readfirstlane((int)sk_start(t, sk_units, nblk));
+            sk_end = __builtin_amdgcn_readfirstlane((int)sk_start(t + 1, sk_units, nblk));
+        } else {
+            const int split = t / ntile;
+            t -= split * ntile;
+            const int GM = a.gm;
+            const int per_group = GM * a.tiles_n;
+            const int g = t / per_group;
+            const int first_m = g * GM;
+            const int gsz = (a.tiles_m - first_m < GM) ? (a.tiles_m - first_m) : GM;
+            const int in_g = t - g * per_group;
+            tile_m = first_m + in_g % gsz;
+            tile_n = in_g / gsz;
+            kt0 = (int)((long long)nk_all * split / a.splits);
+            nk = (int)((long long)nk_all * (split + 1) / a.splits) - kt0;
+            lvl = a.splits > 1 ? split : -1;
+        }
+    }
+    auto next_piece = [&]() -> bool {
+        if (sk_u >= sk_end) return false;
+        const int t = __builtin_amdgcn_readfirstlane(sk_u / nk_all);
+        kt0 = sk_u - t * nk_all;
+        tile_m = __builtin_amdgcn_readfirstlane(t / a.tiles_n);
+        tile_n = t - tile_m * a.tiles_n;
+        const int left = sk_end - sk_u;
+        nk = (nk_all - kt0 < left) ? nk_all - kt0 : left;
+        lvl = nk == nk_all ? -1 : sk_v - __builtin_amdgcn_readfirstlane(sk_owner((long long)(sk_u - kt0), sk_units, (int)gridDim.x));
+        sk_u += nk;
+        return true;
+    };
+    if constexpr (SK) {
+        if (!next_piece()) return;
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const bool late = wave >= 4;
+
+    const int rowb = a.Cx * 2;
+    const int n_pad = a.tiles_n * 256;
+    const int cgroups = a.Cx / 32;
+    int min_dh = a.sign * (0 - a.pad_h), min_dw = a.sign * (0 - a.pad_w);
+    {
+        const int KH = a.ntaps / a.KW;
+        const int dh1 = a.sign * ((KH - 1) * a.dil - a.pad_h), dw1 = a.sign * ((a.KW - 1) * a.dil - a.pad_w);
+        min_dh = dh1 < min_dh ? dh1 : min_dh;
+        min_dw = dw1 < min_dw ? dw1 : min_dw;
+    }
+    const int min_sp = min_dh * a.W + min_dw;
+    const unsigned bias = min_sp < 0 ? (unsigned)(-min_sp) * (unsigned)rowb : 0u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(a.x)) - bias, 0, (int)(a.x_bytes + bias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    constexpr unsigned kOOB = 0x80000000u;
+    // A: instruction j of this wave moves slots [(wave * 4 + j) * 64, +64) of an A slot = 8 whole rows: lane -> (row, chunk)
+    int ld_row[BW_AIPW], ld_chunk[BW_AIPW];
+#pragma unroll
+    for (int j = 0; j < BW_AIPW; j++) {
+        const int q = (wave * BW_AIPW + j) * 64 + lane;
+        const int r = q >> 3;
+        ld_row[j] = r;
+        ld_chunk[j] = (q & 7) ^ (((r >> 1) & 3) | (((r >> 4) & 1) << 2));
+    }
+
+    // fragment addresses: A in a slot of 128-byte rows (half h, k group g: chunk 4 h + 2 g + lh), B in a slot of 64-byte rows
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int fa = ((l31 >> 1) & 3) | (((l31 >> 4) & 1) << 2);
+    const int sw = (l31 >> 2) & 3;
+    int a_frag[2][2], b_frag[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int g = 0; g < 2; g++) a_frag[h][g] = (wm * 64 + l31) * BW_AROW + (((4 * h + 2 * g + lh) ^ fa) << 4);
+#pragma unroll
+    for (int g = 0; g < 2; g++) b_frag[g] = BW_BBASE + (wn * 128 + l31) * BT_ROWB + (((2 * g + lh) ^ sw) << 4);
+    f32x16 acc[TM][TN];
+    bt_bf16x8 av[2][TM], bv[2][TN];
+
+    do {   // one piece of work (SK: several)
+    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
+    unsigned a_off[BW_AIPW], a_bad[BW_AIPW], b_off[BT_IPW];
+#pragma unroll
+    for (int j = 0; j < BW_AIPW; j++) {
+        const int r = ld_row[j];
+        const int m = m0 + r < a.m_end ? m0 + r : -1;
+        if (m >= 0) {
+            const int t2 = m / a.W;
+            const int oh = t2 % a.H, ow = m - t2 * a.W;
+            a_off[j] = (unsigned)m * (unsigned)rowb + (unsigned)ld_chunk[j] * 16u;
+            unsigned rowbad = 0, colbad = 0;
+            const int KH = a.ntaps / a.KW;
+            for (int kh = 0; kh < KH; kh++) {
+                const int ih = oh + a.sign * (kh * a.dil - a.pad_h);
+                rowbad |= ((unsigned)ih < (unsigned)a.H ? 0u : 1u) << kh;
+            }
+            for (int kw = 0; kw < a.KW; kw++) {
+                const int iw = ow + a.sign * (kw * a.dil - a.pad_w);
+                colbad |= ((unsigned)iw < (unsigned)a.W ? 0u : 1u) << kw;
+            }
+            unsigned bad = 0;
+            const unsigned full = a.KW >= 32 ? 0xFFFFFFFFu : ((1u << a.KW) - 1u);
+            for (int kh = 0; kh < KH; kh++) bad |= (((rowbad >> kh) & 1u) ? full : colbad) << (kh * a.KW);
+            a_bad[j] = bad;
+        } else {
+            a_off[j] = 0;
+            a_bad[j] = 0xFFFFFFFFu;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BT_IPW; j++) b_off[j] = (unsigned)((wave * BT_IPW + j) * 64 + lane) * 16u;
+
+    // double step D (of the tile, absolute) -> (channel pair-group, tap); the filter's K step = (tap, chunk 2 cp + half)
+    auto fillA = [&](int slot, int D, bool live) {
+        if constexpr (ABLM & 1) return;
+        const unsigned cp = __umulhi((unsigned)D, a.magic_nt);
+        const unsigned tap = a.ntaps > 1 ? (unsigned)D - cp * (unsigned)a.ntaps : 0u;
+        const unsigned cp_u = a.ntaps > 1 ? cp : (unsigned)D;
+        const unsigned kh = div_magic(tap, a.magic_kw);
+        const int kw = (int)(tap - kh * (unsigned)a.KW);
+        const int dh = a.sign * ((int)kh * a.dil - a.pad_h);
+        const int dw = a.sign * (kw * a.dil - a.pad_w);
+        const unsigned s_x = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)((dh * a.W + dw) * rowb) + cp_u * (unsigned)BW_AROW + bias));
+        const unsigned sh = 31u - (tap & 31u);
+        const unsigned dead = live ? 0u : kOOB;
+        char *as = ldsb + slot * BW_ASLOT + wave * (BW_AIPW * 1024);
+#pragma unroll
+        for (int j = 0; j < BW_AIPW; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t *)(as + j * 1024), 16, (int)(a_off[j] | ((a_bad[j] << sh) & kOOB) | dead), (int)s_x, 0, 0);
+    };
+    auto fillB = [&](int slot, int kt, bool live) {   // kt: half step of the tile, absolute
+        if constexpr (ABLM & 1) return;
+        const unsigned D = (unsigned)kt >> 1, half = (unsigned)kt & 1u;
+        const unsigned cp = __umulhi(D, a.magic_nt);
+        const unsigned tap = a.ntaps > 1 ? D - cp * (unsigned)a.ntaps : 0u;
+        const unsigned cp_u = a.ntaps > 1 ? cp : D;
+        const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(((tap * (unsigned)cgroups + 2u * cp_u + half) * (unsigned)n_pad + (unsigned)n0) * (unsigned)BT_ROWB));
+        const unsigned dead = live ? 0u : kOOB;
+        char *bs = ldsb + BW_BBASE + slot * BT_OPER + wave * (BT_IPW * 1024);
+#pragma unroll
+        for (int j = 0; j < BT_IPW; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_t *)(bs + j * 1024), 16, (int)(b_off[j] | dead), (int)s_w, 0, 0);
+    };
+#define BW_SB __builtin_amdgcn_sched_barrier(0);
+#define BW_RA0(H, G, I, AS) av[G][I] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (AS) * BW_ASLOT + a_frag[H][G] + (I) * (32 * BW_AROW)); BW_SB
+#define BW_RB0(G, J, BS) bv[G][J] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BS) * BT_OPER + b_frag[G] + (J) * (32 * BT_ROWB)); BW_SB
+#define BW_RA(H, G, I, AS) if constexpr (!(ABLM & 2)) { BW_RA0(H, G, I, AS) }
+#define BW_RB(G, J, BS) if constexpr (!(ABLM & 2)) { BW_RB0(G, J, BS) }
+#define BW_MF(G, I, J) if constexpr (!(ABLM & 8)) { acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[G][I], bv[G][J], acc[I][J], 0, 0, 0); BW_SB }
+    // One half step (H = 0 / 1 static).  kt = half step of the piece; as_n / hn = A slot and half of the NEXT half step, bs_n its B
+    // slot; as_f / bs_f = the A / B slots this step's DMAs fill (A[D + 2] when H == 0, B[kt + 3]).
+#define BW_HALF(H, KT, AS_N, HN, BS_N, AS_F, BS_F, D)                                                                              \
+    {                                                                                                                              \
+        BW_SB                                                                                                                      \
+        BW_MF(0, 0, 0) BW_MF(0, 0, 1) BW_MF(0, 0, 2) BW_MF(0, 0, 3) BW_MF(0, 1, 0) BW_MF(0, 1, 1) BW_MF(0, 1, 2) BW_MF(0, 1, 3)   \
+        if (!late) {                                                                                                               \
+            if (H == 0) fillA(AS_F, kt0 + (D) + 2, (D) + 2 < nk);                                                                  \
+            fillB(BS_F, 2 * kt0 + (KT) + 3, (KT) + 3 < 2 * nk);                                                                    \
+        }                                                                                                                          \
+        BW_SB                                                                                                                      \
+        if constexpr (!(ABLM & 4)) {                                                                                               \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                     \
+            if (late) { if (H == 0) wait_vmcnt<BT_IPW>(); else wait_vmcnt<BW_AIPW + BT_IPW>(); }                                   \
+            else wait_vmcnt<BW_AIPW + 2 * BT_IPW>();                                                                               \
+            if constexpr (!(ABLM & 16)) __builtin_amdgcn_s_barrier();                                                              \
+            asm volatile("" ::: "memory");                                                                                         \
+        }                                                                                                                          \
+        if (late) {                                                                                                                \
+            if (H == 0) fillA(AS_F, kt0 + (D) + 2, (D) + 2 < nk);                                                                  \
+            fillB(BS_F, 2 * kt0 + (KT) + 3, (KT) + 3 < 2 * nk);                                                                    \
+        }                                                                                                                          \
+        BW_SB                                                                                                                      \
+        BW_MF(1, 0, 0) BW_RA(HN, 0, 0, AS_N) BW_MF(1, 0, 1) BW_RA(HN, 0, 1, AS_N) BW_MF(1, 0, 2) BW_RB(0, 0, BS_N) BW_MF(1, 0, 3) BW_RB(0, 1, BS_N) \
+        BW_MF(1, 1, 0) BW_RB(0, 2, BS_N) BW_MF(1, 1, 1) BW_RB(0, 3, BS_N) BW_MF(1, 1, 2) BW_MF(1, 1, 3)                           \
+        BW_RB(1, 0, BS_N) BW_RB(1, 1, BS_N) BW_RB(1, 2, BS_N) BW_RB(1, 3, BS_N) BW_RA(HN, 1, 0, AS_N) BW_RA(HN, 1, 1, AS_N)       \
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    __syncthreads();   // the rings are free (SK: the previous piece's epilogue staged through them)
+    // issue order A[0] B[0] A[1] B[1] B[2]: behind B[0] stand 4 + 2 + 2 instructions
+    fillA(0, kt0, true);
+    fillB(0, 2 * kt0, true);
+    fillA(1, kt0 + 1, 1 < nk);
+    fillB(1, 2 * kt0 + 1, true);
+    fillB(2, 2 * kt0 + 2, 2 < 2 * nk);
+    wait_vmcnt<BW_AIPW + 2 * BT_IPW>();
+    __builtin_amdgcn_s_barrier();   // A[0], B[0] have landed
+    asm volatile("" ::: "memory");
+    BW_RA0(0, 0, 0, 0) BW_RA0(0, 0, 1, 0) BW_RB0(0, 0, 0) BW_RB0(0, 1, 0) BW_RB0(0, 2, 0) BW_RB0(0, 3, 0)
+    BW_RB0(1, 0, 0) BW_RB0(1, 1, 0) BW_RB0(1, 2, 0) BW_RB0(1, 3, 0) BW_RA0(0, 1, 0, 0) BW_RA0(0, 1, 1, 0)
+    {
+        int as = 0, bs = 0;   // A slot of double step D, B slot of half step 2 D
+        for (int D = 0; D < nk; D++) {
+            const int as1 = as == BW_NA - 1 ? 0 : as + 1;            // A[D + 1]
+            const int as2 = as1 == BW_NA - 1 ? 0 : as1 + 1;          // A[D + 2]'s slot (= A[D - 1]'s)
+            const int b1 = (bs + 1) & 3, b2 = (bs + 2) & 3, b3 = (bs + 3) & 3;
+            // half 0: next = (D, half 1): same A slot, B slot b1; fills A[D + 2] -> as2, B[2 D + 3] -> b3
+            BW_HALF(0, 2 * D, as, 1, b1, as2, b3, D)
+            // half 1: next = (D + 1, half 0): A slot as1, B slot b2; fills B[2 D + 4] -> slot of B[2 D] = bs
+            BW_HALF(1, 2 * D + 1, as1, 0, b2, as2, bs, D)
+            as = as1;
+            bs = b2;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vmcnt<0>();
+    __syncthreads();
+#undef BW_SB
+#undef BW_RA0
+#undef BW_RB0
+#undef BW_RA
+#undef BW_RB
+#undef BW_MF
+#undef BW_HALF
+
+    float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+    int lane_e = tid & 63;
+    asm volatile("" : "+v"(lane_e));
+    float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (128 + 4));
+    store_acc_tile<TM, TN, 16, YBF>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+    } while (SK && next_piece());
+}
+
 // a.splits: SK = false -> split-K factor (>= 1; > 1 needs a.slab); SK = true -> number of workgroups (CUs), a.slab for the levels
 template <bool SK, bool YBF, int ABLM = 0>
 int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
@@ -372,6 +643,49 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
         const long long nblk = tiles * a.splits;
         if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF, ABLM>), dim3((unsigned)nblk), dim3(BT_WAVES * 64), BT_LDS, stream, a);
+        rc = launch_status();
+        if (rc || a.splits <= 1) return rc;
+        long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(splitk_epilogue_t_kernel<YBF>, dim3((unsigned)g), dim3(256), 0, stream, a);
+        return launch_status();
+    }
+}
+
+template <bool SK, bool YBF, int ABLM = 0>
+int launch_igemm_b16w(IgemmArgs &a, hipStream_t stream) {
+#ifdef EMADAPT_ABLATE_BUILD
+    if constexpr (ABLM == 0 && YBF) {
+        switch (tune(TUNE_ABLATE)) {
+#define EMADAPT_ABL_CASE(m) case m: return launch_igemm_b16w<SK, YBF, m>(a, stream);
+            EMADAPT_ABL_CASE(1) EMADAPT_ABL_CASE(2) EMADAPT_ABL_CASE(3) EMADAPT_ABL_CASE(4) EMADAPT_ABL_CASE(7) EMADAPT_ABL_CASE(8)
+            EMADAPT_ABL_CASE(9) EMADAPT_ABL_CASE(10) EMADAPT_ABL_CASE(14) EMADAPT_ABL_CASE(16)
+#undef EMADAPT_ABL_CASE
+            default: break;
+        }
+    }
+#endif
+    static DynLdsAttr attr;
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16w_kernel<SK, YBF, ABLM>), BW_LDS);
+    if (rc) return rc;
+    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, 256);
+    a.tiles_n = (int)ceil_div(a.N, 256);
+    const int nk_all = a.K / 64;
+    const long long tiles = (long long)a.tiles_m * a.tiles_n;
+    if constexpr (SK) {
+        if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * 16 > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        const int G = streamk_grid(tiles, nk_all, a.splits);
+        const int levels = streamk_levels(tiles, nk_all, a.splits);
+        if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
+        hipLaunchKernelGGL((igemm_b16w_kernel<true, YBF, ABLM>), dim3((unsigned)G), dim3(BT_WAVES * 64), BW_LDS, stream, a);
+        rc = launch_status();
+        if (rc || levels == 0) return rc;
+        hipLaunchKernelGGL(streamk_fixup_t_kernel<YBF>, dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, a, G, nk_all);
+        return launch_status();
+    } else {
+        const long long nblk = tiles * a.splits;
+        if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((igemm_b16w_kernel<false, YBF, ABLM>), dim3((unsigned)nblk), dim3(BT_WAVES * 64), BW_LDS, stream, a);
         rc = launch_status();
         if (rc || a.splits <= 1) return rc;
         long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;

@@ -64,11 +64,23 @@ SMALL = [
     ((2, 16, 16, 128, 256, 4, 4), 5),      # 4x4 rate 4 (fc6's filter), 16 taps
     ((1, 25, 25, 32, 48, 3, 12), 256),     # rate 12 reaches far outside the map
     ((2, 30, 18, 160, 288, 3, 1), 7),
+    ((2, 21, 20, 128, 320, 3, 1), 4),      # Cin and Cout multiples of 64: the 128-byte-piece kernel, both directions, stream-K
+    ((1, 33, 31, 192, 64, 3, 2), 256),     # odd number of double steps per tap group (3 x 64 channels)
 ]
 
 
+@pytest.fixture(params=["narrow", "wide"])
+def variant(request):
+    """narrow = igemm_b16t_kernel (64-byte activation pieces; the default); wide = igemm_b16w_kernel (128-byte pieces, double steps of 64
+    channels) wherever the gathered channel count is a multiple of 64 (tune bf16_tile = 64), the narrow kernel elsewhere."""
+    import em_adapt_tensorflow_amd.ops as ops
+    ops.tune_set("bf16_tile", 64 if request.param == "wide" else 0)
+    yield request.param
+    ops.tune_set("bf16_tile", 0)
+
+
 @pytest.mark.parametrize("shape,cus", SMALL)
-def test_b16t_small_shapes_every_layout(env, shape, cus):
+def test_b16t_small_shapes_every_layout(env, shape, cus, variant):
     ops, do, torch = env
     B, H, W, Cin, Cout, k, dil = shape
     rng = np.random.default_rng(hash(shape) % (1 << 31))
@@ -94,7 +106,8 @@ def test_b16t_small_shapes_every_layout(env, shape, cus):
             assert torch.equal(ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg), got.bfloat16())
         # same sums as the round-1 kernel up to the order of the K steps
         wf, _ = ops.weights_to_bf16(wg, want_dgrad=False)
-        old = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=True, keep_prob=0.5, drop_mask=mg)
+        with ops.tuned(bf16_tile=0):        # (64 is not a tile of the round-1 kernel)
+            old = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=True, keep_prob=0.5, drop_mask=mg)
         assert _rel(got.cpu(), old.cpu()) < 2e-5
     if Cout % 32 == 0:                       # data gradient: the roles of Cin / Cout swap
         dy = torch.tensor(rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)).bfloat16()
