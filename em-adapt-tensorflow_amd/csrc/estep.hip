@@ -54,6 +54,7 @@ constexpr int kThreads = 512;   // 8 waves: two per SIMD (one wave per SIMD leav
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxC = 256;       // classes
 constexpr int kMaxLeaves = 192;  // leaves of NumPy's pairwise-sum tree for HW <= 8192
+constexpr int kMaxLevels = 12;   // depth of that tree
 constexpr int kMaxEPT = 16;      // pixels per thread -> HW <= 8192
 constexpr size_t kLdsBudget = 160 * 1024;
 constexpr int kHistBins = 2048;  // 11-bit first radix pass
@@ -113,23 +114,31 @@ struct EstepArgs {
     int stop_after;  // diagnostic builds (tune "estep_stop"): leave the kernel after phase n (0 = run everything)
     // NumPy's pairwise-summation tree for n = HW (it depends on HW alone): leaves and the post-order combine program, built
     // on the host (pairwise_program).  On the device it was ~50 dependent LDS-stack steps of thread 0: 20 us of the kernel.
-    int nleaf, nprog;
+    // (round 4: the combine tree by LEVELS -- node i of level L adds the values of two earlier nodes -- so that one wave walks it in
+    // <= 8 dependent steps; thread 0 replaying the post-order program with an LDS stack was 6 us per np.mean at 65 x 65)
+    int nleaf, nnode, nlev;
     unsigned short leaf_off[kMaxLeaves];
     unsigned char leaf_n[kMaxLeaves];        // <= 128
-    unsigned char prog[2 * kMaxLeaves];      // 0 = push next leaf, 1 = add
+    unsigned short node_l[kMaxLeaves], node_r[kMaxLeaves];   // value slots of a node's operands: leaf k = slot k, node i = slot nleaf + i
+    unsigned short lev_start[kMaxLevels + 1];               // nodes [lev_start[L], lev_start[L + 1]) depend only on earlier levels
 };
 
 // np.add.reduce of a contiguous float32 array (numpy/core/src/umath/loops_utils.h.src, pairwise_sum): blocks of <= 128 are
 // summed with eight running sums, larger ones are split at n/2 rounded down to a multiple of 8.
 void pairwise_program(EstepArgs &a, int HW) {
-    int nleaf = 0, nprog = 0, sp = 1;
+    int nleaf = 0, sp = 1;
     int s_off[32], s_n[32], s_st[32];
+    // post-order walk of the recursion; a value stack of slot ids replays it: leaves push, a split node pops right then left
+    int vstack[32], vsp = 0;
+    int nl[kMaxLeaves], nr[kMaxLeaves], lev[2 * kMaxLeaves], nnode = 0;   // nodes in creation (post-) order; lev[] per value id
     s_off[0] = 0; s_n[0] = HW; s_st[0] = 0;
     while (sp > 0) {
         const int off = s_off[sp - 1], n = s_n[sp - 1], st = s_st[sp - 1];
         if (n <= 128) {
-            a.leaf_off[nleaf] = (unsigned short)off; a.leaf_n[nleaf] = (unsigned char)n; nleaf++;
-            a.prog[nprog++] = 0;
+            a.leaf_off[nleaf] = (unsigned short)off; a.leaf_n[nleaf] = (unsigned char)n;
+            lev[nleaf] = 0;
+            vstack[vsp++] = nleaf;          // value id of leaf k = k
+            nleaf++;
             sp--;
         } else {
             int n2 = n / 2;
@@ -141,13 +150,34 @@ void pairwise_program(EstepArgs &a, int HW) {
                 s_st[sp - 1] = 2;
                 s_off[sp] = off + n2; s_n[sp] = n - n2; s_st[sp] = 0; sp++;
             } else {
-                a.prog[nprog++] = 1;
+                const int r = vstack[--vsp], l = vstack[--vsp];
+                nl[nnode] = l; nr[nnode] = r;            // value ids: leaves < kMaxLeaves, node i = kMaxLeaves + i (remapped below)
+                const int ll = lev[l < kMaxLeaves ? l : kMaxLeaves + (l - kMaxLeaves)], lr = lev[r < kMaxLeaves ? r : kMaxLeaves + (r - kMaxLeaves)];
+                lev[kMaxLeaves + nnode] = (ll > lr ? ll : lr) + 1;
+                vstack[vsp++] = kMaxLeaves + nnode;
+                nnode++;
                 sp--;
             }
         }
     }
+    // nodes sorted by level (stable); operands renamed to value slots: leaf k -> k, node (sorted position p) -> nleaf + p
+    int order[kMaxLeaves], pos[kMaxLeaves], nlev = 0;
+    for (int i = 0; i < nnode; i++) nlev = lev[kMaxLeaves + i] > nlev ? lev[kMaxLeaves + i] : nlev;
+    int p = 0;
+    a.lev_start[0] = 0;
+    for (int L = 1; L <= nlev; L++) {
+        for (int i = 0; i < nnode; i++)
+            if (lev[kMaxLeaves + i] == L) { order[p] = i; pos[i] = p; p++; }
+        a.lev_start[L] = (unsigned short)p;
+    }
+    for (int q = 0; q < nnode; q++) {
+        const int i = order[q];
+        a.node_l[q] = (unsigned short)(nl[i] < kMaxLeaves ? nl[i] : nleaf + pos[nl[i] - kMaxLeaves]);
+        a.node_r[q] = (unsigned short)(nr[i] < kMaxLeaves ? nr[i] : nleaf + pos[nr[i] - kMaxLeaves]);
+    }
     a.nleaf = nleaf;
-    a.nprog = nprog;
+    a.nnode = nnode;
+    a.nlev = nlev;
 }
 
 // One leaf (n <= 128) of NumPy's float32 pairwise summation.
@@ -180,12 +210,13 @@ struct Lds {
     float *chan;      // [p_res][hwp]
     int *slot;        // [kMaxC]  class -> slot (or -1)
     int *red;         // [2][kWaves]
-    float *leafsum;   // [kMaxLeaves]
+    float *leafsum;   // [2 * kMaxLeaves]: leaf sums, then the tree's inner nodes
     int *leaf_off;    // [kMaxLeaves]
     int *leaf_n;      // [kMaxLeaves]
     int *stk;         // [3][16]
-    unsigned char *prog;  // [2*kMaxLeaves]  0 = push next leaf, 1 = add
-    int *misc;        // [0]=P [1]=nleaf [2]=nprog
+    unsigned short *node_l, *node_r;   // [kMaxLeaves] operand slots of the tree's inner nodes, level by level
+    unsigned short *lev_start;         // [kMaxLevels + 1]
+    int *misc;        // [0]=P [1]=nleaf [2]=nnode [3]=nlev
     float *scal;      // [0]=shift
     unsigned *hist;   // [kHistBins] radix-select histogram
     int *sel;         // [4] selected bin, remaining rank
@@ -199,7 +230,7 @@ __device__ __forceinline__ Lds carve(char *base, int hwp, int p_res) {
     l.slot = reinterpret_cast<int *>(l.chan + (size_t)p_res * hwp);
     l.red = l.slot + kMaxC;
     l.leafsum = reinterpret_cast<float *>(l.red + 2 * kWaves);
-    l.leaf_off = reinterpret_cast<int *>(l.leafsum + kMaxLeaves);
+    l.leaf_off = reinterpret_cast<int *>(l.leafsum + 2 * kMaxLeaves);
     l.leaf_n = l.leaf_off + kMaxLeaves;
     l.stk = l.leaf_n + kMaxLeaves;
     l.misc = l.stk + 48;
@@ -207,37 +238,37 @@ __device__ __forceinline__ Lds carve(char *base, int hwp, int p_res) {
     l.hist = reinterpret_cast<unsigned *>(l.scal + 4);
     l.sel = reinterpret_cast<int *>(l.hist + kHistBins);
     l.perm = reinterpret_cast<unsigned short *>(l.sel + 4);
-    l.prog = reinterpret_cast<unsigned char *>(l.perm + kPermCap);
+    l.node_l = l.perm + kPermCap;
+    l.node_r = l.node_l + kMaxLeaves;
+    l.lev_start = l.node_r + kMaxLeaves;
     return l;
 }
 
 size_t lds_bytes(int hwp, int p_res) {
     return sizeof(float) * ((size_t)hwp + (size_t)p_res * hwp) + sizeof(int) * (kMaxC + 2 * kWaves) +
-           sizeof(float) * kMaxLeaves + sizeof(int) * (2 * kMaxLeaves + 48 + 4) + sizeof(float) * 4 +
-           sizeof(unsigned) * kHistBins + sizeof(int) * 4 + sizeof(unsigned short) * kPermCap + 2 * kMaxLeaves;
+           sizeof(float) * 2 * kMaxLeaves + sizeof(int) * (2 * kMaxLeaves + 48 + 4) + sizeof(float) * 4 +
+           sizeof(unsigned) * kHistBins + sizeof(int) * 4 + sizeof(unsigned short) * (kPermCap + 2 * kMaxLeaves + kMaxLevels + 4);
 }
 
-// np.mean over l.mx[0..HW): leaves in parallel, then the combine program on thread 0.
+// np.mean over l.mx[0..HW): leaves in parallel, then the combine tree level by level on wave 0 (each inner node = left + right,
+// the adds of NumPy's recursion in its order; a level only reads values of earlier levels).
 // Every thread must call; the result is valid on thread 0 only.
 __device__ float np_mean_lds(const Lds &l, int HW, int tid) {
     const int nleaf = l.misc[1];
     if (tid < nleaf) l.leafsum[tid] = np_leaf_sum(l.mx + l.leaf_off[tid], l.leaf_n[tid]);
     __syncthreads();
     float res = 0.f;
-    if (tid == 0) {
-        float st[16];
-        int sp = 0, next = 0;
-        const int nprog = l.misc[2];
-        for (int p = 0; p < nprog; p++) {
-            if (l.prog[p] == 0) {
-                st[sp++] = l.leafsum[next++];
-            } else {
-                float b = st[--sp];
-                float a = st[--sp];
-                st[sp++] = a + b;
-            }
+    if (tid < 64) {
+        const int nnode = l.misc[2], nlev = l.misc[3];
+        for (int L = 0; L < nlev; L++) {
+            const int i1 = l.lev_start[L + 1];
+            for (int i = l.lev_start[L] + tid; i < i1; i += 64) l.leafsum[nleaf + i] = l.leafsum[l.node_l[i]] + l.leafsum[l.node_r[i]];
+            // (one wave: its LDS stores are performed before its later loads; keep the compiler from moving them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        res = __fdiv_rn(st[0], (float)HW);
+        if (tid == 0) res = __fdiv_rn(l.leafsum[nleaf + nnode - 1 + (nnode == 0 ? 1 - nleaf : 0)], (float)HW);   // nnode == 0: the single leaf
     }
     return res;
 }
@@ -531,10 +562,12 @@ __global__ void __launch_bounds__(kThreads, 2) estep_kernel(EstepArgs a) {   // 
     }
     if (tid == 0) {
         l.misc[1] = a.nleaf;
-        l.misc[2] = a.nprog;
+        l.misc[2] = a.nnode;
+        l.misc[3] = a.nlev;
     }
     for (int t = tid; t < a.nleaf; t += kThreads) { l.leaf_off[t] = a.leaf_off[t]; l.leaf_n[t] = a.leaf_n[t]; }
-    for (int t = tid; t < a.nprog; t += kThreads) l.prog[t] = a.prog[t];
+    for (int t = tid; t < a.nnode; t += kThreads) { l.node_l[t] = a.node_l[t]; l.node_r[t] = a.node_r[t]; }
+    if (tid <= a.nlev) l.lev_start[tid] = a.lev_start[tid];
     __syncthreads();
 
     ESTEP_STOP(1);
