@@ -389,6 +389,8 @@ void fill_geometry_bf16(IgemmArgs &a, int &Cxp, const emadapt_conv_desc *d, bool
 struct PlanG {
     int big;     // 1: 256x256 tiles
     int splits;
+    int narrow;  // 1: 128x64 tiles (N <= 64: conv1_x, the data gradients into 64 channels -- round 4: the 128-wide tile multiplied and
+                 //    loaded 64 columns of nothing there)
 };
 
 PlanG plan_bf16(const IgemmArgs &a) {
@@ -397,8 +399,9 @@ PlanG plan_bf16(const IgemmArgs &a) {
     const long long t256 = ceil_div(a.M, 256) * ceil_div(a.N, 256);
     p.big = (a.N >= 256 && t256 >= 192) ? 1 : 0;
     if (force) p.big = force == 256 ? 1 : 0;
+    p.narrow = (!p.big && a.N <= 64 && force != 128) ? 1 : 0;
     p.splits = p.big ? choose_splits(a.M, a.N, a.K, 256, 256, 64, 256.0, 1000e12)
-                     : choose_splits(a.M, a.N, a.K, 128, 128, 64, 512.0, 450e12);
+                     : choose_splits(a.M, a.N, a.K, 128, p.narrow ? 64 : 128, 64, 512.0, 450e12);
     return p;
 }
 
@@ -455,8 +458,9 @@ int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace
             }
     }
 #endif
-    return p.big ? launch_igemm_bf16<256, 256, 128, XBF, YBF>(a, Cxp, stream)
-                 : launch_igemm_bf16<128, 128, 64, XBF, YBF>(a, Cxp, stream);
+    return p.big      ? launch_igemm_bf16<256, 256, 128, XBF, YBF>(a, Cxp, stream)
+           : p.narrow ? launch_igemm_bf16<128, 64, 32, XBF, YBF>(a, Cxp, stream)
+                      : launch_igemm_bf16<128, 128, 64, XBF, YBF>(a, Cxp, stream);
 }
 
 // storage-type dispatch: (x, y) in {f32, bf16}^2
@@ -873,7 +877,8 @@ int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]) {
     int Cxp;
     fill_geometry_bf16(a, Cxp, d, kind == 1);
     const PlanG p = plan_bf16(a);
-    plan[0] = plan[1] = p.big ? 256 : 128;
+    plan[0] = p.big ? 256 : 128;
+    plan[1] = p.big ? 256 : p.narrow ? 64 : 128;
     plan[2] = p.splits;
     return EMADAPT_OK;
 }
