@@ -777,12 +777,17 @@ bool bt_ok(const emadapt_conv_desc *d, bool dgrad, int y_bf16) {
 // (128-byte pieces, work cut in double steps of 64 channels) where the gathered channel count allows it.  Measured
 // (profiles/r04_bf16t_ablation.txt): the wide pieces raise the operand stream's own rate by 8 % (0.578 -> 0.530 ms alone) and
 // the kernel's by nothing -- what the two streams lose is their overlap, on random operands, to the power cap.
-bool bt_wide(const IgemmArgs &a) { return tune(TUNE_BF16_TILE) == 64 && a.Cx % 64 == 0; }
+bool bt_wide(const IgemmArgs &a) { return tune(TUNE_BF16_TILE) == 64 && a.Cx % 64 == 0 && a.N > 128; }
+
+// Tile shape by the output's width: 512 x 64 for N <= 64, 512 x 128 for N <= 128, else 256 x 256 (igemm_b16t.h BtShape)
+inline int bt_bn(const IgemmArgs &a) { return a.N <= 64 ? 64 : a.N <= 128 ? 128 : 256; }
+inline int bt_bm(const IgemmArgs &a) { return a.N <= 128 ? 512 : 256; }
 
 PlanBT plan_b16t(const IgemmArgs &a) {
     const int cus = plan_cus();
     PlanBT p = {a.M, 0, 0, 0};
-    const long long tn = ceil_div(a.N, 256), tm = ceil_div(a.M, 256), t = tm * tn;
+    const int BM = bt_bm(a), BN = bt_bn(a);
+    const long long tn = ceil_div(a.N, BN), tm = ceil_div(a.M, BM), t = tm * tn;
     const int bk = bt_wide(a) ? 64 : BT_BK;
     const int nk = a.K / bk;
     if (t % cus == 0 || t * nk * bk / cus < 16 * BT_BK) return p;   // whole rounds, or too little work per CU to cut into pieces
@@ -793,7 +798,7 @@ PlanBT plan_b16t(const IgemmArgs &a) {
     }
     const long long tm_full = (t / cus) * cus / tn;
     if (tm_full >= 1 && tm_full < tm) {
-        p.main_rows = (int)(tm_full * 256);
+        p.main_rows = (int)(tm_full * BM);
         const long long tail_tiles = (tm - tm_full) * tn;
         p.tail_levels = tail_tiles * nk * bk / cus >= 16 * BT_BK ? streamk_levels(tail_tiles, nk, cus) : -1;
     }
@@ -809,7 +814,10 @@ size_t bt_workspace_bytes(const IgemmArgs &a) {
 
 template <bool SK, bool YBF>
 int launch_bt(IgemmArgs &a, hipStream_t stream) {
-    return bt_wide(a) ? launch_igemm_b16w<SK, YBF>(a, stream) : launch_igemm_b16t<SK, YBF>(a, stream);
+    if (bt_wide(a)) return launch_igemm_b16w<SK, YBF>(a, stream);
+    if (a.N <= 64) return launch_igemm_b16t<SK, YBF, 8, 2>(a, stream);
+    if (a.N <= 128) return launch_igemm_b16t<SK, YBF, 8, 4>(a, stream);
+    return launch_igemm_b16t<SK, YBF>(a, stream);
 }
 
 template <bool YBF>

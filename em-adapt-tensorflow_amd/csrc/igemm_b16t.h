@@ -75,9 +75,11 @@ __global__ void __launch_bounds__(256) filter_tiles_b16_kernel(const float *__re
 
 // Stream-K second stage for bf16-storage outputs (igemm_v2.h's streamk_fixup_kernel is the f32 one): the tiles that more than one
 // workgroup worked on.  One block = 16 rows of one 256 x 256 tile.
-template <bool YBF>
+template <bool YBF, int BM = 256, int BN = 256>
 __global__ void __launch_bounds__(256) streamk_fixup_t_kernel(IgemmArgs a, int G, int nk_all) {
-    const int t = blockIdx.x >> 4, part = blockIdx.x & 15;
+    constexpr int PARTS = BM / 16, QN = BN / 4, ITS = 16 * QN / 256;   // one block = 16 rows of one BM x BN tile
+    static_assert(ITS >= 1 && 16 * QN % 256 == 0, "tile shape");
+    const int t = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
     const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
     const long long U = (long long)a.tiles_m * a.tiles_n * nk_all, u0 = (long long)t * nk_all;
     const int vf = sk_owner(u0, U, G), vl = sk_owner(u0 + nk_all - 1, U, G);
@@ -85,11 +87,11 @@ __global__ void __launch_bounds__(256) streamk_fixup_t_kernel(IgemmArgs a, int G
     if (cnt <= 1) return;
     const long long mn = (long long)(a.m_end - a.m_begin) * a.N;
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
+    for (int it = 0; it < ITS; it++) {
         const int idx = it * 256 + threadIdx.x;
-        const int r = part * 16 + (idx >> 6);
-        const int row = a.m_begin + tile_m * 256 + r;
-        const int col = tile_n * 256 + (idx & 63) * 4;
+        const int r = part * 16 + idx / QN;
+        const int row = a.m_begin + tile_m * BM + r;
+        const int col = tile_n * BN + (idx % QN) * 4;
         if (row >= a.m_end || col >= a.N) continue;
         const long long o = (long long)row * a.N + col;
         const float *sp = a.slab + (o - (long long)a.m_begin * a.N);
@@ -109,9 +111,29 @@ __global__ void __launch_bounds__(256) streamk_fixup_t_kernel(IgemmArgs a, int G
 
 // ABLM (diagnostic library only, tune "ablate"): parts of the K loop COMPILED out -- 1 no DMAs, 2 no fragment reads, 4 no waits /
 // barrier, 8 no MFMAs, 16 no barrier (waits stay); results are garbage, scripts/bf16t_ablate.py reads the time.
-template <bool SK, bool YBF, int ABLM = 0>
+// Tile shapes (round 4, second half): the 8 waves are WMW x (8 / WMW) blocks of 64 x (32 TN) accumulators:
+//     WMW 4, TN 4: 256 x 256 (the default);  WMW 8, TN 4: 512 x 128;  WMW 8, TN 2: 512 x 64
+// The tall tiles serve the layers with 128 or 64 output columns (conv1_2, conv2_x, the data gradients into 64 / 128 channels): the
+// round-1 kernel runs them on 128 x 128 / 128 x 64 tiles with a two-stage pipeline, whose 9-18 K steps per tile each wait out a
+// memory round trip (conv1_2: 0.30 ms against an HBM floor of 0.08); here the ring runs three steps ahead.  A stage is
+// [BM rows][64 B] of activations + [BN rows][64 B] of filter; with BN = 64 only waves 0-3 have filter rows to fetch -- the others
+// issue the same instruction with every lane out of range into a scratch KB behind the ring, so that all waves count alike.
+template <int WMW, int TN>
+struct BtShape {
+    static constexpr int WNW = BT_WAVES / WMW, BM = WMW * 64, BN = WNW * TN * 32;
+    static constexpr int A_OPER = BM * BT_ROWB, B_OPER = BN * BT_ROWB, STAGE = A_OPER + B_OPER;
+    static constexpr int A_IPW = A_OPER / 1024 / BT_WAVES;                                   // DMA instructions per wave and step
+    static constexpr int B_INS = B_OPER / 1024, B_IPW = B_INS >= BT_WAVES ? B_INS / BT_WAVES : 1;
+    static constexpr bool B_SOME = B_INS < BT_WAVES;                                         // only waves < B_INS fetch filter rows
+    static constexpr size_t LDS = (size_t)BT_NBUF * STAGE + (B_SOME ? 1024 : 0);
+    static_assert(A_IPW >= 1 && BM % 128 == 0 && (B_INS % BT_WAVES == 0 || B_INS < BT_WAVES) && LDS <= 160 * 1024, "tile shape");
+};
+
+template <bool SK, bool YBF, int WMW = 4, int TN = 4, int ABLM = 0>
 __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs a) {
-    constexpr int BM = 256, BN = 256, BK = BT_BK, NBUF = BT_NBUF, TM = 2, TN = 4;
+    using SH = BtShape<WMW, TN>;
+    constexpr int BM = SH::BM, BN = SH::BN, BK = BT_BK, NBUF = BT_NBUF, TM = 2;
+    constexpr int A_IPW = SH::A_IPW, B_IPW = SH::B_IPW, STAGE = SH::STAGE, A_OPER = SH::A_OPER;
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
     // ---- work of this workgroup: one (tile, K range) piece, or with SK a sequence of them
@@ -164,13 +186,13 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = wave % WMW, wn = wave / WMW;
     const bool late = wave >= 4;   // (the SIMD partner of wave w is wave w + 4)
 
     // ---- loader side: constants of the launch
     // (the tap offset rides in the DMA's scalar operand, an UNSIGNED addend: the buffer starts `bias` bytes before the tensor)
     const int rowb = a.Cx * 2;             // bytes of a pixel
-    const int n_pad = a.tiles_n * 256;     // filter rows per (tap, group of 32 k) in the tiled filter image
+    const int n_pad = (int)((a.N + 255) / 256) * 256;   // filter rows per (tap, group of 32 k) in the tiled filter image
     const int cgroups = a.Cx / BK;
     int min_dh = a.sign * (0 - a.pad_h), min_dw = a.sign * (0 - a.pad_w);
     {
@@ -186,10 +208,10 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, (int)a.w_bytes, 0x00020000);
     constexpr unsigned kOOB = 0x80000000u;
     // instruction j of this wave moves slots [(wave * IPW + j) * 64, +64) of an operand's image: lane -> (row, slot)
-    int ld_row[BT_IPW], ld_chunk[BT_IPW];
+    int ld_row[A_IPW], ld_chunk[A_IPW];
 #pragma unroll
-    for (int j = 0; j < BT_IPW; j++) {
-        const int q = (wave * BT_IPW + j) * 64 + lane;
+    for (int j = 0; j < A_IPW; j++) {
+        const int q = (wave * A_IPW + j) * 64 + lane;
         ld_row[j] = q >> 2;
         ld_chunk[j] = (q & 3) ^ ((ld_row[j] >> 2) & 3);
     }
@@ -202,16 +224,16 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
 #pragma unroll
     for (int g = 0; g < 2; g++) {
         a_frag[g] = (wm * 64 + l31) * BT_ROWB + (((2 * g + lh) ^ sw) << 4);
-        b_frag[g] = BT_OPER + (wn * 128 + l31) * BT_ROWB + (((2 * g + lh) ^ sw) << 4);
+        b_frag[g] = A_OPER + (wn * (TN * 32) + l31) * BT_ROWB + (((2 * g + lh) ^ sw) << 4);
     }
     f32x16 acc[TM][TN];
     bt_bf16x8 av[2][TM], bv[2][TN];
 
     do {   // one piece of work (SK: several)
     const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
-    unsigned a_off[BT_IPW], a_bad[BT_IPW], b_off[BT_IPW];
+    unsigned a_off[A_IPW], a_bad[A_IPW], b_off[B_IPW];
 #pragma unroll
-    for (int j = 0; j < BT_IPW; j++) {
+    for (int j = 0; j < A_IPW; j++) {
         const int r = ld_row[j];
         const int m = m0 + r < a.m_end ? m0 + r : -1;
         if (m >= 0) {
@@ -236,8 +258,11 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
             a_off[j] = 0;
             a_bad[j] = 0xFFFFFFFFu;
         }
-        b_off[j] = (unsigned)((wave * BT_IPW + j) * 64 + lane) * 16u;   // the filter image is stored in LDS order: plain copies
     }
+    // the filter image is stored in LDS order: plain copies (a wave without filter rows of its own: every lane out of range)
+    const bool b_mine = !SH::B_SOME || wave < SH::B_INS;
+#pragma unroll
+    for (int j = 0; j < B_IPW; j++) b_off[j] = b_mine ? (unsigned)((wave * B_IPW + j) * 64 + lane) * 16u : 0x80000000u;
 
     // DMAs of K step kt (of this piece's tile) into the ring buffer at byte offset `off`: this wave's 2 KB of each operand.
     // K order = (channel group, tap).  A step past the end of the piece (live = false) carries the out-of-range bit on every
@@ -254,14 +279,15 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
         const unsigned s_w = (unsigned)__builtin_amdgcn_readfirstlane((int)(((tap * (unsigned)cgroups + chunk_u) * (unsigned)n_pad + (unsigned)n0) * (unsigned)BT_ROWB));
         const unsigned sh = 31u - (tap & 31u);   // moves this tap's "outside the image" bit to bit 31
         const unsigned dead = live ? 0u : kOOB;
-        char *as = ldsb + off + wave * (BT_IPW * 1024);
+        char *as = ldsb + off + wave * (A_IPW * 1024);
+        char *bs = b_mine ? ldsb + off + A_OPER + wave * (B_IPW * 1024) : ldsb + NBUF * STAGE;   // (scratch KB: zeros nobody reads)
         if constexpr (ABLM & 1) return;
 #pragma unroll
-        for (int j = 0; j < BT_IPW; j++)
+        for (int j = 0; j < A_IPW; j++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void_t *)(as + j * 1024), 16, (int)(a_off[j] | ((a_bad[j] << sh) & kOOB) | dead), (int)s_x, 0, 0);
 #pragma unroll
-        for (int j = 0; j < BT_IPW; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_t *)(as + BT_OPER + j * 1024), 16, (int)(b_off[j] | dead), (int)s_w, 0, 0);
+        for (int j = 0; j < B_IPW; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void_t *)(bs + j * 1024), 16, (int)(b_off[j] | dead), (int)s_w, 0, 0);
     };
 #define BT_SB __builtin_amdgcn_sched_barrier(0);
 #define BT_RA0(G, I, BASE) av[G][I] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BASE) + a_frag[G] + (I) * (32 * BT_ROWB)); BT_SB
@@ -270,26 +296,44 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
 #define BT_RB(G, J, BASE) if constexpr (!(ABLM & 2)) { BT_RB0(G, J, BASE) }
 #define BT_MF(G, I, J) if constexpr (!(ABLM & 8)) { acc[I][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[G][I], bv[G][J], acc[I][J], 0, 0, 0); BT_SB }
     //   NX / PV = byte offsets of the ring buffers of steps kt + 1 and kt - 1 (= kt + 3)
+    // (the loops below are fully unrolled -- TM, TN are template constants -- and every statement ends in a scheduling barrier: the
+    // order written IS the software pipeline)
+    auto read_frag = [&](int G, int n, int BASE) {   // fragment n of k group G: the TM A fragments, then the TN B fragments
+        if (n < TM) { BT_RA(G, n, BASE) } else { BT_RB(G, n - TM, BASE) }
+    };
     auto k_step = [&](int NX, int PV, int kt) {
         BT_SB
-        BT_MF(0, 0, 0) BT_MF(0, 0, 1) BT_MF(0, 0, 2) BT_MF(0, 0, 3) BT_MF(0, 1, 0) BT_MF(0, 1, 1) BT_MF(0, 1, 2) BT_MF(0, 1, 3)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) { BT_MF(0, i, j) }
         // The two waves of a SIMD (w and w + 4) run the same program between the same barriers; issued at the same point, their
         // DMA bursts (~100 cycles of address-unit wait per instruction) would idle the SIMD's matrix pipe together.  Waves 0-3
-        // issue theirs in FRONT of the barrier, waves 4-7 BEHIND it: each half's burst runs beside the other half's 16 MFMAs.
+        // issue theirs in FRONT of the barrier, waves 4-7 BEHIND it: each half's burst runs beside the other half's MFMAs.
         if (!late) fill(PV, kt0 + kt + 3, kt + 3 < nk);
         BT_SB
         if constexpr (!(ABLM & 4)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of this step has arrived
             // this wave's DMAs of step kt + 1 have landed (in flight: kt + 2 and, for waves 0-3, kt + 3)
-            if (late) wait_vmcnt<2 * BT_IPW>(); else wait_vmcnt<2 * 2 * BT_IPW>();
+            if (late) wait_vmcnt<A_IPW + B_IPW>(); else wait_vmcnt<2 * (A_IPW + B_IPW)>();
             if constexpr (!(ABLM & 16)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
         if (late) fill(PV, kt0 + kt + 3, kt + 3 < nk);
         BT_SB
-        BT_MF(1, 0, 0) BT_RA(0, 0, NX) BT_MF(1, 0, 1) BT_RA(0, 1, NX) BT_MF(1, 0, 2) BT_RB(0, 0, NX) BT_MF(1, 0, 3) BT_RB(0, 1, NX)
-        BT_MF(1, 1, 0) BT_RB(0, 2, NX) BT_MF(1, 1, 1) BT_RB(0, 3, NX) BT_MF(1, 1, 2) BT_MF(1, 1, 3)
-        BT_RB(1, 0, NX) BT_RB(1, 1, NX) BT_RB(1, 2, NX) BT_RB(1, 3, NX) BT_RA(1, 0, NX) BT_RA(1, 1, NX)
+        // the second k group's MFMAs, the next step's first-group fragments one behind each of them (TM + TN <= TM * TN reads) ...
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                BT_MF(1, i, j)
+                if (i * TN + j < TM + TN) read_frag(0, i * TN + j, NX);
+            }
+        // ... and its second group behind the last one (B first: the next step's first MFMAs need A's group 0 only)
+#pragma unroll
+        for (int j = 0; j < TN; j++) { BT_RB(1, j, NX) }
+#pragma unroll
+        for (int i = 0; i < TM; i++) { BT_RA(1, i, NX) }
     };
 
 #pragma unroll
@@ -300,17 +344,22 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     __syncthreads();   // the ring is free (SK: the previous piece's epilogue staged through it)
     fill(0, kt0, true);
-    fill(BT_STAGE, kt0 + 1, 1 < nk);
-    fill(2 * BT_STAGE, kt0 + 2, 2 < nk);
-    wait_vmcnt<2 * 2 * BT_IPW>();
+    fill(STAGE, kt0 + 1, 1 < nk);
+    fill(2 * STAGE, kt0 + 2, 2 < nk);
+    wait_vmcnt<2 * (A_IPW + B_IPW)>();
     __builtin_amdgcn_s_barrier();   // step 0 has landed
     asm volatile("" ::: "memory");
-    BT_RA0(0, 0, 0) BT_RA0(0, 1, 0) BT_RB0(0, 0, 0) BT_RB0(0, 1, 0) BT_RB0(0, 2, 0) BT_RB0(0, 3, 0)
-    BT_RB0(1, 0, 0) BT_RB0(1, 1, 0) BT_RB0(1, 2, 0) BT_RB0(1, 3, 0) BT_RA0(1, 0, 0) BT_RA0(1, 1, 0)
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) { BT_RA0(g, i, 0) }
+#pragma unroll
+        for (int j = 0; j < TN; j++) { BT_RB0(g, j, 0) }
+    }
     {
-        int u_off = 0, pv = (NBUF - 1) * BT_STAGE;
+        int u_off = 0, pv = (NBUF - 1) * STAGE;
         for (int kt = 0; kt < nk; kt++) {
-            const int nx = u_off == (NBUF - 1) * BT_STAGE ? 0 : u_off + BT_STAGE;
+            const int nx = u_off == (NBUF - 1) * STAGE ? 0 : u_off + STAGE;
             k_step(nx, pv, kt);
             pv = u_off;
             u_off = nx;
@@ -331,9 +380,9 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
     float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
     int lane_e = tid & 63;
     asm volatile("" : "+v"(lane_e));
-    float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (128 + 4));
-    static_assert(BT_WAVES * 16 * (128 + 4) * 4 <= BT_LDS, "epilogue slabs must fit in the ring");
-    store_acc_tile<TM, TN, 16, YBF>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+    float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (TN * 32 + 4));
+    static_assert(BT_WAVES * 16 * (TN * 32 + 4) * 4 <= SH::LDS, "epilogue slabs must fit in the ring");
+    store_acc_tile<TM, TN, 16, YBF>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * (TN * 32), slab_);
     } while (SK && next_piece());
 }
 
@@ -609,12 +658,13 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16w_kernel(IgemmArgs 
 }
 
 // a.splits: SK = false -> split-K factor (>= 1; > 1 needs a.slab); SK = true -> number of workgroups (CUs), a.slab for the levels
-template <bool SK, bool YBF, int ABLM = 0>
+template <bool SK, bool YBF, int WMW = 4, int TN = 4, int ABLM = 0>
 int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
+    using SH = BtShape<WMW, TN>;
 #ifdef EMADAPT_ABLATE_BUILD
     if constexpr (ABLM == 0 && YBF) {
         switch (tune(TUNE_ABLATE)) {
-#define EMADAPT_ABL_CASE(m) case m: return launch_igemm_b16t<SK, YBF, m>(a, stream);
+#define EMADAPT_ABL_CASE(m) case m: return launch_igemm_b16t<SK, YBF, WMW, TN, m>(a, stream);
             EMADAPT_ABL_CASE(1) EMADAPT_ABL_CASE(2) EMADAPT_ABL_CASE(3) EMADAPT_ABL_CASE(4) EMADAPT_ABL_CASE(7) EMADAPT_ABL_CASE(8)
             EMADAPT_ABL_CASE(9) EMADAPT_ABL_CASE(10) EMADAPT_ABL_CASE(14) EMADAPT_ABL_CASE(16)
 #undef EMADAPT_ABL_CASE
@@ -623,26 +673,26 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
     }
 #endif
     static DynLdsAttr attr;
-    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16t_kernel<SK, YBF, ABLM>), BT_LDS);
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16t_kernel<SK, YBF, WMW, TN, ABLM>), SH::LDS);
     if (rc) return rc;
-    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, 256);
-    a.tiles_n = (int)ceil_div(a.N, 256);
+    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, SH::BM);
+    a.tiles_n = (int)ceil_div(a.N, SH::BN);
     const int nk_all = a.K / BT_BK;
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
     if constexpr (SK) {
-        if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * 16 > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * (SH::BM / 16) > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
         const int G = streamk_grid(tiles, nk_all, a.splits);
         const int levels = streamk_levels(tiles, nk_all, a.splits);
         if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
-        hipLaunchKernelGGL((igemm_b16t_kernel<true, YBF, ABLM>), dim3((unsigned)G), dim3(BT_WAVES * 64), BT_LDS, stream, a);
+        hipLaunchKernelGGL((igemm_b16t_kernel<true, YBF, WMW, TN, ABLM>), dim3((unsigned)G), dim3(BT_WAVES * 64), SH::LDS, stream, a);
         rc = launch_status();
         if (rc || levels == 0) return rc;
-        hipLaunchKernelGGL(streamk_fixup_t_kernel<YBF>, dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, a, G, nk_all);
+        hipLaunchKernelGGL((streamk_fixup_t_kernel<YBF, SH::BM, SH::BN>), dim3((unsigned)(tiles * (SH::BM / 16))), dim3(256), 0, stream, a, G, nk_all);
         return launch_status();
     } else {
         const long long nblk = tiles * a.splits;
         if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF, ABLM>), dim3((unsigned)nblk), dim3(BT_WAVES * 64), BT_LDS, stream, a);
+        hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF, WMW, TN, ABLM>), dim3((unsigned)nblk), dim3(BT_WAVES * 64), SH::LDS, stream, a);
         rc = launch_status();
         if (rc || a.splits <= 1) return rc;
         long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;

@@ -11,7 +11,8 @@ _lib._bind(_build.ABLATE_LIB_PATH)
 from em_adapt_tensorflow_amd import ops
 layer = sys.argv[1] if len(sys.argv) > 1 else "fc7"
 zeros = len(sys.argv) > 2 and sys.argv[2] == "zeros"
-H, Cin, Cout, k, rate = {"fc7": (41, 4096, 4096, 1, 1), "conv4_2": (41, 512, 512, 3, 1), "fc6": (41, 512, 4096, 4, 4)}[layer]
+H, Cin, Cout, k, rate = {"fc7": (41, 4096, 4096, 1, 1), "conv4_2": (41, 512, 512, 3, 1), "fc6": (41, 512, 4096, 4, 4),
+                         "conv1_2": (321, 64, 64, 3, 1), "conv2_2": (161, 128, 128, 3, 1)}[layer]
 B = 16
 g = torch.Generator(device="cuda").manual_seed(1)
 x = torch.randn((B, H, H, Cin), device="cuda", generator=g).relu_().bfloat16()

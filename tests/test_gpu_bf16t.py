@@ -66,6 +66,9 @@ SMALL = [
     ((2, 30, 18, 160, 288, 3, 1), 7),
     ((2, 21, 20, 128, 320, 3, 1), 4),      # Cin and Cout multiples of 64: the 128-byte-piece kernel, both directions, stream-K
     ((1, 33, 31, 192, 64, 3, 2), 256),     # odd number of double steps per tap group (3 x 64 channels)
+    ((2, 40, 33, 64, 128, 3, 1), 3),       # 128 output columns: 512 x 128 tiles (6 of them on 3 "CUs": stream-K); data gradient into 64: 512 x 64
+    ((3, 57, 31, 128, 96, 3, 1), 256),     # 96 columns in a 128-wide tile, 11 M tiles with a tail, plain tiles
+    ((1, 70, 50, 32, 64, 3, 1), 2),        # 64 columns: 512 x 64 tiles, only waves 0-3 fetch filter rows; 7 tiles on 2 "CUs"
 ]
 
 
