@@ -26,3 +26,7 @@ for l in open("$O"):
     d = json.loads(l)
     print("%-150s %8.1f images/s  %7.2f ms/step  conv %s TF" % (d["config"]["workload"][:150], d["value"], d["ms_per_step"], d["roofline"]["all_conv_tflops"]))
 PY
+# round 4: configs[4] "as memory allows" -- 513x513 at batch 32 puts conv1's activations past 2 GiB (batch-sliced launches)
+python3 bench.py --no-alt --steps 4 --warmup 2 --no-cpu-baseline --size 513 --classes 41 --batch 32 2>/dev/null | grep '"metric"' | tee -a $O | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('%-150s %8.1f images/s  %7.2f ms/step' % (d['config']['workload'][:150], d['value'], d['ms_per_step']))"
