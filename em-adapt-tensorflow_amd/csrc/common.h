@@ -80,6 +80,8 @@ enum TuneKey {
                        //    launch's products (0 = the default, 5)
     TUNE_ESTEP_STOP,   // diagnostic builds only (-DEMADAPT_ABLATE_BUILD): leave the E-step kernel after phase n
     TUNE_ABLATE,       // diagnostic builds only: ablation bit mask of the fp32 igemm kernel
+    TUNE_DMA_STAGGER,  // 1: the LDS-DMA kernels without DMA/MFMA wave roles (igemm_x6p.h, igemm_b16t.h) issue every wave's DMA burst at the
+                       //    same point again (round 3's form; A/B of the round-4 stagger of SIMD partners)
     TUNE_RASTER_GM,    // M tiles per group of the plain-tile launches' XCD-aware order (0 = the default, 8): the workgroups resident on
                        //    one XCD cover GM M-tiles x the N-tiles that fit (scripts/raster_sweep.py measures the L2 hit rate and the time)
     TUNE_COUNT

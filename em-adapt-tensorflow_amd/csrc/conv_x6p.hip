@@ -369,6 +369,7 @@ int emadapt_conv_wgrad_x6p(const emadapt_conv_desc *d, const void *x_planes, con
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
     // skip the pixels at which a tile's tap is outside the image (fp32_loader = 2 keeps the dense walk: tests, A/B)
     a.skip = a.ntaps > 1 && tune(TUNE_FP32_LOADER) != 2;
+    a.lockstep = tune(TUNE_DMA_STAGGER) == 1 ? 1 : 0;
     if (a.skip) wp_order_k_tiles(a);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 6.0 * ((double)a.M * d->Cin + (double)a.M * a.N) + 4.0 * a.K * a.N, stream);
     if (a.skip) prof.executed_fraction(taps_inside_fraction(d->H, d->W, d->KH, d->KW, d->dil, a.pad_h, a.pad_w));

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16t_kernel(IgemmArgs 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WMW, wn = wave / WMW;
-    const bool late = wave >= 4;   // (the SIMD partner of wave w is wave w + 4)
+    const bool late = wave >= 4 && !a.lockstep;   // (the SIMD partner of wave w is wave w + 4)
 
     // ---- loader side: constants of the launch
     // (the tap offset rides in the DMA's scalar operand, an UNSIGNED addend: the buffer starts `bias` bytes before the tensor)
@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(BT_WAVES * 64, 2) igemm_b16w_kernel(IgemmArgs 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    const bool late = wave >= 4;
+    const bool late = wave >= 4 && !a.lockstep;
 
     const int rowb = a.Cx * 2;
     const int n_pad = a.tiles_n * 256;

@@ -77,6 +77,7 @@ struct IgemmArgs {
     RowPack pk;          // stream-K launches that skip padding (pk.n > 0)
     unsigned magic_w;    // ceil(2^32 / W)
     int gm;      // M tiles per group of the plain-tile order (tune "raster_gm", default 8)
+    int lockstep;  // 1: every wave issues its DMA burst at the same point (tune "dma_stagger" = 1; default 0: SIMD partners staggered)
     int ablate;  // diagnostic builds only (tune "ablate"): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
 };
 
@@ -378,6 +379,7 @@ void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
     a.magic_cx = magic_u32(a.Cx); a.magic_kw = magic_u32(a.KW); a.magic_nt = magic_u32(a.ntaps);
     a.magic_w = magic_u32(a.W); a.pk.n = 0; a.pk.rowmap = nullptr;
     a.gm = tune(TUNE_RASTER_GM) > 0 ? tune(TUNE_RASTER_GM) : 8;
+    a.lockstep = tune(TUNE_DMA_STAGGER) == 1 ? 1 : 0;
 }
 
 }  // namespace

@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
+    const bool late = wave >= 4 && !a.lockstep;   // (the SIMD partner of wave w is wave w + 4; see k_step)
 
     // ---- loader side: constants of the launch
     // (the tap offset rides in the DMA's scalar operand, an UNSIGNED addend: the buffer starts `bias` bytes before the tensor)
@@ -241,14 +242,21 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
     auto k_step = [&](int u_off, int NX, int PV, int kt) {
         XP_SB
         XP_GROUP(0, 2) XP_GROUP(0, 1) XP_GROUP(0, 0)
-        fill(PV, kt0 + kt + 2, kt + 2 < nk);
+        // (round 4) The two waves of a SIMD, w and w + 4, run this program in lockstep between the same barriers: issued at the same
+        // point, their DMA bursts wait for the address unit together while the SIMD's matrix pipe idles.  Waves 0-3 issue theirs in
+        // FRONT of the barrier, waves 4-7 BEHIND it (into the same stage, free since the previous barrier either way): each half's
+        // burst runs beside the other half's MFMAs.  Measured on the bf16 kernel of igemm_b16t.h (+4-8 %), and here:
+        // profiles/r04_x6p_stagger.txt.  tune "dma_stagger" = 1 switches it off (A/B).
+        if (!late) fill(PV, kt0 + kt + 2, kt + 2 < nk);
         XP_SB
         if constexpr (!(ABLM & 4)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every fragment of this step has arrived (a1 was fetched last)
-            if constexpr (!(ABLM & 32)) wait_vmcnt<2 * XP_IPW>();   // this wave's DMAs of step kt + 1 have landed (those of kt + 2 just left)
+            // this wave's DMAs of step kt + 1 have landed (waves 0-3: those of kt + 2 have just left)
+            if constexpr (!(ABLM & 32)) { if (late) wait_vmcnt<0>(); else wait_vmcnt<2 * XP_IPW>(); }
             if constexpr (!(ABLM & 16)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
+        if (late) fill(PV, kt0 + kt + 2, kt + 2 < nk);
         XP_SB
         XP_MF(1, 0, 0, 0) XP_RA(0, 0, NX) XP_MF(1, 0, 0, 1) XP_RA(0, 1, NX) XP_MF(1, 0, 0, 2) XP_RB(2, 0, NX) XP_MF(1, 0, 0, 3) XP_RB(2, 1, NX)
         XP_MF(1, 0, 1, 0) XP_RB(2, 2, NX) XP_MF(1, 0, 1, 1) XP_RB(2, 3, NX) XP_MF(1, 0, 1, 2) XP_MF(1, 0, 1, 3)

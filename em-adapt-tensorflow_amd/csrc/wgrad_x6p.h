@@ -33,6 +33,7 @@ struct WgradXPArgs {
     unsigned x_bytes, y_bytes;
     unsigned magic_w, magic_h;
     int skip;               // walk only the pixels at which the tile's tap is inside the image
+    int lockstep;           // 1: every wave issues its DMA burst at the same point (tune "dma_stagger" = 1)
     unsigned char korder[256];
 };
 
@@ -107,6 +108,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wk = wave & 3, wn = wave >> 2;
+    const bool late = wave >= 4 && !a.lockstep;   // (the SIMD partner of wave w is wave w + 4)
 
     // ---- loader side
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a.xp), 0, (int)a.x_bytes, 0x00020000);
@@ -196,12 +198,15 @@ __global__ void __launch_bounds__(512, 2) wgrad_x6p_kernel(WgradXPArgs a) {
     auto k_step = [&](int NX, int PV, int st) {
         WP_SB
         WP_GROUP(0, 2) WP_GROUP(0, 1) WP_GROUP(0, 0)
-        fill(PV, st + 2);   // (steps past the end: both pixels dead, zeros)
+        // (round 4: the SIMD partners' bursts staggered around the barrier as in igemm_x6p_kernel -- waves 0-3 in front, 4-7 behind)
+        if (!late) fill(PV, st + 2);   // (steps past the end: both pixels dead, zeros)
         WP_SB
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_vmcnt<6>();   // this wave's DMAs of step st + 1 have landed (those of st + 2 just left)
+        // this wave's DMAs of step st + 1 have landed (waves 0-3: those of st + 2 have just left)
+        if (late) wait_vmcnt<0>(); else wait_vmcnt<6>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (late) fill(PV, st + 2);
         WP_SB
         WP_MF(1, 0, 0, 0) WP_RA(0, 0, NX) WP_MF(1, 0, 0, 1) WP_RA(0, 1, NX) WP_MF(1, 0, 0, 2) WP_RB(2, 0, NX) WP_MF(1, 0, 0, 3) WP_RB(2, 1, NX)
         WP_MF(1, 0, 1, 0) WP_RB(2, 2, NX) WP_MF(1, 0, 1, 1) WP_RB(2, 3, NX) WP_MF(1, 0, 1, 2) WP_MF(1, 0, 1, 3)
