@@ -338,3 +338,47 @@ def test_plane_kernel_plans_sizes_and_shape_rules_need_no_device():
                         kinds.add("plain")
                         assert ws == 0
     assert kinds == {"plain", "stream-k", "packed", "tail"}, kinds
+
+
+def test_executed_fraction_and_new_plan_queries_without_a_device():
+    """Host-only arithmetic of the C ABI added in round 4: executed / algorithmic FLOPs per shape (what bench.py's frac_executed is
+    built from), the bf16 plans, the LDS-DMA bf16 kernels' support rules and plans, and the batch-sliced workspace sizes of tensors
+    of 2 GiB and more."""
+    import ctypes
+    from em_adapt_tensorflow_amd import _lib, ops
+    lib = _lib.load()
+    f = lambda *a, **k: ops.conv_executed_fraction(*a, **k)
+    # fc6 (4x4 rate 4 on 41x41, deeplab.py:92,145): 16 taps, rows / columns -6 and +6 outside for 6 of 41 positions each
+    exact = ((41 - 6) + (41 - 2) + (41 - 2) + (41 - 6)) ** 2 / (16 * 41 * 41)
+    assert abs(f(16, 41, 41, 512, 4096, 4, 4, "wgrad") - exact) < 1e-12               # per-tap pixel boxes: exact
+    assert exact <= f(16, 41, 41, 512, 4096, 4, 4, "fwd") < exact + 0.02               # packed rows: tiles straddling classes pay the union
+    assert f(16, 41, 41, 512, 4096, 4, 4, "fwd") == f(16, 41, 41, 512, 4096, 4, 4, "dgrad")
+    assert f(16, 41, 41, 4096, 4096, 1, 1, "fwd") == 1.0 and f(16, 41, 41, 4096, 4096, 1, 1, "wgrad") == 1.0   # 1x1: nothing to skip
+    assert f(16, 41, 41, 512, 512, 3, 1, "fwd") == 1.0                                 # rate-1 3x3: below the 5 % packing threshold ...
+    assert abs(f(16, 41, 41, 512, 512, 3, 1, "wgrad") - (40 + 41 + 40) ** 2 / (9 * 41 * 41)) < 1e-12   # ... but its filter gradient skips
+    assert f(16, 41, 41, 512, 512, 3, 2, "fwd") < 0.95                                 # conv5_x, rate 2: packed
+    assert f(16, 41, 41, 512, 4096, 4, 4, "fwd", "bf16") == 1.0                        # the bf16 kernels walk the dense reduction
+    assert f(16, 41, 41, 512, 4096, 4, 4, "wgrad", "bf16x6") == f(16, 41, 41, 512, 4096, 4, 4, "wgrad")
+    with ops.tuned(fp32_loader=2):                                                     # the dense plans (tests, A/B): nothing skipped
+        assert f(16, 41, 41, 512, 4096, 4, 4, "fwd") == 1.0 and f(16, 41, 41, 512, 4096, 4, 4, "wgrad") == 1.0
+    # bf16 plans at the benchmark shapes: 256 x 256 tiles for the wide layers, 128 x 64 for the 64-column ones (round 4)
+    assert ops.conv_bf16_plan(16, 41, 41, 4096, 4096, 1, 1)[:2] == (256, 256)
+    assert ops.conv_bf16_plan(16, 321, 321, 64, 64, 3, 1)[:2] == (128, 64) and ops.conv_bf16_plan(16, 161, 161, 128, 64, 3, 1, "dgrad")[:2] == (128, 128)
+    assert ops.conv_bf16_plan(16, 161, 161, 64, 128, 3, 1, "dgrad")[:2] == (128, 64)   # the data gradient's columns are Cin
+    # LDS-DMA bf16 kernels: gathered channels % 32, stream-K where the tiles are not whole rounds
+    d = ops.conv_desc(16, 41, 41, 512, 512, 3, 3, 1)
+    assert ops.conv_bf16t_supported(d, "fwd") and ops.conv_bf16t_supported(d, "dgrad")
+    assert not ops.conv_bf16t_supported(ops.conv_desc(16, 321, 321, 4, 64, 3, 3, 1), "fwd")            # conv1_1: 4 input channels
+    rows, sk, levels, tail = ops.conv_bf16t_plan(16, 41, 41, 512, 512, 3, 1)
+    assert rows == 16 * 41 * 41 and sk == 1 and levels >= 2                             # 212 tiles on 256 CUs
+    rows, sk, levels, tail = ops.conv_bf16t_plan(16, 41, 41, 4096, 4096, 1, 1)
+    assert rows == 24576 and sk == 0 and tail >= 1                                     # 6 whole rounds + a stream-K tail
+    # tensors of 2 GiB and more: one launch is refused by the 32-bit offsets, the entries slice the batch; workspace = the largest slice's
+    big = ops.conv_desc(129, 256, 256, 32, 64, 3, 3, 1)
+    one = ops.conv_desc(127, 256, 256, 32, 64, 3, 3, 1)
+    assert 129 * 256 * 256 * 64 * 4 >= 2 ** 31 > 127 * 256 * 256 * 64 * 4
+    assert lib.emadapt_conv_fwd_workspace_bytes(ctypes.byref(big)) == lib.emadapt_conv_fwd_workspace_bytes(ctypes.byref(one))
+    kn = 3 * 3 * 32 * 64 * 4
+    assert lib.emadapt_conv_wgrad_workspace_bytes(ctypes.byref(big)) >= lib.emadapt_conv_wgrad_workspace_bytes(ctypes.byref(one)) + 2 * kn
+    plan = (ctypes.c_int * 4)()
+    assert lib.emadapt_conv_plan(ctypes.byref(big), 0, plan) == -2                      # (the whole-tensor plan query still says "unsupported")
