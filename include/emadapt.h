@@ -362,7 +362,9 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  *                A forced variant the shape is not eligible for is ignored.
  *   "wgrad_gen"  1: 128x128 wave-specialised filter-gradient kernel | 2: 256x256 second generation (LDS-DMA loaders)
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
- *   "bf16_tile"  128 | 256          "x6_tile"  128 | 256
+ *   "bf16_tile"  128 | 256 (emadapt_conv_*_bf16: 128 also keeps the 128-wide tile where 128 x 64 would be chosen); 64: the LDS-DMA
+ *                entries (emadapt_conv_*_bf16t) fetch the activations in 128-byte pieces (igemm_b16w_kernel) where Cx % 64 == 0
+ *   "x6_tile"    128 | 256
  *   "plan_cus"   number of CUs the launch plans are laid out for (default 256: MI355X)
  *   "fp32_loader" 1: the 256x256 fp32 kernels' loader waves compute their offsets per K step (works for any tap count);
  *                0: loaders specialised for 1x1 / 3x3 / 4x4 filters where the filter has that many taps, and the
@@ -370,6 +372,11 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  *                but every pixel is walked (out-of-image taps contribute zeros)
  *   "pack_pct"   the fp32 forward / data-gradient launches run over packed rows (pixel classes, see emadapt_conv_plan) when
  *                that saves at least this many per cent of the dense launch's products (0 = the built-in threshold)
+ *   "raster_gm"  M tiles per group of the plain-tile launches' XCD-aware order (default 8): the workgroups resident on one XCD cover
+ *                that many M-tiles x the N-tiles that fit (scripts/raster_sweep.py: L2 hit rate and time per setting)
+ *   "dma_stagger" 1: the LDS-DMA kernels without loader waves (bf16x6 plane kernels, emadapt_conv_*_bf16t) issue every wave's DMA
+ *                burst at the same point of the K step (round 3's form); 0 (default): the two waves of a SIMD staggered around
+ *                the step's barrier (round 4: +3-6 %)
  *   "estep_stop", "ablate": honoured by diagnostic builds only (-DEMADAPT_ABLATE_BUILD), ignored otherwise
  *                ("estep_stop" 1..4: leave the E-step kernel after that phase; bits 16 / 32 / 64 / 128: run its rank selection
  *                without the LDS atomics / the histogram scans / the barriers / after the first pass -- timing only)
