@@ -191,3 +191,52 @@ def test_argument_errors(pkg):
     # empty batch is a no-op
     fm, lab = est.estep_labels(np.zeros((0, 4, 4, 3), np.float32), np.zeros((0, 4, 4)), perm=np.array([[1, 2]] * 5))
     assert fm.shape == (0, 4, 4, 3) and lab.shape == (0, 4, 4)
+
+
+def test_labels_only_path_of_the_overflow_geometry_against_c_oracle(pkg):
+    """The training step asks for the label map alone.  Where the class images overflow the LDS (65 x 65 x 41) that call runs
+    estep_prep_kernel (suppress step on the whole chip), the E-step kernel (argmax over its LDS-resident classes only) and
+    estep_finish_kernel (the other class images, merged: larger value, lower class on a tie) -- round 4.  Bit for bit against the C
+    oracle's label map, on: random logits; MORE present classes than fit in LDS (present classes among the non-resident ones);
+    logits quantised to a few values (exact ties between resident and non-resident classes, all-equal rows); suppression off;
+    multi-hot labels; and an f32 row pitch wider than the class count (the logits read in place from a padded buffer)."""
+    est, ops, torch = pkg
+    from oracle import estep_oracle as eo
+    from oracle import estep_oracle_c as eoc
+    rng = np.random.default_rng(23)
+    S, C = 65, 41
+    assert ops._lib.load().emadapt_estep_workspace_bytes(2, S, S, C) > 2 * C * S * S * 4      # overflow geometry
+    cases = []
+    for name, npresent, quant, suppress in [("random", 3, 0, True), ("many present", 12, 0, True), ("ties", 4, 4, True),
+                                            ("all equal", 2, 1, True), ("no suppress", 5, 0, False), ("ties, no suppress", 9, 3, False)]:
+        B = 2
+        logits = rng.normal(0, 2.0, (B, S, S, C)).astype(np.float32)
+        if quant == 1:
+            logits[...] = 0.75
+        elif quant:
+            logits = (np.round(logits * quant) / quant).astype(np.float32)
+        label = np.zeros((B, S, S), np.float32)
+        for b in range(B):
+            for c in rng.choice(np.arange(1, C), size=npresent, replace=False):
+                y, x = rng.integers(0, S - 6, 2)
+                label[b, y:y + 6, x:x + 6] = c
+        cases.append((name, logits, label, suppress))
+    for name, logits, label, suppress in cases:
+        B = logits.shape[0]
+        perms = eo.draw_perms(5, C, seed=int(rng.integers(1 << 30)))
+        _, want = eoc.estep_oracle_c(logits, label, perms, suppress, 5, 1e-5, 0.4, 0.2)
+        lg = torch.tensor(logits, device="cuda:0")
+        lb = torch.tensor(label, device="cuda:0")
+        pm = torch.tensor(np.asarray(perms, dtype=np.int32), device="cuda:0")
+        got, fmap = ops.estep_device(lg, lb, pm, C, suppress, 5, 1e-5, 0.4, 0.2)
+        assert fmap is None and np.array_equal(got.cpu().numpy(), want), (name, int((got.cpu().numpy() != want).sum()))
+        # the same through a padded row pitch (44 floats, as the model's fc8 buffer) and multi-hot labels
+        padded = torch.zeros((B, S, S, 44), device="cuda:0")
+        padded[..., :C] = lg
+        mh = np.zeros((B, C), np.uint8)
+        for b in range(B):
+            for v in np.unique(label[b]).astype(np.int64):
+                mh[b, v] = 1
+        got2, _ = ops.estep_device(padded, torch.tensor(mh, device="cuda:0"), pm, C, suppress, 5, 1e-5, 0.4, 0.2,
+                                   label_kind=ops.LABEL_MULTIHOT)
+        assert np.array_equal(got2.cpu().numpy(), want), name
