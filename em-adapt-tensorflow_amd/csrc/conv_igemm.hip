@@ -636,13 +636,22 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
 // (packed rows: the GEMM row -> pixel table sits behind the slab levels)
 inline size_t rowmap_bytes(const IgemmArgs &a) { return (size_t)ceil_div(a.M, 256) * 256 * sizeof(int); }
 
+// (stream-K launches, variant 5: arrival words + one 256 KB slab per workgroup when tiles are shared -- igemm_v2.h -- whatever
+//  the layer's size; rounds 2-3 kept `levels` [M][N] images: 881 MB for fc6)
 size_t igemm_workspace_bytes(const IgemmArgs &a) {
     const LaunchPlan p = plan_launches(a);
-    if (p.cfg == 5) return (size_t)p.main_splits * a.M * a.N * sizeof(float) + (p.bands ? rowmap_bytes(a) : 0);
+    const size_t sk = streamk_workspace_bytes(plan_cus());
+    if (p.cfg == 5) return (p.main_splits > 0 ? sk : 0) + (p.bands ? rowmap_bytes(a) : 0);
     size_t b = p.main_splits > 1 ? (size_t)p.main_splits * p.main_rows * a.N * sizeof(float) : 0;
-    if (p.tail_cfg == 5) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
+    if (p.tail_cfg == 5) b = b > (p.tail_splits > 0 ? sk : 0) ? b : (p.tail_splits > 0 ? sk : 0);   // (the launches run one after the other)
     else if (p.tail_splits > 1) b += (size_t)p.tail_splits * (a.M - p.main_rows) * a.N * sizeof(float);
     return b;
+}
+
+// a.sk_flags / a.slab of a stream-K launch from the start of the workspace
+inline void set_streamk_workspace(IgemmArgs &a, void *workspace, bool shared_tiles) {
+    a.sk_flags = shared_tiles ? static_cast<unsigned *>(workspace) : nullptr;
+    a.slab = shared_tiles ? reinterpret_cast<float *>(static_cast<char *>(workspace) + streamk_flag_bytes(plan_cus())) : nullptr;
 }
 
 // Tap count the second-generation kernel's loaders are specialised for (0: the generic loaders).  The specialised form
@@ -700,17 +709,18 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
             double exec = 1.0;
             if (!build_row_pack(a, (int)ceil_div(a.N, 256), &exec)) return EMADAPT_ERR_INVALID;   // (the plan was made from the same geometry)
             prof.executed_fraction(exec);
-            a.pk.rowmap = reinterpret_cast<const int *>(static_cast<char *>(workspace) + (size_t)p.main_splits * a.M * a.N * sizeof(float));
+            a.pk.rowmap = reinterpret_cast<const int *>(static_cast<char *>(workspace) + (p.main_splits > 0 ? streamk_workspace_bytes(plan_cus()) : 0));
         }
         a.m_begin = 0;
         a.m_end = a.M;
         a.splits = plan_cus();
-        a.slab = p.main_splits > 0 ? static_cast<float *>(workspace) : nullptr;
+        set_streamk_workspace(a, workspace, p.main_splits > 0);
         return launch_variant<BT>(5, a, stream);
     }
     a.m_begin = 0;
     a.m_end = p.main_rows;
     a.splits = p.main_splits;
+    a.sk_flags = nullptr;
     a.slab = p.main_splits > 1 ? static_cast<float *>(workspace) : nullptr;
     int rc = launch_variant<BT>(p.cfg, a, stream);
     if (rc || p.tail_cfg == 0) return rc;
@@ -718,7 +728,7 @@ int dispatch_igemm(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStr
     a.m_end = a.M;
     if (p.tail_cfg == 5) {
         a.splits = plan_cus();
-        a.slab = p.tail_splits > 0 ? static_cast<float *>(workspace) : nullptr;
+        set_streamk_workspace(a, workspace, p.tail_splits > 0);
     } else {
         a.splits = p.tail_splits;
         a.slab = p.tail_splits > 1 ? static_cast<float *>(workspace) : nullptr;  // the main launch of a split plan uses no slab

@@ -71,14 +71,15 @@ struct IgemmArgs {
     unsigned magic_cx, magic_kw;  // ceil(2^32/Cx), ceil(2^32/KW): k / Cx and tap / KW by one v_mul_hi_u32
     int m_begin, m_end;  // output rows (pixels) this launch covers: [m_begin, m_end)
     int splits;          // split-K: K steps are divided over `splits` workgroups per tile (partials -> slab)
-    float *slab;         // [splits][M][N] fp32 partials when splits > 1
+    float *slab;         // [splits][M][N] fp32 partials when splits > 1 (stream-K launches of igemm2_kernel: one 256x256 accumulator image per workgroup)
+    unsigned *sk_flags;  // stream-K launches of igemm2_kernel: one arrival word per workgroup, zeroed ahead of the launch
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
     unsigned magic_nt;   // ceil(2^32/ntaps)
     RowPack pk;          // stream-K launches that skip padding (pk.n > 0)
     unsigned magic_w;    // ceil(2^32 / W)
     int gm;      // M tiles per group of the plain-tile order (tune "raster_gm", default 8)
     int lockstep;  // 1: every wave issues its DMA burst at the same point (tune "dma_stagger" = 1; default 0: SIMD partners staggered)
-    int ablate;  // diagnostic builds only (tune "ablate"): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads
+    int ablate;  // diagnostic builds only (tune "ablate"): 1 = no global loads, 2 = no LDS stores, 4 = no barrier, 8 = no A loads, 16 = no B loads, 32 = no epilogue, 64 = no fragment reads (igemm2_kernel)
 };
 
 // 16-byte buffer load with hardware range checking: an offset at/after the end of the buffer returns 0,

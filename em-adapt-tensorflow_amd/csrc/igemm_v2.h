@@ -66,9 +66,25 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // Stream-K work split (SK kernels): the K steps of all tiles, tile after tile, form one line of U = tiles * nk units that
 // is cut into G equal pieces, one per workgroup (G = number of CUs): a workgroup runs the tail of one tile, possibly whole
-// tiles, and the head of the next.  Whole tiles get the fused epilogue; a piece of a tile goes to slab level
-// (workgroup - first workgroup of that tile), and streamk_fixup_kernel adds a tile's pieces in workgroup order
-// (= ascending k: deterministic) and applies the epilogue.  No CU idles in a partial last round, whatever the tile count.
+// tiles, and the head of the next.  No CU idles in a partial last round, whatever the tile count.  A tile that several
+// workgroups share is combined INSIDE the launch (round 4; rounds 2-3 wrote every piece to an [M][N] slab level and a second
+// kernel, ~40 us per launch and 21 launches per step, added the levels and applied the epilogue):
+//   * only the FIRST piece of a workgroup can start inside a tile (kt0 > 0: the tile's tail, or -- a share shorter than a
+//     tile -- its middle); every later piece starts at k = 0.  So a workgroup publishes at most one partial tile, and it
+//     does so early: its accumulators, in register order (64 lanes x 16 bytes per store: no staging), go to ITS slab
+//     (slab[workgroup], 256 KB) with write-through (sc1) stores, every wave drains them, and after the piece's closing
+//     barrier one lane raises flag[workgroup];
+//   * the workgroup that runs the HEAD of a shared tile (k = 0: always the last piece of its share, finished when the
+//     others' first pieces are long done) polls the flags of the next workgroups in turn, adds their slabs to its
+//     accumulators -- head + next + next: ascending k, the order of the second kernel it replaces, so the sums are the
+//     same bit for bit -- with sc1 loads (L1-bypassing; MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload,
+//     drained, relaxed agent-scope flag, sc1 loads by the wave that polled) and runs the fused epilogue like a whole tile.
+// The wait is bounded (kSkSpinMax polls of ~0.2 us: a publisher that never arrives -- it cannot, unless the launch shares the
+// chip with a kernel that never ends -- poisons the tile with NaNs instead of hanging the queue); the flags are zeroed by a
+// memset node ahead of every launch.
+typedef __attribute__((address_space(1))) unsigned sk_flag_t;
+constexpr unsigned kSkSpinMax = 1u << 23;
+constexpr int kSkSlabFloats = 256 * 256;   // one workgroup's accumulators (8 waves x 64 lanes x 128 registers)
 __host__ __device__ inline long long sk_start(long long v, long long U, int G) { return v * U / G; }
 __host__ __device__ inline int sk_owner(long long u, long long U, int G) { return (int)(((u + 1) * G - 1) / U); }   // piece holding unit u
 
@@ -358,6 +374,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     float2 bt[2][BT ? TN : 1];
     float4 bf[2][BT ? 1 : 2];
     auto read_q = [&](int buf, int q, int slot) {
+        if (ABL(64)) return;
         const float *as = As + buf * A_BUF;
         const float *bs = (BT ? lds : Bs) + buf * B_BUF;   // (BT: b_idx already counts from the start of LDS)
         const int hi = (q >> 2) * 16;   // chunks 4..7 of a 32-float row
@@ -428,13 +445,76 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         for (int kt = 0; kt < nk; kt++) k_step(kt % NBUF, (kt + 1) % NBUF, kt + 1 < nk);
     }
 
-    float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+    float *slab_ = !SK && lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
     // the epilogue derives its lane coordinates afresh (opaque to the optimiser): hoisted out of the piece loop they would
     // stay live through the MFMA loop, which has no vector register to spare (the compiler then spills operand fragments)
     int lane_e = tid & 63;
     asm volatile("" : "+v"(lane_e));
     const int l31e = lane_e & 31, lhe = lane_e >> 5;
-    if constexpr (BT) {
+    if constexpr (SK) {
+        // register v of the accumulator block (v = (i * TN + j) * 4 + quad) <-> bytes [(wave * 32 + v) * 1024 + lane * 16, +16) of a slab
+        // (the wave's 32 KB are the buffer: wave and slab index ride in the descriptor's base, scalar)
+        const unsigned lane_off = (unsigned)(lane_e * 16);
+        constexpr int kWaveFloats = kSkSlabFloats / CONS;
+        if (lvl > 0) {
+            // a piece that starts inside its tile: publish the accumulators (see the note at sk_start)
+            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(a.slab + (long long)sk_v * kSkSlabFloats + wave * kWaveFloats, 0, kWaveFloats * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int qd = 0; qd < 4; qd++) {
+                        u32x4 v;
+                        v.x = __float_as_uint(acc[i][j][qd * 4 + 0]); v.y = __float_as_uint(acc[i][j][qd * 4 + 1]);
+                        v.z = __float_as_uint(acc[i][j][qd * 4 + 2]); v.w = __float_as_uint(acc[i][j][qd * 4 + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, sr, (int)lane_off, ((i * TN + j) * 4 + qd) * 1024, 16);   // aux 16 = sc1
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, ahead of the barrier that precedes the flag
+        }
+        if (lvl == 0) {
+            // head of a shared tile: the rest arrives from the next sk_more workgroups
+            // (the piece list has moved on: sk_u - nk is this tile's first unit)
+            const int sk_more = __builtin_amdgcn_readfirstlane(sk_owner((long long)(sk_u - nk) + nk_tile - 1, sk_units, (int)gridDim.x)) - sk_v;
+            for (int l = 1; l <= sk_more; l++) {
+                const sk_flag_t *f = ((const sk_flag_t *)a.sk_flags) + (sk_v + l);
+                bool ok = false;
+                for (unsigned spins = 0; spins < kSkSpinMax; spins++) {
+                    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
+                const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(a.slab + (long long)(sk_v + l) * kSkSlabFloats + wave * kWaveFloats, 0, ok ? kWaveFloats * 4 : 0, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                        typedef float f32x8_ __attribute__((ext_vector_type(8)));
+                        f32x4_ v[4];
+#pragma unroll
+                        for (int qd = 0; qd < 4; qd++)
+                            v[qd] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(sr, (int)lane_off, ((i * TN + j) * 4 + qd) * 1024, 16));   // sc1
+                        // (one 16-wide add: element-wise updates of the accumulator tuples cost the MFMA loop its registers)
+                        const f32x8_ lo = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(v[2], v[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[i][j] += __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                        // (4 loads in flight per lane, 32 KB per workgroup; 8 -- two blocks at a time -- do not fit beside the accumulators:
+                        //  the compiler then spills inside the MFMA loop)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                // (the publisher never arrived -- see the note at sk_start: a NaN in every 32 x 32 block of the tile)
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j][0] = ok ? acc[i][j][0] : __builtin_nanf("");
+            }
+        }
+    }
+    if (ABL(32)) {   // (diagnostic builds: no epilogue -- one lane keeps the accumulators alive)
+        if (lane_e == 77) a.y[0] = acc[0][0][0] + acc[1][3][15];
+    } else if (SK && lvl > 0) {
+        // (published above)
+    } else if constexpr (BT) {
         // data gradient: columns l31 + 32*j -> the LDS-staged vector epilogue of the round-1 kernels (igemm_common.h); the
         // ring is dead after the last barrier
         static_assert(CONS * 16 * (128 + 4) <= NBUF * (A_BUF + B_BUF), "epilogue slabs must fit in the ring");
@@ -500,11 +580,16 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             }
         }
     }
-    if constexpr (SK) __syncthreads();   // pairs with the loaders' barrier: the ring may be refilled
+    if constexpr (SK) {
+        __syncthreads();   // pairs with the loaders' barrier: the ring may be refilled
+        if (lvl > 0 && tid == 0)   // every wave's slab stores were drained ahead of the barrier
+            __hip_atomic_store(((sk_flag_t *)a.sk_flags) + sk_v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     } while (SK && next_piece());
 }
 
-// Stream-K second stage: the tiles that more than one workgroup worked on.  One block = 16 rows of one 256 x 256 tile.
+// Stream-K second stage of the plane kernels (igemm_x6p.h; igemm2_kernel combines its shared tiles inside the launch): the tiles that
+// more than one workgroup worked on, from [M][N] slab levels.  One block = 16 rows of one 256 x 256 tile.
 __global__ void __launch_bounds__(256) streamk_fixup_kernel(IgemmArgs a, int G, int nk_all) {
     const int t = blockIdx.x >> 4, part = blockIdx.x & 15;
     const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
@@ -548,6 +633,10 @@ __global__ void __launch_bounds__(256) streamk_fixup_kernel(IgemmArgs a, int G, 
 // the workgroups of a tile are consecutive and its slab levels dense).
 inline int streamk_grid_units(long long U, int cus) { return (int)(U < cus ? (U > 0 ? U : 1) : cus); }
 inline int streamk_grid(long long tiles, int nk_all, int cus) { return streamk_grid_units(tiles * nk_all, cus); }
+
+// Workspace of a stream-K launch on G workgroups with shared tiles: [arrival words, padded][G slabs of 256 KB]
+inline size_t streamk_flag_bytes(int G) { return ((size_t)G * sizeof(unsigned) + 255) / 256 * 256; }
+inline size_t streamk_workspace_bytes(int G) { return streamk_flag_bytes(G) + (size_t)G * kSkSlabFloats * sizeof(float); }
 
 // Slab levels a stream-K launch over `tiles` tiles of nk_all K steps on `cus` CUs needs (0: every tile is whole).
 inline int streamk_levels(long long tiles, int nk_all, int cus) {
@@ -721,7 +810,7 @@ int launch_igemm2(IgemmArgs &a, hipStream_t stream) {
     a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, BM);
     a.tiles_n = (int)ceil_div(a.N, BN);
     if constexpr (SK) {
-        // a.splits = CUs to lay the pieces out for, a.slab = streamk_levels(...) slabs of [rows][N]
+        // a.splits = CUs to lay the pieces out for; a.sk_flags / a.slab = the workspace of streamk_workspace_bytes(G) when tiles are shared
         const int nk_all = a.K / BK;
         const long long tiles = (long long)a.tiles_m * a.tiles_n;
         if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * 16 > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
@@ -733,11 +822,11 @@ int launch_igemm2(IgemmArgs &a, hipStream_t stream) {
             rc = launch_status();
             if (rc) return rc;
         }
-        if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
+        if (levels > 0) {   // shared tiles: arrival words (zeroed here, ahead of every launch) + one slab per workgroup
+            if (!a.slab || !a.sk_flags) return EMADAPT_ERR_WORKSPACE;
+            EMADAPT_HIP_TRY(hipMemsetAsync(a.sk_flags, 0, streamk_flag_bytes(G), stream));
+        }
         hipLaunchKernelGGL((igemm2_kernel<WMW, WNW, BK, PW, NBUF, DIST, BT, NT, true>), dim3((unsigned)G), dim3(THREADS), lds, stream, a);
-        rc = launch_status();
-        if (rc || levels == 0) return rc;
-        hipLaunchKernelGGL(streamk_fixup_kernel, dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, a, G, nk_all);
         return launch_status();
     } else {
         const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;

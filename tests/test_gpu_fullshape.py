@@ -230,6 +230,40 @@ def test_stream_k_tail_launch_on_a_small_shape(env):
     assert np.array_equal(got, again)
 
 
+@pytest.mark.parametrize("layer,shape", [("conv4_2", (16, 41, 41, 512, 512, 3, 1)), ("conv5_2", (16, 41, 41, 512, 512, 3, 2)),
+                                         ("conv3_2", (16, 81, 81, 256, 256, 3, 1))])
+def test_stream_k_combine_inside_the_launch_sees_fresh_partial_tiles(env, layer, shape):
+    """Tiles shared by two or three workgroups are combined INSIDE the stream-K launch (csrc/igemm_v2.h: write-through slab per
+    workgroup, arrival word, sc1 loads by the workgroup that runs the tile's head).  The slabs sit at the same workspace addresses
+    launch after launch, so a combine that read a STALE copy (an L1 / L2 line left by an earlier launch) would go unnoticed on
+    repeated inputs: here every launch gets new operands, the workspace is read by another kernel in between (plain loads leave
+    its lines in the caches), and each result is held against the split-free plan of the same kernel (variant 4, one workgroup per
+    tile: other sums, 2e-5) and against itself launched again (bitwise).  Benchmark shapes: 212 / 212 / 411 tiles on 256 CUs,
+    every tile shared."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    plan = ops.conv_plan(B, H, W, Cin, Cout, k, dil), ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=True)
+    assert plan[0][0] == 5 and plan[0][2] >= 2 and plan[1][0] == 5 and plan[1][2] >= 2, plan
+    g = torch.Generator(device="cuda").manual_seed(11)
+    w = torch.randn((k, k, Cin, Cout), device="cuda", generator=g) * float(np.sqrt(2.0 / (k * k * Cin)))
+    b = torch.randn((Cout,), device="cuda", generator=g) * 0.1
+    for it in range(6):
+        x = torch.randn((B, H, W, Cin), device="cuda", generator=g).relu_() * (1.0 + it)   # (new values, new magnitudes)
+        dy = torch.randn((B, H, W, Cout), device="cuda", generator=g) * (1.0 + it)
+        y = ops.conv_fwd(x, w, b, dil, relu=True)
+        dx = ops.conv_dgrad(dy, w, dil, gate=x)
+        ws = ops._WS.get(1, x.device)
+        float(ws[: 64 << 20].float().sum())     # another kernel reads the slabs' lines
+        assert torch.equal(y, ops.conv_fwd(x, w, b, dil, relu=True)), (layer, it)
+        assert torch.equal(dx, ops.conv_dgrad(dy, w, dil, gate=x)), (layer, it)
+        with ops.tuned(fp32_tile=4, splitk=1):
+            y4 = ops.conv_fwd(x, w, b, dil, relu=True)
+            dx4 = ops.conv_dgrad(dy, w, dil, gate=x)
+        assert float((y - y4).abs().max()) <= 2e-5 * float(y4.abs().max()), (layer, it)
+        assert float((dx - dx4).abs().max()) <= 2e-5 * float(dx4.abs().max()), (layer, it)
+        assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(dx).all())
+
+
 def test_builtin_dropout_draws_do_not_depend_on_the_launch_plan(env):
     """The counter-hash dropout generator is keyed by the GLOBAL output element, so every tile variant -- row splits,
     split-K second stages, stream-K pieces and their fix-up pass -- must drop exactly the same elements for a seed."""

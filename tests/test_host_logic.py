@@ -236,8 +236,9 @@ def test_latest_checkpoint_is_chosen_by_step_number_or_index(tmp_path):
 
 
 def test_stream_k_plans_and_their_workspace_are_consistent():
-    """Launch plans need no device: over a sweep of shapes and CU counts the stream-K plans (variant 5) report their slab
-    levels, and the workspace query asks for exactly levels x rows x N floats (main launch) plus the tail launch's slabs."""
+    """Launch plans need no device: over a sweep of shapes and CU counts the stream-K plans (variant 5) report the largest
+    number of workgroups that share a tile, and the workspace query asks for exactly the arrival words + one 256 KB accumulator
+    image per workgroup (tiles are combined inside the launch: csrc/igemm_v2.h) when any tile is shared, plus the row table."""
     import ctypes
     from em_adapt_tensorflow_amd import _lib, ops
     lib = _lib.load()
@@ -262,11 +263,15 @@ def test_stream_k_plans_and_their_workspace_are_consistent():
                 if cfg == 5:   # (plan[3] = number of pixel classes of a padding-skipping launch, 0 or >= 2; such a launch also
                     #  keeps its GEMM row -> pixel table, one int per row of its whole tiles, behind the slab levels)
                     table = -(-M // 256) * 256 * 4 if tail_s else 0
-                    assert main_rows == M and tail_s != 1 and tail_s <= 36 and ws == main_s * M * N * 4 + table, (cfg, main_rows, main_s, tail_s, ws)
+                    g = cus or 256
+                    sk = -(-g * 4 // 256) * 256 + g * 256 * 256 * 4
+                    assert main_rows == M and tail_s != 1 and tail_s <= 36 and ws == (sk if main_s else 0) + table, (cfg, main_rows, main_s, tail_s, ws)
                     assert main_s != 1, "a tile with partial sums has at least two pieces"
                 elif main_rows < M:
+                    g = cus or 256
+                    sk = -(-g * 4 // 256) * 256 + g * 256 * 256 * 4
                     assert cfg in (2, 4) and main_rows % 256 == 0
-                    assert ws >= (M - main_rows) * N * 4 * (tail_s if tail_s > 1 else 0)
+                    assert ws >= min(sk, (M - main_rows) * N * 4 * tail_s) * (1 if tail_s > 1 else 0)
                 else:
                     assert ws == (main_s * M * N * 4 if main_s > 1 else 0)
     assert {1, 3, 4, 5} <= seen, seen
