@@ -145,9 +145,9 @@ PlanXP plan_x6p(const IgemmArgs &a) {
 
 size_t xp_workspace_bytes(const IgemmArgs &a) {
     const PlanXP p = plan_x6p(a);
-    size_t b = (size_t)p.main_levels * p.main_rows * a.N * sizeof(float);
+    // stream-K launches with shared tiles: arrival words + one 256 KB slab per workgroup (igemm_v2.h), then the row table
+    size_t b = p.main_levels > 0 || (p.main_rows < a.M && p.tail_levels > 0) ? streamk_workspace_bytes(plan_cus()) : 0;
     if (p.bands) b += (size_t)ceil_div(a.M, 256) * 256 * sizeof(int);
-    if (p.main_rows < a.M && p.tail_levels > 0) b += (size_t)p.tail_levels * (a.M - p.main_rows) * a.N * sizeof(float);
     return b;
 }
 
@@ -165,21 +165,24 @@ int dispatch_x6p(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStrea
             double exec = 1.0;
             if (!build_row_pack(a, (int)ceil_div(a.N, 256), &exec)) return EMADAPT_ERR_INVALID;
             prof.executed_fraction(exec);
-            a.pk.rowmap = reinterpret_cast<const int *>(static_cast<char *>(workspace) + (size_t)p.main_levels * a.M * a.N * sizeof(float));
+            a.pk.rowmap = reinterpret_cast<const int *>(static_cast<char *>(workspace) + (p.main_levels > 0 ? streamk_workspace_bytes(plan_cus()) : 0));
         }
         a.splits = plan_cus();
-        a.slab = p.main_levels > 0 ? static_cast<float *>(workspace) : nullptr;
+        a.sk_flags = p.main_levels > 0 ? static_cast<unsigned *>(workspace) : nullptr;
+        a.slab = p.main_levels > 0 ? reinterpret_cast<float *>(static_cast<char *>(workspace) + streamk_flag_bytes(plan_cus())) : nullptr;
         return launch_igemm_x6p<true>(a, stream);
     }
     a.splits = 1;
     a.slab = nullptr;
+    a.sk_flags = nullptr;
     int rc = launch_igemm_x6p<false>(a, stream);
     if (rc || p.main_rows >= a.M) return rc;
     a.m_begin = p.main_rows;
     a.m_end = a.M;
     if (p.tail_levels < 0) return launch_igemm_x6p<false>(a, stream);
     a.splits = plan_cus();
-    a.slab = p.tail_levels > 0 ? static_cast<float *>(workspace) : nullptr;
+    a.sk_flags = p.tail_levels > 0 ? static_cast<unsigned *>(workspace) : nullptr;
+    a.slab = p.tail_levels > 0 ? reinterpret_cast<float *>(static_cast<char *>(workspace) + streamk_flag_bytes(plan_cus())) : nullptr;
     return launch_igemm_x6p<true>(a, stream);
 }
 

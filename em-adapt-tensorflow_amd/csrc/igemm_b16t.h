@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) filter_tiles_b16_kernel(const float *__re
     }
 }
 
-// Stream-K second stage for bf16-storage outputs (igemm_v2.h's streamk_fixup_kernel is the f32 one): the tiles that more than one
+// Stream-K second stage for bf16-storage outputs (the f32 kernels -- igemm_v2.h, igemm_x6p.h -- combine their shared tiles inside the launch since round 4): the tiles that more than one
 // workgroup worked on.  One block = 16 rows of one 256 x 256 tile.
 template <bool YBF, int BM = 256, int BN = 256>
 __global__ void __launch_bounds__(256) streamk_fixup_t_kernel(IgemmArgs a, int G, int nk_all) {

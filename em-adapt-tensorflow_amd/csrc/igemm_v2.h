@@ -588,47 +588,6 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     } while (SK && next_piece());
 }
 
-// Stream-K second stage of the plane kernels (igemm_x6p.h; igemm2_kernel combines its shared tiles inside the launch): the tiles that
-// more than one workgroup worked on, from [M][N] slab levels.  One block = 16 rows of one 256 x 256 tile.
-__global__ void __launch_bounds__(256) streamk_fixup_kernel(IgemmArgs a, int G, int nk_all) {
-    const int t = blockIdx.x >> 4, part = blockIdx.x & 15;
-    const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
-    // the tile's K steps on the unit line
-    long long U = (long long)a.tiles_m * a.tiles_n * nk_all, u0 = (long long)t * nk_all;
-    int nk_tile = nk_all;
-    if (a.pk.n > 0) {
-        int run = 0;
-        while (run + 1 < a.pk.nruns && tile_m >= a.pk.run_tile0[run + 1]) run++;
-        nk_tile = (a.Cx / 16) * (int)a.pk.run_nkh[run] * (int)a.pk.run_nkw[run];
-        U = a.pk.run_u0[a.pk.nruns];
-        u0 = a.pk.run_u0[run] + (long long)((tile_m - a.pk.run_tile0[run]) * a.tiles_n + tile_n) * nk_tile;
-    }
-    const int vf = sk_owner(u0, U, G), vl = sk_owner(u0 + nk_tile - 1, U, G);
-    const int cnt = vl - vf + 1;
-    if (cnt <= 1) return;   // one workgroup ran the whole reduction of this tile and wrote it with the fused epilogue
-    const long long mn = (long long)(a.m_end - a.m_begin) * a.N;   // one slab level
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int idx = it * 256 + threadIdx.x;
-        const int r = part * 16 + (idx >> 6);
-        const int row = a.pk.n > 0 ? a.pk.rowmap[a.m_begin + tile_m * 256 + r] : PixelRows()(a, a.m_begin + tile_m * 256 + r);
-        const int col = tile_n * 256 + (idx & 63) * 4;
-        if (row < 0 || col >= a.N) continue;
-        const long long o = (long long)row * a.N + col;
-        const float *sp = a.slab + (o - (long long)a.m_begin * a.N);
-        float4 v = *reinterpret_cast<const float4 *>(sp);
-        for (int l = 1; l < cnt; l++) {
-            const float4 u = *reinterpret_cast<const float4 *>(sp + l * mn);
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-        }
-        v.x = epilogue(a, v.x, col + 0, o + 0);
-        v.y = epilogue(a, v.y, col + 1, o + 1);
-        v.z = epilogue(a, v.z, col + 2, o + 2);
-        v.w = epilogue(a, v.w, col + 3, o + 3);
-        *reinterpret_cast<float4 *>(a.y + o) = v;
-    }
-}
-
 // Workgroups of a stream-K launch over U units: one per CU, but never more than units (every piece list is then non-empty, so
 // the workgroups of a tile are consecutive and its slab levels dense).
 inline int streamk_grid_units(long long U, int cus) { return (int)(U < cus ? (U > 0 ? U : 1) : cus); }

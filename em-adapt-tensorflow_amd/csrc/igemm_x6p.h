@@ -303,9 +303,68 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
 #undef XP_MF
 #undef XP_GROUP
 
-    float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
+    float *slab_ = !SK && lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
     int lane_e = tid & 63;
     asm volatile("" : "+v"(lane_e));
+    if constexpr (SK) {
+        // Shared tiles are combined inside the launch, exactly as igemm2_kernel does it (igemm_v2.h, note at sk_start): a piece that
+        // starts inside its tile (always the first of its workgroup) publishes its accumulators in register order to slab[workgroup]
+        // with write-through stores and raises flag[workgroup]; the workgroup with the tile's head adds the following workgroups'
+        // slabs in ascending k and runs the fused epilogue.  (This kernel has registers to spare: 8 loads in flight per lane.)
+        const unsigned lane_off = (unsigned)(lane_e * 16);
+        constexpr int kWaveFloats = kSkSlabFloats / XP_WAVES;
+        if (lvl > 0) {
+            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(a.slab + (long long)sk_v * kSkSlabFloats + wave * kWaveFloats, 0, kWaveFloats * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int qd = 0; qd < 4; qd++) {
+                        u32x4 v;
+                        v.x = __float_as_uint(acc[i][j][qd * 4 + 0]); v.y = __float_as_uint(acc[i][j][qd * 4 + 1]);
+                        v.z = __float_as_uint(acc[i][j][qd * 4 + 2]); v.w = __float_as_uint(acc[i][j][qd * 4 + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, sr, (int)lane_off, ((i * TN + j) * 4 + qd) * 1024, 16);   // aux 16 = sc1
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, then the barrier, then ONE lane's flag
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(((sk_flag_t *)a.sk_flags) + sk_v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;   // (nothing else to store; the next piece starts with a barrier)
+        }
+        if (lvl == 0) {
+            const int sk_more = __builtin_amdgcn_readfirstlane(sk_owner((long long)(sk_u - nk) + nk_tile - 1, sk_units, (int)gridDim.x)) - sk_v;
+            for (int l = 1; l <= sk_more; l++) {
+                const sk_flag_t *f = ((const sk_flag_t *)a.sk_flags) + (sk_v + l);
+                bool ok = false;
+                for (unsigned spins = 0; spins < kSkSpinMax; spins++) {
+                    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
+                const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(a.slab + (long long)(sk_v + l) * kSkSlabFloats + wave * kWaveFloats, 0, ok ? kWaveFloats * 4 : 0, 0x00020000);
+                typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                typedef float f32x8_ __attribute__((ext_vector_type(8)));
+#pragma unroll
+                for (int t = 0; t < TM * TN; t += 2) {
+                    f32x4_ v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        v[e] = __builtin_bit_cast(f32x4_, __builtin_amdgcn_raw_buffer_load_b128(sr, (int)lane_off, (t * 4 + e) * 1024, 16));   // sc1
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const f32x8_ lo = __builtin_shufflevector(v[4 * u], v[4 * u + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        const f32x8_ hi = __builtin_shufflevector(v[4 * u + 2], v[4 * u + 3], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[(t + u) / TN][(t + u) % TN] += __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; i++)   // (a publisher that never arrived: a NaN in every 32 x 32 block)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j][0] = ok ? acc[i][j][0] : __builtin_nanf("");
+            }
+        }
+    }
     float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (128 + 4));
     static_assert(XP_WAVES * 16 * (128 + 4) * 4 <= XP_LDS, "epilogue slabs must fit in the ring");
     // (after the last step's barrier nobody reads the ring and no DMA is in flight: the waves stage their accumulators through it)
@@ -355,11 +414,11 @@ int launch_igemm_x6p(IgemmArgs &a, hipStream_t stream) {
             rc = launch_status();
             if (rc) return rc;
         }
-        if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
+        if (levels > 0) {   // shared tiles: arrival words (zeroed ahead of every launch) + one slab per workgroup
+            if (!a.slab || !a.sk_flags) return EMADAPT_ERR_WORKSPACE;
+            EMADAPT_HIP_TRY(hipMemsetAsync(a.sk_flags, 0, streamk_flag_bytes(G), stream));
+        }
         hipLaunchKernelGGL((igemm_x6p_kernel<true, ABLM>), dim3((unsigned)G), dim3(XP_WAVES * 64), XP_LDS, stream, a);
-        rc = launch_status();
-        if (rc || levels == 0) return rc;
-        hipLaunchKernelGGL(streamk_fixup_kernel, dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, a, G, nk_all);
         return launch_status();
     } else {
         const long long nblk = (long long)a.tiles_m * a.tiles_n * a.splits;

@@ -12,7 +12,7 @@ import re
 # position of the direction flag BT in each fp32 kernel's template argument list (csrc/conv_igemm.hip, igemm_v2.h)
 _BT_POS = {"igemm2_kernel": 6, "igemm_kernel": 4, "igemm_ws_kernel": 0}
 _CONV = re.compile(r"\b((?:igemm|wgrad)\w*_kernel)\b(?:<([^>]*)>)?")
-_SECOND_STAGE = ("streamk_fixup", "splitk_epilogue", "slab_sum", "rowmap")
+_SECOND_STAGE = ("streamk_fixup", "splitk_epilogue", "slab_sum", "rowmap")   # (streamk_fixup: profiles of rounds 2-3 and the opt-in bf16t kernels)
 
 
 def conv_kernel(name):
