@@ -15,6 +15,9 @@ plans by itself.  Here:
     2e-5, with `plan_cus` shrunk so that the row split (m_begin / m_end), the partial last tile and the slab reuse of
     the tail launch are hit at awkward sizes.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -262,6 +265,46 @@ def test_stream_k_combine_inside_the_launch_sees_fresh_partial_tiles(env, layer,
         assert float((y - y4).abs().max()) <= 2e-5 * float(y4.abs().max()), (layer, it)
         assert float((dx - dx4).abs().max()) <= 2e-5 * float(dx4.abs().max()), (layer, it)
         assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(dx).all())
+
+
+def _contend_worker(rank, out_dir):
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import em_adapt_tensorflow_amd.ops as ops
+    torch.cuda.set_device(0)
+    B, H, W, Cin, Cout, k, dil = 16, 41, 41, 512, 512, 3, 1
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    w = torch.randn((k, k, Cin, Cout), device="cuda", generator=g) * 0.02
+    b = torch.randn((Cout,), device="cuda", generator=g) * 0.1
+    worst, bad = 0.0, 0
+    ops.conv_fwd(torch.zeros((B, H, W, Cin), device="cuda"), w, b, dil, relu=True)   # (library loaded, workspace allocated)
+    torch.cuda.synchronize()
+    open(os.path.join(out_dir, "ready%d" % rank), "w").close()      # both processes enter the loop together
+    t_end = __import__("time").time() + 60
+    while not os.path.exists(os.path.join(out_dir, "ready%d" % (1 - rank))) and __import__("time").time() < t_end:
+        __import__("time").sleep(0.001)
+    for it in range(300):
+        x = torch.randn((B, H, W, Cin), device="cuda", generator=g).relu_()
+        y = ops.conv_fwd(x, w, b, dil, relu=True)                 # stream-K, every tile shared
+        with ops.tuned(fp32_tile=4, splitk=1):
+            y4 = ops.conv_fwd(x, w, b, dil, relu=True)            # one workgroup per tile
+        bad += int(not bool(torch.isfinite(y).all()))
+        worst = max(worst, float((y - y4).abs().max()) / float(y4.abs().max()))
+    torch.cuda.synchronize()
+    with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
+        f.write("%g %d" % (worst, bad))
+
+
+@pytest.mark.timeout(300)
+def test_stream_k_combine_when_the_chip_is_shared_with_another_process(env, tmp_path):
+    """Two processes launch the 256-workgroup stream-K kernel on the ONE GPU at the same time, so the workgroups of a launch are not
+    all resident together and a tile's head may have to wait for a workgroup that has not been dispatched yet (the wait is a bounded
+    poll: csrc/igemm_v2.h).  Every result must still be complete and equal the plain-tile plan's to 2e-5 -- and nothing may hang."""
+    import torch.multiprocessing as mp
+    mp.spawn(_contend_worker, args=(str(tmp_path),), nprocs=2, join=True)
+    for r in range(2):
+        worst, bad = open(tmp_path / ("r%d.txt" % r)).read().split()
+        assert int(bad) == 0 and float(worst) < 2e-5, (r, worst, bad)
 
 
 def test_builtin_dropout_draws_do_not_depend_on_the_launch_plan(env):
