@@ -613,7 +613,7 @@ def sgd_momentum(w, v, accum, lr, momentum, accum_scale=1.0):
 
 
 def conv_plan(B, H, W, Cin, Cout, k, dil=1, dgrad=False):
-    """(tile variant, main rows, main split-K / stream-K slab levels, tail split-K -- or, for a stream-K launch that skips
+    """(tile variant, main rows, main split-K factor / for stream-K the most workgroups sharing a tile, tail split-K -- or, for a stream-K launch that skips
     the zero padding of a dilated filter, its number of pixel classes) of the fp32 forward / data-gradient launch plan."""
     d = conv_desc(B, H, W, Cin, Cout, k, k, dil)
     out = (ctypes.c_int * 4)()

@@ -154,7 +154,12 @@ int emadapt_conv_fwd(const emadapt_conv_desc *d, const float *x, const float *w,
 /* workspace (fwd and dgrad): optional.  Layers whose output has only a few hundred 128x128 tiles are run
  * split-K (fp32 partial slabs in the workspace + a fused, fixed-order reduce/epilogue kernel) so that the
  * workgroups fill whole rounds of the 256 CUs; with workspace == NULL (or too small) the same result is
- * produced unsplit.  *_workspace_bytes returns what the split plan for this shape needs (0 = none). */
+ * produced unsplit.  *_workspace_bytes returns what the split plan for this shape needs (0 = none).
+ * Stream-K launches (layers whose 256 x 256 tiles are not a whole number of rounds: conv3-conv5, fc6, the tails of fc7) keep
+ * one arrival word and one 256 KB accumulator image per workgroup there -- 64 MB + 1 KB on 256 CUs whatever the layer -- and
+ * combine the tiles that several workgroups share INSIDE the launch, in ascending k (deterministic; since round 4, ABI
+ * unchanged: rounds 2-3 asked for up to three [M][N] images and ran a second kernel).  The words are zeroed by a memset node the
+ * entry point enqueues ahead of the launch; the caller provides the bytes and nothing else. */
 
 /* Data gradient (Conv2DBackpropInput of the autodiff in deeplab.py:192):
  *   dx[b,h,w,ci] = sum_{taps,co} dy[b,h-off,w-off,co] * w[tap,ci,co]
@@ -268,10 +273,10 @@ int emadapt_conv_wgrad_x6(const emadapt_conv_desc *d, const float *x, const floa
  * emadapt_conv_x6p_supported(d, kind) (kind 0 forward, 1 data gradient, 2 filter gradient) says whether a convolution is taken
  * -- forward / data gradient: reduction channels (Cin resp. Cout) in whole groups of 16 and at least 256 output columns (Cout
  * resp. Cin; a multiple of 4), at most 32 taps; filter gradient: Cin a multiple of 256, Cout >= 128 and a multiple of 16; all:
- * plane images below 2 GiB -- the others stay on the x6 entry points and return EMADAPT_ERR_UNSUPPORTED here.  Workspace: stream-K slab levels
+ * plane images below 2 GiB -- the others stay on the x6 entry points and return EMADAPT_ERR_UNSUPPORTED here.  Workspace: the stream-K slabs
  * (+ the row table of packed rows) resp. split-M slabs, as for the fp32 kernels; EMADAPT_ERR_WORKSPACE when it is too small.
- * emadapt_conv_x6p_plan: plan[0] rows of the first launch, [1] 1 = stream-K, [2] its slab levels, [3] pixel classes of packed
- * rows (0 = off), [4] slab levels of the stream-K launch over the remaining rows (-1: a plain launch). */
+ * emadapt_conv_x6p_plan: plan[0] rows of the first launch, [1] 1 = stream-K, [2] the most workgroups sharing one of its tiles, [3] pixel classes of packed
+ * rows (0 = off), [4] the same count for the stream-K launch over the remaining rows (-1: a plain launch). */
 size_t emadapt_planes_bytes(long long rows, int C);
 int emadapt_split_planes(const float *x, void *planes, long long rows, int C, void *stream);
 size_t emadapt_filter_tiles_bytes(const emadapt_conv_desc *d, int dgrad);
@@ -384,11 +389,11 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
 int emadapt_tune_set(const char *key, int value);
 /* The plan emadapt_conv_fwd (dgrad = 0) / emadapt_conv_dgrad (dgrad = 1) will use for this shape, given enough workspace:
  * plan[0] = tile variant ("fp32_tile" numbering), plan[1] = rows of the main launch, plan[2] = its split-K factor
- * (variant 5: the number of partial-sum slab levels), plan[3] = split-K factor / slab levels of the launch over the
+ * (variant 5: the largest number of workgroups that share a tile, 0 = none shared), plan[3] = split-K factor / slab levels of the launch over the
  * remaining rows (0 = there is none; variant 5 has no second launch: plan[3] is then the number of pixel classes when the
  * launch skips the filter rows / columns that lie outside the image -- its GEMM rows are the pixels class after class and a
  * tile reduces over the union of its classes' tap boxes; the row -> pixel table takes ceil(M / 256) * 256 ints of the
- * workspace behind the slab levels -- else 0). */
+ * workspace behind the stream-K slabs -- else 0). */
 int emadapt_conv_plan(const emadapt_conv_desc *d, int dgrad, int plan[4]);
 int emadapt_tune_get(const char *key, int *value);
 /* Executed / algorithmic FLOPs of the launches a conv entry makes for this shape (host arithmetic, no device needed): kind 0
