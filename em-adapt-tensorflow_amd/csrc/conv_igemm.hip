@@ -654,8 +654,8 @@ inline void set_streamk_workspace(IgemmArgs &a, void *workspace, bool shared_til
     a.slab = shared_tiles ? reinterpret_cast<float *>(static_cast<char *>(workspace) + streamk_flag_bytes(plan_cus())) : nullptr;
 }
 
-// Tap count the second-generation kernel's loaders are specialised for (0: the generic loaders).  The specialised form
-// reads the activation through a buffer that starts up to (pad_h * W + pad_w) pixels before the tensor: its extent must
+// > 0: the second-generation kernel's loaders take the scalar-offset form (igemm_v2.h, NT); 0: the generic loaders.  The scalar
+// form reads the activation through a buffer that starts up to (pad_h * W + pad_w) pixels before the tensor: its extent must
 // still fit the 31 bits of a buffer offset.
 int specialised_taps(const IgemmArgs &a) {
     if (tune(TUNE_FP32_LOADER) == 1) return 0;
@@ -671,17 +671,11 @@ int launch_variant(int cfg, IgemmArgs &a, hipStream_t stream) {
         case 1: return launch_igemm<256, 64, 16, 64, BT>(a, stream);
         case 2: return launch_igemm<256, 256, 32, 128, BT>(a, stream);
         case 4: {
-            const int nt = specialised_taps(a);
-            if (nt == 1) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1, false>(a, stream);
-            if (nt == 9) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 9, false>(a, stream);
-            if (nt == 16) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 16, false>(a, stream);
+            if (specialised_taps(a) > 0) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1, false>(a, stream);
             return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 0, false>(a, stream);
         }
         case 5: {   // (a.splits = workgroups, a.slab = slab levels: dispatch_igemm)
-            const int nt = specialised_taps(a);
-            if (nt == 1) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1, true>(a, stream);
-            if (nt == 9) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 9, true>(a, stream);
-            if (nt == 16) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 16, true>(a, stream);
+            if (specialised_taps(a) > 0) return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 1, true>(a, stream);
             return launch_igemm2<4, 2, 16, 4, 4, 3, BT, 0, true>(a, stream);
         }
         default: return launch_igemm_ws<BT>(a, stream);

@@ -90,9 +90,11 @@ __host__ __device__ inline int sk_owner(long long u, long long U, int G) { retur
 
 // NBUF LDS buffers, tiles are fetched DIST K steps ahead of their use (NBUF >= DIST + 1): a DMA has DIST - 1 whole K steps
 // plus the rest of its own to land (with DIST = 1 the kernel ran at the mercy of the L2 / HBM latency: 66 % on conv4_x).
-// NT = filter taps the loaders are specialised for (1, 9, 16; 0 = any count up to 32, per-step vector arithmetic): with NT
-// known, a loader keeps one ready-made per-lane offset per (row group, tap) -- validity folded in as the out-of-range bit --
-// and a K step issues its DMAs with no vector instruction at all (the loaders share their SIMD's issue port with two MFMA waves).
+// NT > 0 (instantiated as 1; the value no longer matters): the loaders issue their gathers with a per-lane offset that is constant
+// over the K loop -- what moves from step to step rides in the instruction's scalar offset -- plus the tap's validity bit (two
+// vector instructions per gather; the loaders share their SIMD's issue port with two MFMA waves), and the MFMA waves' loop is
+// unrolled over the ring.  NT = 0: per-step vector address arithmetic, run-time ring position (any shape the scalar form cannot
+// address: specialised_taps() in conv_igemm.hip).
 template <int WMW, int WNW, int BK, int PW, int NBUF, int DIST, bool BT, int NT, bool SK>
 __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmArgs a) {
     constexpr int CONS = WMW * WNW;          // consumer (MFMA) waves
@@ -262,14 +264,6 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             }
         }
 
-        unsigned va[A_N][NT > 0 ? NT : 1];   // NT > 0: per-(row group, tap) offsets, out-of-range bit set where the tap is outside
-        if constexpr (NT > 0) {
-#pragma unroll
-            for (int j = 0; j < A_N; j++)
-#pragma unroll
-                for (int t = 0; t < NT; t++) va[j][t] = a_off[j] | ((a_bad[j] >> t) & 1u ? kOOB : 0u);
-        }
-
         // Fill LDS buffer `buf` with the tile of K step kt (DMA; the caller awaits completion).
         auto fill = [&](int buf, int kt) {
             const unsigned chunk = __umulhi((unsigned)kt, magic_nt_t);
@@ -297,11 +291,14 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
                     if constexpr (!BT) dma16s(wr, bs + (j * PW + pw) * 256, b_off[j], s_w);
                     else dma16s(wr, bs + (j * PW + pw) * RPI * BK, b_off[j], s_w);
                 }
+                // the lane's offset is constant over the K loop (the tap's offset rides in the scalar operand); what changes is
+                // whether the tap reads inside the image from this lane's pixel: its bit of a_bad moved to the out-of-range bit,
+                // two vector instructions per gather.  (Rounds 2-3 kept one ready-made offset per (row group, tap) and picked it by
+                // a scalar compare chain; the compiler turned that into an indexed array in SCRATCH, read back before every
+                // step's gathers behind a vmcnt wait that also drained the fetches in flight: -0.3 ms per step, round 4.)
+                if (!ABL(8)) {
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    if (tap_u != (unsigned)t || ABL(8)) continue;   // scalar compare chain: the tap is wave-uniform
-#pragma unroll
-                    for (int j = 0; j < A_N; j++) dma16s(xr, as + (j * PW + pw) * RPI * BK, va[j][t], s_x);
+                    for (int j = 0; j < A_N; j++) dma16s(xr, as + (j * PW + pw) * RPI * BK, a_off[j] | ((a_bad[j] << sh) & kOOB), s_x);
                 }
                 return;
             }
