@@ -38,8 +38,12 @@ extern "C" {
  *        non-resident channels) and emadapt_estep() returns EMADAPT_ERR_WORKSPACE below that; map_out is output only and
  *        emadapt_estep_needs_map() is 0 for every supported geometry.  A caller written against 100 that sized its workspace
  *        by the constant it knew must re-query emadapt_estep_workspace_bytes().  Added: emadapt_prof_collect2 (executed
- *        FLOPs), emadapt_conv_*: tensors of 2 GiB and more (batch-sliced launches). */
-#define EMADAPT_ABI_VERSION 200
+ *        FLOPs), emadapt_conv_*: tensors of 2 GiB and more (batch-sliced launches).
+ *   201  round 4, no signature changed: what emadapt_conv_{fwd,dgrad}[_x6p]_workspace_bytes() return for the stream-K launches
+ *        (conv3-conv5, fc6, fc7's last rows) is now arrival words + one 256 KB accumulator image per workgroup (64 MB + 1 KB on
+ *        256 CUs) instead of up to three [M][N] images (881 MB for fc6): a caller that re-queries per shape needs no change; one
+ *        that cached a size per shape from 200 over-allocates, never under-allocates. */
+#define EMADAPT_ABI_VERSION 201
 int emadapt_version(void);
 const char *emadapt_strerror(int code);
 int emadapt_last_hip_error(void);          /* hipError_t of the last failing HIP call on this thread */
