@@ -65,6 +65,9 @@ PROTOTYPES = {
     "emadapt_conv_dgrad": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_float, _vp, c_size_t, _vp]),
     "emadapt_conv_wgrad_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "emadapt_conv_wgrad": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_size_t, _vp]),
+    "emadapt_conv_wgrad_bias_fused": (c_int, [POINTER(ConvDesc)]),
+    "emadapt_conv_wgrad_bias_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "emadapt_conv_wgrad_bias": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, c_size_t, _vp]),
     "emadapt_filter_kmajor": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp]),
     "emadapt_conv_fwd_x6_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "emadapt_conv_fwd_x6": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_int, c_float, _vp, c_uint64, _vp, c_size_t, _vp]),

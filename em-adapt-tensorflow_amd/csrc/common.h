@@ -84,6 +84,7 @@ enum TuneKey {
                        //    same point again (round 3's form; A/B of the round-4 stagger of SIMD partners)
     TUNE_RASTER_GM,    // M tiles per group of the plain-tile launches' XCD-aware order (0 = the default, 8): the workgroups resident on
                        //    one XCD cover GM M-tiles x the N-tiles that fit (scripts/raster_sweep.py measures the L2 hit rate and the time)
+    TUNE_WGRAD_BIAS,   // 1: emadapt_conv_wgrad_bias_fused() answers 0 everywhere (the separate bias-gradient kernel: A/B, tests)
     TUNE_COUNT
 };
 int tune(TuneKey key);

@@ -39,6 +39,7 @@ struct WgradArgs {
     int skip;                       // wgrad2_kernel<UT>: walk only the pixels at which the tile's tap is inside the image
     unsigned char korder[256];      // with skip: k tile run by the workgroups of logical k index i (balances the taps' unequal
                                     // pixel counts over the XCDs: see order_k_tiles)
+    float *bias_part;               // wgrad_ws_kernel: [splits][4 producer waves][N] column sums of dy (BiasAddGrad partials), or null
 };
 
 // 16-byte buffer load with hardware range checking (offsets with bit 31 set are out of range -> zeros).
@@ -111,6 +112,11 @@ __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
         const int y_n = n0 + y_nq * 4;
         const bool nvalid = y_n < a.N;
         float4 rx[X_N], ry[Y_N];
+        // BiasAddGrad for free (round 4): the producers of the workgroups with k tile 0 see every dy row of their pixel range pass
+        // through their registers exactly once; each thread keeps the column sums of its four columns (the separate bias-gradient
+        // kernel re-read 1.4 GB of conv1_x / conv2_x gradients per step for the same numbers)
+        const bool do_bias = a.bias_part != nullptr && tile_k == 0;
+        float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
         auto load_tile = [&](int mb) {
 #pragma unroll
             for (int j = 0; j < X_N; j++) {
@@ -135,6 +141,10 @@ __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
 #pragma unroll
             for (int j = 0; j < Y_N; j++)
                 *reinterpret_cast<float4 *>(&Ys[buf * BMR * BN + (y_r0 + j * Y_RSTEP) * BN + y_nq * 4]) = ry[j];
+            if (do_bias) {   // (rows past the pixel range arrive as zeros)
+#pragma unroll
+                for (int j = 0; j < Y_N; j++) { bsum.x += ry[j].x; bsum.y += ry[j].y; bsum.z += ry[j].z; bsum.w += ry[j].w; }
+            }
         };
         load_tile(m_begin);
         store_tile(0);
@@ -144,6 +154,17 @@ __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
             store_tile((st + 1) & 1);
             load_tile(m_begin + (st + 2) * BMR);
             __syncthreads();
+        }
+        if (do_bias) {
+            // the lanes of a wave that hold the same four columns (lane % YQ) add up, lane < YQ writes the wave's row of partials;
+            // waves and splits are added by the second stage in a fixed order
+#pragma unroll
+            for (int off = 32; off >= YQ; off >>= 1) {
+                bsum.x += __shfl_xor(bsum.x, off, 64); bsum.y += __shfl_xor(bsum.y, off, 64);
+                bsum.z += __shfl_xor(bsum.z, off, 64); bsum.w += __shfl_xor(bsum.w, off, 64);
+            }
+            if ((tid & 63) < YQ && nvalid)
+                *reinterpret_cast<float4 *>(a.bias_part + ((long long)split * 4 + (tid >> 6)) * a.N + y_n) = bsum;
         }
         return;
     }
@@ -605,8 +626,40 @@ size_t emadapt_conv_wgrad_workspace_bytes(const emadapt_conv_desc *d) {
     return (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
 }
 
+// BiasAddGrad fused into the filter gradient: possible where the round-1 kernel runs (its producers hold every dy row in registers)
+// and the tensors fit one launch
+static bool wgrad_fuses_bias(const emadapt_conv_desc *d) {
+    return check_desc(d) == EMADAPT_OK && d->B > 0 && make_plan(d).gen == 1 && tune(TUNE_WGRAD_BIAS) != 1;
+}
+static size_t wgrad_bias_offset(const emadapt_conv_desc *d) { return (emadapt_conv_wgrad_workspace_bytes(d) + 255) & ~(size_t)255; }
+
+int emadapt_conv_wgrad_bias_fused(const emadapt_conv_desc *d) { return wgrad_fuses_bias(d) ? 1 : 0; }
+
+size_t emadapt_conv_wgrad_bias_workspace_bytes(const emadapt_conv_desc *d) {
+    if (!wgrad_fuses_bias(d)) return 0;
+    return wgrad_bias_offset(d) + (size_t)make_plan(d).splits * 4 * d->Cout * sizeof(float);
+}
+
+static int wgrad_run(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, float *db, void *workspace,
+                     size_t workspace_bytes, void *stream_);
+
 int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, void *workspace,
                        size_t workspace_bytes, void *stream_) {
+    return wgrad_run(d, x, dy, dw, nullptr, workspace, workspace_bytes, stream_);
+}
+
+int emadapt_conv_wgrad_bias(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, float *db, void *workspace,
+                            size_t workspace_bytes, void *stream_) {
+    if (!d || !db || (reinterpret_cast<uintptr_t>(db) & 15)) return EMADAPT_ERR_INVALID;
+    if (!wgrad_fuses_bias(d)) return EMADAPT_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < emadapt_conv_wgrad_bias_workspace_bytes(d)) return EMADAPT_ERR_WORKSPACE;
+    return wgrad_run(d, x, dy, dw, db, workspace, workspace_bytes, stream_);
+}
+
+}  // extern "C"
+
+static int wgrad_run(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, float *db, void *workspace,
+                     size_t workspace_bytes, void *stream_) {
     int rc = check_desc(d);
     if (rc == EMADAPT_ERR_UNSUPPORTED && x && dy && dw) {   // a tensor of 2 GiB or more: per-slice gradients, added in slice order
         const int bs = slice_batch(d, true);
@@ -648,6 +701,7 @@ int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *
     a.tiles_k = p.tiles_k; a.tiles_n = p.tiles_n; a.splits = p.splits; a.rows_per_split = p.rows_per_split;
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * 4); a.y_bytes = (unsigned)((long long)a.M * d->Cout * 4);
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
+    a.bias_part = db ? reinterpret_cast<float *>(static_cast<char *>(workspace) + wgrad_bias_offset(d)) : nullptr;   // (gen 1 only: emadapt_conv_wgrad_bias)
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, 4.0 * ((double)a.M * d->Cin + (double)a.M * a.N + (double)a.K * a.N), stream);
     const bool ut = d->Cin % 256 == 0 && tune(TUNE_FP32_LOADER) != 1;   // a 256-wide k tile lies inside one tap
     // skip the pixels at which a tile's tap is outside the image (fp32_loader = 2 keeps the dense walk: tests, A/B); the
@@ -660,7 +714,6 @@ int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *
     rc = p.gen == 2 ? (ut ? launch_wgrad2<true>(a, stream) : launch_wgrad2<false>(a, stream)) : (p.bn == 64) ? launch_wgrad<64>(a, stream) : launch_wgrad<128>(a, stream);
     if (rc) return rc;
     if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
+    if (!rc && db) rc = launch_slab_sum(a.bias_part, p.splits * 4, d->Cout, db, stream);   // splits x producer waves, in order
     return rc;
 }
-
-}  // extern "C"

@@ -635,6 +635,7 @@ class ADAPT(Network):
                 x_in = bufs["act"][prev.name] if prev is not None else bufs["x_in"]
                 if bf16:
                     ops.conv_wgrad_bf16(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
+                    ops.bias_grad(d, out=op.gb_pad)
                 elif x6:
                     e = bufs["xp"][op.name]
                     if e["wgrad"] or (e["dgrad"] and prev is not None):
@@ -645,9 +646,10 @@ class ADAPT(Network):
                         ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
                     else:
                         ops.conv_wgrad_x6(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
+                    ops.bias_grad(d, out=op.gb_pad)
                 else:
-                    ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
-                ops.bias_grad(d, out=op.gb_pad)
+                    # (the bias gradient rides in the filter-gradient launch where the library fuses it: conv1_x .. conv3_1, fc8)
+                    ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad, bias_out=op.gb_pad)
                 seg = op.seg
                 s, n = seg["start"], seg["nw"] + seg["nb"]
                 ops.sgd_accumulate(self._flat["accum"][s:s + n], self._flat["grads"][s:s + n],

@@ -112,14 +112,25 @@ def conv_dgrad(dy, w, dil=1, gate=None, gate_scale=1.0, out=None):
     return dx
 
 
-def conv_wgrad(x, dy, KH, KW, dil=1, out=None):
-    """Gradient w.r.t. the HWIO filter (deterministic split-M reduction)."""
-    _check(x, name="x"); _check(dy, name="dy")
+def conv_wgrad(x, dy, KH, KW, dil=1, out=None, bias_out=None):
+    """Gradient w.r.t. the HWIO filter (deterministic split-M reduction).  bias_out (f32 [Cout]): also BiasAddGrad, the column sums
+    of dy -- in the same launch where the library fuses it (emadapt_conv_wgrad_bias: the layers on the round-1 kernel), else by
+    the separate kernel (bias_grad)."""
+    _check(x, name="x"); _check(dy, name="dy"); _check(bias_out, name="bias_out")
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
     dw = out if out is not None else torch.empty((KH, KW, Cin, Cout), dtype=torch.float32, device=x.device)
     _check(dw, name="out")
+    if bias_out is not None:
+        if bias_out.numel() != Cout:
+            raise ValueError("bias_out has %d elements, the gradient %d channels" % (bias_out.numel(), Cout))
+        if _lib.load().emadapt_conv_wgrad_bias_fused(ctypes.byref(d)):
+            nbytes = _lib.load().emadapt_conv_wgrad_bias_workspace_bytes(ctypes.byref(d))
+            ws = _WS.get(nbytes, x.device)
+            _lib.call("emadapt_conv_wgrad_bias", ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(bias_out), _p(ws), ws.numel(), _stream())
+            return dw
+        bias_grad(dy, out=bias_out)
     nbytes = _lib.load().emadapt_conv_wgrad_workspace_bytes(ctypes.byref(d))
     ws = _WS.get(nbytes, x.device)
     _lib.call("emadapt_conv_wgrad", ctypes.byref(d), _p(x), _p(dy), _p(dw), _p(ws), ws.numel(), _stream())

@@ -42,8 +42,9 @@ extern "C" {
  *   201  round 4, no signature changed: what emadapt_conv_{fwd,dgrad}[_x6p]_workspace_bytes() return for the stream-K launches
  *        (conv3-conv5, fc6, fc7's last rows) is now arrival words + one 256 KB accumulator image per workgroup (64 MB + 1 KB on
  *        256 CUs) instead of up to three [M][N] images (881 MB for fc6): a caller that re-queries per shape needs no change; one
- *        that cached a size per shape from 200 over-allocates, never under-allocates. */
-#define EMADAPT_ABI_VERSION 201
+ *        that cached a size per shape from 200 over-allocates, never under-allocates.
+ *   202  round 4, added: emadapt_conv_wgrad_bias (+ _fused, _workspace_bytes): filter gradient and bias gradient in one launch. */
+#define EMADAPT_ABI_VERSION 202
 int emadapt_version(void);
 const char *emadapt_strerror(int code);
 int emadapt_last_hip_error(void);          /* hipError_t of the last failing HIP call on this thread */
@@ -181,6 +182,16 @@ int emadapt_conv_dgrad(const emadapt_conv_desc *d, const float *dy, const float 
 size_t emadapt_conv_wgrad_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_wgrad(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* The same launch also returning BiasAddGrad, db[co] = sum_{b,h,w} dy[b,h,w,co] (the bias half of the gradients of
+ * deeplab.py:192), where the filter-gradient kernel holds every dy row in registers anyway -- the layers on the round-1
+ * kernel: conv1_x, conv2_x, conv3_1, fc8, whose gradients are 80 % of the bytes emadapt_bias_grad re-reads per step.
+ * emadapt_conv_wgrad_bias_fused(d): 1 where this entry takes the shape (else EMADAPT_ERR_UNSUPPORTED: call emadapt_conv_wgrad
+ * and emadapt_bias_grad).  Deterministic (per producer wave and pixel split, added in a fixed order); dw is bit-identical to
+ * emadapt_conv_wgrad's, db differs from emadapt_bias_grad's in the order of the fp32 sum only.  (ABI 202) */
+int emadapt_conv_wgrad_bias_fused(const emadapt_conv_desc *d);
+size_t emadapt_conv_wgrad_bias_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_wgrad_bias(const emadapt_conv_desc *d, const float *x, const float *dy, float *dw, float *db,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- bf16-compute variants (configurations C3/C4: bf16 compute, fp32 master weights
  * and fp32 accumulation).  Same semantics, shapes and epilogues as the fp32 entry points above; the operands
@@ -386,6 +397,8 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  *   "dma_stagger" 1: the LDS-DMA kernels without loader waves (bf16x6 plane kernels, emadapt_conv_*_bf16t) issue every wave's DMA
  *                burst at the same point of the K step (round 3's form); 0 (default): the two waves of a SIMD staggered around
  *                the step's barrier (round 4: +3-6 %)
+ *   "wgrad_bias" 1: emadapt_conv_wgrad_bias_fused() answers 0 for every shape (callers then use emadapt_conv_wgrad +
+ *                emadapt_bias_grad: A/B of the fused bias gradient, tests of the fallback)
  *   "estep_stop", "ablate": honoured by diagnostic builds only (-DEMADAPT_ABLATE_BUILD), ignored otherwise
  *                ("estep_stop" 1..4: leave the E-step kernel after that phase; bits 16 / 32 / 64 / 128: run its rank selection
  *                without the LDS atomics / the histogram scans / the barriers / after the first pass -- timing only)

@@ -97,6 +97,38 @@ def test_conv_wgrad_split_m_is_deterministic_and_right(env):
     assert _rel(a, wt.grad) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 97, 95, 8, 64, 3, 1), (3, 33, 31, 24, 40, 3, 2), (2, 50, 49, 16, 128, 3, 1), (1, 41, 41, 64, 24, 1, 1),
+                                   (2, 37, 35, 4, 72, 3, 1), (1, 19, 17, 256, 256, 3, 2)])
+def test_filter_gradient_with_the_bias_gradient_in_the_same_launch(env, shape):
+    """emadapt_conv_wgrad_bias (BiasAddGrad summed by the producers of the round-1 filter-gradient kernel): column tails (N not a
+    multiple of the tile), one and many pixel splits, k tiles beyond the first; dw bit-identical to the plain entry, db against
+    fp64, repeatable bit for bit; the last shape is one the 256 x 256 kernel takes -- ops falls back to the separate kernel."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    rng = np.random.default_rng(sum(shape))
+    x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
+    dy = rng.normal(0.3, 1, (B, H, W, Cout)).astype(np.float32)
+    xg, dyg = _t(torch, x), _t(torch, dy)
+    d = ops.conv_desc(B, H, W, Cin, Cout, k, k, dil)
+    fused = bool(ops._lib.load().emadapt_conv_wgrad_bias_fused(__import__("ctypes").byref(d)))
+    assert fused == (shape != (1, 19, 17, 256, 256, 3, 2))
+    for cus in (0, 1, 7):
+        with ops.tuned(plan_cus=cus):
+            db = torch.full((Cout,), 7.0, device="cuda")
+            dw = ops.conv_wgrad(xg, dyg, k, k, dil, bias_out=db)
+            db2 = torch.empty((Cout,), device="cuda")
+            dw2 = ops.conv_wgrad(xg, dyg, k, k, dil, bias_out=db2)
+            assert torch.equal(db, db2) and torch.equal(dw, dw2)
+            assert torch.equal(dw, ops.conv_wgrad(xg, dyg, k, k, dil)), "the filter gradient must not depend on the bias output"
+        want = dy.astype(np.float64).sum((0, 1, 2))
+        assert np.abs(db.cpu().numpy() - want).max() < 2e-6 * np.abs(dy).sum((0, 1, 2)).max(), (shape, cus)
+        assert _rel(ops.bias_grad(dyg).cpu().numpy(), want) < 1e-5
+    with ops.tuned(wgrad_bias=1):   # the knob that turns the fusion off: same filter gradient, the separate kernel's bias gradient
+        db3 = torch.empty((Cout,), device="cuda")
+        assert torch.equal(ops.conv_wgrad(xg, dyg, k, k, dil, bias_out=db3), ops.conv_wgrad(xg, dyg, k, k, dil))
+        assert torch.equal(db3, ops.bias_grad(dyg))
+
+
 def test_dropout_epilogue(env):
     ops, do, torch = env
     rng = np.random.default_rng(3)
