@@ -183,20 +183,23 @@ __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
     __syncthreads();
     for (int st = 0; st < nsteps; st++) {
         const int cur = st & 1;
-        const float *xs = Xs + cur * BMR * BKO + wk * WK + l31;
-        const float *ys = Ys + cur * BMR * BN + wn * WN + l31;
+        // a wave's 32-wide tiles sit 64 floats apart (k: wk*32 + i*64, n: wn*32 + j*64), not side by side: the two reads of a
+        // k-pair are then ONE ds_read2st64_b32 whose row rides in the 8-bit offsets -- with adjacent tiles (ds_read2_b32,
+        // offsets in dwords up to 255) every k-pair paid a v_add for its row address, one vector instruction per two MFMAs
+        const float *xs = Xs + cur * BMR * BKO + wk * 32 + l31;
+        const float *ys = Ys + cur * BMR * BN + wn * 32 + l31;
         float av[2][TK], bv[2][TN];
 #pragma unroll
-        for (int i = 0; i < TK; i++) av[0][i] = xs[lh * BKO + i * 32];
+        for (int i = 0; i < TK; i++) av[0][i] = xs[lh * BKO + i * 64];
 #pragma unroll
-        for (int j = 0; j < TN; j++) bv[0][j] = ys[lh * BN + j * 32];
+        for (int j = 0; j < TN; j++) bv[0][j] = ys[lh * BN + j * 64];
 #pragma unroll
         for (int kk = 0; kk < NKK; kk++) {
             if (kk + 1 < NKK) {
 #pragma unroll
-                for (int i = 0; i < TK; i++) av[(kk + 1) & 1][i] = xs[((kk + 1) * 2 + lh) * BKO + i * 32];
+                for (int i = 0; i < TK; i++) av[(kk + 1) & 1][i] = xs[((kk + 1) * 2 + lh) * BKO + i * 64];
 #pragma unroll
-                for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = ys[((kk + 1) * 2 + lh) * BN + j * 32];
+                for (int j = 0; j < TN; j++) bv[(kk + 1) & 1][j] = ys[((kk + 1) * 2 + lh) * BN + j * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -213,11 +216,11 @@ __global__ void __launch_bounds__(512, 4) wgrad_ws_kernel(WgradArgs a) {
     for (int i = 0; i < TK; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) {
-            const int col = n0 + wn * WN + j * 32 + l31;
+            const int col = n0 + wn * 32 + j * 64 + l31;
             const bool col_ok = col < a.N;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int row = k0 + wk * WK + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = k0 + wk * 32 + i * 64 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (col_ok && row < a.K) out[(long long)row * a.N + col] = acc[i][j][r];
             }
         }
