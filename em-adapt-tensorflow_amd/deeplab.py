@@ -643,10 +643,11 @@ class ADAPT(Network):
                     if e["wgrad"]:
                         ops.conv_wgrad_x6p(e["x"], bufs["dyp"], e["d"], out=op.gw_pad)
                     elif e["small"]:
-                        ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
+                        ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad, bias_out=op.gb_pad)
                     else:
                         ops.conv_wgrad_x6(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
-                    ops.bias_grad(d, out=op.gb_pad)
+                    if e["wgrad"] or not e["small"]:
+                        ops.bias_grad(d, out=op.gb_pad)
                 else:
                     # (the bias gradient rides in the filter-gradient launch where the library fuses it: conv1_x .. conv3_1, fc8)
                     ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad, bias_out=op.gb_pad)
