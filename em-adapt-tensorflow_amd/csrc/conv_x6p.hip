@@ -129,7 +129,11 @@ PlanXP plan_x6p(const IgemmArgs &a) {
         }
     }
     if (t % cus == 0 || t * nk16 / cus < 32) return p;   // whole rounds, or too little work per CU to cut into pieces
-    if (a.N <= 1024 || t < cus) {
+    // fewer tiles than CUs: stream-K over everything.  Otherwise whole rounds run as plain tiles in the XCD-aware order -- the 32
+    // workgroups of an XCD then walk the SAME K step of neighbouring tiles and share its operand slices in that L2, which these
+    // kernels feel (fc7 as one stream-K launch: 16 % slower, profiles/r04_streamk_combine.txt) -- and only the rows of the partial
+    // last round run stream-K (conv3_x: 256 + 155 tiles; round 3 ran all 411 stream-K because N <= 1024 bounded the slab levels)
+    if (t < cus) {
         p.main_sk = 1;
         p.main_levels = streamk_levels(t, nk16, cus);
         return p;

@@ -110,13 +110,16 @@ SHAPES = [
 ]
 
 
-@pytest.fixture(params=["auto", "cus3", "cus8_dense"])
+@pytest.fixture(params=["auto", "cus3", "cus8_dense", "cus16"])
 def plan(request):
     """auto: the plans of a 256-CU part; cus3 / cus8: plans laid out for 3 / 8 CUs, which turns these small shapes into several
-    rounds of tiles, stream-K pieces with slab levels and tail launches; dense: no packed rows, no pixel skipping."""
+    rounds of plain tiles + a stream-K launch over the rows of the partial last round (round 4: whole rounds always run as plain
+    tiles), packed rows stream-K; cus16: fewer tiles than CUs -- stream-K over everything; dense: no packed rows, no pixel skipping."""
     import em_adapt_tensorflow_amd.ops as ops
     if request.param == "cus3":
         ops.tune_set("plan_cus", 3)
+    elif request.param == "cus16":     # more CUs than most of these shapes have tiles: stream-K over everything, every tile shared
+        ops.tune_set("plan_cus", 16)
     elif request.param == "cus8_dense":
         ops.tune_set("plan_cus", 8)
         ops.tune_set("fp32_loader", 2)
@@ -178,10 +181,13 @@ def test_plans_of_the_forced_layouts_differ(env):
     d = ops.conv_desc(1, 41, 41, 512, 272, 3, 3, 1)
     auto = ops.conv_x6p_plan(d)
     assert auto[1] == 0 and auto[0] == 1681                      # 14 tiles on 256 CUs: plain tiles
-    ops.tune_set("plan_cus", 3)
+    ops.tune_set("plan_cus", 16)
     try:
         sk = ops.conv_x6p_plan(d)
-        assert sk[1] == 1 and sk[2] >= 2                         # 14 tiles on 3 CUs: stream-K, pieces of tiles -> slab levels
+        assert sk[1] == 1 and sk[2] >= 2                         # 14 tiles on 16 CUs: stream-K, tiles shared by several workgroups
+        ops.tune_set("plan_cus", 3)
+        t3 = ops.conv_x6p_plan(d)
+        assert t3[1] == 0 and t3[0] == 6 * 256 and t3[4] >= 2    # on 3 CUs: 4 whole rounds of plain tiles (6 M tiles x 2) + a stream-K tail
         d4 = ops.conv_desc(6, 11, 11, 64, 256, 4, 4, 4)
         assert ops.conv_x6p_plan(d4)[3] > 0                      # 4x4 rate 4 on an 11x11 map: packed rows
         ops.tune_set("fp32_loader", 2)

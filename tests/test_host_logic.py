@@ -341,7 +341,7 @@ def test_plane_kernel_plans_sizes_and_shape_rules_need_no_device():
                     assert classes == 0 and levels == 0 and 0 < rows <= Mx
                     if rows < Mx:
                         kinds.add("tail")
-                        assert rows % 256 == 0 and N > 1024 and tail != 1 and ws == (sk_ws if tail > 0 else 0)
+                        assert rows % 256 == 0 and tail != 1 and ws == (sk_ws if tail > 0 else 0)
                     else:
                         kinds.add("plain")
                         assert ws == 0
