@@ -85,6 +85,8 @@ enum TuneKey {
     TUNE_RASTER_GM,    // M tiles per group of the plain-tile launches' XCD-aware order (0 = the default, 8): the workgroups resident on
                        //    one XCD cover GM M-tiles x the N-tiles that fit (scripts/raster_sweep.py measures the L2 hit rate and the time)
     TUNE_WGRAD_BIAS,   // 1: emadapt_conv_wgrad_bias_fused() answers 0 everywhere (the separate bias-gradient kernel: A/B, tests)
+    TUNE_SK_DROP_FLAG, // tests only: 1 = the stream-K publishers do not raise their arrival words and the heads give up after 2^12 polls
+                       //    -- exercises the bounded wait (a shared tile then comes out as NaNs instead of hanging the queue)
     TUNE_COUNT
 };
 int tune(TuneKey key);

@@ -73,6 +73,7 @@ struct IgemmArgs {
     int splits;          // split-K: K steps are divided over `splits` workgroups per tile (partials -> slab)
     float *slab;         // [splits][M][N] fp32 partials when splits > 1 (stream-K launches of igemm2_kernel: one 256x256 accumulator image per workgroup)
     unsigned *sk_flags;  // stream-K launches of igemm2_kernel: one arrival word per workgroup, zeroed ahead of the launch
+    int sk_drop_flag;    // tests only (tune "sk_drop_flag"): publishers keep their arrival words down, heads give up after 2^12 polls
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
     unsigned magic_nt;   // ceil(2^32/ntaps)
     RowPack pk;          // stream-K launches that skip padding (pk.n > 0)
@@ -381,6 +382,8 @@ void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
     a.magic_w = magic_u32(a.W); a.pk.n = 0; a.pk.rowmap = nullptr;
     a.gm = tune(TUNE_RASTER_GM) > 0 ? tune(TUNE_RASTER_GM) : 8;
     a.lockstep = tune(TUNE_DMA_STAGGER) == 1 ? 1 : 0;
+    a.sk_drop_flag = tune(TUNE_SK_DROP_FLAG) == 1 ? 1 : 0;
+    a.sk_flags = nullptr;
 }
 
 }  // namespace

@@ -476,7 +476,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             for (int l = 1; l <= sk_more; l++) {
                 const sk_flag_t *f = ((const sk_flag_t *)a.sk_flags) + (sk_v + l);
                 bool ok = false;
-                for (unsigned spins = 0; spins < kSkSpinMax; spins++) {
+                for (unsigned spins = 0; spins < (a.sk_drop_flag ? (1u << 12) : kSkSpinMax); spins++) {
                     if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = true; break; }
                     __builtin_amdgcn_s_sleep(8);
                 }
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
     }
     if constexpr (SK) {
         __syncthreads();   // pairs with the loaders' barrier: the ring may be refilled
-        if (lvl > 0 && tid == 0)   // every wave's slab stores were drained ahead of the barrier
+        if (lvl > 0 && tid == 0 && !a.sk_drop_flag)   // every wave's slab stores were drained ahead of the barrier
             __hip_atomic_store(((sk_flag_t *)a.sk_flags) + sk_v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     } while (SK && next_piece());

@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
                     }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, then the barrier, then ONE lane's flag
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(((sk_flag_t *)a.sk_flags) + sk_v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !a.sk_drop_flag) __hip_atomic_store(((sk_flag_t *)a.sk_flags) + sk_v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;   // (nothing else to store; the next piece starts with a barrier)
         }
         if (lvl == 0) {
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
             for (int l = 1; l <= sk_more; l++) {
                 const sk_flag_t *f = ((const sk_flag_t *)a.sk_flags) + (sk_v + l);
                 bool ok = false;
-                for (unsigned spins = 0; spins < kSkSpinMax; spins++) {
+                for (unsigned spins = 0; spins < (a.sk_drop_flag ? (1u << 12) : kSkSpinMax); spins++) {
                     if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = true; break; }
                     __builtin_amdgcn_s_sleep(8);
                 }

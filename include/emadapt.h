@@ -399,6 +399,8 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  *                the step's barrier (round 4: +3-6 %)
  *   "wgrad_bias" 1: emadapt_conv_wgrad_bias_fused() answers 0 for every shape (callers then use emadapt_conv_wgrad +
  *                emadapt_bias_grad: A/B of the fused bias gradient, tests of the fallback)
+ *   "sk_drop_flag" tests only: 1 = the stream-K publishers keep their arrival words down and the heads give up after 2^12 polls
+ *                (the bounded wait: a shared tile then comes out as NaNs, the launch ends)
  *   "estep_stop", "ablate": honoured by diagnostic builds only (-DEMADAPT_ABLATE_BUILD), ignored otherwise
  *                ("estep_stop" 1..4: leave the E-step kernel after that phase; bits 16 / 32 / 64 / 128: run its rank selection
  *                without the LDS atomics / the histogram scans / the barriers / after the first pass -- timing only)

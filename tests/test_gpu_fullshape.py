@@ -307,6 +307,31 @@ def test_stream_k_combine_when_the_chip_is_shared_with_another_process(env, tmp_
         assert int(bad) == 0 and float(worst) < 2e-5, (r, worst, bad)
 
 
+@pytest.mark.timeout(120)
+def test_stream_k_wait_for_a_publisher_is_bounded(env):
+    """The head of a shared tile polls the arrival words of the workgroups behind it -- a bounded poll (csrc/igemm_v2.h): with the
+    publishers' words held down (tune sk_drop_flag, tests only) the launch must END, its shared tiles poisoned with NaNs rather than
+    silently wrong, and the next launch must be clean again.  fp32 kernel and the bf16x6 plane kernel."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k = 16, 41, 41, 512, 512, 3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn((B, H, W, Cin), device="cuda", generator=g).relu_()
+    w = torch.randn((k, k, Cin, Cout), device="cuda", generator=g) * 0.02
+    b = torch.randn((Cout,), device="cuda", generator=g) * 0.1
+    d = ops.conv_desc(B, H, W, Cin, Cout, k, k, 1)
+    xp, wkp = ops.split_planes(x), ops.filter_tiles(w)
+    good = ops.conv_fwd(x, w, b, 1, relu=True)
+    good6 = ops.conv_fwd_x6p(xp, wkp, d, b, relu=True)
+    with ops.tuned(sk_drop_flag=1):
+        bad = ops.conv_fwd(x, w, b, 1, relu=False)
+        bad6 = ops.conv_fwd_x6p(xp, wkp, d, b, relu=False)
+        torch.cuda.synchronize()
+    for t in (bad, bad6):
+        nan_rows = torch.isnan(t).any(dim=-1).reshape(-1)
+        assert bool(nan_rows.any()), "a tile whose publisher never arrived must not look valid"
+    assert torch.equal(ops.conv_fwd(x, w, b, 1, relu=True), good) and torch.equal(ops.conv_fwd_x6p(xp, wkp, d, b, relu=True), good6)
+
+
 def test_builtin_dropout_draws_do_not_depend_on_the_launch_plan(env):
     """The counter-hash dropout generator is keyed by the GLOBAL output element, so every tile variant -- row splits,
     split-K second stages, stream-K pieces and their fix-up pass -- must drop exactly the same elements for a seed."""
