@@ -27,6 +27,18 @@ class EmadaptError(RuntimeError):
         super().__init__("%s failed: %s%s" % (where, msg, extra))
 
 
+class EmadaptDeviceError(EmadaptError):
+    """A kernel recorded a failure in the device status word (include/emadapt.h, emadapt_status_poll): ``flags`` holds its bits
+    (STATUS_STREAMK_TIMEOUT ...).  While the word was raised the optimiser kernels skipped their updates."""
+
+    def __init__(self, flags, where):
+        super().__init__(-6, where)
+        self.flags = flags
+
+
+STATUS_STREAMK_TIMEOUT = 1
+
+
 class ConvDesc(ctypes.Structure):
     """Mirror of emadapt_conv_desc (include/emadapt.h)."""
 
@@ -113,6 +125,12 @@ PROTOTYPES = {
     "emadapt_l2_loss": (c_int, [_vp, c_int64, _vp, _vp, c_size_t, _vp]),
     "emadapt_sgd_accumulate": (c_int, [_vp, _vp, _vp, c_int64, c_int64, c_float, c_float, _vp]),
     "emadapt_sgd_momentum": (c_int, [_vp, _vp, _vp, c_int64, c_float, c_float, c_float, _vp]),
+    "emadapt_sgd_accumulate_momentum": (c_int, [_vp, _vp, _vp, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float, _vp]),
+    "emadapt_sgd_momentum_payload": (c_int, [_vp, _vp, _vp, _vp, c_int, c_int64, c_float, c_float, c_float, _vp]),
+    "emadapt_grad_pack": (c_int, [_vp, c_int64, _vp, c_int, c_int64, _vp]),
+    "emadapt_grad_owner_sum": (c_int, [_vp, c_int, c_int, c_int64, _vp, _vp]),
+    "emadapt_status_word": (c_int, [POINTER(_vp)]),
+    "emadapt_status_poll": (c_int, [POINTER(ctypes.c_uint), c_int, _vp]),
     "emadapt_conv_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
     "emadapt_tune_set": (c_int, [ctypes.c_char_p, c_int]),
     "emadapt_tune_get": (c_int, [ctypes.c_char_p, POINTER(c_int)]),

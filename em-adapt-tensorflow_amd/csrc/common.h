@@ -30,6 +30,10 @@ inline int launch_status() {
     return EMADAPT_OK;
 }
 
+// Device address of the status word of the current device (include/emadapt.h, emadapt_status_poll): a __device__ variable of
+// the library's code object -- no allocation, no stream operation, safe under graph capture.  nullptr when HIP cannot resolve it.
+unsigned *status_word();
+
 // ---- per-kernel event timing (bench.py roofline; see emadapt_prof_* in emadapt.h) ----
 struct ProfScope {
     ProfScope(int kind, double flops, double bytes, hipStream_t stream);
@@ -63,6 +67,13 @@ double exec_fraction_x6p(const emadapt_conv_desc *d, int kind);    // conv_x6p.h
 // n * d < 2^32 (checked on the host for every quantity divided this way); d == 1 is encoded as magic 0 (identity).
 inline unsigned magic_u32(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 __device__ __forceinline__ unsigned div_magic(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
+
+// ReLU and the ReLU-gradient gate as the fused epilogues apply them.  Both PROPAGATE a NaN like tf.nn.relu (deeplab.py:71,100: TF's
+// max(x, 0) returns NaN for NaN) -- `v > 0 ? v : 0` maps NaN to 0 and would erase the poison a timed-out stream-K head leaves in a
+// tile (round-4 verdict) or an overflowed activation.  relu(-0.0) is -0.0 (the comparison is false), which no consumer tells
+// from +0.0.  The gate keeps ReluGrad's select (gate > 0 ? dy : 0) for numbers and lets a NaN gradient through either branch.
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float gate_keep_nan(float gate, float v_scaled) { return gate > 0.f ? v_scaled : (v_scaled != v_scaled ? v_scaled : 0.f); }
 
 // ---- launch-plan overrides (emadapt_tune_set in emadapt.h): 0 = automatic.  They select among kernel variants that
 // all compute the same result (the parity tests run every variant on small awkward shapes through them).

@@ -96,7 +96,7 @@ template <bool GBF>
 __device__ __forceinline__ float epilogue_t(const IgemmArgs &a, float v, int col, long long o) {
     if (a.epi != EMADAPT_EPI_NONE && a.bias) v += a.bias[col];
     if (a.epi == EMADAPT_EPI_BIAS_RELU) {
-        v = v > 0.f ? v : 0.f;
+        v = relu_keep_nan(v);
         if (a.keep < 1.0f) {
             const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
             v = kp ? drop_scale(a, v) : 0.f;
@@ -104,7 +104,7 @@ __device__ __forceinline__ float epilogue_t(const IgemmArgs &a, float v, int col
     }
     if (a.gate) {
         const float g = GBF ? (float)reinterpret_cast<const __bf16 *>(a.gate)[o] : a.gate[o];
-        v = g > 0.f ? v * a.scale : 0.f;
+        v = gate_keep_nan(g, v * a.scale);
     }
     return v;
 }

@@ -585,8 +585,9 @@ LaunchPlan plan_launches(const IgemmArgs &a) {
     //  of variant 1, several workgroups per CU, keep it moving: 0.245 -> 0.208 ms, profiles/r03_fp32_experiments.txt)
     int cfg = (a.N <= 64 || a.K <= 32) ? 1 : big ? (v2_ok(a, 16) ? 4 : 2) : split4 ? 4 : 3;
     // Variant 5 = the 256x256 kernel with the stream-K work split (igemm_v2.h): whenever the tile count is not a whole number
-    // of rounds and every CU still gets a few dozen K steps.  N <= 1024 bounds the slab levels ([rows][N] each); the
-    // N = 4096 layers keep the rows-of-whole-rounds + tail plan (8 % of their rows run on the 128x128 kernel).
+    // of rounds and every CU still gets a few dozen K steps.  N <= 1024: wider layers (N = 4096) keep the rows-of-whole-rounds + tail
+    // plan -- not for workspace (since round 4 a stream-K launch needs 64 MB whatever the layer) but because on the stream-K unit
+    // line no two workgroups of an XCD share a K phase, which costs fc7 2.7 % in fp32 and 16 % on the plane kernels.
     const int nk16 = a.K / 16;
     if (cfg != 1 && v2_ok(a, 16) && a.N >= 256 && a.N <= 1024 && t256 % cus != 0 && t256 * nk16 / cus >= 32) cfg = 5;
     if (force >= 1 && force <= 5 && !(force >= 4 && !v2_ok(a, 16))) cfg = force;
@@ -752,12 +753,24 @@ double exec_fraction_fp32(const emadapt_conv_desc *d, int kind) {
 
 extern "C" {
 
-size_t emadapt_conv_fwd_workspace_bytes(const emadapt_conv_desc *d) {
-    if (d && d->B > 0 && check_desc(d) == EMADAPT_ERR_UNSUPPORTED && slice_batch(d, false) > 0) {   // batch-sliced launch: the largest slice
-        emadapt_conv_desc s = *d;
-        s.B = slice_batch(d, false);
-        return s.B < d->B ? emadapt_conv_fwd_workspace_bytes(&s) : 0;
+// batch-sliced launches (tensors of 2 GiB and more): every slice is planned on its own, and the ragged last slice (B % bs images)
+// may take a plan with MORE workspace than the full ones (the cost model's split counts are not monotone in M): the larger of the two
+static size_t sliced_workspace_bytes(const emadapt_conv_desc *d, size_t (*per_slice)(const emadapt_conv_desc *)) {
+    emadapt_conv_desc s = *d;
+    s.B = slice_batch(d, false);
+    if (s.B >= d->B) return 0;
+    size_t w = per_slice(&s);
+    if (d->B % s.B != 0) {
+        s.B = d->B % s.B;
+        const size_t w2 = per_slice(&s);
+        w = w2 > w ? w2 : w;
     }
+    return w;
+}
+
+size_t emadapt_conv_fwd_workspace_bytes(const emadapt_conv_desc *d) {
+    if (d && d->B > 0 && check_desc(d) == EMADAPT_ERR_UNSUPPORTED && slice_batch(d, false) > 0)
+        return sliced_workspace_bytes(d, emadapt_conv_fwd_workspace_bytes);
     if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
     IgemmArgs a;
     fill_geometry(a, d, false);
@@ -765,11 +778,8 @@ size_t emadapt_conv_fwd_workspace_bytes(const emadapt_conv_desc *d) {
 }
 
 size_t emadapt_conv_dgrad_workspace_bytes(const emadapt_conv_desc *d) {
-    if (d && d->B > 0 && check_desc(d) == EMADAPT_ERR_UNSUPPORTED && slice_batch(d, false) > 0) {
-        emadapt_conv_desc s = *d;
-        s.B = slice_batch(d, false);
-        return s.B < d->B ? emadapt_conv_dgrad_workspace_bytes(&s) : 0;
-    }
+    if (d && d->B > 0 && check_desc(d) == EMADAPT_ERR_UNSUPPORTED && slice_batch(d, false) > 0)
+        return sliced_workspace_bytes(d, emadapt_conv_dgrad_workspace_bytes);
     if (check_desc(d) != EMADAPT_OK || d->B == 0) return 0;
     IgemmArgs a;
     fill_geometry(a, d, true);

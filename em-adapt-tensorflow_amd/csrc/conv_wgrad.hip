@@ -610,11 +610,19 @@ static int slice_batch(const emadapt_conv_desc *d, bool) {
     return b < 1 ? 0 : (int)(b < d->B ? b : d->B);
 }
 
-// batch-sliced filter gradient (tensors of 2 GiB and more): workspace = [one slice's own workspace][slices x KN floats]
+// batch-sliced filter gradient (tensors of 2 GiB and more): workspace = [one slice's own workspace][slices x KN floats].  The ragged
+// last slice (B % bs images) is planned on its own and the split count of a plan is not monotone in the pixel count: size for the
+// LARGER of the two slice plans, so that no slice can find the workspace short after earlier slices were enqueued (advisor, round 4).
 static size_t wgrad_slice_ws(const emadapt_conv_desc *d, int bs) {
     emadapt_conv_desc s = *d;
     s.B = bs;
-    return (emadapt_conv_wgrad_workspace_bytes(&s) + 255) & ~(size_t)255;
+    size_t w = emadapt_conv_wgrad_workspace_bytes(&s);
+    if (d->B % bs != 0) {
+        s.B = d->B % bs;
+        const size_t w2 = emadapt_conv_wgrad_workspace_bytes(&s);
+        w = w2 > w ? w2 : w;
+    }
+    return (w + 255) & ~(size_t)255;
 }
 
 size_t emadapt_conv_wgrad_workspace_bytes(const emadapt_conv_desc *d) {

@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ 
             float a[N];
             ldv(gate + (long long)t * N, a);
 #pragma unroll
-            for (int e = 0; e < N; e++) acc[e] = a[e] > 0.f ? acc[e] : 0.f;
+            for (int e = 0; e < N; e++) acc[e] = gate_keep_nan(a[e], acc[e]);
         }
         stv(dx + (long long)t * N, acc);
     }
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_rows_kernel(const T *__restri
             float g[N];
             ldv(gate + xo, g);
 #pragma unroll
-            for (int e = 0; e < N; e++) acc[e] = g[e] > 0.f ? acc[e] : 0.f;
+            for (int e = 0; e < N; e++) acc[e] = gate_keep_nan(g[e], acc[e]);
         }
         stv(dx + xo, acc);
     }
@@ -374,14 +374,28 @@ __global__ void __launch_bounds__(256) l2_partial_kernel(const float *__restrict
 // ------------------------------------------------------------------------------------------
 // optimiser (deeplab.py:202-205)
 // ------------------------------------------------------------------------------------------
+// The optimiser's arithmetic, PINNED.  hipcc contracts `mu * v + a * s` into an fma around EITHER product by its own heuristics: two
+// kernels with the same source expression (Momentum on a loaded accumulator / on one computed in registers) came out 1 ulp apart on
+// 28 % of the elements.  These spell out what the round-1..4 vector kernels compiled to (the values every checkpoint and test since
+// round 1 were produced with): the decay and accumulate steps are fmas, Momentum rounds mu * v and fuses the gradient term, the
+// weight step is an fma.  (HIP's default -ffp-contract=fast-honor-pragmas honours the pragma in mul_rn.)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float opt_decay(float g, float wd, float w) { return __builtin_fmaf(wd, w, g); }                       // g + wd w
+__device__ __forceinline__ float opt_accum(float a, float g, float scale) { return __builtin_fmaf(g, scale, a); }                  // a + g scale
+__device__ __forceinline__ float opt_velocity(float mu, float v, float a, float s) { return __builtin_fmaf(a, s, mul_rn(mu, v)); }  // mu v + a s
+__device__ __forceinline__ float opt_step(float w, float lr, float v) { return __builtin_fmaf(-lr, v, w); }                        // w - lr v
+
 __global__ void __launch_bounds__(256) sgd_accumulate_kernel(float *__restrict__ accum, const float *__restrict__ g,
                                                            const float *__restrict__ w, long long n,
                                                            long long n_decay, float wd, float scale) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         float gi = g[i];
-        if (i < n_decay) gi = gi + wd * w[i];
-        accum[i] = accum[i] + gi * scale;
+        if (i < n_decay) gi = opt_decay(gi, wd, w[i]);
+        accum[i] = opt_accum(accum[i], gi, scale);
     }
 }
 
@@ -394,40 +408,181 @@ __global__ void __launch_bounds__(256) sgd_accumulate_kernel_v4(float *__restric
         float4 gi = ld4(g + i * 4);
         if (i < n_decay4) {
             const float4 wi = ld4(w + i * 4);
-            gi.x = gi.x + wd * wi.x; gi.y = gi.y + wd * wi.y; gi.z = gi.z + wd * wi.z; gi.w = gi.w + wd * wi.w;
+            gi.x = opt_decay(gi.x, wd, wi.x); gi.y = opt_decay(gi.y, wd, wi.y); gi.z = opt_decay(gi.z, wd, wi.z); gi.w = opt_decay(gi.w, wd, wi.w);
         }
         float4 a = ld4(accum + i * 4);
-        a.x = a.x + gi.x * scale; a.y = a.y + gi.y * scale; a.z = a.z + gi.z * scale; a.w = a.w + gi.w * scale;
+        a.x = opt_accum(a.x, gi.x, scale); a.y = opt_accum(a.y, gi.y, scale); a.z = opt_accum(a.z, gi.z, scale); a.w = opt_accum(a.w, gi.w, scale);
         st4(accum + i * 4, a);
     }
 }
 
+// The device status word (include/emadapt.h, emadapt_status_poll): while a kernel has a failure recorded there the optimiser
+// kernels return at once, on the device -- a gradient with a poisoned tile never reaches weights, momentum or accumulators, and no
+// host synchronisation is needed for that (the word is read once per wave: a scalar load).
+__device__ __forceinline__ bool status_raised(const unsigned *status) { return status && __builtin_nontemporal_load(status) != 0u; }
+
 __global__ void __launch_bounds__(256) sgd_momentum_kernel(float *__restrict__ w, float *__restrict__ v,
                                                          float *__restrict__ accum, long long n, float lr, float mu,
-                                                         float ascale) {
+                                                         float ascale, const unsigned *__restrict__ status) {
+    if (status_raised(status)) return;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        const float vi = mu * v[i] + accum[i] * ascale;
+        const float vi = opt_velocity(mu, v[i], accum[i], ascale);
         v[i] = vi;
-        w[i] = w[i] - lr * vi;
+        w[i] = opt_step(w[i], lr, vi);
         accum[i] = 0.f;
     }
 }
 
 __global__ void __launch_bounds__(256) sgd_momentum_kernel_v4(float *__restrict__ w, float *__restrict__ v,
                                                             float *__restrict__ accum, long long n4, float lr,
-                                                            float mu, float ascale) {
+                                                            float mu, float ascale, const unsigned *__restrict__ status) {
+    if (status_raised(status)) return;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const float4 a = ld4(accum + i * 4);
         float4 vi = ld4(v + i * 4);
         float4 wi = ld4(w + i * 4);
-        vi.x = mu * vi.x + a.x * ascale; vi.y = mu * vi.y + a.y * ascale;
-        vi.z = mu * vi.z + a.z * ascale; vi.w = mu * vi.w + a.w * ascale;
-        wi.x = wi.x - lr * vi.x; wi.y = wi.y - lr * vi.y; wi.z = wi.z - lr * vi.z; wi.w = wi.w - lr * vi.w;
+        vi.x = opt_velocity(mu, vi.x, a.x, ascale); vi.y = opt_velocity(mu, vi.y, a.y, ascale);
+        vi.z = opt_velocity(mu, vi.z, a.z, ascale); vi.w = opt_velocity(mu, vi.w, a.w, ascale);
+        wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
         st4(v + i * 4, vi);
         st4(w + i * 4, wi);
         st4(accum + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
+// The same update reading the SUMMED GRADIENT from the gathered payload of the data-parallel exchange (f32 or bf16, dist.py)
+// instead of the accumulator -- the exchanged values never travel back into the accumulator, which is only zeroed (the clean op,
+// deeplab.py:203).  VN elements per thread: 4 (f32 payload) or 8 (bf16 payload: 16 bytes).
+template <typename P>
+__global__ void __launch_bounds__(256) sgd_momentum_payload_kernel(float *__restrict__ w, float *__restrict__ v,
+                                                                 float *__restrict__ accum, const P *__restrict__ payload,
+                                                                 long long nv, float lr, float mu, float ascale,
+                                                                 const unsigned *__restrict__ status) {
+    constexpr int VN = VW<P>::N;
+    if (status_raised(status)) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        float g[VN];
+        ldv(payload + i * VN, g);
+#pragma unroll
+        for (int q = 0; q < VN / 4; q++) {
+            const long long o = i * VN + q * 4;
+            float4 vi = ld4(v + o);
+            float4 wi = ld4(w + o);
+            vi.x = opt_velocity(mu, vi.x, g[q * 4 + 0], ascale); vi.y = opt_velocity(mu, vi.y, g[q * 4 + 1], ascale);
+            vi.z = opt_velocity(mu, vi.z, g[q * 4 + 2], ascale); vi.w = opt_velocity(mu, vi.w, g[q * 4 + 3], ascale);
+            wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
+            st4(v + o, vi);
+            st4(w + o, wi);
+            st4(accum + o, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+}
+template <typename P>
+__global__ void __launch_bounds__(256) sgd_momentum_payload_tail_kernel(float *__restrict__ w, float *__restrict__ v,
+                                                                      float *__restrict__ accum, const P *__restrict__ payload,
+                                                                      long long i0, long long n, float lr, float mu, float ascale,
+                                                                      const unsigned *__restrict__ status) {
+    if (status_raised(status)) return;
+    for (long long i = i0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float vi = opt_velocity(mu, v[i], (float)payload[i], ascale);
+        v[i] = vi;
+        w[i] = opt_step(w[i], lr, vi);
+        accum[i] = 0.f;
+    }
+}
+
+// accumulate (deeplab.py:202) + apply_gradients (:204-205) + clean (:203) of ONE micro-batch in one pass, for accum_num == 1
+// without a gradient exchange: the accumulator would only carry (g + wd w) * gscale from one kernel to the next.  The arithmetic
+// is the two kernels' (0 + (g + wd w) gscale, then mu v + that * ascale), operation for operation: the weights come out bit for bit
+// as from emadapt_sgd_accumulate followed by emadapt_sgd_momentum on a zero accumulator.  20 bytes per parameter instead of 40.
+__global__ void __launch_bounds__(256) sgd_accumulate_momentum_kernel_v4(float *__restrict__ w, float *__restrict__ v,
+                                                                       const float *__restrict__ g, long long n4, long long n_decay4,
+                                                                       float wd, float gscale, float lr, float mu, float ascale,
+                                                                       const unsigned *__restrict__ status) {
+    if (status_raised(status)) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 gi = ld4(g + i * 4);
+        float4 wi = ld4(w + i * 4);
+        float4 vi = ld4(v + i * 4);
+        if (i < n_decay4) { gi.x = opt_decay(gi.x, wd, wi.x); gi.y = opt_decay(gi.y, wd, wi.y); gi.z = opt_decay(gi.z, wd, wi.z); gi.w = opt_decay(gi.w, wd, wi.w); }
+        const float4 a = make_float4(opt_accum(0.f, gi.x, gscale), opt_accum(0.f, gi.y, gscale), opt_accum(0.f, gi.z, gscale), opt_accum(0.f, gi.w, gscale));
+        vi.x = opt_velocity(mu, vi.x, a.x, ascale); vi.y = opt_velocity(mu, vi.y, a.y, ascale);
+        vi.z = opt_velocity(mu, vi.z, a.z, ascale); vi.w = opt_velocity(mu, vi.w, a.w, ascale);
+        wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
+        st4(v + i * 4, vi);
+        st4(w + i * 4, wi);
+    }
+}
+__global__ void __launch_bounds__(256) sgd_accumulate_momentum_kernel(float *__restrict__ w, float *__restrict__ v,
+                                                                    const float *__restrict__ g, long long n, long long n_decay,
+                                                                    float wd, float gscale, float lr, float mu, float ascale,
+                                                                    const unsigned *__restrict__ status) {
+    if (status_raised(status)) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float wi = w[i];
+        if (i < n_decay) gi = opt_decay(gi, wd, wi);
+        const float a = opt_accum(0.f, gi, gscale);
+        const float vi = opt_velocity(mu, v[i], a, ascale);
+        v[i] = vi;
+        w[i] = opt_step(wi, lr, vi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Staging of the data-parallel gradient exchange (dist.py, algo "direct": reduce-scatter + all-gather as two all-to-all steps).
+// The exchange maps the reference's micro-batches to ranks (deeplab.py:202: accum += g / accum_num); these kernels are the only
+// arithmetic on that path and replace round 4's torch copy_/add_ sequences (6 + W launches and ~8 passes per bucket) by one pass each.
+// ------------------------------------------------------------------------------------------
+// pack: send[0:n] = P(accum[0:n]) (bf16: round to nearest even, once), send[n:npad] = 0 (whole shards for every rank)
+template <typename P>
+__global__ void __launch_bounds__(256) grad_pack_kernel(const float *__restrict__ src, long long n, P *__restrict__ dst, long long npad) {
+    constexpr int VN = VW<P>::N;
+    const long long nv = npad / VN;   // (npad % VN == 0 and both pointers 16-byte aligned: checked by the host, else the scalar kernel)
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        float x[VN];
+#pragma unroll
+        for (int q = 0; q < VN / 4; q++) {
+            const long long o = i * VN + q * 4;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o + 4 <= n) t = ld4(src + o);
+            else if (o < n) { t.x = src[o]; if (o + 1 < n) t.y = src[o + 1]; if (o + 2 < n) t.z = src[o + 2]; }
+            x[q * 4 + 0] = t.x; x[q * 4 + 1] = t.y; x[q * 4 + 2] = t.z; x[q * 4 + 3] = t.w;
+        }
+        stv(dst + i * VN, x);
+    }
+}
+template <typename P>
+__global__ void __launch_bounds__(256) grad_pack_scalar_kernel(const float *__restrict__ src, long long n, P *__restrict__ dst, long long npad) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = (P)(i < n ? src[i] : 0.f);
+}
+// owner sum: out[i] = P( fp32(recv[0][i]) + fp32(recv[1][i]) + ... + fp32(recv[W-1][i]) ), the adds in fp32 in RANK ORDER (every
+// element is summed exactly once, by its owner: all ranks end up with the same bits), the sum rounded once.  recv = [W][shard].
+template <typename P>
+__global__ void __launch_bounds__(256) grad_owner_sum_kernel(const P *__restrict__ recv, int W, long long shard, P *__restrict__ out) {
+    constexpr int VN = VW<P>::N;
+    const long long nv = shard / VN;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        float acc[VN];
+        ldv(recv + i * VN, acc);
+        for (int r = 1; r < W; r++) {
+            float x[VN];
+            ldv(recv + (long long)r * shard + i * VN, x);
+#pragma unroll
+            for (int e = 0; e < VN; e++) acc[e] = acc[e] + x[e];
+        }
+        stv(out + i * VN, acc);
+    }
+}
+template <typename P>
+__global__ void __launch_bounds__(256) grad_owner_sum_scalar_kernel(const P *__restrict__ recv, int W, long long shard, P *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < shard; i += (long long)gridDim.x * blockDim.x) {
+        float acc = (float)recv[i];
+        for (int r = 1; r < W; r++) acc = acc + (float)recv[(long long)r * shard + i];
+        out[i] = (P)acc;
     }
 }
 
@@ -698,13 +853,108 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
     if (!w || !v || !accum || n < 0) return EMADAPT_ERR_INVALID;
     if (n == 0) return EMADAPT_OK;
     hipStream_t stream = as_stream(stream_);
+    const unsigned *status = status_word();
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 24.0, stream);
     if (n % 4 == 0 && aligned16(w) && aligned16(v) && aligned16(accum)) {
         hipLaunchKernelGGL(sgd_momentum_kernel_v4, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, w, v, accum,
-                           (long long)(n / 4), lr, momentum, accum_scale);
+                           (long long)(n / 4), lr, momentum, accum_scale, status);
     } else {
         hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, w, v, accum,
-                           (long long)n, lr, momentum, accum_scale);
+                           (long long)n, lr, momentum, accum_scale, status);
+    }
+    return launch_status();
+}
+
+int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *payload, int payload_dtype, int64_t n, float lr,
+                                 float momentum, float scale, void *stream_) {
+    if (!w || !v || !accum || !payload || n < 0 || (payload_dtype != EMADAPT_DT_F32 && payload_dtype != EMADAPT_DT_BF16))
+        return EMADAPT_ERR_INVALID;
+    if (n == 0) return EMADAPT_OK;
+    hipStream_t stream = as_stream(stream_);
+    const unsigned *status = status_word();
+    const bool bf = payload_dtype == EMADAPT_DT_BF16;
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * (20.0 + (bf ? 2.0 : 4.0)), stream);
+    const int vn = bf ? 8 : 4;
+    const bool vec = aligned16(w) && aligned16(v) && aligned16(accum) && aligned16(payload);
+    const int64_t nvec = vec ? n / vn : 0;
+    if (nvec > 0) {
+        if (bf)
+            hipLaunchKernelGGL(sgd_momentum_payload_kernel<__bf16>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, stream, w, v, accum,
+                               static_cast<const __bf16 *>(payload), (long long)nvec, lr, momentum, scale, status);
+        else
+            hipLaunchKernelGGL(sgd_momentum_payload_kernel<float>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, stream, w, v, accum,
+                               static_cast<const float *>(payload), (long long)nvec, lr, momentum, scale, status);
+        int rc = launch_status();
+        if (rc) return rc;
+    }
+    if (nvec * vn < n) {
+        if (bf)
+            hipLaunchKernelGGL(sgd_momentum_payload_tail_kernel<__bf16>, dim3(grid_for(n - nvec * vn, 256, 4096)), dim3(256), 0, stream, w, v,
+                               accum, static_cast<const __bf16 *>(payload), (long long)(nvec * vn), (long long)n, lr, momentum, scale, status);
+        else
+            hipLaunchKernelGGL(sgd_momentum_payload_tail_kernel<float>, dim3(grid_for(n - nvec * vn, 256, 4096)), dim3(256), 0, stream, w, v,
+                               accum, static_cast<const float *>(payload), (long long)(nvec * vn), (long long)n, lr, momentum, scale, status);
+        return launch_status();
+    }
+    return EMADAPT_OK;
+}
+
+int emadapt_sgd_accumulate_momentum(float *w, float *v, const float *g, int64_t n, int64_t n_decay, float weight_decay,
+                                    float gscale, float lr, float momentum, float ascale, void *stream_) {
+    if (!w || !v || !g || n < 0 || n_decay < 0 || n_decay > n) return EMADAPT_ERR_INVALID;
+    if (n == 0) return EMADAPT_OK;
+    hipStream_t stream = as_stream(stream_);
+    const unsigned *status = status_word();
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 20.0, stream);
+    if (n % 4 == 0 && n_decay % 4 == 0 && aligned16(w) && aligned16(v) && aligned16(g)) {
+        hipLaunchKernelGGL(sgd_accumulate_momentum_kernel_v4, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, w, v, g,
+                           (long long)(n / 4), (long long)(n_decay / 4), weight_decay, gscale, lr, momentum, ascale, status);
+    } else {
+        hipLaunchKernelGGL(sgd_accumulate_momentum_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, w, v, g, (long long)n,
+                           (long long)n_decay, weight_decay, gscale, lr, momentum, ascale, status);
+    }
+    return launch_status();
+}
+
+int emadapt_grad_pack(const float *src, int64_t n, void *dst, int dst_dtype, int64_t npad, void *stream_) {
+    if (!src || !dst || n < 0 || npad < n || (dst_dtype != EMADAPT_DT_F32 && dst_dtype != EMADAPT_DT_BF16)) return EMADAPT_ERR_INVALID;
+    if (npad == 0) return EMADAPT_OK;
+    hipStream_t stream = as_stream(stream_);
+    const bool bf = dst_dtype == EMADAPT_DT_BF16;
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 4.0 + (double)npad * (bf ? 2.0 : 4.0), stream);
+    const int vn = bf ? 8 : 4;
+    const bool vec = npad % vn == 0 && aligned16(src) && aligned16(dst);
+    if (bf) {
+        __bf16 *d = static_cast<__bf16 *>(dst);
+        if (vec) hipLaunchKernelGGL(grad_pack_kernel<__bf16>, dim3(grid_for(npad / vn, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad);
+        else hipLaunchKernelGGL(grad_pack_scalar_kernel<__bf16>, dim3(grid_for(npad, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad);
+    } else {
+        float *d = static_cast<float *>(dst);
+        if (vec) hipLaunchKernelGGL(grad_pack_kernel<float>, dim3(grid_for(npad / vn, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad);
+        else hipLaunchKernelGGL(grad_pack_scalar_kernel<float>, dim3(grid_for(npad, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad);
+    }
+    return launch_status();
+}
+
+int emadapt_grad_owner_sum(const void *recv, int dtype, int world, int64_t shard, void *out, void *stream_) {
+    if (!recv || !out || world < 1 || shard < 0 || (dtype != EMADAPT_DT_F32 && dtype != EMADAPT_DT_BF16)) return EMADAPT_ERR_INVALID;
+    if (shard == 0) return EMADAPT_OK;
+    hipStream_t stream = as_stream(stream_);
+    const bool bf = dtype == EMADAPT_DT_BF16;
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)shard * (world + 1) * (bf ? 2.0 : 4.0), stream);
+    const int vn = bf ? 8 : 4;
+    // (every rank's slice of recv must start on a 16-byte boundary for the vector form: shard % vn == 0)
+    const bool vec = shard % vn == 0 && aligned16(recv) && aligned16(out);
+    if (bf) {
+        const __bf16 *r = static_cast<const __bf16 *>(recv);
+        __bf16 *o = static_cast<__bf16 *>(out);
+        if (vec) hipLaunchKernelGGL(grad_owner_sum_kernel<__bf16>, dim3(grid_for(shard / vn, 256, 4096)), dim3(256), 0, stream, r, world, (long long)shard, o);
+        else hipLaunchKernelGGL(grad_owner_sum_scalar_kernel<__bf16>, dim3(grid_for(shard, 256, 4096)), dim3(256), 0, stream, r, world, (long long)shard, o);
+    } else {
+        const float *r = static_cast<const float *>(recv);
+        float *o = static_cast<float *>(out);
+        if (vec) hipLaunchKernelGGL(grad_owner_sum_kernel<float>, dim3(grid_for(shard / vn, 256, 4096)), dim3(256), 0, stream, r, world, (long long)shard, o);
+        else hipLaunchKernelGGL(grad_owner_sum_scalar_kernel<float>, dim3(grid_for(shard, 256, 4096)), dim3(256), 0, stream, r, world, (long long)shard, o);
     }
     return launch_status();
 }

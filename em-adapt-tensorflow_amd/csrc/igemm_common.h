@@ -73,6 +73,7 @@ struct IgemmArgs {
     int splits;          // split-K: K steps are divided over `splits` workgroups per tile (partials -> slab)
     float *slab;         // [splits][M][N] fp32 partials when splits > 1 (stream-K launches of igemm2_kernel: one 256x256 accumulator image per workgroup)
     unsigned *sk_flags;  // stream-K launches of igemm2_kernel: one arrival word per workgroup, zeroed ahead of the launch
+    unsigned *status;    // the device status word (common.h status_word): a head whose wait ran out raises EMADAPT_STATUS_STREAMK_TIMEOUT
     int sk_drop_flag;    // tests only (tune "sk_drop_flag"): publishers keep their arrival words down, heads give up after 2^12 polls
     int tap_inner;       // 1: K order = (channel chunk, tap) -- needs Cx % BK == 0 (host decides)
     unsigned magic_nt;   // ceil(2^32/ntaps)
@@ -155,13 +156,13 @@ __device__ __forceinline__ void dropout_keep2(unsigned long long seed, unsigned 
 __device__ __forceinline__ float epilogue(const IgemmArgs &a, float v, int col, long long o) {
     if (a.epi != EMADAPT_EPI_NONE && a.bias) v += a.bias[col];
     if (a.epi == EMADAPT_EPI_BIAS_RELU) {
-        v = v > 0.f ? v : 0.f;
+        v = relu_keep_nan(v);
         if (a.keep < 1.0f) {
             const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
             v = kp ? drop_scale(a, v) : 0.f;  // tf.nn.dropout divides by keep_prob
         }
     }
-    if (a.gate) v = a.gate[o] > 0.f ? v * a.scale : 0.f;
+    if (a.gate) v = gate_keep_nan(a.gate[o], v * a.scale);
     return v;
 }
 
@@ -234,7 +235,7 @@ __device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 
                 }
                 if (a.epi == EMADAPT_EPI_BIAS_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                    for (int e = 0; e < 8; e++) v[e] = relu_keep_nan(v[e]);
                     if (a.keep < 1.0f) {
 #pragma unroll
                         for (int e = 0; e < 8; e += 2) {   // (o is a multiple of 4: (o + e, o + e + 1) is a pair of the generator)
@@ -259,7 +260,7 @@ __device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 
                         g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; e++) v[e] = g[e] > 0.f ? v[e] * a.scale : 0.f;
+                    for (int e = 0; e < 8; e++) v[e] = gate_keep_nan(g[e], v[e] * a.scale);
                 }
                 if constexpr (YBF) {
                     bf16x8_t ov;
@@ -384,6 +385,7 @@ void fill_geometry(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
     a.lockstep = tune(TUNE_DMA_STAGGER) == 1 ? 1 : 0;
     a.sk_drop_flag = tune(TUNE_SK_DROP_FLAG) == 1 ? 1 : 0;
     a.sk_flags = nullptr;
+    a.status = status_word();
 }
 
 }  // namespace

@@ -417,6 +417,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         }
         __syncthreads();
     };
+    int sk_bad = 0;   // (scalar) a publisher of a tile this workgroup heads never arrived
     do {   // one piece of work (SK: several)
     const bool packed = SK && a.pk.n > 0;
     const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (packed: a GEMM row)
@@ -499,7 +500,10 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
                         //  the compiler then spills inside the MFMA loop)
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                // (the publisher never arrived -- see the note at sk_start: a NaN in every 32 x 32 block of the tile)
+                // (the publisher never arrived -- see the note at sk_start: a NaN in every 32 x 32 block of the tile, which the epilogues
+                // propagate, and the launch's failure in the device status word: the optimiser kernels then skip their update and
+                // emadapt_status_poll reports it -- raised at the end of the kernel: an atomic HERE cost the MFMA loop 700 bytes of spills)
+                sk_bad |= __builtin_amdgcn_readfirstlane(ok ? 0 : 1);
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -551,7 +555,7 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
                     v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;   // (bias4 = 0 when there is no bias)
                     if (a.epi == EMADAPT_EPI_BIAS_RELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                        for (int e = 0; e < 4; e++) v[e] = relu_keep_nan(v[e]);
                         if (a.keep < 1.0f) {
                             unsigned mk = 0;
                             if (a.mask) mk = *reinterpret_cast<const unsigned *>(a.mask + o);   // four keep bytes (o % 4 == 0)
@@ -567,10 +571,10 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
                     }
                     if (a.gate) {
                         const float4 g = *reinterpret_cast<const float4 *>(a.gate + o);
-                        v[0] = g.x > 0.f ? v[0] * a.scale : 0.f;
-                        v[1] = g.y > 0.f ? v[1] * a.scale : 0.f;
-                        v[2] = g.z > 0.f ? v[2] * a.scale : 0.f;
-                        v[3] = g.w > 0.f ? v[3] * a.scale : 0.f;
+                        v[0] = gate_keep_nan(g.x, v[0] * a.scale);
+                        v[1] = gate_keep_nan(g.y, v[1] * a.scale);
+                        v[2] = gate_keep_nan(g.z, v[2] * a.scale);
+                        v[3] = gate_keep_nan(g.w, v[3] * a.scale);
                     }
                     *reinterpret_cast<float4 *>(a.y + o) = make_float4(v[0], v[1], v[2], v[3]);
                 }
@@ -583,6 +587,10 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
             __hip_atomic_store(((sk_flag_t *)a.sk_flags) + sk_v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     } while (SK && next_piece());
+    if constexpr (SK) {
+        if (sk_bad && a.status && (threadIdx.x & 63) == 0)
+            __hip_atomic_fetch_or(a.status, EMADAPT_STATUS_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Workgroups of a stream-K launch over U units: one per CU, but never more than units (every piece list is then non-empty, so

@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
     f32x16 acc[TM][TN];
     xp_bf16x8 av[3][TM], bv[3][TN];
 
+    int sk_bad = 0;   // (scalar) a publisher of a tile this workgroup heads never arrived
     do {   // one piece of work (SK: several)
     const bool packed = SK && a.pk.n > 0;
     const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;   // (packed: m0 is a GEMM row, a.pk.rowmap gives the pixel)
@@ -358,8 +359,10 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // (a publisher that never arrived: a NaN in every 32 x 32 block, and the failure in the device status word -- igemm_v2.h)
+                sk_bad |= __builtin_amdgcn_readfirstlane(ok ? 0 : 1);   // (raised at the end of the kernel)
 #pragma unroll
-                for (int i = 0; i < TM; i++)   // (a publisher that never arrived: a NaN in every 32 x 32 block)
+                for (int i = 0; i < TM; i++)
 #pragma unroll
                     for (int j = 0; j < TN; j++) acc[i][j][0] = ok ? acc[i][j][0] : __builtin_nanf("");
             }
@@ -373,6 +376,10 @@ __global__ void __launch_bounds__(XP_WAVES * 64, 2) igemm_x6p_kernel(IgemmArgs a
     else
         store_acc_tile<TM, TN, 16, false>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
     } while (SK && next_piece());
+    if constexpr (SK) {
+        if (sk_bad && a.status && (threadIdx.x & 63) == 0)
+            __hip_atomic_fetch_or(a.status, EMADAPT_STATUS_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <bool SK, int ABLM = 0>

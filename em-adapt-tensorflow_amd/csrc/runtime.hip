@@ -32,6 +32,24 @@ std::mutex g_attr_mu;
 
 int tune(TuneKey key) { return g_tune[key].load(std::memory_order_relaxed); }
 
+// The status word: one per device, living in the code object (a module is loaded per device, so the symbol has an address per
+// device); its address is looked up once per device and cached.
+__device__ unsigned g_device_status[4];   // [0] the flags; the rest pads the word onto a line of its own use
+namespace {
+std::mutex g_status_mu;
+unsigned *g_status_ptr[64];
+}  // namespace
+unsigned *status_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return nullptr;
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    if (dev < 64 && g_status_ptr[dev]) return g_status_ptr[dev];
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_device_status)) != hipSuccess) return nullptr;
+    if (dev < 64) g_status_ptr[dev] = static_cast<unsigned *>(p);
+    return static_cast<unsigned *>(p);
+}
+
 int DynLdsAttr::ensure(const void *kernel, size_t bytes) {
     int dev = 0;
     EMADAPT_HIP_TRY(hipGetDevice(&dev));
@@ -94,6 +112,7 @@ const char *emadapt_strerror(int code) {
         case EMADAPT_ERR_HIP: return "HIP runtime error";
         case EMADAPT_ERR_WORKSPACE: return "workspace missing or too small";
         case EMADAPT_ERR_NODEVICE: return "no gfx950 device";
+        case EMADAPT_ERR_DEVICE_STATUS: return "a kernel reported a failure in the device status word";
         default: return "unknown error";
     }
 }
@@ -104,6 +123,24 @@ int emadapt_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int emadapt_status_word(void **device_ptr) {
+    if (!device_ptr) return EMADAPT_ERR_INVALID;
+    *device_ptr = status_word();
+    return *device_ptr ? EMADAPT_OK : EMADAPT_ERR_HIP;
+}
+
+int emadapt_status_poll(unsigned *flags, int clear, void *stream_) {
+    unsigned *word = status_word();
+    if (!word) return EMADAPT_ERR_HIP;
+    hipStream_t stream = as_stream(stream_);
+    unsigned host = 0;
+    EMADAPT_HIP_TRY(hipMemcpyAsync(&host, word, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    if (clear) EMADAPT_HIP_TRY(hipMemsetAsync(word, 0, sizeof(unsigned), stream));
+    EMADAPT_HIP_TRY(hipStreamSynchronize(stream));
+    if (flags) *flags = host;
+    return host ? EMADAPT_ERR_DEVICE_STATUS : EMADAPT_OK;
 }
 
 int emadapt_tune_set(const char *key, int value) {

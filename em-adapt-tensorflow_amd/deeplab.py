@@ -92,6 +92,13 @@ class ADAPT(Network):
         self._weight_decay = 0.0
         self._momentum = 0.9
         self._gradsync = None
+        # config "fused_update": with accum_num == 1 and no gradient exchange the accumulator only carries one micro-batch's gradient
+        # from the accumulate kernel to the Momentum kernel; fused, backward() skips the accumulate launches and apply_update() runs
+        # accumulate + Momentum + clean as ONE pass per layer (ops.sgd_accumulate_momentum: bit-identical weights, half the bytes).
+        # The accumulator then stays zero between the two "ops" of deeplab.py:267-270, so it is opt-in for callers that drive
+        # micro_step / apply_update themselves; train(), where nobody looks in between, switches it on.
+        self._fused = bool(self.config.get("fused_update", False))
+        self._pending_fused = False
         self._perm_pool = None
         self._perm_pos = 0
         self.init_model = None
@@ -592,8 +599,10 @@ class ADAPT(Network):
             # all xGMI links, on a side stream); "grad_dtype": "fp32" | "bf16" payload (bf16 needs "direct"; dist.py)
             grad_dtype = str(self.config.get("grad_dtype", "fp32"))
             algo = str(self.config.get("allreduce_algo", "direct" if grad_dtype == "bf16" else "allreduce"))
+            # (direct exchange: the summed gradients stay in GradSync.gathered, which apply_update's Momentum kernel reads in place)
             self._gradsync = GradSync(self._flat["accum"], [(s["start"], s["end"]) for s in self._bucket_order()],
-                                      bucket_bytes=int(self.config.get("bucket_mb", 32)) << 20, algo=algo, payload=grad_dtype)
+                                      bucket_bytes=int(self.config.get("bucket_mb", 32)) << 20, algo=algo, payload=grad_dtype,
+                                      writeback=False)
 
     def _bucket_order(self):
         return [self._segments[op.name] for op in reversed(self._plan) if op.kind == "conv"]
@@ -623,6 +632,8 @@ class ADAPT(Network):
         # config "allreduce_release_at": a layer name -- held until backward reaches that layer (dist.py: a policy to be
         # chosen by measurement on a multi-GPU node; bench.py reports the exposed time of either)
         sync = self._gradsync if last_micro else None
+        fused = self._fused and self.accum_num == 1 and self._gradsync is None   # (see __init__: apply_update does the accumulate)
+        self._pending_fused = fused
         release_at = self.config.get("allreduce_release_at", None)
         if sync is not None and release_at is not None and any(o.name == release_at for o in plan):
             sync.hold()
@@ -653,8 +664,9 @@ class ADAPT(Network):
                     ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad, bias_out=op.gb_pad)
                 seg = op.seg
                 s, n = seg["start"], seg["nw"] + seg["nb"]
-                ops.sgd_accumulate(self._flat["accum"][s:s + n], self._flat["grads"][s:s + n],
-                                   self._flat["params"][s:s + n], seg["nw"], self._weight_decay, inv_accum)
+                if not fused:
+                    ops.sgd_accumulate(self._flat["accum"][s:s + n], self._flat["grads"][s:s + n],
+                                       self._flat["params"][s:s + n], seg["nw"], self._weight_decay, inv_accum)
                 if last_micro and self._gradsync is not None:
                     self._gradsync.segment_ready(seg["start"], seg["end"])
                 if prev is None:
@@ -696,11 +708,23 @@ class ADAPT(Network):
     def apply_update(self):
         """accum_gradient_update + accum_gradient_clean (deeplab.py:203-205,268-270)."""
         scale = 1.0
-        if self._gradsync is not None:
-            self._gradsync.wait()
-            scale = 1.0 / self._gradsync.world_size
         f = self._flat
-        ops.sgd_momentum(f["params"], f["momentum"], f["accum"], self.net["lr"], self._momentum, scale)
+        gs = self._gradsync
+        if gs is not None:
+            gs.wait()
+            scale = 1.0 / gs.world_size
+        if self._pending_fused:
+            for op in self._plan:   # accumulate + apply_gradients + clean of the one micro-batch, one pass per layer
+                if op.kind == "conv":
+                    s, n = op.seg["start"], op.seg["nw"] + op.seg["nb"]
+                    ops.sgd_accumulate_momentum(f["params"][s:s + n], f["momentum"][s:s + n], f["grads"][s:s + n], op.seg["nw"],
+                                                self._weight_decay, 1.0 / float(self.accum_num), self.net["lr"], self._momentum, scale)
+            self._pending_fused = False
+        elif gs is not None and not gs.writeback:
+            # the exchanged sum lives in the gathered payload (f32 or bf16); the accumulator is only zeroed (the clean op)
+            ops.sgd_momentum_payload(f["params"], f["momentum"], f["accum"], gs.gathered, self.net["lr"], self._momentum, scale)
+        else:
+            ops.sgd_momentum(f["params"], f["momentum"], f["accum"], self.net["lr"], self._momentum, scale)
         self._w16_seen = None  # the master weights moved: the bf16 images are refreshed by the next forward
         self._step += 1
 
@@ -746,6 +770,8 @@ class ADAPT(Network):
         log("config -- lr:%f weight_decay:%f momentum:%f batch_size:%f epoches:%f" % (
             base_lr, weight_decay, momentum, batch_size, epoches))
         epoch, i = 0.0, 0
+        if "fused_update" not in self.config:
+            self._fused = True   # (takes effect where accum_num == 1 and there is no gradient exchange: backward())
         iterations_per_epoch_train = max(self.data.get_data_len() // (batch_size * world), 1)
         saver_dir = self.config.get("saver_path", "saver")
 
@@ -773,11 +799,18 @@ class ADAPT(Network):
             if i % 500 == 10:
                 loss = self.eval_loss(data_x, data_y, 0.5)
                 log("epoch:%f, iteration:%f, lr:%f, loss:%f" % (epoch, i, self.net["lr"], loss))
+                # once per logging interval (the loop synchronises here anyway): a failure a kernel recorded in the device status
+                # word (a stream-K wait that ran out: the optimiser kernels have been skipping their updates since) raises
+                # EmadaptDeviceError, and a loss that is no longer finite stops the run -- TF's session.run would have raised
+                ops.status_poll(clear=True, raise_on_error=True)
+                if not np.isfinite(loss):
+                    raise FloatingPointError("loss is %r at iteration %d (lr %g)" % (loss, i, self.net["lr"]))
             if i % 6000 == 5999:
                 save("norm", "norm", i)
             i += 1
             epoch = i / iterations_per_epoch_train
         torch.cuda.synchronize(self.device)
+        ops.status_poll(clear=True, raise_on_error=True)   # (before anything is saved)
         if self.config.get("save_final", True):
             save("norm", "norm", i)
         end_time = time.time()

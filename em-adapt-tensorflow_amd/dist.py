@@ -35,8 +35,15 @@ Two exchange algorithms (round 4), both leaving the SUM over ranks in the fp32 a
   once, one xGMI link each ("Distributed communication backend"): rank j owns shard j of a bucket; (1)
   ``all_to_all_single`` sends shard j of the local gradients to rank j; (2) rank j adds the W contributions IN FP32, IN RANK
   ORDER (deterministic; each element is summed exactly once, by its owner, so all ranks end up with the same bits); (3)
-  ``all_gather_into_tensor`` returns the summed shards.  The work runs on a SIDE stream (comm + the cast / sum kernels), ordered
+  ``all_gather_into_tensor`` returns the summed shards.  The work runs on a SIDE stream (comm + the pack / sum kernels), ordered
   behind the point of the compute stream at which the bucket became final; ``wait()`` makes the compute stream wait for it.
+  Round 5: the arithmetic of (1)-(3) on GPU tensors is two kernels of the HIP library behind the C ABI -- ``emadapt_grad_pack`` (accumulator
+  slice -> send buffer, one pass) and ``emadapt_grad_owner_sum`` (W shards added in fp32 in rank order, rounded once, one pass) -- instead
+  of 6 + W torch launches and ~8 passes per bucket; a fp32 bucket of whole shards is sent straight from the accumulator (no pack at
+  all); and the gathered payload is NOT copied back into the accumulator: it lands in a full-size buffer (``gathered``) that
+  ``emadapt_sgd_momentum_payload`` reads directly (``writeback=False``, what ADAPT uses; the default True keeps ``flat`` = the sum for
+  callers that want it there).  CPU tensors (the gloo tests) run the same arithmetic as torch ops -- the model the kernels are tested
+  against bit for bit (tests/test_gpu_dp.py).
 
 ``payload="bf16"`` (``direct`` only; BASELINE configs[2] / [3], whose bf16 backward pass -- ~7 ms -- cannot hide 260 MB per
 update): both all-to-all steps carry bf16, halving the bytes on every link: the exchanged gradient is
@@ -50,8 +57,13 @@ import torch
 import torch.distributed as dist
 
 
+def _ops():
+    from . import ops   # (the HIP library; imported on first use so that CPU-only gloo tests never load it)
+    return ops
+
+
 class GradSync:
-    def __init__(self, flat, segments, bucket_bytes=64 << 20, group=None, algo="allreduce", payload="fp32"):
+    def __init__(self, flat, segments, bucket_bytes=64 << 20, group=None, algo="allreduce", payload="fp32", writeback=True):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("torch.distributed is not initialised")
         if algo not in ("allreduce", "direct") or payload not in ("fp32", "bf16"):
@@ -65,6 +77,10 @@ class GradSync:
         self.group = group
         self.algo = algo
         self.payload = payload
+        # direct exchange only: False = the summed gradients stay in `gathered` (payload type) and flat[...] keeps the LOCAL values --
+        # the optimiser reads `gathered` (ops.sgd_momentum_payload); True = they are also copied back into flat
+        self.writeback = bool(writeback) or algo != "direct"
+        self.gathered = None
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.total = max(e for _, e in segments)
@@ -96,7 +112,10 @@ class GradSync:
             self._recv = torch.empty(n, dtype=pdt, device=flat.device)
             self._shard = torch.empty(n // W, dtype=flat.dtype, device=flat.device)
             self._shard_p = torch.empty(n // W, dtype=pdt, device=flat.device) if payload == "bf16" else self._shard
-            self._gath = torch.empty(n, dtype=pdt, device=flat.device)
+            # the gathered payload of EVERY bucket, each at its own offset (all buckets but the last are whole shards, so bucket
+            # [s, e) lives at [s, s + npad)): what the optimiser reads when nothing is written back
+            s_last, e_last = self.buckets[-1]
+            self.gathered = torch.zeros(s_last + -(-(e_last - s_last) // W) * W, dtype=pdt, device=flat.device)
             if flat.is_cuda:
                 self._side = torch.cuda.Stream(device=flat.device)
         self.wire_bytes_per_update = self._wire_bytes()
@@ -109,27 +128,38 @@ class GradSync:
         return int(2 * (W - 1) / W * self.total * el)
 
     def _exchange_direct(self, s, e):
-        """flat[s:e] <- sum over ranks, by shard owners (see the module docstring).  Runs on the current stream."""
+        """flat[s:e] summed over ranks by shard owners (see the module docstring) into gathered[s:s+npad] (and back into flat[s:e]
+        with `writeback`).  Runs on the current stream."""
         W = self.world_size
         n = e - s
         npad = -(-n // W) * W
         sh = npad // W
-        send, recv, gath = self._send[:npad], self._recv[:npad], self._gath[:npad]
-        send[:n].copy_(self.flat[s:e])           # fp32 -> payload type (bf16: round to nearest even)
-        if npad > n:
-            send[n:].zero_()
-        dist.all_to_all_single(recv, send, group=self.group)
-        acc = self._shard[:sh]
-        acc.copy_(recv[:sh])                     # contribution of rank 0, then 1, 2, ... : fixed order, fp32 adds
-        for r in range(1, W):
-            acc.add_(recv[r * sh:(r + 1) * sh])
-        if self.payload == "bf16":
-            out = self._shard_p[:sh]
-            out.copy_(acc)                       # the sum, rounded once
+        recv, gath = self._recv[:npad], self.gathered[s:s + npad]
+        hip = self.flat.is_cuda
+        if self.payload != "bf16" and npad == n:
+            send = self.flat[s:e]                    # whole fp32 shards: sent as they lie in the accumulator
         else:
-            out = acc
+            send = self._send[:npad]
+            if hip:
+                _ops().grad_pack(self.flat[s:e], send)   # fp32 -> payload type (bf16: round to nearest even), zero padding: one pass
+            else:
+                send[:n].copy_(self.flat[s:e])
+                if npad > n:
+                    send[n:].zero_()
+        dist.all_to_all_single(recv, send, group=self.group)
+        out = self._shard_p[:sh]
+        if hip:
+            _ops().grad_owner_sum(recv, W, out)      # ranks 0, 1, 2, ... added in fp32, rounded once: one pass
+        else:
+            acc = self._shard[:sh]
+            acc.copy_(recv[:sh])                     # contribution of rank 0, then 1, 2, ... : fixed order, fp32 adds
+            for r in range(1, W):
+                acc.add_(recv[r * sh:(r + 1) * sh])
+            if self.payload == "bf16":
+                out.copy_(acc)                       # the sum, rounded once
         dist.all_gather_into_tensor(gath, out, group=self.group)
-        self.flat[s:e].copy_(gath[:n])
+        if self.writeback:
+            self.flat[s:e].copy_(gath[:n])
 
     def _event(self):
         e = torch.cuda.Event(enable_timing=True)

@@ -623,6 +623,71 @@ def sgd_momentum(w, v, accum, lr, momentum, accum_scale=1.0):
               float(accum_scale), _stream())
 
 
+def sgd_accumulate_momentum(w, v, g, n_decay, weight_decay, gscale, lr, momentum, ascale=1.0):
+    """accumulate + Momentum + clean of one micro-batch in one pass (accum_num == 1, no exchange): bit-identical weights."""
+    _check(w, name="w"); _check(v, name="v"); _check(g, name="g")
+    _lib.call("emadapt_sgd_accumulate_momentum", _p(w), _p(v), _p(g), w.numel(), int(n_decay), float(weight_decay), float(gscale),
+              float(lr), float(momentum), float(ascale), _stream())
+
+
+def _payload_dt(t, name):
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous GPU tensor" % name)
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise TypeError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
+
+
+def sgd_momentum_payload(w, v, accum, payload, lr, momentum, scale=1.0):
+    """Momentum reading the summed gradient from the gathered payload of the gradient exchange (f32 or bf16); accum is zeroed."""
+    _check(w, name="w"); _check(v, name="v"); _check(accum, name="accum")
+    dt = _payload_dt(payload, "payload")
+    if payload.numel() < w.numel():
+        raise ValueError("payload holds %d elements, the parameters %d" % (payload.numel(), w.numel()))
+    _lib.call("emadapt_sgd_momentum_payload", _p(w), _p(v), _p(accum), _p(payload), dt, w.numel(), float(lr), float(momentum),
+              float(scale), _stream())
+
+
+def grad_pack(src, dst):
+    """dst[:n] = payload(src) (bf16: round to nearest even), dst[n:] = 0.  src f32 [n]; dst f32 or bf16 [npad >= n]."""
+    _check(src, name="src")
+    dt = _payload_dt(dst, "dst")
+    if dst.numel() < src.numel():
+        raise ValueError("dst is shorter than src")
+    _lib.call("emadapt_grad_pack", _p(src), src.numel(), _p(dst), dt, dst.numel(), _stream())
+    return dst
+
+
+def grad_owner_sum(recv, world, out):
+    """out[i] = payload(sum_r f32(recv[r * shard + i])), fp32 adds in rank order; recv [world * shard], out [shard]."""
+    dt = _payload_dt(recv, "recv")
+    if _payload_dt(out, "out") != dt or recv.numel() != world * out.numel():
+        raise ValueError("recv must be [world x shard] of out's type")
+    _lib.call("emadapt_grad_owner_sum", _p(recv), dt, int(world), out.numel(), _p(out), _stream())
+    return out
+
+
+def status_word():
+    """Device address of the status word (tests)."""
+    p = ctypes.c_void_p()
+    _lib.call("emadapt_status_word", ctypes.byref(p))
+    return p.value
+
+
+def status_poll(clear=True, raise_on_error=True):
+    """Copy the device status word to the host on the current stream and SYNCHRONISE it; returns the flags (0 = clean).  With
+    raise_on_error a raised word becomes EmadaptDeviceError (after clearing it when `clear`)."""
+    flags = ctypes.c_uint(0)
+    rc = _lib.load().emadapt_status_poll(ctypes.byref(flags), 1 if clear else 0, _stream())
+    if rc not in (0, -6):
+        raise _lib.EmadaptError(rc, "emadapt_status_poll")
+    if flags.value and raise_on_error:
+        raise _lib.EmadaptDeviceError(flags.value, "device status 0x%x" % flags.value)
+    return flags.value
+
+
 def conv_plan(B, H, W, Cin, Cout, k, dil=1, dgrad=False):
     """(tile variant, main rows, main split-K factor / for stream-K the most workgroups sharing a tile, tail split-K -- or, for a stream-K launch that skips
     the zero padding of a dilated filter, its number of pixel classes) of the fp32 forward / data-gradient launch plan."""

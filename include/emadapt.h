@@ -30,6 +30,7 @@ extern "C" {
 #define EMADAPT_ERR_HIP (-3)         /* a HIP runtime call failed (see emadapt_last_hip_error)   */
 #define EMADAPT_ERR_WORKSPACE (-4)   /* workspace too small                                      */
 #define EMADAPT_ERR_NODEVICE (-5)    /* no usable gfx950 device                                  */
+#define EMADAPT_ERR_DEVICE_STATUS (-6) /* a kernel raised a bit of the device status word (emadapt_status_poll) */
 
 /* ABI history (emadapt_version() returns the library's EMADAPT_ABI_VERSION; 10000*major + 100*minor + patch):
  *   100  rounds 1-2.
@@ -43,12 +44,38 @@ extern "C" {
  *        (conv3-conv5, fc6, fc7's last rows) is now arrival words + one 256 KB accumulator image per workgroup (64 MB + 1 KB on
  *        256 CUs) instead of up to three [M][N] images (881 MB for fc6): a caller that re-queries per shape needs no change; one
  *        that cached a size per shape from 200 over-allocates, never under-allocates.
- *   202  round 4, added: emadapt_conv_wgrad_bias (+ _fused, _workspace_bytes): filter gradient and bias gradient in one launch. */
-#define EMADAPT_ABI_VERSION 202
+ *   202  round 4, added: emadapt_conv_wgrad_bias (+ _fused, _workspace_bytes): filter gradient and bias gradient in one launch.
+ *        Also in 201/202 and NOT recorded then (advisor finding, round 4): emadapt_estep_workspace_bytes() grew again for the
+ *        geometries whose class images overflow the LDS -- 256 + B*(C+3)*roundup4(H*W)*4 + align16(4*B) bytes (class images,
+ *        per-pixel maxima, partial argmax value / class, the images' shifts) instead of 256 + B*C*roundup4(H*W)*4; a caller
+ *        that sized the workspace from the old comment gets EMADAPT_ERR_WORKSPACE: re-query.
+ *   203  round 5, added: the device status word (emadapt_status_word / emadapt_status_poll, EMADAPT_ERR_DEVICE_STATUS): a
+ *        stream-K launch whose bounded wait for another workgroup's partial tile ran out raises EMADAPT_STATUS_STREAMK_TIMEOUT
+ *        there (the tile is also poisoned with NaNs, which the fused ReLU / ReLU-gradient gate now PROPAGATE like
+ *        tf.nn.relu), and emadapt_sgd_momentum / emadapt_sgd_momentum_payload leave weights, momentum and accumulators
+ *        untouched while the word is non-zero.  Added: the gradient-exchange staging entries (emadapt_grad_pack,
+ *        emadapt_grad_owner_sum, emadapt_sgd_momentum_payload), emadapt_sgd_accumulate_momentum. */
+#define EMADAPT_ABI_VERSION 203
 int emadapt_version(void);
 const char *emadapt_strerror(int code);
 int emadapt_last_hip_error(void);          /* hipError_t of the last failing HIP call on this thread */
 int emadapt_device_count(void);            /* does not initialise a context */
+
+/* Device status word: one sticky 32-bit word per device in which kernels record failures the host cannot see from a launch's
+ * return code (every entry is asynchronous).  Bits:
+ *   EMADAPT_STATUS_STREAMK_TIMEOUT  a head workgroup of a stream-K launch (conv3-conv5, fc6, fc7's last rows) gave up waiting
+ *                                   for the partial tile of the workgroup behind it (bounded spin, ~1.7 s per publisher: only
+ *                                   a co-tenant kernel that never ends, or a hung queue, gets there); that tile of the output
+ *                                   holds NaNs.
+ * While the word is non-zero the optimiser entries (emadapt_sgd_momentum, emadapt_sgd_momentum_payload,
+ * emadapt_sgd_accumulate_momentum) are no-ops ON THE DEVICE -- no host synchronisation is needed to keep a poisoned gradient
+ * out of the weights.  emadapt_status_poll copies the word to *flags on `stream`, SYNCHRONISES that stream, optionally clears
+ * the word, and returns EMADAPT_ERR_DEVICE_STATUS when it was non-zero (EMADAPT_OK when clean): call it where a
+ * synchronisation is acceptable (the reference's loop logs every 500 iterations, deeplab.py:273).  emadapt_status_word returns
+ * the device address (tests, graph captures).  Replaces nothing in the reference: TF raises from session.run. */
+#define EMADAPT_STATUS_STREAMK_TIMEOUT 1u
+int emadapt_status_word(void **device_ptr);
+int emadapt_status_poll(unsigned *flags, int clear, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * E-step (weak-label assignment)
@@ -92,8 +119,10 @@ int emadapt_estep_host(float *map, int B, int H, int W, int C, const void *label
                        int64_t label_len, const int32_t *perms, int suppress_others, int num_iter,
                        float margin_others, int k_bg, int k_fg, int64_t *labels_out);
 
-/* Bytes of device workspace emadapt_estep needs: 256, plus B*C*roundup4(H*W) floats when H*W*C is too large for every class
- * that may be present in an image to stay in LDS (513x513 / 41 classes: the other channels then live there, class-major). */
+/* Bytes of device workspace emadapt_estep needs: 256, plus -- when H*W*C is too large for every class that may be present in
+ * an image to stay in LDS (513x513 / 41 classes) -- B*(C+3)*roundup4(H*W) floats (every class image class-major, the per-pixel
+ * maxima, the partial argmax's value and class planes) and align16(4*B) bytes (the images' shifts):
+ *     256 + B*(C+3)*roundup4(H*W)*4 + align16(4*B).   Always query; do not hard-code (ABI history 200-202). */
 size_t emadapt_estep_workspace_bytes(int B, int H, int W, int C);
 
 /* 0 for every supported geometry (map_out may always be NULL), <0 for an unsupported one.  The first version returned 1 when
@@ -368,6 +397,26 @@ int emadapt_sgd_accumulate(float *accum, const float *g, const float *w, int64_t
  * (deeplab.py:203-205): v = momentum*v + accum*accum_scale; w -= lr*v; accum = 0. */
 int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, float momentum,
                          float accum_scale, void *stream);
+/* The two ops above for ONE micro-batch in one pass (accum_num == 1, no gradient exchange; the accumulator is not touched and
+ * stays zero): v = momentum*v + (0 + (g + [i < n_decay] weight_decay*w) * gscale) * ascale; w -= lr*v -- operation for
+ * operation what emadapt_sgd_accumulate followed by emadapt_sgd_momentum compute on a zero accumulator, so the weights are
+ * bit-identical (tests/test_gpu_kernels.py); 20 bytes per parameter instead of 40.  (ABI 203) */
+int emadapt_sgd_accumulate_momentum(float *w, float *v, const float *g, int64_t n, int64_t n_decay, float weight_decay,
+                                    float gscale, float lr, float momentum, float ascale, void *stream);
+
+/* ---- staging of the data-parallel gradient exchange (dist.py; the reference's accum += g/accum_num, deeplab.py:202, with
+ * micro-batches mapped to ranks).  The exchange is reduce-scatter + all-gather written as two all-to-all steps over all xGMI
+ * links; these are its only arithmetic, one pass each.  dtype = EMADAPT_DT_* of the payload on the wire.  (ABI 203)
+ *   emadapt_grad_pack        send[0:n] = payload(src[0:n]) (bf16: round to nearest even), send[n:npad] = 0
+ *   emadapt_grad_owner_sum   out[i] = payload( f32(recv[0][i]) + f32(recv[1][i]) + ... ), fp32 adds in rank order, rounded
+ *                            once; recv = [world][shard] as all_to_all_single delivers it; out = this rank's summed shard
+ *   emadapt_sgd_momentum_payload   emadapt_sgd_momentum reading the summed gradient from the gathered payload (f32 or bf16)
+ *                            instead of the accumulator, which it only zeroes (the clean op): the gathered values never
+ *                            travel back into the accumulator. */
+int emadapt_grad_pack(const float *src, int64_t n, void *dst, int dst_dtype, int64_t npad, void *stream);
+int emadapt_grad_owner_sum(const void *recv, int dtype, int world, int64_t shard, void *out, void *stream);
+int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *payload, int payload_dtype, int64_t n,
+                                 float lr, float momentum, float scale, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Launch-plan overrides.  Every convolution picks a kernel variant and a split factor from its shape; these

@@ -1,0 +1,352 @@
+// bf16 GEMM lab for the round-5 question: does ONE MFMA wave per SIMD with a 128 x 128 accumulator block (4 waves per workgroup, the
+// whole 512-register file) beat TWO waves per SIMD with 64 x 128 blocks (8 waves) on a 256 x 256 x 32 LDS-DMA tile loop -- a third less
+// LDS fragment traffic per FLOP against nobody to cover a wave's DMA issue -- and which MFMA shape does the chip clock higher on?
+// Plain GEMM C[M][N] = A[M][K] B[N][K]^T at fc7's shape (M 28,672 = 112 tile rows: 7 whole rounds, N 4096, K 4096), random bf16 operands, both operands
+// pre-tiled in LDS order (the best case for the delivery side: every DMA instruction is a contiguous KB) or A gathered from row-major
+// rows in 64-byte pieces (what a 1 x 1 convolution does).  Variants by template:
+//     NW 8 | 4 (waves; per-wave block 64 x 128 | 128 x 128), SHAPE 32 (v_mfma_f32_32x32x16_bf16) | 16 (v_mfma_f32_16x16x32_bf16),
+//     ABL bits: 1 no DMAs (operands of step 0 re-used), 2 no MFMAs, 4 no fragment reads
+// Ring of NBUF stages x (A 16 KB + B 16 KB), fetched NBUF - 1 steps ahead, one barrier per K step; XCD-aware tile order.
+//   hipcc --offload-arch=gfx950 -O3 scripts/bf16_quad_lab.hip -o /tmp/quad_lab && /tmp/quad_lab
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include <vector>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int BK = 32, ROWB = 64, OPER = 256 * ROWB, STAGE = 2 * OPER;
+__host__ __device__ inline int swz(int r) { return (-(r >> 2)) & 3; }   // slot s of row r holds k chunk s ^ swz(r): conflict-free for both MFMA shapes
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// tiled image of an [R][K] row-major bf16 matrix: [K / 32][R rows][4 slots of 16 B]; one thread per slot
+__global__ void tile_kernel(const __bf16 *src, uint4 *dst, int R, int K) {
+    const long long total = (long long)(K / BK) * R * 4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int slot = (int)(idx & 3);
+        const long long t = idx >> 2;
+        const int row = (int)(t % R), g = (int)(t / R);
+        const int chunk = slot ^ swz(row);
+        dst[idx] = *reinterpret_cast<const uint4 *>(src + (long long)row * K + g * BK + chunk * 8);
+    }
+}
+
+__global__ void ref_kernel(const __bf16 *A, const __bf16 *B, float *out, int K, const int *rows, const int *cols, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < K; k++) s += (float)A[(long long)rows[i] * K + k] * (float)B[(long long)cols[i] * K + k];
+    out[i] = s;
+}
+
+template <int NW, int SHAPE, int NBUF, int ABL, bool AGATHER>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) gemm_kernel(const char *__restrict__ At, const char *__restrict__ Bt, const char *__restrict__ Arow,
+                                                                       __bf16 *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int TM = NW == 8 ? 2 : 4, TN = 4;            // per-wave block in 32 x 32 units
+    constexpr int WMW = 8 / TM;                            // waves along M (x 8 / TN = 2 along N)
+    constexpr int IPW = 16 / NW;                           // DMA instructions per wave, operand and step
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WMW, wn = wave / WMW;
+    int tile_m, tile_n;
+    {
+        const int nblk = tiles_m * tiles_n, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 8;
+        const int per_group = GM * tiles_n, g = t / per_group, first_m = g * GM;
+        const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM, in_g = t - g * per_group;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
+    const int m0 = tile_m * 256, n0 = tile_n * 256, nk = K / BK;
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(AGATHER ? Arow : At), 0, (int)((long long)M * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Bt), 0, (int)((long long)N * K * 2), 0x00020000);
+    unsigned a_off[IPW], b_off[IPW];
+#pragma unroll
+    for (int j = 0; j < IPW; j++) {
+        const int q = (wave * IPW + j) * 64 + lane;
+        if constexpr (AGATHER) {
+            const int row = q >> 2, chunk = (q & 3) ^ swz(row);
+            a_off[j] = (unsigned)(m0 + row) * (unsigned)(K * 2) + chunk * 16;
+        } else {
+            a_off[j] = (unsigned)q * 16u;
+        }
+        b_off[j] = (unsigned)q * 16u;
+    }
+    auto fill = [&](int off, int kt, bool live) {
+        if constexpr (ABL & 1) { if (kt >= NBUF) return; }   // (every stage filled once: the loop then runs on resident operands)
+        const unsigned dead = live ? 0u : 0x80000000u;
+        const unsigned s_a = AGATHER ? (unsigned)kt * ROWB : ((unsigned)kt * (unsigned)M + (unsigned)m0) * ROWB;
+        const unsigned s_b = ((unsigned)kt * (unsigned)N + (unsigned)n0) * ROWB;
+        char *as = lds + off + wave * (IPW * 1024), *bs = lds + off + OPER + wave * (IPW * 1024);
+#pragma unroll
+        for (int j = 0; j < IPW; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lds_void_t *)(as + j * 1024), 16, (int)(a_off[j] | dead), (int)s_a, 0, 0);
+#pragma unroll
+        for (int j = 0; j < IPW; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_void_t *)(bs + j * 1024), 16, (int)(b_off[j] | dead), (int)s_b, 0, 0);
+    };
+#define SB __builtin_amdgcn_sched_barrier(0);
+    constexpr int NACC = SHAPE == 32 ? TM * TN : 4 * TM * TN;
+    typedef typename std::conditional<SHAPE == 32, f32x16, f32x4>::type acc_t;
+    acc_t acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++)
+#pragma unroll
+        for (int r = 0; r < (SHAPE == 32 ? 16 : 4); r++) acc[i][r] = 0.f;
+
+    // fragments of one K step (32 k): SHAPE 32: 2 k groups x (TM A + TN B); SHAPE 16: 2 TM A + 2 TN B (16-row fragments, k = 32 each)
+    constexpr int NA = 2 * TM, NB = 2 * TN;
+    bf16x8 av[NA], bv[NB];
+    int a_base, b_base;
+    if constexpr (SHAPE == 32) {
+        const int l31 = lane & 31, lh = lane >> 5;
+        a_base = (wm * TM * 32 + l31) * ROWB + ((lh ^ swz(l31)) << 4);   // k group g adds (2 g) to the chunk: XOR with 2 (chunk = 2 g + lh)
+        b_base = OPER + (wn * TN * 32 + l31) * ROWB + ((lh ^ swz(l31)) << 4);
+    } else {
+        const int l15 = lane & 15, lq = lane >> 4;
+        a_base = (wm * TM * 32 + l15) * ROWB + ((lq ^ swz(l15)) << 4);   // (rows l15 + 16 i: swz(row) = swz(l15) ^ ... see rd_a)
+        b_base = OPER + (wn * TN * 32 + l15) * ROWB + ((lq ^ swz(l15)) << 4);
+    }
+    // address of fragment n of A / B inside a stage
+    auto a_addr = [&](int n) -> int {
+        if constexpr (SHAPE == 32) { const int g = n / TM, i = n % TM; return (a_base ^ (g << 5)) + i * 32 * ROWB; }   // rows + 32 i: swz unchanged
+        else { return a_base + n * 16 * ROWB; }   // (swz(l15 + 16 i) == swz(l15): 16 rows are 4 row quads)
+    };
+    auto b_addr = [&](int n) -> int {
+        if constexpr (SHAPE == 32) { const int g = n / TN, j = n % TN; return (b_base ^ (g << 5)) + j * 32 * ROWB; }
+        else { return b_base + n * 16 * ROWB; }
+    };
+#pragma unroll
+    for (int n = 0; n < NA; n++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) av[n][e] = (__bf16)((float)((lane * 7 + n * 3 + e) & 63) * 0.03125f - 1.0f);
+#pragma unroll
+    for (int n = 0; n < NB; n++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) bv[n][e] = (__bf16)((float)((lane * 5 + n * 11 + e) & 63) * 0.03125f - 1.0f);
+    auto rd_a = [&](int n, int base) {
+        if constexpr (!(ABL & 4)) { av[n] = *reinterpret_cast<const bf16x8 *>(lds + base + a_addr(n)); if constexpr (ABL & 2) asm volatile("" ::"v"(av[n])); SB }
+    };
+    auto rd_b = [&](int n, int base) {
+        if constexpr (!(ABL & 4)) { bv[n] = *reinterpret_cast<const bf16x8 *>(lds + base + b_addr(n)); if constexpr (ABL & 2) asm volatile("" ::"v"(bv[n])); SB }
+    };
+    auto mf = [&](int g, int i, int j) {   // SHAPE 32: k group g, blocks (i, j); SHAPE 16: g = 0, 16-row blocks i (0 .. 2 TM), j (0 .. 2 TN)
+        if constexpr (ABL & 2) return;
+        if constexpr (SHAPE == 32) acc[i * TN + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[g * TM + i], bv[g * TN + j], acc[i * TN + j], 0, 0, 0);
+        else acc[i * NB + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i * NB + j], 0, 0, 0);
+        SB
+    };
+
+    // ---- pipeline: the MFMAs of a step in two halves; barrier between them; the next step's fragments behind the MFMAs of the second half
+    // (they go into the registers the first half is done with: first-half fragments = A/B of k group 0 (SHAPE 32) resp. A rows 0 .. TM - 1
+    // with all B (SHAPE 16)).  The DMAs of step kt + NBUF - 1 leave in front of the barrier.
+    constexpr int AHEAD = NBUF - 1;
+#pragma unroll
+    for (int s = 0; s < AHEAD; s++) fill(s * STAGE, s, s < nk);
+    wait_vmcnt<(AHEAD - 1) * 2 * IPW>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < NA; n++) rd_a(n, 0);
+#pragma unroll
+    for (int n = 0; n < NB; n++) rd_b(n, 0);
+    int cur = 0, pv = AHEAD * STAGE;
+    for (int kt = 0; kt < nk; kt++) {
+        const int nx = cur == (NBUF - 1) * STAGE ? 0 : cur + STAGE;
+        SB
+        if constexpr (SHAPE == 32) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) mf(0, i, j);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < NB; j++) mf(0, i, j);
+        }
+        fill(pv, kt + AHEAD, kt + AHEAD < nk);
+        SB
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<(AHEAD - 1) * 2 * IPW>();   // this wave's DMAs of step kt + 1 have landed
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        SB
+        if constexpr (SHAPE == 32) {
+            // second k group; behind its MFMAs the next step's first-group fragments (TM + TN reads), then the second group's
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    mf(1, i, j);
+                    if (n < TM) rd_a(n, nx); else if (n < TM + TN) rd_b(n - TM, nx);
+                    n++;
+                }
+#pragma unroll
+            for (int j = 0; j < TN; j++) rd_b(TN + j, nx);
+#pragma unroll
+            for (int i = 0; i < TM; i++) rd_a(TM + i, nx);
+        } else {
+            // A rows TM .. 2 TM - 1 (16-row fragments) with all B, column by column: behind the first MFMAs the next step's A rows
+            // 0 .. TM - 1, behind each finished column its B fragment of the next step, at the end the other A rows
+            int n = 0;
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+#pragma unroll
+                for (int i = TM; i < 2 * TM; i++) {
+                    mf(0, i, j);
+                    if (n < TM) rd_a(n, nx);
+                    n++;
+                }
+                rd_b(j, nx);
+            }
+#pragma unroll
+            for (int i = TM; i < 2 * TM; i++) rd_a(i, nx);
+        }
+        pv = cur;
+        cur = nx;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vmcnt<0>();
+    __syncthreads();
+    // ---- epilogue: accumulators -> LDS (per wave [16 rows][TN * 32 + 4] floats) -> bf16, 16-byte stores
+    float *stage = reinterpret_cast<float *>(lds) + wave * (16 * (TN * 32 + 4));
+    constexpr int SP = TN * 32 + 4;
+#pragma unroll
+    for (int rb = 0; rb < TM * 2; rb++) {   // blocks of 16 rows (fully unrolled: the accumulator indices are constants)
+        if constexpr (SHAPE == 32) {
+            const int l31 = lane & 31, lh = lane >> 5, i = rb >> 1, h = rb & 1;
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int rr = 0; rr < 8; rr++) {
+                    const int r = h * 8 + rr;
+                    stage[((r & 3) + 8 * ((r >> 2) & 1) + 4 * lh) * SP + j * 32 + l31] = acc[i * TN + j][r];
+                }
+        } else {
+            const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) stage[(4 * lq + r) * SP + j * 16 + l15] = acc[rb * NB + j][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 16 * (TN * 4) / 64; it++) {
+            const int idx = it * 64 + lane, row_l = idx / (TN * 4), ch = idx % (TN * 4);
+            const int row = m0 + wm * TM * 32 + rb * 16 + row_l, col = n0 + wn * TN * 32 + ch * 8;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (__bf16)stage[row_l * SP + ch * 8 + e];
+            if (row < M) *reinterpret_cast<bf16x8 *>(C + (long long)row * N + col) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef SB
+}
+
+struct Ctx {
+    int M, N, K;
+    char *At, *Bt, *Arow, *Brow;
+    __bf16 *C;
+};
+
+template <int NW, int SHAPE, int NBUF, int ABL, bool AG>
+float run(const Ctx &c, const char *name, bool check) {
+    const size_t ldsb = (size_t)NBUF * STAGE;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<NW, SHAPE, NBUF, ABL, AG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const int tm = c.M / 256, tn = c.N / 256;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto launch = [&]() { hipLaunchKernelGGL((gemm_kernel<NW, SHAPE, NBUF, ABL, AG>), dim3(tm * tn), dim3(NW * 64), ldsb, 0, c.At, c.Bt, c.Arow, c.C, c.M, c.N, c.K, tm, tn); };
+    for (int i = 0; i < 5; i++) launch();
+    CK(hipDeviceSynchronize());
+    float best = 1e9f, sum = 0.f;
+    const int reps = 5, per = 10;
+    for (int r = 0; r < reps; r++) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < per; i++) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= per;
+        best = ms < best ? ms : best;
+        sum += ms;
+    }
+    const double fl = 2.0 * c.M * (double)c.N * c.K;
+    printf("%-44s  mean %.4f ms  best %.4f ms  %7.1f TF (%.1f %% of 2516.6)\n", name, sum / reps, best, fl / (sum / reps) * 1e-9, fl / (sum / reps) * 1e-9 / 2516.6 * 100);
+    if (check && ABL == 0) {
+        const int n = 64;
+        std::vector<int> rows(n), cols(n);
+        for (int i = 0; i < n; i++) { rows[i] = (int)((i * 7919LL + 13) % c.M); cols[i] = (int)((i * 104729LL + 7) % c.N); }
+        int *dr, *dc; float *dout;
+        CK(hipMalloc(&dr, n * 4)); CK(hipMalloc(&dc, n * 4)); CK(hipMalloc(&dout, n * 4));
+        CK(hipMemcpy(dr, rows.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dc, cols.data(), n * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(ref_kernel, dim3(1), dim3(64), 0, 0, (const __bf16 *)c.Arow, (const __bf16 *)c.Brow, dout, c.K, dr, dc, n);
+        std::vector<float> ref(n);
+        CK(hipMemcpy(ref.data(), dout, n * 4, hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int i = 0; i < n; i++) {
+            __bf16 g;
+            CK(hipMemcpy(&g, c.C + (long long)rows[i] * c.N + cols[i], 2, hipMemcpyDeviceToHost));
+            const double d = fabs((double)(float)g - ref[i]) / (fabs(ref[i]) + 1.0);
+            worst = d > worst ? d : worst;
+        }
+        printf("    check: worst relative error of 64 sampled outputs %.3g %s\n", worst, worst < 2e-2 ? "ok" : "WRONG");
+        CK(hipFree(dr)); CK(hipFree(dc)); CK(hipFree(dout));
+    }
+    return sum / reps;
+}
+
+int main(int argc, char **argv) {
+    Ctx c;
+    c.M = 28672; c.N = 4096; c.K = 4096;   // 112 x 16 tiles = 7 whole rounds of 256 CUs (fc7: M 26,896)
+    const bool zeros = argc > 1 && !strcmp(argv[1], "zeros");
+    const size_t na = (size_t)c.M * c.K, nb = (size_t)c.N * c.K;
+    std::vector<unsigned short> ha(na), hb(nb);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
+    for (size_t i = 0; i < na; i++) { const float f = zeros ? 0.f : ((int)(rnd() >> 8) - (1 << 23)) * (1.0f / (1 << 23)); unsigned u; memcpy(&u, &f, 4); ha[i] = (unsigned short)(u >> 16); }
+    for (size_t i = 0; i < nb; i++) { const float f = zeros ? 0.f : ((int)(rnd() >> 8) - (1 << 23)) * (1.0f / (1 << 23)); unsigned u; memcpy(&u, &f, 4); hb[i] = (unsigned short)(u >> 16); }
+    CK(hipMalloc(&c.Arow, na * 2)); CK(hipMalloc(&c.Brow, nb * 2)); CK(hipMalloc(&c.At, na * 2)); CK(hipMalloc(&c.Bt, nb * 2));
+    CK(hipMalloc(&c.C, (size_t)c.M * c.N * 2));
+    CK(hipMemcpy(c.Arow, ha.data(), na * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(c.Brow, hb.data(), nb * 2, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, 0, (const __bf16 *)c.Arow, (uint4 *)c.At, c.M, c.K);
+    hipLaunchKernelGGL(tile_kernel, dim3(4096), dim3(256), 0, 0, (const __bf16 *)c.Brow, (uint4 *)c.Bt, c.N, c.K);
+    CK(hipDeviceSynchronize());
+    printf("# bf16 GEMM M %d N %d K %d, %s operands, 256 x 256 x 32 tiles, ring fetched NBUF - 1 ahead; %d tiles on 256 CUs\n", c.M, c.N, c.K, zeros ? "ALL-ZERO" : "random",
+           c.M / 256 * (c.N / 256));
+    for (int round = 0; round < 2; round++) {
+        printf("## round %d\n", round);
+        run<8, 32, 4, 0, false>(c, "8 waves 64x128  32x32x16  ring 4  tiled A", round == 0);
+        run<4, 32, 4, 0, false>(c, "4 waves 128x128 32x32x16  ring 4  tiled A", round == 0);
+        run<4, 32, 5, 0, false>(c, "4 waves 128x128 32x32x16  ring 5  tiled A", round == 0);
+        run<8, 16, 4, 0, false>(c, "8 waves 64x128  16x16x32  ring 4  tiled A", round == 0);
+        run<4, 16, 4, 0, false>(c, "4 waves 128x128 16x16x32  ring 4  tiled A", round == 0);
+        run<4, 16, 5, 0, false>(c, "4 waves 128x128 16x16x32  ring 5  tiled A", round == 0);
+        run<8, 32, 4, 0, true>(c, "8 waves 64x128  32x32x16  ring 4  gathered A", round == 0);
+        run<4, 32, 4, 0, true>(c, "4 waves 128x128 32x32x16  ring 4  gathered A", round == 0);
+        run<4, 16, 4, 0, true>(c, "4 waves 128x128 16x16x32  ring 4  gathered A", round == 0);
+    }
+    printf("## parts compiled out (results are garbage)\n");
+    run<8, 32, 4, 1, false>(c, "8w 32x32x16: no DMAs", false);
+    run<8, 32, 4, 2, false>(c, "8w 32x32x16: no MFMAs", false);
+    run<8, 32, 4, 6, false>(c, "8w 32x32x16: DMAs + barrier only", false);
+    run<8, 32, 4, 5, false>(c, "8w 32x32x16: MFMAs alone", false);
+    run<4, 32, 4, 1, false>(c, "4w 32x32x16: no DMAs", false);
+    run<4, 32, 4, 2, false>(c, "4w 32x32x16: no MFMAs", false);
+    run<4, 32, 4, 6, false>(c, "4w 32x32x16: DMAs + barrier only", false);
+    run<4, 32, 4, 5, false>(c, "4w 32x32x16: MFMAs alone", false);
+    run<4, 16, 4, 1, false>(c, "4w 16x16x32: no DMAs", false);
+    run<4, 16, 4, 5, false>(c, "4w 16x16x32: MFMAs alone", false);
+    run<8, 16, 4, 5, false>(c, "8w 16x16x32: MFMAs alone", false);
+    return 0;
+}

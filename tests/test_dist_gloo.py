@@ -170,12 +170,22 @@ def _direct_worker(rank, world, port, out_dir):
             gs.segment_ready(s, e)
         gs.wait()
         assert np.array_equal(flat.numpy(), np.load(os.path.join(out_dir, "%s_%d.npy" % (payload, rank))))
+        # writeback=False (what ADAPT uses: the optimiser kernel reads the gathered payload in place): flat keeps the LOCAL
+        # values, `gathered` holds the sum in the payload's type, every bucket at its own offset
+        flat.copy_(mine)
+        gs2 = GradSync(flat, segs, bucket_bytes=2048 * 4, algo="direct", payload=payload, writeback=False)
+        assert gs2.gathered.dtype == (torch.bfloat16 if payload == "bf16" else torch.float32) and gs2.gathered.numel() >= total
+        for s, e in segs:
+            gs2.segment_ready(s, e)
+        gs2.wait()
+        assert np.array_equal(flat.numpy(), mine.numpy())
+        assert np.array_equal(gs2.gathered[:total].float().numpy(), np.load(os.path.join(out_dir, "%s_%d.npy" % (payload, rank))))
     np.save(os.path.join(out_dir, "mine%d.npy" % rank), mine.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])   # (8: the node the scaling bench runs on; the last bucket is 4 elements short of whole shards)
 def test_direct_exchange_and_bf16_payload(tmp_path, world):
     port = _free_port()
     mp.spawn(_direct_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)

@@ -261,6 +261,65 @@ def test_sgd_kernels_and_padding(env):
     assert np.array_equal(back, src)
 
 
+@pytest.mark.parametrize("n,n_decay", [(64 * 1024 + 512, 64 * 1024), (1027, 1001), (8, 8), (4096, 0)])
+def test_fused_accumulate_momentum_is_the_two_kernels_bit_for_bit(env, n, n_decay):
+    """emadapt_sgd_accumulate_momentum (accum_num == 1: accumulate + apply_gradients + clean in one pass, deeplab.py:202-205) must
+    leave the weights and the momentum exactly as emadapt_sgd_accumulate followed by emadapt_sgd_momentum do on a zero accumulator --
+    vector and scalar forms, with and without decayed elements, and negative zeros in the gradient."""
+    ops, do, torch = env
+    g = torch.Generator(device="cuda").manual_seed(n)
+    w = torch.randn(n, device="cuda", generator=g)
+    v = torch.randn(n, device="cuda", generator=g) * 0.1
+    grad = torch.randn(n, device="cuda", generator=g) * 1e-2
+    grad[::7] = -0.0
+    grad[3::11] = 0.0
+    for gscale, ascale in ((1.0, 1.0), (1.0, 0.5), (0.25, 1.0)):
+        w1, v1, acc = w.clone(), v.clone(), torch.zeros(n, device="cuda")
+        ops.sgd_accumulate(acc, grad, w1, n_decay, 5e-4, gscale)
+        ops.sgd_momentum(w1, v1, acc, 1e-3, 0.9, ascale)
+        w2, v2 = w.clone(), v.clone()
+        ops.sgd_accumulate_momentum(w2, v2, grad, n_decay, 5e-4, gscale, 1e-3, 0.9, ascale)
+        assert torch.equal(w1, w2) and torch.equal(v1.view(torch.int32), v2.view(torch.int32)), (gscale, ascale)
+
+
+@pytest.mark.parametrize("world,n", [(2, 4096), (3, 4099), (8, 1476), (8, 32768 + 8), (8, 65536), (5, 7)])
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_gradient_exchange_staging_kernels(env, world, n, payload):
+    """The three kernels of the data-parallel exchange (dist.py algo "direct"; deeplab.py:202 with micro-batches mapped to ranks)
+    against the arithmetic model the gloo tests pin on CPU tensors: pack = one RNE rounding + zero padding to whole shards; owner
+    sum = fp32 adds in rank order, rounded once; Momentum on the gathered payload = Momentum on the accumulator it would have been
+    copied into.  Bit for bit, vector and scalar forms, wide dynamic range."""
+    ops, do, torch = env
+    pdt = torch.bfloat16 if payload == "bf16" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(world * 100003 + n)
+    src = torch.randn(n, device="cuda", generator=g) * torch.exp(torch.randn(n, device="cuda", generator=g) * 3)
+    npad = -(-n // world) * world
+    sh = npad // world
+    send = torch.full((npad,), 7.0, dtype=pdt, device="cuda")
+    ops.grad_pack(src, send)
+    want = torch.zeros(npad, dtype=pdt, device="cuda")
+    want[:n] = src.to(pdt)
+    assert torch.equal(send.view(torch.int16 if payload == "bf16" else torch.int32), want.view(torch.int16 if payload == "bf16" else torch.int32))
+    # owner sum over `world` contributions of wildly different magnitudes
+    recv = (torch.randn(world * sh, device="cuda", generator=g) * torch.exp(torch.randn(world * sh, device="cuda", generator=g) * 3)).to(pdt)
+    out = torch.empty(sh, dtype=pdt, device="cuda")
+    ops.grad_owner_sum(recv, world, out)
+    acc = recv[:sh].float()
+    for r in range(1, world):
+        acc = acc + recv[r * sh:(r + 1) * sh].float()
+    assert torch.equal(out.float(), acc.to(pdt).float())
+    # Momentum reading the payload
+    nw = (n // 4) * 4 if n >= 8 else n
+    w = torch.randn(nw, device="cuda", generator=g)
+    v = torch.randn(nw, device="cuda", generator=g) * 0.1
+    gathered = (torch.randn(npad, device="cuda", generator=g) * 1e-2).to(pdt)
+    w1, v1, a1 = w.clone(), v.clone(), gathered[:nw].float().clone()
+    ops.sgd_momentum(w1, v1, a1, 1e-3, 0.9, 1.0 / world)
+    w2, v2, a2 = w.clone(), v.clone(), torch.ones(nw, device="cuda")
+    ops.sgd_momentum_payload(w2, v2, a2, gathered, 1e-3, 0.9, 1.0 / world)
+    assert torch.equal(w1, w2) and torch.equal(v1, v2) and float(a2.abs().max()) == 0.0
+
+
 def test_profiler_counts_launches(env):
     ops, do, torch = env
     ops.prof_reset()

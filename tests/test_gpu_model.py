@@ -181,3 +181,32 @@ def test_full_size_config5(env, preset):
     got = adapt.net["e_argmax"].cpu().numpy()
     assert np.array_equal(got, want_labels)               # bit-identical label map
     assert len(np.unique(got)) >= 2 and np.isfinite(float(adapt.loss["norm"].cpu()))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_update_leaves_the_same_weights_bit_for_bit(env, dtype):
+    """config "fused_update" (what train() switches on for accum_num == 1 without a gradient exchange): backward() skips the
+    per-layer accumulate launches and apply_update() runs accumulate + Momentum + clean as one pass per layer
+    (emadapt_sgd_accumulate_momentum).  Weights and momentum after three steps must be bit-identical to the three-op path of
+    deeplab.py:202-205, and the accumulator must stay zero."""
+    ADAPT, do, eo, torch = env
+    B, size, C, width = 2, 65, 5, 8
+    images, labels = do.synthetic_batch(B, size, C, seed=3)
+    images = (images / 50.0).astype(np.float32)
+    perms = eo.draw_perms(5, C, seed=7)
+    flats = []
+    for fused in (False, True):
+        adapt = ADAPT({"input_size": (size, size), "category_num": C, "width": width, "accum_num": 1, "batch_size": B,
+                       "compute_dtype": dtype, "fused_update": fused, "seed": 5})
+        adapt.build()
+        adapt.pre_train(base_lr=1e-2, weight_decay=1e-3, momentum=0.9, batch_size=B)
+        for _ in range(3):
+            adapt.micro_step(images, labels, keep_prob=0.5, perms=perms)
+            if fused:
+                assert float(adapt._flat["accum"].abs().max()) == 0.0   # bypassed
+            adapt.apply_update()
+        torch.cuda.synchronize()
+        assert float(adapt._flat["accum"].abs().max()) == 0.0
+        flats.append((adapt._flat["params"].clone(), adapt._flat["momentum"].clone()))
+    assert torch.equal(flats[0][0], flats[1][0]) and torch.equal(flats[0][1], flats[1][1])
+    assert float(flats[0][1].abs().max()) > 0
