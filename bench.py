@@ -93,6 +93,16 @@ def parse():
                     help="N > 1: allreduce = one RCCL all-reduce per bucket (ring: one xGMI link's bandwidth per step); direct = "
                          "reduce-scatter + all-gather as two all-to-all steps, every rank talking to all 7 peers at once, on a side "
                          "stream (dist.py); auto = allreduce for fp32 payloads, direct for bf16")
+    ap.add_argument("--no-fused-update", action="store_true",
+                    help="run accumulate / Momentum / clean as the reference's three ops (deeplab.py:202-205) instead of one pass per "
+                         "layer (config fused_update: what ADAPT.train switches on for accum_num 1 without a gradient exchange; same "
+                         "weights bit for bit)")
+    ap.add_argument("--bf16t", default="auto", choices=["auto", "always", "never"],
+                    help="--dtype bf16: which layers run forward / data gradient on the LDS-DMA kernel (csrc/igemm_b16t.h)")
+    ap.add_argument("--overhead-steps", type=int, default=-1,
+                    help="N > 1 / --force-dist: after the timed region, this many more steps WITHOUT the gradient exchange in the same "
+                         "process (-1 = as many as --steps, 0 = skip): allreduce.overhead_ms_per_step = step time with the exchange - "
+                         "without (exposed_ms only sees the compute stream's wait; contention with the exchange's kernels shows here)")
     ap.add_argument("--launch-timeout", type=float, default=0.0,
                     help="N > 1 started without a launcher: seconds after which the workers are ended (0 = no limit)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
@@ -329,7 +339,8 @@ def main():
     cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
            "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb,
-           "allreduce_release_at": None if args.release_at == "none" else args.release_at, "grad_dtype": args.grad_dtype, "x6_planes": args.x6_planes}
+           "allreduce_release_at": None if args.release_at == "none" else args.release_at, "grad_dtype": args.grad_dtype, "x6_planes": args.x6_planes,
+           "fused_update": not args.no_fused_update, "bf16t": args.bf16t}
     if args.allreduce_algo != "auto":
         cfg["allreduce_algo"] = args.allreduce_algo
     for kv in filter(None, args.tune.split(",")):
@@ -343,7 +354,8 @@ def main():
     # E-step visiting orders for every step, drawn like the reference does and parked in HBM
     random.seed(3 + rank)
     total_steps = args.warmup + args.steps
-    host = np.stack([draw_perms(5, args.classes, rng=random) for _ in range(max(total_steps, 1))])
+    n_extra = 2 + (args.steps if args.overhead_steps < 0 else args.overhead_steps)   # (the exchange-overhead leg, when there is one)
+    host = np.stack([draw_perms(5, args.classes, rng=random) for _ in range(max(total_steps, 1) + n_extra)])
     adapt._perm_pool = torch.as_tensor(host).to(device)
     adapt._perm_pos = 0
 
@@ -386,6 +398,21 @@ def main():
         ops.prof_reset()
     gs_stats = adapt._gradsync.stats() if adapt._gradsync is not None else None
     rank_ms = [(t_local - t0) / max(args.steps, 1) * 1e3]
+    ms_without_exchange = None
+    n_over = args.steps if args.overhead_steps < 0 else args.overhead_steps
+    if adapt._gradsync is not None and n_over > 0:
+        # the same steps with the exchange switched off (same process, same buffers; the ranks' weights drift apart from here on,
+        # which nothing below depends on): what the exchange COSTS the step, hidden or not
+        gs_keep, adapt._gradsync = adapt._gradsync, None
+        for i in range(2):
+            step(total_steps + i)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(n_over):
+            step(total_steps + 2 + i)
+        fence()
+        ms_without_exchange = (time.perf_counter() - t1) / n_over * 1e3
+        adapt._gradsync = gs_keep
     if distributed:
         from em_adapt_tensorflow_amd.dist import all_reduce_max
         # the communicator's own size, not argv's: what the collectives really ran over
@@ -394,6 +421,8 @@ def main():
         dist.all_gather_object(gathered, rank_ms[0])
         rank_ms = [float(x) for x in gathered]
         dt = all_reduce_max(dt, device)
+        if ms_without_exchange is not None:
+            ms_without_exchange = all_reduce_max(ms_without_exchange, device)
         if gs_stats is not None and gs_stats["exposed_ms"] is not None:
             gs_stats["exposed_ms_max_over_ranks"] = all_reduce_max(gs_stats["exposed_ms"], device)
     loss = float(adapt.loss["norm"].cpu())
@@ -429,6 +458,7 @@ def main():
                 "workload_key": workload_key(args),
                 "global_batch": global_batch,
                 "parallelism": "dp%d" % world,
+                "fused_update": bool(adapt._fused and adapt._gradsync is None),
                 "gflop_per_image_fwd_bwd": round(fb_flops / 1e9, 1),
                 "params": adapt.parameter_count(),
             },
@@ -478,11 +508,20 @@ def main():
             # on exactly this workload (matched on its structured key, not on prose)
             key = workload_key(args)
             here = os.path.dirname(os.path.abspath(__file__))
+            from em_adapt_tensorflow_amd import _build
+            lib_hash = _build.source_hash()
+            out["roofline"]["traffic_source"] = "none: no committed counter profile of this workload"
             for tpath in sorted(glob.glob(os.path.join(here, "profiles", "r*_traffic*.json")), reverse=True):
                 try:
                     tj = json.load(open(tpath))
                     if tj.get("key") != key:
                         continue
+                    if tj.get("source_hash") != lib_hash:
+                        # the profile was taken on other kernel sources: a number carried forward would be a stale claim
+                        out["roofline"]["traffic_source"] = "stale: %s was taken on kernel sources %s, these are %s (re-run scripts/make_profiles.sh)" % (
+                            os.path.relpath(tpath, here), tj.get("source_hash"), lib_hash)
+                        continue
+                    out["roofline"]["traffic_source"] = os.path.relpath(tpath, here)
                     per_step = tj["per_step"][dom]
                     calls = d["launches"] / max(prof_steps, 1)
                     out["roofline"]["traffic"] = round((per_step["read_bytes"] + per_step["write_bytes"]) / max(calls, 1))
@@ -499,7 +538,22 @@ def main():
             if e["ms"] > 0:
                 out["estep"] = {"ms": round(e["ms"] / max(e["launches"], 1), 4),
                                 "achieved_GBps": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 2), "bound": "hbm",
-                                "peak_GBps": 8000}
+                                "peak_GBps": 8000, "algorithmic_bytes": round(e["bytes"] / max(e["launches"], 1)),
+                                "traffic": None}
+                # counter-based HBM bytes of the E-step's kernels per call (FETCH_SIZE x 2 + WRITE_SIZE: the same passes and the
+                # same staleness rule as roofline.traffic)
+                for tpath in sorted(glob.glob(os.path.join(here, "profiles", "r*_traffic*.json")), reverse=True):
+                    try:
+                        tj = json.load(open(tpath))
+                        if tj.get("key") == key and tj.get("source_hash") == lib_hash and "estep" in tj:
+                            es = tj["estep"]
+                            out["estep"]["traffic"] = round(es["read_bytes"] + es["write_bytes"])
+                            out["estep"]["traffic_GBps"] = round((es["read_bytes"] + es["write_bytes"]) / (e["ms"] / max(e["launches"], 1) * 1e-3) / 1e9, 2)
+                            out["estep"]["l2_hit_rate"] = es.get("l2_hit_rate")
+                            out["estep"]["traffic_source"] = os.path.relpath(tpath, here)
+                            break
+                    except (OSError, KeyError, ValueError):
+                        continue
         if gs_stats is not None:
             # data-parallel evidence: how much of the gradient all-reduce was NOT hidden under backward
             out["allreduce"] = {
@@ -513,6 +567,10 @@ def main():
                 "release_at": args.release_at,
                 "exposed_ms_per_step": None if gs_stats["exposed_ms"] is None else round(gs_stats.get("exposed_ms_max_over_ranks", gs_stats["exposed_ms"]), 3),
                 "backward_window_ms": None if gs_stats["backward_window_ms"] is None else round(gs_stats["backward_window_ms"], 3),
+                # step time with the exchange - the same steps without it, same process (MAX over ranks each): contention included
+                "overhead_ms_per_step": None if ms_without_exchange is None else round(ms - ms_without_exchange, 3),
+                "ms_per_step_without_exchange": None if ms_without_exchange is None else round(ms_without_exchange, 3),
+                "staging": "HIP kernels (emadapt_grad_pack / _owner_sum / emadapt_sgd_momentum_payload)" if gs_stats["algo"] == "direct" else "none (RCCL all-reduce in place)",
             }
             if "trace" in gs_stats:
                 out["allreduce"]["trace_last_update"] = gs_stats["trace"]

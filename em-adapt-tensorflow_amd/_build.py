@@ -34,6 +34,20 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources and the C ABI header, in name order: what a committed counter profile
+    was taken on.  bench.py refuses to quote roofline.traffic from a profile whose hash differs (a claim carried forward would go
+    stale silently when the kernels change)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))) + [
+        os.path.join(PKG_DIR, "..", "include", "emadapt.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _deps_mtime():
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h"))
     return max(os.path.getmtime(p) for p in hdrs)

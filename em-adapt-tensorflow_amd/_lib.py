@@ -140,6 +140,7 @@ PROTOTYPES = {
     "emadapt_conv_executed_fraction": (c_int, [POINTER(ConvDesc), c_int, c_int, POINTER(c_double)]),
     "emadapt_conv_bf16_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
     "emadapt_conv_bf16t_supported": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "emadapt_conv_bf16t_pays": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "emadapt_filter_tiles_bf16_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "emadapt_filter_tiles_bf16": (c_int, [POINTER(ConvDesc), _vp, _vp, c_int, _vp]),
     "emadapt_conv_bf16t_workspace_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),

@@ -773,22 +773,12 @@ bool bt_ok(const emadapt_conv_desc *d, bool dgrad, int y_bf16) {
            M * N < (1LL << 40);
 }
 
-// The kernel variant: igemm_b16t_kernel (64-byte activation pieces) by default; tune "bf16_tile" = 64 selects igemm_b16w_kernel
-// (128-byte pieces, work cut in double steps of 64 channels) where the gathered channel count allows it.  Measured
-// (profiles/r04_bf16t_ablation.txt): the wide pieces raise the operand stream's own rate by 8 % (0.578 -> 0.530 ms alone) and
-// the kernel's by nothing -- what the two streams lose is their overlap, on random operands, to the power cap.
-bool bt_wide(const IgemmArgs &a) { return tune(TUNE_BF16_TILE) == 64 && a.Cx % 64 == 0 && a.N > 128; }
-
-// Tile shape by the output's width: 512 x 64 for N <= 64, 512 x 128 for N <= 128, else 256 x 256 (igemm_b16t.h BtShape)
-inline int bt_bn(const IgemmArgs &a) { return a.N <= 64 ? 64 : a.N <= 128 ? 128 : 256; }
-inline int bt_bm(const IgemmArgs &a) { return a.N <= 128 ? 512 : 256; }
-
 PlanBT plan_b16t(const IgemmArgs &a) {
     const int cus = plan_cus();
     PlanBT p = {a.M, 0, 0, 0};
-    const int BM = bt_bm(a), BN = bt_bn(a);
+    constexpr int BM = 256, BN = 256;
     const long long tn = ceil_div(a.N, BN), tm = ceil_div(a.M, BM), t = tm * tn;
-    const int bk = bt_wide(a) ? 64 : BT_BK;
+    const int bk = BT_BK;
     const int nk = a.K / bk;
     if (t % cus == 0 || t * nk * bk / cus < 16 * BT_BK) return p;   // whole rounds, or too little work per CU to cut into pieces
     if (a.N <= 1024 || t < cus) {
@@ -813,12 +803,7 @@ size_t bt_workspace_bytes(const IgemmArgs &a) {
 }
 
 template <bool SK, bool YBF>
-int launch_bt(IgemmArgs &a, hipStream_t stream) {
-    if (bt_wide(a)) return launch_igemm_b16w<SK, YBF>(a, stream);
-    if (a.N <= 64) return launch_igemm_b16t<SK, YBF, 8, 2>(a, stream);
-    if (a.N <= 128) return launch_igemm_b16t<SK, YBF, 8, 4>(a, stream);
-    return launch_igemm_b16t<SK, YBF>(a, stream);
-}
+int launch_bt(IgemmArgs &a, hipStream_t stream) { return launch_igemm_b16t<SK, YBF>(a, stream); }
 
 template <bool YBF>
 int dispatch_b16t(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStream_t stream) {
@@ -1002,6 +987,18 @@ int emadapt_conv_bf16t_supported(const emadapt_conv_desc *d, int kind, int y_dty
     return bt_ok(d, kind == 1, y_dtype) ? 1 : 0;
 }
 
+/* Where the model sends a layer to this kernel instead of the register-staged one: the shapes it was measured faster on
+ * (profiles/r05_bf16t_bench.txt) -- outputs of at least four rounds of 256 x 256 tiles on the CUs, i.e. fc6 / fc7 of the `ref` preset
+ * at batch 16 (59 / 49 % of the dense matrix rate against 53 / 47 %).  Launches of one or two rounds (conv3 - conv5: 212 - 411
+ * tiles) run stream-K here with a second-stage kernel and lose to the older kernel's single round. */
+int emadapt_conv_bf16t_pays(const emadapt_conv_desc *d, int kind, int y_dtype) {
+    if (!emadapt_conv_bf16t_supported(d, kind, y_dtype) || d->B == 0) return 0;
+    const long long M = (long long)d->B * d->H * d->W;
+    const int N = kind == 1 ? d->Cin : d->Cout;
+    // (N >= 256: a narrower output wastes the 256-wide tile's MFMAs -- conv1_2 / conv2_x have thousands of tiles and 64 / 128 columns)
+    return N >= 256 && ceil_div(M, 256) * ceil_div(N, 256) >= 4LL * plan_cus() ? 1 : 0;
+}
+
 size_t emadapt_filter_tiles_bf16_bytes(const emadapt_conv_desc *d, int dgrad) {
     if (check_desc(d) != EMADAPT_OK) return 0;
     const int rows = dgrad ? d->Cin : d->Cout, kdim = dgrad ? d->Cout : d->Cin;
@@ -1016,14 +1013,17 @@ int emadapt_filter_tiles_bf16(const emadapt_conv_desc *d, const float *w, void *
     const int rows = dgrad ? d->Cin : d->Cout, kdim = dgrad ? d->Cout : d->Cin;
     if (kdim % BT_BK != 0) return EMADAPT_ERR_UNSUPPORTED;
     const int rows_pad = (int)(ceil_div(rows, 256) * 256), taps = d->KH * d->KW;
-    long long g = ((long long)taps * (kdim / BT_BK) * rows_pad * 4 + 255) / 256;
-    if (g > 16384) g = 16384;
-    if (dgrad)
-        hipLaunchKernelGGL(filter_tiles_b16_kernel<true>, dim3((unsigned)g), dim3(256), 0, as_stream(stream_), w,
-                           reinterpret_cast<uint4 *>(tiles), d->Cin, d->Cout, kdim, taps, rows_pad);
-    else
-        hipLaunchKernelGGL(filter_tiles_b16_kernel<false>, dim3((unsigned)g), dim3(256), 0, as_stream(stream_), w,
-                           reinterpret_cast<uint4 *>(tiles), d->Cin, d->Cout, kdim, taps, rows_pad);
+    if (dgrad) {
+        long long g = ((long long)taps * (kdim / BT_BK) * rows_pad * 4 + 255) / 256;
+        if (g > 16384) g = 16384;
+        hipLaunchKernelGGL(filter_tiles_b16_dgrad_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream_), w, reinterpret_cast<uint4 *>(tiles),
+                           d->Cin, d->Cout, taps, rows_pad);
+    } else {
+        const long long g = (long long)taps * (kdim / BT_BK) * (rows_pad / 64);
+        if (g > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(filter_tiles_b16_fwd_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream_), w, reinterpret_cast<uint4 *>(tiles),
+                           d->Cin, d->Cout, rows_pad);
+    }
     return launch_status();
 }
 

@@ -99,6 +99,7 @@ class ADAPT(Network):
         # micro_step / apply_update themselves; train(), where nobody looks in between, switches it on.
         self._fused = bool(self.config.get("fused_update", False))
         self._pending_fused = False
+        self._bt = {}
         self._perm_pool = None
         self._perm_pos = 0
         self.init_model = None
@@ -428,6 +429,30 @@ class ADAPT(Network):
                 self._plane_fwd, self._plane_dgrad = plane_fwd, plane_dgrad
                 self._w16_seen = None
             bufs["dyp"] = torch.empty(max(dyp_bytes, 16), dtype=torch.uint8, device=dev)
+        if self.compute_dtype == "bf16":
+            # which layers run forward / data gradient on the LDS-DMA kernel (csrc/igemm_b16t.h: 16x16x32 MFMAs, DMA waves) at this
+            # batch size -- config "bf16t": "auto" (default: where the library says it pays: fc6 / fc7 at batch 16), "always"
+            # (wherever it can run: the parity tests), "never" -- and their tiled filter images (instead of the plain bf16 images)
+            mode = str(self.config.get("bf16t", "auto"))
+            take = {"auto": ops.conv_bf16t_pays, "always": ops.conv_bf16t_supported, "never": lambda *a, **k: False}[mode]
+            bt = {}
+            plan = self._plan
+            for i, op in enumerate(plan):
+                if op.kind != "conv":
+                    continue
+                ih, iw = op.in_hw
+                d = ops.conv_desc(B, ih, iw, op.cin_p, op.cout_p, op.k, op.k, op.rate)
+                x_bf16 = i > 0 and adt == torch.bfloat16                     # (the image into conv1_1 is f32)
+                y_bf16 = op is not plan[-1] and adt == torch.bfloat16        # (the logits are f32)
+                e = dict(fwd=x_bf16 and take(d, "fwd", y_bf16), dgrad=i > 0 and op is not plan[-1] and take(d, "dgrad", True))
+                for key, flag, dg in (("wt16", e["fwd"], False), ("wtd16", e["dgrad"], True)):
+                    if flag and op.seg.get(key) is None:
+                        op.seg[key] = ops.filter_tiles_bf16(op.w_pad, dgrad=dg)
+                bt[op.name] = e
+            if bt != self._bt:
+                self._bt = bt
+                self._w16_seen = None
+            bufs["bt"] = bt
         bufs["gA"] = torch.empty(maxn, dtype=adt, device=dev)   # activation gradients ping-pong between these two
         bufs["gB"] = torch.empty(maxn, dtype=adt, device=dev)
         S1, S2 = self.out_hw
@@ -459,7 +484,14 @@ class ADAPT(Network):
         for op in self._plan:
             if op.kind == "conv":
                 if self.compute_dtype == "bf16":
-                    ops.weights_to_bf16(op.w_pad, op.seg["wf16"], op.seg["wd16"])
+                    e = self._bt.get(op.name, {"fwd": False, "dgrad": False})
+                    if not (e["fwd"] and e["dgrad"]):
+                        ops.weights_to_bf16(op.w_pad, None if e["fwd"] else op.seg["wf16"], None if e["dgrad"] else op.seg["wd16"],
+                                            want_fwd=not e["fwd"], want_dgrad=not e["dgrad"])
+                    if e["fwd"]:
+                        ops.filter_tiles_bf16(op.w_pad, dgrad=False, out=op.seg["wt16"])
+                    if e["dgrad"]:
+                        ops.filter_tiles_bf16(op.w_pad, dgrad=True, out=op.seg["wtd16"])
                 else:
                     if op.seg["kmajor"] or not self._plane_fwd.get(op.name, True):
                         ops.filter_kmajor(op.w_pad, op.seg["wk32"])
@@ -494,7 +526,10 @@ class ADAPT(Network):
                 if op.drop and kp < 1.0 and drop_masks is not None:
                     mask = self._pad_mask(drop_masks[op.name], op)
                 seed = self._drop_seed(op)
-                if bf16:
+                if bf16 and bufs["bt"][op.name]["fwd"]:
+                    ops.conv_fwd_bf16t(x, op.seg["wt16"], (op.k, op.k), op.cout_p, op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
+                                       drop_mask=mask, drop_seed=seed, out=out)
+                elif bf16:
                     ops.conv_fwd_bf16(x, op.seg["wf16"], (op.k, op.k), op.b_pad, op.rate, relu=op.relu, keep_prob=kp,
                                       drop_mask=mask, drop_seed=seed, out=out)
                 elif x6:
@@ -676,7 +711,9 @@ class ADAPT(Network):
                 if prev.kind == "conv" and prev.relu:
                     gate = x_in
                     scale = (1.0 / keep) if (prev.drop and keep < 1.0) else 1.0
-                if bf16:
+                if bf16 and bufs["bt"][op.name]["dgrad"]:
+                    d = ops.conv_dgrad_bf16t(d, op.seg["wtd16"], (op.k, op.k), op.cin_p, op.rate, gate=gate, gate_scale=scale, out=out)
+                elif bf16:
                     d = ops.conv_dgrad_bf16(d, op.seg["wd16"], (op.k, op.k), op.rate, gate=gate, gate_scale=scale, out=out)
                 elif x6:
                     if bufs["xp"][op.name]["dgrad"]:

@@ -227,6 +227,11 @@ def conv_bf16t_supported(d, kind, out_bf16=True):
     return bool(_lib.load().emadapt_conv_bf16t_supported(ctypes.byref(d), {"fwd": 0, "dgrad": 1}[kind], 1 if out_bf16 else 0))
 
 
+def conv_bf16t_pays(d, kind, out_bf16=True):
+    """supported AND the faster bf16 kernel for this shape (include/emadapt.h): what the model asks per layer and batch size."""
+    return bool(_lib.load().emadapt_conv_bf16t_pays(ctypes.byref(d), {"fwd": 0, "dgrad": 1}[kind], 1 if out_bf16 else 0))
+
+
 def conv_bf16t_plan(B, H, W, Cin, Cout, k, dil=1, kind="fwd"):
     """(rows of the first launch, 1 = stream-K, its slab levels, slab levels of the launch over the remaining rows / -1)."""
     d = conv_desc(B, H, W, Cin, Cout, k, k, dil)

@@ -262,10 +262,12 @@ int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dty
  * plan[2] = split-K / split-M factor.  The parity tests assert through it that the benchmark shapes run the big tiles.  (ABI 200) */
 int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]);
 
-/* ---- bf16 forward / data gradient on LDS-DMA (round 4; csrc/igemm_b16t.h).  For bf16-STORED activations whose gathered channel
- * count is a multiple of 32 (every layer from conv1_2 on; kind 0: Cin % 32 == 0, kind 1: Cout % 32 == 0) the operand tiles go
- * global -> LDS by DMA, no producer wavefronts, with the filter pre-tiled in LDS order:
- *     tiled image  [tap][k / 32][row, zero rows up to a multiple of 256][4 x 16 B, slot s of row r = k chunk s ^ ((r >> 2) & 3)]
+/* ---- bf16 forward / data gradient on LDS-DMA (csrc/igemm_b16t.h; round 5: 8 MFMA wavefronts on v_mfma_f32_16x16x32_bf16 + 4 DMA
+ * wavefronts, what the model runs for its layers with 256 and more output columns).  For bf16-STORED activations whose gathered
+ * channel count is a multiple of 32 (every layer from conv1_2 on; kind 0: Cin % 32 == 0, kind 1: Cout % 32 == 0) the operand tiles
+ * go global -> LDS by DMA with the filter pre-tiled in LDS order:
+ *     tiled image  [tap][k / 32][row, zero rows up to a multiple of 256][4 x 16 B, slot s of row r = k chunk s ^ ((-(r >> 2)) & 3)]
+ *     (ABI 203: round 4's image swizzled with (r >> 2) & 3 -- an image built by a 202 library is not valid for a 203 one)
  *     dgrad = 0: rows = Cout, k = Cin;  dgrad = 1: rows = Cin, k = Cout     (emadapt_filter_tiles_bf16, once per optimizer step)
  * Same arithmetic as emadapt_conv_fwd_bf16 / _dgrad_bf16 (bf16 operands rounded RNE, exact products, fp32 sums; the K order of
  * the sum differs), same epilogues, bitwise reproducible.  y_dtype / dx_dtype: EMADAPT_DT_*; the gate has dx's storage type.
@@ -273,6 +275,9 @@ int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]);
  * rounds of 256 x 256 tiles on the CUs), [1] 1 = that launch is stream-K, [2] its slab levels, [3] slab levels of the stream-K
  * launch over the remaining rows (-1: plain tiles; 0 with plan[0] == M: there is none).  (ABI 200) */
 int emadapt_conv_bf16t_supported(const emadapt_conv_desc *d, int kind, int y_dtype);
+/* supported AND measured faster than emadapt_conv_{fwd,dgrad}_bf16 for this shape (four and more rounds of 256 x 256 tiles on the
+ * CUs: fc6 / fc7 at batch 16); what the model asks per layer and batch size.  (ABI 203) */
+int emadapt_conv_bf16t_pays(const emadapt_conv_desc *d, int kind, int y_dtype);
 size_t emadapt_filter_tiles_bf16_bytes(const emadapt_conv_desc *d, int dgrad);
 int emadapt_filter_tiles_bf16(const emadapt_conv_desc *d, const float *w, void *tiles, int dgrad, void *stream);
 size_t emadapt_conv_bf16t_workspace_bytes(const emadapt_conv_desc *d, int kind);
@@ -431,8 +436,7 @@ int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *p
  *                A forced variant the shape is not eligible for is ignored.
  *   "wgrad_gen"  1: 128x128 wave-specialised filter-gradient kernel | 2: 256x256 second generation (LDS-DMA loaders)
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
- *   "bf16_tile"  128 | 256 (emadapt_conv_*_bf16: 128 also keeps the 128-wide tile where 128 x 64 would be chosen); 64: the LDS-DMA
- *                entries (emadapt_conv_*_bf16t) fetch the activations in 128-byte pieces (igemm_b16w_kernel) where Cx % 64 == 0
+ *   "bf16_tile"  128 | 256 (emadapt_conv_*_bf16: 128 also keeps the 128-wide tile where 128 x 64 would be chosen)
  *   "x6_tile"    128 | 256
  *   "plan_cus"   number of CUs the launch plans are laid out for (default 256: MI355X)
  *   "fp32_loader" 1: the 256x256 fp32 kernels' loader waves compute their offsets per K step (works for any tap count);
@@ -443,7 +447,7 @@ int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *p
  *                that saves at least this many per cent of the dense launch's products (0 = the built-in threshold)
  *   "raster_gm"  M tiles per group of the plain-tile launches' XCD-aware order (default 8): the workgroups resident on one XCD cover
  *                that many M-tiles x the N-tiles that fit (scripts/raster_sweep.py: L2 hit rate and time per setting)
- *   "dma_stagger" 1: the LDS-DMA kernels without loader waves (bf16x6 plane kernels, emadapt_conv_*_bf16t) issue every wave's DMA
+ *   "dma_stagger" 1: the LDS-DMA kernels without loader waves (the bf16x6 plane kernels) issue every wave's DMA
  *                burst at the same point of the K step (round 3's form); 0 (default): the two waves of a SIMD staggered around
  *                the step's barrier (round 4: +3-6 %)
  *   "wgrad_bias" 1: emadapt_conv_wgrad_bias_fused() answers 0 for every shape (callers then use emadapt_conv_wgrad +

@@ -45,7 +45,7 @@ __global__ void ref_kernel(const __bf16 *A, const __bf16 *B, float *out, int K, 
     out[i] = s;
 }
 
-template <int NW, int SHAPE, int NBUF, int ABL, bool AGATHER>
+template <int NW, int SHAPE, int NBUF, int ABL, bool AGATHER, bool STAG = false>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) gemm_kernel(const char *__restrict__ At, const char *__restrict__ Bt, const char *__restrict__ Arow,
                                                                        __bf16 *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n) {
     constexpr int TM = NW == 8 ? 2 : 4, TN = 4;            // per-wave block in 32 x 32 units
@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) gemm_kernel(const ch
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WMW, wn = wave / WMW;
+    const bool late = STAG && wave >= 4;   // (the SIMD partner of wave w is wave w + 4: its DMA burst goes behind the barrier)
     int tile_m, tile_n;
     {
         const int nblk = tiles_m * tiles_n, bid = blockIdx.x;
@@ -171,12 +172,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) gemm_kernel(const ch
 #pragma unroll
                 for (int j = 0; j < NB; j++) mf(0, i, j);
         }
-        fill(pv, kt + AHEAD, kt + AHEAD < nk);
+        if (!late) fill(pv, kt + AHEAD, kt + AHEAD < nk);
         SB
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_vmcnt<(AHEAD - 1) * 2 * IPW>();   // this wave's DMAs of step kt + 1 have landed
+        if (late) wait_vmcnt<(AHEAD - 2) * 2 * IPW>(); else wait_vmcnt<(AHEAD - 1) * 2 * IPW>();   // this wave's DMAs of step kt + 1 have landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (late) fill(pv, kt + AHEAD, kt + AHEAD < nk);
         SB
         if constexpr (SHAPE == 32) {
             // second k group; behind its MFMAs the next step's first-group fragments (TM + TN reads), then the second group's
@@ -252,20 +254,164 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) gemm_kernel(const ch
 #undef SB
 }
 
+// 8 MFMA waves (64 x 128 each, v_mfma_f32_16x16x32_bf16, B fragments streamed through a 3-deep rotation: 164 registers) + 4 DMA waves
+// that issue all 32 LDS-DMA instructions of a K step -- the shape of the fp32 second-generation kernel (igemm_v2.h).  Ring of 5 stages
+// fetched 3 steps ahead; the stage a step's DMAs overwrite is the one read two steps ago (a step's later B fragments are read behind
+// its barrier).
+template <int ABL, bool AGATHER>
+__global__ void __launch_bounds__(768, 3) gemm12_kernel(const char *__restrict__ At, const char *__restrict__ Bt, const char *__restrict__ Arow,
+                                                        __bf16 *__restrict__ C, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int NBUF = 5, AHEAD = 3, TM = 2, TN = 4, WMW = 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n;
+    {
+        const int nblk = tiles_m * tiles_n, bid = blockIdx.x;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 8;
+        const int per_group = GM * tiles_n, g = t / per_group, first_m = g * GM;
+        const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM, in_g = t - g * per_group;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
+    const int m0 = tile_m * 256, n0 = tile_n * 256, nk = K / BK;
+    if (wave >= 8) {
+        // ================= DMA waves: 4 A + 4 B instructions per K step each
+        constexpr int IPW = 4;
+        const int lw = wave - 8;
+        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(AGATHER ? Arow : At), 0, (int)((long long)M * K * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(Bt), 0, (int)((long long)N * K * 2), 0x00020000);
+        unsigned a_off[IPW], b_off[IPW];
+#pragma unroll
+        for (int j = 0; j < IPW; j++) {
+            const int q = (lw * IPW + j) * 64 + lane;
+            if constexpr (AGATHER) {
+                const int row = q >> 2, chunk = (q & 3) ^ swz(row);
+                a_off[j] = (unsigned)(m0 + row) * (unsigned)(K * 2) + chunk * 16;
+            } else {
+                a_off[j] = (unsigned)q * 16u;
+            }
+            b_off[j] = (unsigned)q * 16u;
+        }
+        auto fill = [&](int off, int kt, bool live) {
+            if constexpr (ABL & 1) { if (kt >= NBUF) return; }
+            const unsigned dead = live ? 0u : 0x80000000u;
+            const unsigned s_a = AGATHER ? (unsigned)kt * ROWB : ((unsigned)kt * (unsigned)M + (unsigned)m0) * ROWB;
+            const unsigned s_b = ((unsigned)kt * (unsigned)N + (unsigned)n0) * ROWB;
+            char *as = lds + off + lw * (IPW * 1024), *bs = lds + off + OPER + lw * (IPW * 1024);
+#pragma unroll
+            for (int j = 0; j < IPW; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, (lds_void_t *)(as + j * 1024), 16, (int)(a_off[j] | dead), (int)s_a, 0, 0);
+#pragma unroll
+            for (int j = 0; j < IPW; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(br, (lds_void_t *)(bs + j * 1024), 16, (int)(b_off[j] | dead), (int)s_b, 0, 0);
+        };
+#pragma unroll
+        for (int s = 0; s < AHEAD; s++) fill(s * STAGE, s, s < nk);
+        wait_vmcnt<(AHEAD - 1) * 2 * IPW>();
+        __builtin_amdgcn_s_barrier();   // step 0 has landed
+        int dst = AHEAD * STAGE;
+        for (int kt = 0; kt < nk; kt++) {
+            fill(dst, kt + AHEAD, kt + AHEAD < nk);
+            wait_vmcnt<(AHEAD - 1) * 2 * IPW>();   // step kt + 1 has landed
+            __builtin_amdgcn_s_barrier();
+            dst = dst == (NBUF - 1) * STAGE ? 0 : dst + STAGE;
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+        return;
+    }
+    // ================= MFMA waves
+    const int wm = wave % WMW, wn = wave / WMW;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int a_base = (wm * TM * 32 + l15) * ROWB + ((lq ^ swz(l15)) << 4);
+    const int b_base = OPER + (wn * TN * 32 + l15) * ROWB + ((lq ^ swz(l15)) << 4);
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
+    bf16x8 av[4], bv[3];
+#define SB __builtin_amdgcn_sched_barrier(0);
+#define RDA(I, BASE) if constexpr (!(ABL & 4)) { av[I] = *reinterpret_cast<const bf16x8 *>(lds + (BASE) + a_base + (I) * 16 * ROWB); if constexpr (ABL & 2) asm volatile("" ::"v"(av[I])); SB }
+#define RDB(S, J, BASE) if constexpr (!(ABL & 4)) { bv[S] = *reinterpret_cast<const bf16x8 *>(lds + (BASE) + b_base + (J) * 16 * ROWB); if constexpr (ABL & 2) asm volatile("" ::"v"(bv[S])); SB }
+#define MF(I, J, S) if constexpr (!(ABL & 2)) { acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[I], bv[S], acc[I][J], 0, 0, 0); SB }
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) av[n][e] = (__bf16)((float)((lane * 7 + n * 3 + e) & 63) * 0.03125f - 1.0f);
+#pragma unroll
+    for (int n = 0; n < 3; n++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) bv[n][e] = (__bf16)((float)((lane * 5 + n * 11 + e) & 63) * 0.03125f - 1.0f);
+    __builtin_amdgcn_s_barrier();   // step 0 has landed
+    asm volatile("" ::: "memory");
+    RDA(0, 0) RDA(1, 0) RDA(2, 0) RDA(3, 0) RDB(0, 0, 0) RDB(1, 1, 0)
+    int cur = 0;
+    // column j of the wave's block: 4 MFMAs on B fragment j; fragment j + 2 is fetched in front of them (from the next stage once
+    // j + 2 >= 8: behind the barrier, which sits in front of column 4).  The rotation slot of column j of step kt is (j + 2 kt) % 3
+    // (8 columns advance it by 2 per step): three bodies, O = 0, 2, 1.
+#define COL(J, O)                                                                                                          \
+        if ((J) == 4) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); SB }                                  \
+        if ((J) + 2 < 8) { RDB(((J) + 2 + (O)) % 3, (J) + 2, cur) } else { RDB(((J) + 2 + (O)) % 3, (J) + 2 - 8, nx) }     \
+        MF(0, J, ((J) + (O)) % 3) if ((J) == 7) { RDA(0, nx) }                                                             \
+        MF(1, J, ((J) + (O)) % 3) if ((J) == 7) { RDA(1, nx) }                                                             \
+        MF(2, J, ((J) + (O)) % 3) if ((J) == 7) { RDA(2, nx) }                                                             \
+        MF(3, J, ((J) + (O)) % 3) if ((J) == 7) { RDA(3, nx) }
+#define STEP(O)                                                                                         \
+        {                                                                                               \
+            const int nx = cur == (NBUF - 1) * STAGE ? 0 : cur + STAGE;                                 \
+            SB                                                                                          \
+            COL(0, O) COL(1, O) COL(2, O) COL(3, O) COL(4, O) COL(5, O) COL(6, O) COL(7, O)             \
+            cur = nx;                                                                                   \
+        }
+    for (int kt = 0; kt < nk; kt += 3) {
+        STEP(0)
+        if (kt + 1 < nk) STEP(2)
+        if (kt + 2 < nk) STEP(1)
+    }
+#undef STEP
+#undef COL
+#undef RDA
+#undef RDB
+#undef MF
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    float *stage = reinterpret_cast<float *>(lds) + wave * (16 * (TN * 32 + 4));
+    constexpr int SP = TN * 32 + 4;
+#pragma unroll
+    for (int rb = 0; rb < TM * 2; rb++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) stage[(4 * lq + r) * SP + j * 16 + l15] = acc[rb][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 16 * (TN * 4) / 64; it++) {
+            const int idx = it * 64 + lane, row_l = idx / (TN * 4), ch = idx % (TN * 4);
+            const int row = m0 + wm * TM * 32 + rb * 16 + row_l, col = n0 + wn * TN * 32 + ch * 8;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (__bf16)stage[row_l * SP + ch * 8 + e];
+            if (row < M) *reinterpret_cast<bf16x8 *>(C + (long long)row * N + col) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef SB
+}
+
 struct Ctx {
     int M, N, K;
     char *At, *Bt, *Arow, *Brow;
     __bf16 *C;
 };
 
-template <int NW, int SHAPE, int NBUF, int ABL, bool AG>
-float run(const Ctx &c, const char *name, bool check) {
-    const size_t ldsb = (size_t)NBUF * STAGE;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<NW, SHAPE, NBUF, ABL, AG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-    const int tm = c.M / 256, tn = c.N / 256;
+template <typename L>
+float timeit(const Ctx &c, const char *name, L launch, bool check) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto launch = [&]() { hipLaunchKernelGGL((gemm_kernel<NW, SHAPE, NBUF, ABL, AG>), dim3(tm * tn), dim3(NW * 64), ldsb, 0, c.At, c.Bt, c.Arow, c.C, c.M, c.N, c.K, tm, tn); };
+    CK(hipMemset(c.C, 0, (size_t)c.M * c.N * 2));
     for (int i = 0; i < 5; i++) launch();
     CK(hipDeviceSynchronize());
     float best = 1e9f, sum = 0.f;
@@ -282,8 +428,8 @@ float run(const Ctx &c, const char *name, bool check) {
         sum += ms;
     }
     const double fl = 2.0 * c.M * (double)c.N * c.K;
-    printf("%-44s  mean %.4f ms  best %.4f ms  %7.1f TF (%.1f %% of 2516.6)\n", name, sum / reps, best, fl / (sum / reps) * 1e-9, fl / (sum / reps) * 1e-9 / 2516.6 * 100);
-    if (check && ABL == 0) {
+    printf("%-52s  mean %.4f ms  best %.4f ms  %7.1f TF (%.1f %% of 2516.6)\n", name, sum / reps, best, fl / (sum / reps) * 1e-9, fl / (sum / reps) * 1e-9 / 2516.6 * 100);
+    if (check) {
         const int n = 64;
         std::vector<int> rows(n), cols(n);
         for (int i = 0; i < n; i++) { rows[i] = (int)((i * 7919LL + 13) % c.M); cols[i] = (int)((i * 104729LL + 7) % c.N); }
@@ -304,6 +450,23 @@ float run(const Ctx &c, const char *name, bool check) {
         CK(hipFree(dr)); CK(hipFree(dc)); CK(hipFree(dout));
     }
     return sum / reps;
+}
+
+template <int NW, int SHAPE, int NBUF, int ABL, bool AG, bool STAG = false>
+float run(const Ctx &c, const char *name, bool check) {
+    const size_t ldsb = (size_t)NBUF * STAGE;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<NW, SHAPE, NBUF, ABL, AG, STAG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const int tm = c.M / 256, tn = c.N / 256;
+    return timeit(c, name, [&]() { hipLaunchKernelGGL((gemm_kernel<NW, SHAPE, NBUF, ABL, AG, STAG>), dim3(tm * tn), dim3(NW * 64), ldsb, 0, c.At, c.Bt, c.Arow, c.C, c.M, c.N, c.K, tm, tn); },
+                  check && ABL == 0);
+}
+
+template <int ABL, bool AG>
+float run12(const Ctx &c, const char *name, bool check) {
+    const size_t ldsb = (size_t)5 * STAGE;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm12_kernel<ABL, AG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    const int tm = c.M / 256, tn = c.N / 256;
+    return timeit(c, name, [&]() { hipLaunchKernelGGL((gemm12_kernel<ABL, AG>), dim3(tm * tn), dim3(768), ldsb, 0, c.At, c.Bt, c.Arow, c.C, c.M, c.N, c.K, tm, tn); }, check && ABL == 0);
 }
 
 int main(int argc, char **argv) {
@@ -327,26 +490,30 @@ int main(int argc, char **argv) {
     for (int round = 0; round < 2; round++) {
         printf("## round %d\n", round);
         run<8, 32, 4, 0, false>(c, "8 waves 64x128  32x32x16  ring 4  tiled A", round == 0);
-        run<4, 32, 4, 0, false>(c, "4 waves 128x128 32x32x16  ring 4  tiled A", round == 0);
-        run<4, 32, 5, 0, false>(c, "4 waves 128x128 32x32x16  ring 5  tiled A", round == 0);
+        run<8, 32, 4, 0, false, true>(c, "8 waves 64x128  32x32x16  ring 4  tiled A  staggered", round == 0);
         run<8, 16, 4, 0, false>(c, "8 waves 64x128  16x16x32  ring 4  tiled A", round == 0);
+        run<8, 16, 4, 0, false, true>(c, "8 waves 64x128  16x16x32  ring 4  tiled A  staggered", round == 0);
+        run<8, 16, 5, 0, false, true>(c, "8 waves 64x128  16x16x32  ring 5  tiled A  staggered", round == 0);
+        run<8, 16, 4, 0, true, true>(c, "8 waves 64x128  16x16x32  ring 4  gathered A  staggered", round == 0);
+        run12<0, false>(c, "8 + 4 DMA waves  16x16x32  ring 5  tiled A", round == 0);
+        run12<0, true>(c, "8 + 4 DMA waves  16x16x32  ring 5  gathered A", round == 0);
+        run<4, 32, 4, 0, false>(c, "4 waves 128x128 32x32x16  ring 4  tiled A", round == 0);
         run<4, 16, 4, 0, false>(c, "4 waves 128x128 16x16x32  ring 4  tiled A", round == 0);
-        run<4, 16, 5, 0, false>(c, "4 waves 128x128 16x16x32  ring 5  tiled A", round == 0);
-        run<8, 32, 4, 0, true>(c, "8 waves 64x128  32x32x16  ring 4  gathered A", round == 0);
-        run<4, 32, 4, 0, true>(c, "4 waves 128x128 32x32x16  ring 4  gathered A", round == 0);
-        run<4, 16, 4, 0, true>(c, "4 waves 128x128 16x16x32  ring 4  gathered A", round == 0);
     }
     printf("## parts compiled out (results are garbage)\n");
     run<8, 32, 4, 1, false>(c, "8w 32x32x16: no DMAs", false);
     run<8, 32, 4, 2, false>(c, "8w 32x32x16: no MFMAs", false);
     run<8, 32, 4, 6, false>(c, "8w 32x32x16: DMAs + barrier only", false);
     run<8, 32, 4, 5, false>(c, "8w 32x32x16: MFMAs alone", false);
-    run<4, 32, 4, 1, false>(c, "4w 32x32x16: no DMAs", false);
-    run<4, 32, 4, 2, false>(c, "4w 32x32x16: no MFMAs", false);
-    run<4, 32, 4, 6, false>(c, "4w 32x32x16: DMAs + barrier only", false);
-    run<4, 32, 4, 5, false>(c, "4w 32x32x16: MFMAs alone", false);
-    run<4, 16, 4, 1, false>(c, "4w 16x16x32: no DMAs", false);
-    run<4, 16, 4, 5, false>(c, "4w 16x16x32: MFMAs alone", false);
+    run<8, 16, 4, 1, false>(c, "8w 16x16x32: no DMAs", false);
+    run<8, 16, 4, 2, false>(c, "8w 16x16x32: no MFMAs", false);
     run<8, 16, 4, 5, false>(c, "8w 16x16x32: MFMAs alone", false);
+    run12<1, false>(c, "8+4w 16x16x32: no DMAs", false);
+    run12<2, false>(c, "8+4w 16x16x32: no MFMAs", false);
+    run12<6, false>(c, "8+4w 16x16x32: DMAs + barrier only", false);
+    run12<5, false>(c, "8+4w 16x16x32: MFMAs alone", false);
+    run<4, 32, 4, 1, false>(c, "4w 32x32x16: no DMAs", false);
+    run<4, 32, 4, 5, false>(c, "4w 32x32x16: MFMAs alone", false);
+    run<4, 16, 4, 5, false>(c, "4w 16x16x32: MFMAs alone", false);
     return 0;
 }

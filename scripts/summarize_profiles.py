@@ -15,6 +15,7 @@ def newest(pattern):
     return max(glob.glob(pattern), key=os.path.getmtime)
 
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (em_adapt_tensorflow_amd._build.source_hash)
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = "gpurun_out/profiles_%s" % R
 DST = "profiles"
@@ -77,6 +78,43 @@ for name, a in agg.items():
             rd / 1e9, wr / 1e9, (rd + wr) / 1e9 / max(n, 1), 100 * hit))
 open("%s/%s_pmc_conv_kernels.txt" % (DST, R), "w").write("\n".join(out) + "\n")
 
+# The E-step's kernels in the same passes (north_star: "rocprof counters report achieved HBM GB/s on the E-step scan"): per call of
+# emadapt_estep (= its launches: the batch-maximum pre-kernel, the scan, and for geometries that overflow the LDS prep / finish)
+eout = ["# E-step kernels in the same rocprofv3 --pmc passes (last step): HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB as reported;",
+        "# gfx950 correction as above), L2 hit rate, wave-cycle split; algorithmic bytes (SURVEY 8d) = logits once + int64 labels.", ""]
+eagg = collections.OrderedDict()
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    rows = load(newest("%s/%s/runc/*_counter_collection.csv" % (SRC, sub)))
+    es = [r for r in rows if re.search(r"estep", r["name"])]
+    per_step = max(len(es) // 2, 1)
+    for r in es[len(es) - per_step:]:
+        a = eagg.setdefault(r["name"], collections.defaultdict(float))
+        a["launches_" + sub] += 1
+        a["ns_" + sub] += r["ns"]
+        for k, v in r.items():
+            if k not in ("name", "ns"):
+                a[k] += v
+estep_traffic = {"read_bytes": 0.0, "write_bytes": 0.0, "hit": 0.0, "miss": 0.0, "ns": 0.0}
+for name, a in eagg.items():
+    rd, wr = 2 * a.get("FETCH_SIZE", 0.0) * 1024, a.get("WRITE_SIZE", 0.0) * 1024
+    hit = a["TCC_HIT_sum"] / max(a["TCC_HIT_sum"] + a["TCC_MISS_sum"], 1)
+    wc = max(a["SQ_WAVE_CYCLES"], 1)
+    eout.append("%-28s launches %d  time %7.1f us  HBM read %8.1f KB  write %7.1f KB  (%.1f GB/s)  L2 hit %.1f%%  wave: wait_any %.1f%% wait_inst %.1f%% active %.1f%%  lds_bank_conflict %d" % (
+        name, a["launches_pmc_sq"], a["ns_pmc_sq"] / 1e3, rd / 1e3, wr / 1e3, (rd + wr) / max(a["ns_pmc_fetch"], 1), 100 * hit,
+        100 * a["SQ_WAIT_ANY"] / wc, 100 * a["SQ_WAIT_INST_ANY"] / wc, 100 * a["SQ_ACTIVE_INST_ANY"] / wc, a["SQ_LDS_BANK_CONFLICT"]))
+    estep_traffic["read_bytes"] += rd
+    estep_traffic["write_bytes"] += wr
+    estep_traffic["hit"] += a["TCC_HIT_sum"]
+    estep_traffic["miss"] += a["TCC_MISS_sum"]
+    estep_traffic["ns"] += a["ns_pmc_sq"]
+if eagg:
+    tot = estep_traffic["read_bytes"] + estep_traffic["write_bytes"]
+    eout.append("TOTAL per emadapt_estep call: HBM-side %.1f KB (read %.1f + write %.1f) in %.1f us = %.1f GB/s of 8000 (%.2f %%)" % (
+        tot / 1e3, estep_traffic["read_bytes"] / 1e3, estep_traffic["write_bytes"] / 1e3, estep_traffic["ns"] / 1e3,
+        tot / max(estep_traffic["ns"], 1), 100 * tot / max(estep_traffic["ns"], 1) / 8000))
+    open("%s/%s_pmc_estep_kernels.txt" % (DST, R), "w").write("\n".join(eout) + "\n")
+    print("\n".join(eout))
+
 # HBM bytes per step and kernel class (bench.py's roofline.traffic).  The class of a launch comes from its position in the
 # step (scripts/kernel_classes.py: forward launches precede the first filter-gradient launch), cross-checked against the BT
 # template argument of the fp32 kernels read by position.
@@ -113,6 +151,9 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/
                      "L2-miss (fabric) traffic, Infinity-Cache hits included; class of a launch = its position in the step "
                      "(scripts/kernel_classes.py)",
            "dtype": line["dtype"], "workload": line["config"]["workload"], "key": line["config"].get("workload_key"),
+           "source_hash": __import__("importlib").import_module("em_adapt_tensorflow_amd._build").source_hash(),
+           "estep": ({"read_bytes": estep_traffic["read_bytes"], "write_bytes": estep_traffic["write_bytes"],
+                      "l2_hit_rate": round(estep_traffic["hit"] / max(estep_traffic["hit"] + estep_traffic["miss"], 1), 4)} if eagg else None),
            "per_step": traffic, "per_kernel": per_kernel},
           open("%s/%s_traffic.json" % (DST, R), "w"), indent=1)
 print("\n".join(out))

@@ -23,7 +23,9 @@ STUB = textwrap.dedent("""
     assert os.environ["LOCAL_RANK"] == str(rank) and os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["MASTER_PORT"]
     if mode == "fail" and rank == 1:
         sys.exit(7)
-    if mode in ("fail", "hang") and rank == 0:
+    if mode == "fail5" and rank == 5:      # (the eight-worker job: a rank in the middle dies before the rendezvous)
+        sys.exit(9)
+    if mode in ("fail", "hang", "fail5") and rank == 0:
         open(sys.argv[2], "w").write(str(os.getpid()))
         time.sleep(600)
     import torch, torch.distributed as dist
@@ -57,6 +59,26 @@ def test_two_gloo_ranks_relay_exactly_rank0s_line(tmp_path):
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d == {"n_gpus": 2, "sum": 3.0}
+
+
+def test_eight_gloo_ranks_relay_exactly_rank0s_line(tmp_path):
+    """The node the scaling bench runs on has eight GPUs: the launcher with EIGHT workers (rendezvous, environment, one relayed
+    line) -- nothing here needs a GPU, so the W = 8 launcher path is not an unknown on the day SCALE is not skipped."""
+    out = io.StringIO()
+    rc = bench.launch_workers(8, [sys.executable, _stub(tmp_path), "ok"], timeout=300, out=out)
+    assert rc == 0
+    lines = [l for l in out.getvalue().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    assert json.loads(lines[0]) == {"n_gpus": 8, "sum": 36.0}
+
+
+def test_rank_5_of_8_dying_ends_the_other_seven(tmp_path):
+    pidfile = tmp_path / "rank0.pid"
+    t0 = time.monotonic()
+    rc = bench.launch_workers(8, [sys.executable, _stub(tmp_path), "fail5", str(pidfile)], timeout=300, out=io.StringIO())
+    assert rc == 9
+    assert time.monotonic() - t0 < 120         # did not wait for rank 0's sleep or for the others' rendezvous time-out
+    assert _gone(int(pidfile.read_text()))
 
 
 def _gone(pid):

@@ -216,8 +216,8 @@ def test_bf16_dropout_epilogue_matches_fp32_kernel_mask(env):
     assert 0.45 < frac < 0.55
 
 
-@pytest.mark.parametrize("act", ["bf16", "fp32"])
-def test_bf16_micro_step_tracks_the_bf16_oracle(act):
+@pytest.mark.parametrize("act,bt", [("bf16", "auto"), ("fp32", "auto"), ("bf16", "always")])
+def test_bf16_micro_step_tracks_the_bf16_oracle(act, bt):
     """ADAPT(compute_dtype="bf16"): forward, E-step, backward, accumulate and update against the oracle's bf16
     arithmetic model (operands of every conv inner product rounded to bf16, exact accumulation; fp64 elsewhere).
     Two bf16 computations that differ only in summation order agree to ~1e-7 until the first activation lands close
@@ -226,14 +226,16 @@ def test_bf16_micro_step_tracks_the_bf16_oracle(act):
     In backward, ReLU gates of near-zero activations flip for that fraction of elements, an L2 error of
     sqrt(fraction): measured <= 4e-2 per layer, while the bf16 model itself sits 4..24 % from the fp32 graph.
     Bars: logits 1e-2 (max), loss 5e-3, gradients 8e-2 (relative L2) per layer and 5e-2 on average.  The kernels
-    themselves are held to 2e-5 above.  Label maps must be bit-identical to the oracle E-step on the GPU's logits."""
+    themselves are held to 2e-5 above.  Label maps must be bit-identical to the oracle E-step on the GPU's logits.
+    bt = "always": every layer the LDS-DMA kernel can take (csrc/igemm_b16t.h: conv1_2 .. fc7 forward, conv2_1 .. fc7 data gradient
+    at this width) runs on it -- what "auto" does for fc6 / fc7 at the benchmark's batch size."""
     import torch
     from em_adapt_tensorflow_amd.deeplab import ADAPT
     from oracle import deeplab_oracle as do
     from oracle import estep_oracle as eo
     B, width, size, C = 2, 8, 65, 5
     adapt = ADAPT({"input_size": (size, size), "category_num": C, "width": width, "accum_num": 1, "batch_size": B,
-                   "compute_dtype": "bf16", "act_dtype": act})
+                   "compute_dtype": "bf16", "act_dtype": act, "bf16t": bt})
     adapt.build()
     oracle = do.DeepLabOracle(category_num=C, width=width, dtype=torch.float64, compute_dtype="bf16", act_dtype=act)
     oracle32 = do.DeepLabOracle(category_num=C, width=width, dtype=torch.float64)
@@ -260,7 +262,14 @@ def test_bf16_micro_step_tracks_the_bf16_oracle(act):
 
     # the filter images follow the master weights
     w6 = adapt._segments["fc6"]
-    assert torch.equal(w6["wd16"][:, :, :w6["pshape"][3]], w6["w_pad"].bfloat16().reshape(w6["wd16"].shape[0], w6["pshape"][2], -1))
+    on_t = adapt._bt["fc6"]
+    if bt == "always":
+        import em_adapt_tensorflow_amd.ops as ops
+        assert on_t["fwd"] and on_t["dgrad"] and adapt._bt["conv3_2"]["fwd"] and adapt._bt["conv3_2"]["dgrad"], adapt._bt
+        assert torch.equal(w6["wt16"], ops.filter_tiles_bf16(w6["w_pad"])) and torch.equal(w6["wtd16"], ops.filter_tiles_bf16(w6["w_pad"], dgrad=True))
+    else:
+        assert not any(e["fwd"] or e["dgrad"] for e in adapt._bt.values())   # (too few tiles at this size for "auto")
+        assert torch.equal(w6["wd16"][:, :, :w6["pshape"][3]], w6["w_pad"].bfloat16().reshape(w6["wd16"].shape[0], w6["pshape"][2], -1))
 
     adapt.micro_step(images, labels, keep_prob=0.5, perms=perms, drop_masks=masks)
     torch.cuda.synchronize()
@@ -283,14 +292,18 @@ def test_bf16_micro_step_tracks_the_bf16_oracle(act):
         assert _l2(acc_b, db) < 8e-2, layer
     assert np.mean(errs) < 5e-2
 
-    before = adapt._segments["fc8"]["wf16"].clone()
+    key = "wt16" if adapt._bt["fc8"]["fwd"] else "wf16"   # (the image fc8's forward pass reads in this mode)
+    before = adapt._segments["fc8"][key].clone()
     adapt.apply_update()
     adapt.forward(images, keep_prob=1.0)
     torch.cuda.synchronize()
     seg = adapt._segments["fc8"]
-    assert not torch.equal(before, seg["wf16"]), "the bf16 images must be refreshed after the optimizer step"
+    assert not torch.equal(before, seg[key]), "the bf16 images must be refreshed after the optimizer step"
     kh, kw, cin_p, cout_p = seg["pshape"]
-    assert torch.equal(seg["wf16"][:, :, :cin_p], seg["w_pad"].bfloat16().reshape(1, cin_p, cout_p).permute(0, 2, 1))
+    if key == "wf16":
+        assert torch.equal(seg["wf16"][:, :, :cin_p], seg["w_pad"].bfloat16().reshape(1, cin_p, cout_p).permute(0, 2, 1))
+    if bt == "always":
+        assert torch.equal(w6["wt16"], ops.filter_tiles_bf16(w6["w_pad"])), "the tiled images must be refreshed too"
 
 
 def test_bf16_training_tracks_fp32_training():

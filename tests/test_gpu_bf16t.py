@@ -1,5 +1,5 @@
-"""GPU parity of the LDS-DMA bf16 forward / data-gradient kernel (csrc/igemm_b16t.h; BASELINE configs[2] / [3] arithmetic: bf16
-operands, fp32 accumulation) through the C ABI: the tiled filter image bit for bit against a NumPy restatement of its layout, then
+"""GPU parity of the LDS-DMA bf16 forward / data-gradient kernel (csrc/igemm_b16t.h, round 5: 8 MFMA waves on
+v_mfma_f32_16x16x32_bf16 + 4 DMA waves; BASELINE configs[2] / [3] arithmetic: bf16 operands, fp32 accumulation) through the C ABI: the tiled filter image bit for bit against a NumPy restatement of its layout, then
 forward (bias / ReLU / dropout mask) and data gradient (plain / gated) against the fp64 oracle evaluated on the same bf16-rounded
 operands (2e-5: only the fp32 summation order differs), bf16 outputs = the f32 outputs rounded once, every result repeatable bit
 for bit, in every launch layout -- plain tiles, stream-K with slab levels, whole rounds + stream-K tail -- forced onto small
@@ -26,7 +26,7 @@ def _rel(got, want):
 
 
 def _tiles_ref(w, dgrad):
-    """[tap][k / 32][rows padded to 256][4 slots x 8], slot s of row r = k chunk s ^ ((r >> 2) & 3); bf16 bit patterns."""
+    """[tap][k / 32][rows padded to 256][4 slots x 8], slot s of row r = k chunk s ^ ((-(r >> 2)) & 3); bf16 bit patterns."""
     import torch
     KH, KW, Cin, Cout = w.shape
     wb = torch.tensor(w).bfloat16().view(torch.int16).numpy().reshape(KH * KW, Cin, Cout)
@@ -36,7 +36,7 @@ def _tiles_ref(w, dgrad):
     out = np.zeros((taps, kdim // 32, rp, 4, 8), np.int16)
     for r in range(rows):
         for s in range(4):
-            c = s ^ ((r >> 2) & 3)
+            c = s ^ ((-(r >> 2)) & 3)
             out[:, :, r, s, :] = m[:, r, :].reshape(taps, kdim // 32, 4, 8)[:, :, c, :]
     return out.reshape(-1)
 
@@ -64,26 +64,17 @@ SMALL = [
     ((2, 16, 16, 128, 256, 4, 4), 5),      # 4x4 rate 4 (fc6's filter), 16 taps
     ((1, 25, 25, 32, 48, 3, 12), 256),     # rate 12 reaches far outside the map
     ((2, 30, 18, 160, 288, 3, 1), 7),
-    ((2, 21, 20, 128, 320, 3, 1), 4),      # Cin and Cout multiples of 64: the 128-byte-piece kernel, both directions, stream-K
-    ((1, 33, 31, 192, 64, 3, 2), 256),     # odd number of double steps per tap group (3 x 64 channels)
-    ((2, 40, 33, 64, 128, 3, 1), 3),       # 128 output columns: 512 x 128 tiles (6 of them on 3 "CUs": stream-K); data gradient into 64: 512 x 64
-    ((3, 57, 31, 128, 96, 3, 1), 256),     # 96 columns in a 128-wide tile, 11 M tiles with a tail, plain tiles
-    ((1, 70, 50, 32, 64, 3, 1), 2),        # 64 columns: 512 x 64 tiles, only waves 0-3 fetch filter rows; 7 tiles on 2 "CUs"
+    ((2, 21, 20, 128, 320, 3, 1), 4),      # both directions stream-K
+    ((1, 33, 31, 192, 64, 3, 2), 256),     # 6 K steps per tap: pieces of 1 .. 5 steps exercise all three bodies of the fragment rotation
+    ((2, 40, 33, 64, 128, 3, 1), 3),       # 128 output columns in a 256-wide tile (zero filter rows); 11 M tiles on 3 "CUs": stream-K
+    ((3, 57, 31, 128, 96, 3, 1), 256),     # 96 columns, 21 M tiles with a tail, plain tiles
+    ((1, 70, 50, 32, 64, 3, 1), 2),        # 64 columns; 14 tiles on 2 "CUs"; 9 K steps per tile
+    ((1, 16, 16, 32, 256, 1, 1), 256),     # ONE K step per tile: prologue and closing barriers only
 ]
 
 
-@pytest.fixture(params=["narrow", "wide"])
-def variant(request):
-    """narrow = igemm_b16t_kernel (64-byte activation pieces; the default); wide = igemm_b16w_kernel (128-byte pieces, double steps of 64
-    channels) wherever the gathered channel count is a multiple of 64 (tune bf16_tile = 64), the narrow kernel elsewhere."""
-    import em_adapt_tensorflow_amd.ops as ops
-    ops.tune_set("bf16_tile", 64 if request.param == "wide" else 0)
-    yield request.param
-    ops.tune_set("bf16_tile", 0)
-
-
 @pytest.mark.parametrize("shape,cus", SMALL)
-def test_b16t_small_shapes_every_layout(env, shape, cus, variant):
+def test_b16t_small_shapes_every_layout(env, shape, cus):
     ops, do, torch = env
     B, H, W, Cin, Cout, k, dil = shape
     rng = np.random.default_rng(hash(shape) % (1 << 31))
@@ -109,8 +100,7 @@ def test_b16t_small_shapes_every_layout(env, shape, cus, variant):
             assert torch.equal(ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg), got.bfloat16())
         # same sums as the round-1 kernel up to the order of the K steps
         wf, _ = ops.weights_to_bf16(wg, want_dgrad=False)
-        with ops.tuned(bf16_tile=0):        # (64 is not a tile of the round-1 kernel)
-            old = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=True, keep_prob=0.5, drop_mask=mg)
+        old = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=True, keep_prob=0.5, drop_mask=mg)
         assert _rel(got.cpu(), old.cpu()) < 2e-5
     if Cout % 32 == 0:                       # data gradient: the roles of Cin / Cout swap
         dy = torch.tensor(rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)).bfloat16()

@@ -267,6 +267,37 @@ def test_stream_k_combine_inside_the_launch_sees_fresh_partial_tiles(env, layer,
         assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(dx).all())
 
 
+def test_stream_k_combine_with_the_slabs_left_by_another_shape(env):
+    """Stale-line check of the in-launch combine ("memory-model contract"): launches of DIFFERENT shapes alternate, so every
+    slab and arrival word a launch reads was last written by a launch with another tile count, another piece list and other values
+    (conv4_2: 212 tiles x 288 K steps, conv3_2: 411 x 144, fc6's data gradient over packed rows: 3392 units per CU) -- a head that
+    read a line cached from the previous launch, or that saw a flag of the previous launch before this launch's memset node, would
+    combine a foreign partial tile.  Each result against the one-workgroup-per-tile plan (2e-5) and bitwise against its repeat."""
+    ops, do, torch = env
+    shapes = [(16, 41, 41, 512, 512, 3, 1), (16, 81, 81, 256, 256, 3, 1), (16, 41, 41, 512, 1024, 4, 4)]
+    g = torch.Generator(device="cuda").manual_seed(31)
+    ws, xs = [], []
+    for B, H, W, Cin, Cout, k, dil in shapes:
+        ws.append((torch.randn((k, k, Cin, Cout), device="cuda", generator=g) * float(np.sqrt(2.0 / (k * k * Cin))),
+                   torch.randn((Cout,), device="cuda", generator=g) * 0.1))
+    assert ops.status_poll(clear=True, raise_on_error=False) == 0
+    for it in range(3):
+        outs = []
+        for (B, H, W, Cin, Cout, k, dil), (w, b) in zip(shapes, ws):
+            assert ops.conv_plan(B, H, W, Cin, Cout, k, dil)[0] == 5 and ops.conv_plan(B, H, W, Cin, Cout, k, dil, dgrad=True)[0] == 5
+            x = torch.randn((B, H, W, Cin), device="cuda", generator=g).relu_() * (1.0 + it)
+            dy = torch.randn((B, H, W, Cout), device="cuda", generator=g) * (2.0 - 0.5 * it)
+            outs.append((x, dy, ops.conv_fwd(x, w, b, dil, relu=True), ops.conv_dgrad(dy, w, dil, gate=x)))   # back to back, no sync
+        for (B, H, W, Cin, Cout, k, dil), (w, b), (x, dy, y, dx) in zip(shapes, ws, outs):
+            with ops.tuned(fp32_tile=4, splitk=1, fp32_loader=2):
+                y4 = ops.conv_fwd(x, w, b, dil, relu=True)
+                dx4 = ops.conv_dgrad(dy, w, dil, gate=x)
+            assert float((y - y4).abs().max()) <= 2e-5 * float(y4.abs().max()), (it, Cout)
+            assert float((dx - dx4).abs().max()) <= 2e-5 * float(dx4.abs().max()), (it, Cout)
+            assert torch.equal(y, ops.conv_fwd(x, w, b, dil, relu=True)) and torch.equal(dx, ops.conv_dgrad(dy, w, dil, gate=x))
+    assert ops.status_poll(clear=True, raise_on_error=False) == 0
+
+
 @pytest.mark.parametrize("layer,shape", [("conv4_2", (16, 41, 41, 512, 512, 3, 1)), ("conv3_2", (16, 81, 81, 256, 256, 3, 1))])
 def test_stream_k_combine_when_not_every_workgroup_is_resident(env, layer, shape):
     """A stream-K launch laid out for MORE workgroups than the chip holds (tune plan_cus = 384 on 256 CUs; the kernel takes a whole

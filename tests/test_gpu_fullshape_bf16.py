@@ -94,19 +94,19 @@ def test_bf16_benchmark_shape_against_fp64_oracle_on_rounded_operands(env, name,
     assert torch.equal(ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg, gate_scale=scale), dx1.bfloat16())   # bf16 gate -> bf16 dx
     del dx1
 
-    # the LDS-DMA kernels (csrc/igemm_b16t.h; opt-in at the C ABI) at the same shapes: 64-byte and 128-byte activation pieces,
-    # whole rounds + stream-K tail (fc6 / fc7 forward) resp. stream-K over everything, bf16 outputs
+    # the LDS-DMA kernel (csrc/igemm_b16t.h: 8 MFMA waves on v_mfma_f32_16x16x32_bf16 + 4 DMA waves, round 5) at the same shapes:
+    # whole rounds + stream-K tail (fc6 / fc7 forward) resp. stream-K over everything, f32 and bf16 outputs
     d = ops.conv_desc(B, H, W, Cin, Cout, k, k, dil)
     if ops.conv_bf16t_supported(d, "fwd") and ops.conv_bf16t_supported(d, "dgrad"):
         wt, wtd = ops.filter_tiles_bf16(wg), ops.filter_tiles_bf16(wg, dgrad=True)
-        for piece in (0, 64):
-            with ops.tuned(bf16_tile=piece):
-                yt = ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, out_dtype=torch.float32, **kw)
-                assert _rel(yt.cpu(), want_y) < 2e-5, piece
-                assert torch.equal(yt, ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, out_dtype=torch.float32, **kw)), piece
-                dxt = ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=xg.float(), gate_scale=scale)
-                assert _rel(dxt.cpu(), want_dx) < 2e-5, piece
-                del yt, dxt
+        yt = ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, out_dtype=torch.float32, **kw)
+        assert _rel(yt.cpu(), want_y) < 2e-5
+        assert torch.equal(yt, ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, out_dtype=torch.float32, **kw))
+        assert torch.equal(ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, **kw), yt.bfloat16())
+        dxt = ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=xg.float(), gate_scale=scale)
+        assert _rel(dxt.cpu(), want_dx) < 2e-5
+        assert torch.equal(ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=xg, gate_scale=scale), dxt.bfloat16())
+        del yt, dxt
 
     # filter gradient
     dw1 = ops.conv_wgrad_bf16(xg, dyg, k, k, dil)
