@@ -795,11 +795,11 @@ PlanBT plan_b16t(const IgemmArgs &a) {
     return p;
 }
 
+// stream-K launches with shared tiles: [arrival words, padded][one 256 KB accumulator image per workgroup] (igemm_v2.h)
 size_t bt_workspace_bytes(const IgemmArgs &a) {
     const PlanBT p = plan_b16t(a);
-    size_t b = (size_t)p.main_levels * p.main_rows * a.N * sizeof(float);
-    if (p.main_rows < a.M && p.tail_levels > 0) b += (size_t)p.tail_levels * (a.M - p.main_rows) * a.N * sizeof(float);
-    return b;
+    const bool shared = (p.main_sk && p.main_levels > 0) || (p.main_rows < a.M && p.tail_levels > 0);
+    return shared ? streamk_workspace_bytes(plan_cus()) : 0;
 }
 
 template <bool SK, bool YBF>
@@ -815,9 +815,13 @@ int dispatch_b16t(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStre
     a.pk.rowmap = nullptr;
     a.m_begin = 0;
     a.m_end = p.main_rows;
+    auto sk_ws = [&](int levels) {   // the stream-K workspace: arrival words, then the accumulator images
+        a.sk_flags = levels > 0 ? static_cast<unsigned *>(workspace) : nullptr;
+        a.slab = levels > 0 ? reinterpret_cast<float *>(static_cast<char *>(workspace) + streamk_flag_bytes(plan_cus())) : nullptr;
+    };
     if (p.main_sk) {
         a.splits = plan_cus();
-        a.slab = p.main_levels > 0 ? static_cast<float *>(workspace) : nullptr;
+        sk_ws(p.main_levels);
         return launch_bt<true, YBF>(a, stream);
     }
     a.splits = 1;
@@ -828,7 +832,7 @@ int dispatch_b16t(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStre
     a.m_end = a.M;
     if (p.tail_levels < 0) return launch_bt<false, YBF>(a, stream);
     a.splits = plan_cus();
-    a.slab = p.tail_levels > 0 ? static_cast<float *>(workspace) : nullptr;
+    sk_ws(p.tail_levels);
     return launch_bt<true, YBF>(a, stream);
 }
 
@@ -988,15 +992,24 @@ int emadapt_conv_bf16t_supported(const emadapt_conv_desc *d, int kind, int y_dty
 }
 
 /* Where the model sends a layer to this kernel instead of the register-staged one: the shapes it was measured faster on
- * (profiles/r05_bf16t_bench.txt) -- outputs of at least four rounds of 256 x 256 tiles on the CUs, i.e. fc6 / fc7 of the `ref` preset
- * at batch 16 (59 / 49 % of the dense matrix rate against 53 / 47 %).  Launches of one or two rounds (conv3 - conv5: 212 - 411
- * tiles) run stream-K here with a second-stage kernel and lose to the older kernel's single round. */
+ * (profiles/r05_bf16t_bench.txt, same process, same tensors) --
+ *   * outputs of four and more rounds of 256 x 256 tiles on the CUs: fc6 / fc7 of the `ref` preset at batch 16 (forward 60.7 / 51.2 %
+ *     of the dense matrix rate against 53.7 / 48.4 %, data gradient 55.3 / 46.5 against 50.8 / 45.0);
+ *   * one and a half rounds and more with a long reduction (K >= 2304): conv3_2 / conv3_3 (411 tiles, stream-K with the in-launch
+ *     combine: 41.6 / 40.2 % against 39.2 / 37.1), LargeFOV's fc6 forward (424 tiles: 46.5 against 40.0 %);
+ *   * a thousand and more K steps per CU whatever the tile count: fc6's data gradient.
+ * Elsewhere the older kernel stays: a single round of 212 tiles (conv4_x / conv5_x) ties -- stream-K's two prologues, one published and
+ * one combined accumulator image per CU cost what the 17 % of idle CUs do -- short reductions (conv3_1, conv4_1, LargeFOV's fc7:
+ * 32 - 72 K steps per tile) lose to it, and outputs narrower than a tile (conv1_2, conv2_x) waste the tile's MFMAs. */
 int emadapt_conv_bf16t_pays(const emadapt_conv_desc *d, int kind, int y_dtype) {
     if (!emadapt_conv_bf16t_supported(d, kind, y_dtype) || d->B == 0) return 0;
     const long long M = (long long)d->B * d->H * d->W;
-    const int N = kind == 1 ? d->Cin : d->Cout;
-    // (N >= 256: a narrower output wastes the 256-wide tile's MFMAs -- conv1_2 / conv2_x have thousands of tiles and 64 / 128 columns)
-    return N >= 256 && ceil_div(M, 256) * ceil_div(N, 256) >= 4LL * plan_cus() ? 1 : 0;
+    const int N = kind == 1 ? d->Cin : d->Cout, Cx = kind == 1 ? d->Cout : d->Cin;
+    const long long tiles = ceil_div(M, 256) * ceil_div(N, 256), K = (long long)d->KH * d->KW * Cx;
+    const int cus = plan_cus();
+    // (third class: few tiles with a very long reduction -- fc6's data gradient: 212 tiles x 2048 K steps = 1696 steps per CU as one
+    // stream-K launch, 55.3 % against 50.8 % for the older kernel's six-way split-K)
+    return N >= 256 && (tiles >= 4LL * cus || (2 * tiles >= 3LL * cus && K >= 2304) || tiles * (K / 32) >= 1024LL * cus) ? 1 : 0;
 }
 
 size_t emadapt_filter_tiles_bf16_bytes(const emadapt_conv_desc *d, int dgrad) {

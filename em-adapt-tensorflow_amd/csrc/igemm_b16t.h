@@ -34,7 +34,8 @@
 //     own barrier, so the stage of step kt - 1 is still in use when step kt's DMAs are issued: ring of 5 for 3 steps ahead), then a
 //     counted vmcnt wait (two steps stay in flight) and the barrier that publishes step kt + 1.
 //   * work split: plain tiles (XCD-aware order, optional split-K into slab levels) or stream-K (SK: the K steps of all tiles cut
-//     into one piece per CU; partial tiles go to slab levels and streamk_fixup_t_kernel adds them in workgroup order).
+//     into one piece per CU; tiles shared by several workgroups are combined inside the launch like the fp32 kernel's: write-through
+//     accumulator image per workgroup, arrival word, the head's workgroup adds in ascending k and runs the fused epilogue).
 // Requirements: activations stored bf16 (x_dtype = EMADAPT_DT_BF16), Cx % 32 == 0, KH*KW <= 32, N % 8 == 0 for bf16 outputs,
 // images below 2 GiB.  Replaces round 4's igemm_b16t_kernel / igemm_b16w_kernel (8 waves issuing their own DMAs; 64- and 128-byte
 // activation pieces) and their tall-tile instantiations, none of which the model used.
@@ -115,42 +116,6 @@ __global__ void __launch_bounds__(256) filter_tiles_b16_fwd_kernel(const float *
 #pragma unroll
     for (int e = 0; e < 8; e++) v[e] = (__bf16)t[chunk * 8 + e][row_l];
     out[(((long long)tap * G + g) * rows_pad + row) * 4 + slot] = *reinterpret_cast<uint4 *>(&v);
-}
-
-// Stream-K second stage for bf16-storage outputs (the f32 kernels -- igemm_v2.h, igemm_x6p.h -- combine their shared tiles inside the
-// launch since round 4): the tiles that more than one workgroup worked on.  One block = 16 rows of one 256 x 256 tile.
-template <bool YBF, int BM = 256, int BN = 256>
-__global__ void __launch_bounds__(256) streamk_fixup_t_kernel(IgemmArgs a, int G, int nk_all) {
-    constexpr int PARTS = BM / 16, QN = BN / 4, ITS = 16 * QN / 256;   // one block = 16 rows of one BM x BN tile
-    static_assert(ITS >= 1 && 16 * QN % 256 == 0, "tile shape");
-    const int t = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
-    const int tile_m = t / a.tiles_n, tile_n = t - tile_m * a.tiles_n;
-    const long long U = (long long)a.tiles_m * a.tiles_n * nk_all, u0 = (long long)t * nk_all;
-    const int vf = sk_owner(u0, U, G), vl = sk_owner(u0 + nk_all - 1, U, G);
-    const int cnt = vl - vf + 1;
-    if (cnt <= 1) return;
-    const long long mn = (long long)(a.m_end - a.m_begin) * a.N;
-#pragma unroll
-    for (int it = 0; it < ITS; it++) {
-        const int idx = it * 256 + threadIdx.x;
-        const int r = part * 16 + idx / QN;
-        const int row = a.m_begin + tile_m * BM + r;
-        const int col = tile_n * BN + (idx % QN) * 4;
-        if (row >= a.m_end || col >= a.N) continue;
-        const long long o = (long long)row * a.N + col;
-        const float *sp = a.slab + (o - (long long)a.m_begin * a.N);
-        float4 v = *reinterpret_cast<const float4 *>(sp);
-        for (int l = 1; l < cnt; l++) {
-            const float4 u = *reinterpret_cast<const float4 *>(sp + l * mn);
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-        }
-        v.x = epilogue_t<YBF>(a, v.x, col + 0, o + 0);
-        v.y = epilogue_t<YBF>(a, v.y, col + 1, o + 1);
-        v.z = epilogue_t<YBF>(a, v.z, col + 2, o + 2);
-        v.w = epilogue_t<YBF>(a, v.w, col + 3, o + 3);
-        if constexpr (YBF) *reinterpret_cast<uint2 *>(reinterpret_cast<__bf16 *>(a.y) + o) = cvt4(v);
-        else *reinterpret_cast<float4 *>(a.y + o) = v;
-    }
 }
 
 // Tile epilogue of a 64 x 128 block held as 4 x 8 accumulator tiles of the 16 x 16 MFMA (C/D layout: column = lane & 15, row =
@@ -398,6 +363,7 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
             // staging area
             wait_vmcnt<0>();
             __syncthreads();
+            if constexpr (SK) __syncthreads();   // (pairs with the MFMA waves' barrier between a publisher's slab stores and its arrival word)
         } while (SK && next_piece());
         return;
     }
@@ -411,6 +377,7 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
     const int b_base = OPER + (wn * 128 + l15) * BT_ROWB + ((lq ^ bt_swz(l15)) << 4);
     bt_f32x4 acc[4][8];
     bt_bf16x8 av[4], bv[3];
+    int sk_bad = 0;   // (scalar) a publisher of a tile this workgroup heads never arrived
 #pragma unroll
     for (int n = 0; n < 4; n++)
 #pragma unroll
@@ -471,13 +438,75 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();   // (pairs with the DMA waves' closing barrier: no DMA is in flight, nobody reads the ring)
 
-    float *slab_ = lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;
     int lane_e = tid & 63;
     asm volatile("" : "+v"(lane_e));
-    float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (128 + 4));
-    static_assert(BT_MWAVES * 16 * (128 + 4) * 4 <= BT_LDS, "epilogue slabs must fit in the ring");
-    store_acc_tile16<YBF>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+    if constexpr (SK) {
+        // Tiles shared by several workgroups are combined INSIDE the launch, exactly as in the fp32 kernel (igemm_v2.h, note at sk_start:
+        // only a workgroup's FIRST piece can start inside a tile, so it publishes at most one partial tile, early, and a tile's head
+        // is the LAST piece of the workgroup in front): the publisher stores its accumulators in register order -- register
+        // (i * 8 + j) of wave w <-> bytes [(w * 32 + i * 8 + j) * 1024 + lane * 16, +16) of slab[workgroup] -- with write-through (sc1)
+        // stores, every storing wave drains them, the workgroup's barrier follows, ONE lane raises the arrival word; the head polls the
+        // words of the workgroups behind it in turn, reads their slabs with sc1 loads and adds them in ascending k.  The memory-model
+        // contract is DESIGN.md 4.1's (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 hand-off table).
+        const unsigned lane_off = (unsigned)(lane_e * 16);
+        constexpr int kWaveFloats = kSkSlabFloats / BT_MWAVES;
+        if (lvl > 0) {
+            const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(a.slab + (long long)sk_v * kSkSlabFloats + wave * kWaveFloats, 0, kWaveFloats * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), sr, (int)lane_off, (i * 8 + j) * 1024, 16);   // aux 16 = sc1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, ahead of the barrier that precedes the arrival word
+        }
+        if (lvl == 0) {
+            // head of a shared tile (the piece list has moved on: sk_u - nk is this tile's first unit)
+            const int sk_more = __builtin_amdgcn_readfirstlane(sk_owner((long long)(sk_u - nk) + nk_all - 1, sk_units, (int)gridDim.x)) - sk_v;
+            for (int l = 1; l <= sk_more; l++) {
+                const sk_flag_t *f = ((const sk_flag_t *)a.sk_flags) + (sk_v + l);
+                bool ok = false;
+                for (unsigned spins = 0; spins < (a.sk_drop_flag ? (1u << 12) : kSkSpinMax); spins++) {
+                    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the poll)
+                const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(a.slab + (long long)(sk_v + l) * kSkSlabFloats + wave * kWaveFloats, 0, ok ? kWaveFloats * 4 : 0, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    bt_f32x4 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        v[j] = __builtin_bit_cast(bt_f32x4, __builtin_amdgcn_raw_buffer_load_b128(sr, (int)lane_off, (i * 8 + j) * 1024, 16));   // sc1
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[i][j] += v[j];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // (a publisher that never arrived -- a co-tenant kernel that never ends: a NaN in every 16 x 16 block of the tile, which
+                // the epilogue propagates, and the failure in the device status word, raised when the kernel ends)
+                sk_bad |= __builtin_amdgcn_readfirstlane(ok ? 0 : 1);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[i][j][0] = ok ? acc[i][j][0] : __builtin_nanf("");
+            }
+        }
+    }
+    if (!(SK && lvl > 0)) {
+        float *slab_ = !SK && lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;   // (split-K levels of the plain launches)
+        float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (128 + 4));
+        static_assert(BT_MWAVES * 16 * (128 + 4) * 4 <= BT_LDS, "epilogue slabs must fit in the ring");
+        store_acc_tile16<YBF>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+    }
+    if constexpr (SK) {
+        __syncthreads();   // every wave's slab stores were drained ahead of this barrier
+        if (lvl > 0 && tid == 0 && !a.sk_drop_flag)
+            __hip_atomic_store(((sk_flag_t *)a.sk_flags) + sk_v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     } while (SK && next_piece());
+    if constexpr (SK) {
+        if (sk_bad && a.status && (threadIdx.x & 63) == 0)
+            __hip_atomic_fetch_or(a.status, EMADAPT_STATUS_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // a.splits: SK = false -> split-K factor (>= 1; > 1 needs a.slab); SK = true -> number of workgroups (CUs), a.slab for the levels
@@ -501,14 +530,15 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
     const int nk_all = a.K / BT_BK;
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
     if constexpr (SK) {
+        // a.splits = CUs to lay the pieces out for; a.sk_flags / a.slab = the workspace of streamk_workspace_bytes(G) when tiles are shared
         if (a.splits < 1 || tiles * nk_all > 0x7fffffffLL || tiles * 16 > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
         const int G = streamk_grid(tiles, nk_all, a.splits);
         const int levels = streamk_levels(tiles, nk_all, a.splits);
-        if (levels > 0 && !a.slab) return EMADAPT_ERR_WORKSPACE;
+        if (levels > 0) {   // shared tiles: arrival words (zeroed here, ahead of every launch) + one accumulator image per workgroup
+            if (!a.slab || !a.sk_flags) return EMADAPT_ERR_WORKSPACE;
+            EMADAPT_HIP_TRY(hipMemsetAsync(a.sk_flags, 0, streamk_flag_bytes(G), stream));
+        }
         hipLaunchKernelGGL((igemm_b16t_kernel<true, YBF, ABLM>), dim3((unsigned)G), dim3(BT_THREADS), BT_LDS, stream, a);
-        rc = launch_status();
-        if (rc || levels == 0) return rc;
-        hipLaunchKernelGGL((streamk_fixup_t_kernel<YBF, 256, 256>), dim3((unsigned)(tiles * 16)), dim3(256), 0, stream, a, G, nk_all);
         return launch_status();
     } else {
         const long long nblk = tiles * a.splits;

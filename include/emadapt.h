@@ -272,11 +272,15 @@ int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]);
  * Same arithmetic as emadapt_conv_fwd_bf16 / _dgrad_bf16 (bf16 operands rounded RNE, exact products, fp32 sums; the K order of
  * the sum differs), same epilogues, bitwise reproducible.  y_dtype / dx_dtype: EMADAPT_DT_*; the gate has dx's storage type.
  * emadapt_conv_bf16t_supported: 1 when the shape qualifies.  emadapt_conv_bf16t_plan: plan[0] rows of the first launch (whole
- * rounds of 256 x 256 tiles on the CUs), [1] 1 = that launch is stream-K, [2] its slab levels, [3] slab levels of the stream-K
- * launch over the remaining rows (-1: plain tiles; 0 with plan[0] == M: there is none).  (ABI 200) */
+ * rounds of 256 x 256 tiles on the CUs), [1] 1 = that launch is stream-K, [2] the most workgroups that share one of its tiles (0:
+ * every tile whole), [3] the same for the stream-K launch over the remaining rows (-1: plain tiles; 0 with plan[0] == M: there is
+ * none).  Stream-K launches with shared tiles combine them INSIDE the launch (ABI 203; round 4 ran a second kernel over slab
+ * levels): emadapt_conv_bf16t_workspace_bytes is then arrival words + one 256 KB accumulator image per workgroup (64 MB + 1 KB on 256
+ * CUs), 0 otherwise.  (ABI 200) */
 int emadapt_conv_bf16t_supported(const emadapt_conv_desc *d, int kind, int y_dtype);
 /* supported AND measured faster than emadapt_conv_{fwd,dgrad}_bf16 for this shape (four and more rounds of 256 x 256 tiles on the
- * CUs: fc6 / fc7 at batch 16); what the model asks per layer and batch size.  (ABI 203) */
+ * CUs: fc6 / fc7 at batch 16; one and a half rounds and more with K >= 2304: conv3_2 / conv3_3, LargeFOV's fc6 forward); what the
+ * model asks per layer and batch size.  (ABI 203) */
 int emadapt_conv_bf16t_pays(const emadapt_conv_desc *d, int kind, int y_dtype);
 size_t emadapt_filter_tiles_bf16_bytes(const emadapt_conv_desc *d, int dgrad);
 int emadapt_filter_tiles_bf16(const emadapt_conv_desc *d, const float *w, void *tiles, int dgrad, void *stream);
