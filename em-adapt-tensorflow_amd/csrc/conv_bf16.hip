@@ -736,8 +736,18 @@ int launch_wgrad_bf16(const WgradBf16Args &a, hipStream_t stream) {
     return launch_status();
 }
 
+}  // namespace
+
+#include "wgrad_b16t.h"   // the LDS-DMA filter-gradient kernel for bf16-stored tensors (uses WgradBf16Args, the bt_* vector types)
+
+namespace {
+
+// tune "wgrad_gen" = 1 keeps the round-1 kernel everywhere (A/B, parity of both)
 template <bool XBF, bool DBF>
 int launch_wgrad_bf16_plan(const PlanW &p, const WgradBf16Args &a, hipStream_t stream) {
+    if constexpr (XBF && DBF) {
+        if (p.bko == 256 && a.Cin % 256 == 0 && a.N % 8 == 0 && tune(TUNE_WGRAD_GEN) != 1) return launch_wgrad_b16t(a, stream);
+    }
     return p.bko == 256 ? launch_wgrad_bf16<256, 256, 32, XBF, DBF>(a, stream)
          : p.bn == 64   ? launch_wgrad_bf16<128, 64, 64, XBF, DBF>(a, stream)
                         : launch_wgrad_bf16<128, 128, 64, XBF, DBF>(a, stream);

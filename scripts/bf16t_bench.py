@@ -18,6 +18,7 @@ ap.add_argument("--preset", default="ref")
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--tune", default="")
 ap.add_argument("--layers", default="")
+ap.add_argument("--kinds", default="", help="fwd,dgrad,wgrad (wgrad: old = the round-1 kernel via tune wgrad_gen = 1, new = csrc/wgrad_b16t.h where it applies)")
 args = ap.parse_args()
 for kv in filter(None, args.tune.split(",")):
     ops.tune_set(kv.split("=")[0], int(kv.split("=")[1]))
@@ -57,13 +58,22 @@ for name, (H, Cin, Cout, k, dil) in LAYERS:
     y = torch.empty((B, H, H, Cout), dtype=torch.bfloat16, device="cuda")
     dx = torch.empty((B, H, H, Cin), dtype=torch.bfloat16, device="cuda")
     fl = 2.0 * B * H * H * k * k * Cin * Cout
+    dwo = torch.empty((k, k, Cin, Cout), device="cuda")
+
+    def wgrad_old():
+        with ops.tuned(wgrad_gen=1):
+            ops.conv_wgrad_bf16(x, dy, k, k, dil, out=dwo)
+
     for kind, old, new in (("fwd", lambda: ops.conv_fwd_bf16(x, wf, (k, k), b, dil, relu=True, out=y),
                             lambda: ops.conv_fwd_bf16t(x, wt, (k, k), Cout, b, dil, relu=True, out=y)),
                            ("dgrad", lambda: ops.conv_dgrad_bf16(dy, wd, (k, k), dil, gate=x, out=dx),
-                            lambda: ops.conv_dgrad_bf16t(dy, wtd, (k, k), Cin, dil, gate=x, out=dx))):
+                            lambda: ops.conv_dgrad_bf16t(dy, wtd, (k, k), Cin, dil, gate=x, out=dx)),
+                           ("wgrad", wgrad_old, lambda: ops.conv_wgrad_bf16(x, dy, k, k, dil, out=dwo))):
+        if args.kinds and kind not in args.kinds.split(","):
+            continue
         t_old, t_new = timed(old), timed(new)
         tot["old"] += t_old
         tot["new"] += t_new
         print("%-8s %-6s %9.4f %6.1f%%   %9.4f %6.1f%%   %s" % (name, kind, t_old, 100 * fl / t_old / 1e-3 / PEAK, t_new,
-                                                             100 * fl / t_new / 1e-3 / PEAK, ops.conv_bf16t_plan(B, H, H, Cin, Cout, k, dil, kind)), flush=True)
+                                                             100 * fl / t_new / 1e-3 / PEAK, ops.conv_bf16_plan(B, H, H, Cin, Cout, k, dil, kind) if kind == "wgrad" else ops.conv_bf16t_plan(B, H, H, Cin, Cout, k, dil, kind)), flush=True)
 print("sum: old %.3f ms, b16t %.3f ms" % (tot["old"], tot["new"]))
