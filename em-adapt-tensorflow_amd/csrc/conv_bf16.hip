@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_t_kernel(IgemmArgs a) {
 }  // namespace
 
 #include "igemm_b16t.h"   // the LDS-DMA kernel for bf16-stored activations (uses epilogue_t / cvt4 / splitk_epilogue_t_kernel above)
+#include "conv_p3.h"      // the patch kernel for the 3 x 3 layers with 128 and fewer output columns
 
 namespace {
 
@@ -394,7 +395,8 @@ struct PlanG {
 };
 
 PlanG plan_bf16(const IgemmArgs &a) {
-    const int force = tune(TUNE_BF16_TILE);  // 128|256 forces a configuration (the parity tests run both on small shapes)
+    int force = tune(TUNE_BF16_TILE);  // 128|256 forces a configuration (the parity tests run both on small shapes)
+    if (force == 1 || force == 3) force = 0;   // (1: automatic without the patch kernel; 3: the patch kernel where eligible -- both: this plan elsewhere)
     PlanG p;
     const long long t256 = ceil_div(a.M, 256) * ceil_div(a.N, 256);
     p.big = (a.N >= 256 && t256 >= 192) ? 1 : 0;
@@ -434,6 +436,18 @@ int launch_igemm_bf16(IgemmArgs &a, int Cxp, hipStream_t stream) {
 
 template <bool XBF, bool YBF>
 int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    // 3 x 3 layers with N <= 128 on bf16-stored activations: the patch kernel (conv_p3.h), OPT-IN (tune "bf16_tile" = 3): measured in the
+    // step it is 0.5 % behind the implicit-GEMM kernels it would replace (profiles/r05_p3_patch_kernel.txt: per layer 9 - 11 % ahead in
+    // isolation, but a K step of these layers is 16 - 32 MFMAs and the step-wise barrier of eight waves, the DMA issue rate and the
+    // per-tile epilogue each cost as much as the MFMAs)
+    if constexpr (XBF) {
+        const int force = tune(TUNE_BF16_TILE);
+        if (force == 3 && p3_ok(a, true)) {
+            a.m_begin = 0;
+            a.m_end = a.M;
+            return launch_p3<YBF>(a, Cxp, stream);
+        }
+    }
     PlanG p = plan_bf16(a);
     if (p.splits > 1 && (!workspace || workspace_bytes < igemm_bf16_workspace_bytes(a))) p.splits = 1;
 #ifdef EMADAPT_ABLATE_BUILD
@@ -683,9 +697,9 @@ PlanW make_plan_bf16(const emadapt_conv_desc *d) {
     PlanW p;
     const long long M = (long long)d->B * d->H * d->W;
     const int K = d->KH * d->KW * d->Cin;
-    const int force = tune(TUNE_BF16_TILE);  // 128|256 (the parity tests run both)
+    const int force = tune(TUNE_BF16_TILE);  // 128|256 (the parity tests run both; 1 / 3 concern the forward / data-gradient patch kernel only)
     bool big = K >= 256 && d->Cout >= 256;
-    if (force) big = force == 256;
+    if (force == 128 || force == 256) big = force == 256;
     p.bko = big ? 256 : 128;
     p.bn = big ? 256 : (d->Cout <= 64 ? 64 : 128);
     p.tiles_k = (int)ceil_div(K, p.bko);
@@ -883,6 +897,12 @@ int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]) {
     IgemmArgs a;
     int Cxp;
     fill_geometry_bf16(a, Cxp, d, kind == 1);
+    if (tune(TUNE_BF16_TILE) == 3 && d->B > 0 && p3_ok(a, true)) {   // (opt-in; bf16-stored activations assumed: what the model keeps)
+        P3Geo g;
+        p3_geometry(d->B, d->H, d->W, d->dil, g);
+        plan[0] = 3; plan[1] = g.TH; plan[2] = g.TW;
+        return EMADAPT_OK;
+    }
     const PlanG p = plan_bf16(a);
     plan[0] = p.big ? 256 : 128;
     plan[1] = p.big ? 256 : p.narrow ? 64 : 128;

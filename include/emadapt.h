@@ -259,7 +259,12 @@ int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dty
                             float *dw, void *workspace, size_t workspace_bytes, void *stream);
 /* The plan a bf16 launch will take for this shape (kind 0 forward, 1 data gradient, 2 filter gradient): plan[0] x plan[1] = the
  * output tile (forward / data gradient: pixels x channels, 256 x 256 or 128 x 128; filter gradient: filter rows x columns),
- * plan[2] = split-K / split-M factor.  The parity tests assert through it that the benchmark shapes run the big tiles.  (ABI 200) */
+ * plan[2] = split-K / split-M factor.  The parity tests assert through it that the benchmark shapes run the big tiles.  (ABI 200)
+ * ABI 203: with tune "bf16_tile" = 3 (opt-in) plan[0] == 3 for forward / data gradient = the PATCH kernel (csrc/conv_p3.h: 3 x 3
+ * filters, rate 1 or 2, at most 128 output columns, gathered channels a multiple of 32, bf16-stored activations -- conv1_2, conv2_x
+ * and the data gradients into 64 / 128 channels): the input patch of a plan[1] x plan[2]-pixel output tile is staged in LDS once per
+ * 32 channels and read by all nine taps (the implicit-GEMM kernels fetch every activation nine times); same arithmetic model, same
+ * epilogues, bitwise reproducible.  Not the default: it ties the implicit-GEMM kernels in the step. */
 int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]);
 
 /* ---- bf16 forward / data gradient on LDS-DMA (csrc/igemm_b16t.h; round 5: 8 MFMA wavefronts on v_mfma_f32_16x16x32_bf16 + 4 DMA
@@ -440,7 +445,8 @@ int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *p
  *                A forced variant the shape is not eligible for is ignored.
  *   "wgrad_gen"  1: 128x128 wave-specialised filter-gradient kernel | 2: 256x256 second generation (LDS-DMA loaders)
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
- *   "bf16_tile"  128 | 256 (emadapt_conv_*_bf16: 128 also keeps the 128-wide tile where 128 x 64 would be chosen)
+ *   "bf16_tile"  128 | 256 (emadapt_conv_*_bf16: 128 also keeps the 128-wide tile where 128 x 64 would be chosen); 3: the patch kernel
+ *                (csrc/conv_p3.h) for the 3 x 3 layers with at most 128 output columns on bf16-stored activations, automatic elsewhere
  *   "x6_tile"    128 | 256
  *   "plan_cus"   number of CUs the launch plans are laid out for (default 256: MI355X)
  *   "fp32_loader" 1: the 256x256 fp32 kernels' loader waves compute their offsets per K step (works for any tap count);
