@@ -98,6 +98,8 @@ enum TuneKey {
     TUNE_WGRAD_BIAS,   // 1: emadapt_conv_wgrad_bias_fused() answers 0 everywhere (the separate bias-gradient kernel: A/B, tests)
     TUNE_SK_DROP_FLAG, // tests only: 1 = the stream-K publishers do not raise their arrival words and the heads give up after 2^12 polls
                        //    -- exercises the bounded wait (a shared tile then comes out as NaNs instead of hanging the queue)
+    TUNE_BF16T_SK,     // 1: the LDS-DMA bf16 kernel's launches run stream-K over ALL rows whatever N (default: N > 1024 runs the rows of whole
+                       //    rounds as plain tiles + a stream-K tail); A/B
     TUNE_COUNT
 };
 int tune(TuneKey key);

@@ -805,7 +805,10 @@ PlanBT plan_b16t(const IgemmArgs &a) {
     const int bk = BT_BK;
     const int nk = a.K / bk;
     if (t % cus == 0 || t * nk * bk / cus < 16 * BT_BK) return p;   // whole rounds, or too little work per CU to cut into pieces
-    if (a.N <= 1024 || t < cus) {
+    // one round that fills at least three quarters of the CUs (conv4_x / conv5_x: 212 tiles): plain tiles -- stream-K's second
+    // prologue, published and combined accumulator image per CU cost more than the idle quarter (0.107 against 0.119 ms on conv4_2)
+    if (t <= cus && 4 * t >= 3LL * cus) return p;
+    if (a.N <= 1024 || t < cus || tune(TUNE_BF16T_SK) == 1) {
         p.main_sk = 1;
         p.main_levels = streamk_levels(t, nk, cus);
         return p;
@@ -1028,9 +1031,10 @@ int emadapt_conv_bf16t_supported(const emadapt_conv_desc *d, int kind, int y_dty
  *   * one and a half rounds and more with a long reduction (K >= 2304): conv3_2 / conv3_3 (411 tiles, stream-K with the in-launch
  *     combine: 41.6 / 40.2 % against 39.2 / 37.1), LargeFOV's fc6 forward (424 tiles: 46.5 against 40.0 %);
  *   * a thousand and more K steps per CU whatever the tile count: fc6's data gradient.
- * Elsewhere the older kernel stays: a single round of 212 tiles (conv4_x / conv5_x) ties -- stream-K's two prologues, one published and
- * one combined accumulator image per CU cost what the 17 % of idle CUs do -- short reductions (conv3_1, conv4_1, LargeFOV's fc7:
- * 32 - 72 K steps per tile) lose to it, and outputs narrower than a tile (conv1_2, conv2_x) waste the tile's MFMAs. */
+ *   * a single round of 212 tiles with K >= 4608 (conv4_2 .. conv5_3) as PLAIN tiles (as stream-K it only ties: two prologues, one
+ *     published and one combined accumulator image per CU cost what the 17 % of idle CUs do).
+ * Elsewhere the older kernel stays: short reductions (conv3_1, conv4_1, LargeFOV's fc7: 32 - 72 K steps per tile) lose to it, and
+ * outputs narrower than a tile (conv1_2, conv2_x) waste the tile's MFMAs. */
 int emadapt_conv_bf16t_pays(const emadapt_conv_desc *d, int kind, int y_dtype) {
     if (!emadapt_conv_bf16t_supported(d, kind, y_dtype) || d->B == 0) return 0;
     const long long M = (long long)d->B * d->H * d->W;
@@ -1038,8 +1042,10 @@ int emadapt_conv_bf16t_pays(const emadapt_conv_desc *d, int kind, int y_dtype) {
     const long long tiles = ceil_div(M, 256) * ceil_div(N, 256), K = (long long)d->KH * d->KW * Cx;
     const int cus = plan_cus();
     // (third class: few tiles with a very long reduction -- fc6's data gradient: 212 tiles x 2048 K steps = 1696 steps per CU as one
-    // stream-K launch, 55.3 % against 50.8 % for the older kernel's six-way split-K)
-    return N >= 256 && (tiles >= 4LL * cus || (2 * tiles >= 3LL * cus && K >= 2304) || tiles * (K / 32) >= 1024LL * cus) ? 1 : 0;
+    // stream-K launch, 55.3 % against 50.8 % for the older kernel's six-way split-K; fourth: a single round of at least three quarters
+    // of the CUs with K >= 4608 -- conv4_2 .. conv5_3 as plain tiles: 47 - 50 % against 44 - 45 %)
+    return N >= 256 && (tiles >= 4LL * cus || (2 * tiles >= 3LL * cus && K >= 2304) || tiles * (K / 32) >= 1024LL * cus ||
+                        (tiles <= cus && 4 * tiles >= 3LL * cus && K >= 4608)) ? 1 : 0;
 }
 
 size_t emadapt_filter_tiles_bf16_bytes(const emadapt_conv_desc *d, int dgrad) {

@@ -447,8 +447,11 @@ int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *p
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
  *   "bf16_tile"  128 | 256 (emadapt_conv_*_bf16: 128 also keeps the 128-wide tile where 128 x 64 would be chosen); 3: the patch kernel
  *                (csrc/conv_p3.h) for the 3 x 3 layers with at most 128 output columns on bf16-stored activations, automatic elsewhere
+ *   "bf16t_sk"   1: the tiled-filter bf16 launches (emadapt_conv_*_bf16t) run ALL their tiles as one stream-K launch instead of whole
+ *                rounds of plain tiles + a stream-K launch over the last partial round (A/B aid: measured slower on fc6 / fc7,
+ *                profiles/r05_bf16t_bench.txt)
  *   "x6_tile"    128 | 256
- *   "plan_cus"   number of CUs the launch plans are laid out for (default 256: MI355X)
+ *   "plan_cus"  number of CUs the launch plans are laid out for (default 256: MI355X)
  *   "fp32_loader" 1: the 256x256 fp32 kernels' loader waves compute their offsets per K step (works for any tap count);
  *                0: loaders specialised for 1x1 / 3x3 / 4x4 filters where the filter has that many taps, and the
  *                filter-gradient kernel walks only the pixels at which a tile's tap is inside the image; 2: like 0

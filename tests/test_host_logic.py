@@ -378,7 +378,13 @@ def test_executed_fraction_and_new_plan_queries_without_a_device():
     assert ops.conv_bf16t_supported(d, "fwd") and ops.conv_bf16t_supported(d, "dgrad")
     assert not ops.conv_bf16t_supported(ops.conv_desc(16, 321, 321, 4, 64, 3, 3, 1), "fwd")            # conv1_1: 4 input channels
     rows, sk, levels, tail = ops.conv_bf16t_plan(16, 41, 41, 512, 512, 3, 1)
-    assert rows == 16 * 41 * 41 and sk == 1 and levels >= 2                             # 212 tiles on 256 CUs
+    assert rows == 16 * 41 * 41 and sk == 0 and levels == 0                             # 212 tiles on 256 CUs: one round of plain tiles (round 5)
+    rows, sk, levels, tail = ops.conv_bf16t_plan(16, 81, 81, 256, 256, 3, 1)
+    assert rows == 16 * 81 * 81 and sk == 1 and levels >= 2                             # 411 tiles: stream-K, shared tiles combined in-launch
+    d3, d41 = ops.conv_desc(16, 81, 81, 256, 256, 3, 3, 1), ops.conv_desc(16, 41, 41, 256, 512, 3, 3, 1)
+    assert ops.conv_bf16t_pays(d, "fwd") and ops.conv_bf16t_pays(d, "dgrad") and ops.conv_bf16t_pays(d3, "fwd") and not ops.conv_bf16t_pays(d41, "fwd")
+    assert ops.conv_bf16t_pays(ops.conv_desc(16, 41, 41, 512, 4096, 4, 4, 4), "dgrad")   # fc6's data gradient: 1696 K steps per CU
+    assert not ops.conv_bf16t_pays(ops.conv_desc(16, 161, 161, 128, 128, 3, 3, 1), "fwd")   # narrower than a tile
     rows, sk, levels, tail = ops.conv_bf16t_plan(16, 41, 41, 4096, 4096, 1, 1)
     assert rows == 24576 and sk == 0 and tail >= 1                                     # 6 whole rounds + a stream-K tail
     # tensors of 2 GiB and more: one launch is refused by the 32-bit offsets, the entries slice the batch; workspace = the largest slice's
