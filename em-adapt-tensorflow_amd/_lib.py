@@ -114,6 +114,9 @@ PROTOTYPES = {
                                         _vp]),
     "emadapt_conv_wgrad_bf16_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "emadapt_conv_wgrad_bf16": (c_int, [POINTER(ConvDesc), _vp, c_int, _vp, c_int, _vp, _vp, c_size_t, _vp]),
+    "emadapt_conv_wgrad_bias_bf16_fused": (c_int, [POINTER(ConvDesc), c_int, c_int]),
+    "emadapt_conv_wgrad_bias_bf16_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "emadapt_conv_wgrad_bias_bf16": (c_int, [POINTER(ConvDesc), _vp, c_int, _vp, c_int, _vp, _vp, _vp, c_size_t, _vp]),
     "emadapt_bias_grad_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "emadapt_bias_grad": (c_int, [_vp, c_int64, c_int, _vp, _vp, c_size_t, _vp]),
     "emadapt_maxpool_fwd": (c_int, [_vp, c_int, c_int, c_int, c_int, c_int, _vp, _vp, _vp]),

@@ -31,6 +31,8 @@
 
 namespace emadapt {
 int launch_slab_sum(const float *slab, int nslab, long long n, float *out, hipStream_t stream);
+int launch_slab_sum2(const float *slab_a, int nslab_a, long long n_a, float *out_a, const float *slab_b, int nslab_b, long long n_b,
+                     float *out_b, hipStream_t stream);
 }
 
 namespace {
@@ -498,6 +500,8 @@ struct WgradBf16Args {
     const float *x;   // [B,H,W,Cin]
     const float *dy;  // [M][N]
     float *out;       // dw or slab base: [splits][K][N]
+    float *bias_out;  // null, or the partial column sums of dy (BiasAddGrad): [splits][tiles_k][N] -- the workgroup of k tile t adds up
+                      // the K steps st with st % tiles_k == t of its split and columns (db itself when splits * tiles_k == 1); needs dy stored bf16
     int H, W, Cin, N, KW, dil, pad_h, pad_w;
     int M, K, ntaps;
     int tiles_k, tiles_n, splits;
@@ -582,6 +586,14 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
         const int y_n = n0 + y_nq * YE;
         const bool nvalid = y_n < a.N;
         u32x4 rx[X_N], ry[Y_N];
+        // BiasAddGrad rides along (DBF): every dy piece of the workgroup's pixel range and columns passes through a producer register
+        // exactly once (rows past the range arrive as zeros).  The workgroups that share a pixel range and columns -- one per k tile
+        // -- divide the steps among them (step st belongs to k tile st % tiles_k); each lane keeps the sums of its 8 columns
+        const bool do_bias = DBF && a.bias_out != nullptr;
+        int bias_st = tile_k;   // the next step whose dy pieces this workgroup adds up
+        float bs[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) bs[e] = 0.f;
         auto as_f4 = [](const u32x4 &v) {
             return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         };
@@ -603,10 +615,21 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
             if constexpr (XBF) *reinterpret_cast<u32x4 *>(d) = rx[j];
             else *reinterpret_cast<uint2 *>(d) = cvt4(as_f4(rx[j]));
         };
-        auto store_y = [&](int buf, int j) {
+        auto store_y = [&](int buf, int j, bool sum) {
             char *d = Ys + buf * TILE_Y + (y_r0 + j * Y_RSTEP) * PY + y_nq * (YE * 2);
-            if constexpr (DBF) *reinterpret_cast<u32x4 *>(d) = ry[j];
-            else *reinterpret_cast<uint2 *>(d) = cvt4(as_f4(ry[j]));
+            if constexpr (DBF) {
+                *reinterpret_cast<u32x4 *>(d) = ry[j];
+                if (sum) {
+                    const unsigned w4[4] = {ry[j].x, ry[j].y, ry[j].z, ry[j].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        bs[2 * e] += __uint_as_float(w4[e] << 16);
+                        bs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+                    }
+                }
+            } else {
+                *reinterpret_cast<uint2 *>(d) = cvt4(as_f4(ry[j]));
+            }
         };
 #pragma unroll
         for (int j = 0; j < X_N; j++) load_x(m_begin, j);
@@ -614,8 +637,12 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
         for (int j = 0; j < Y_N; j++) load_y(m_begin, j);
 #pragma unroll
         for (int j = 0; j < X_N; j++) { store_x(0, j); load_x(m_begin + BMR, j); }  // rows >= m_end: zero-filled
+        {
+            const bool sum = do_bias && bias_st == 0;
+            if (sum) bias_st += a.tiles_k;
 #pragma unroll
-        for (int j = 0; j < Y_N; j++) { store_y(0, j); load_y(m_begin + BMR, j); }
+            for (int j = 0; j < Y_N; j++) { store_y(0, j, sum); load_y(m_begin + BMR, j); }
+        }
         __syncthreads();
         // steady state: park register j in LDS, re-arm it with the load of the step after next (loads stay in flight)
         for (int st = 0; st < nsteps; st++) {
@@ -623,9 +650,29 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
             const int mb = m_begin + (st + 2) * BMR;
 #pragma unroll
             for (int j = 0; j < X_N; j++) { store_x(buf, j); load_x(mb, j); }
+            const bool sum = do_bias && bias_st == st + 1;   // (this iteration parks step st + 1)
+            if (sum) bias_st += a.tiles_k;
 #pragma unroll
-            for (int j = 0; j < Y_N; j++) { store_y(buf, j); load_y(mb, j); }
+            for (int j = 0; j < Y_N; j++) { store_y(buf, j, sum); load_y(mb, j); }
             __syncthreads();
+        }
+        if constexpr (DBF) {
+            if (do_bias) {   // (workgroup-uniform: the MFMA waves meet the barrier below too)
+                // lanes of a wave with the same columns (lane % YQ), then the four producer waves through the idle X stage, in a fixed order
+#pragma unroll
+                for (int sft = YQ; sft < 64; sft <<= 1)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) bs[e] += __shfl_xor(bs[e], sft);
+                float *sh = reinterpret_cast<float *>(ldsb);   // [4][BN]
+                const int lane = tid & 63, pw = tid >> 6;
+                if (lane < YQ) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) sh[pw * BN + lane * 8 + e] = bs[e];
+                }
+                __syncthreads();
+                if (tid < BN && n0 + tid < a.N)
+                    a.bias_out[((long long)split * a.tiles_k + tile_k) * a.N + n0 + tid] = (sh[tid] + sh[BN + tid]) + (sh[2 * BN + tid] + sh[3 * BN + tid]);
+            }
         }
         return;
     }
@@ -672,6 +719,7 @@ __global__ void __launch_bounds__((BKO / 64 * 2 + 4) * 64, BKO == 128 ? 4 : 3) w
         }
         __syncthreads();
     }
+    if (DBF && a.bias_out != nullptr) __syncthreads();   // (the producers' bias-gradient exchange)
     float *out = a.out + (long long)split * a.K * a.N;
 #pragma unroll
     for (int i = 0; i < TK; i++)
@@ -983,26 +1031,31 @@ size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d) {
     return (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
 }
 
-int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
-                            float *dw, void *workspace, size_t workspace_bytes, void *stream_) {
+static int wgrad_bf16_impl(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
+                           float *dw, float *db, void *workspace, size_t workspace_bytes, void *stream_) {
     int rc = check_desc_wgrad(d);
     if (rc) return rc;
     if (!x || !dy || !dw) return EMADAPT_ERR_INVALID;
     if ((x_dtype | dy_dtype) & ~1) return EMADAPT_ERR_INVALID;
     if ((x_dtype && d->Cin % 8 != 0) || (dy_dtype && d->Cout % 8 != 0)) return EMADAPT_ERR_UNSUPPORTED;
-    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(workspace)) return EMADAPT_ERR_INVALID;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(workspace) || !aligned16(db)) return EMADAPT_ERR_INVALID;
     hipStream_t stream = as_stream(stream_);
     const long long KN = (long long)d->KH * d->KW * d->Cin * d->Cout;
     if (d->B == 0) {
         EMADAPT_HIP_TRY(hipMemsetAsync(dw, 0, KN * sizeof(float), stream));
+        if (db) EMADAPT_HIP_TRY(hipMemsetAsync(db, 0, (size_t)d->Cout * sizeof(float), stream));
         return EMADAPT_OK;
     }
     const PlanW p = make_plan_bf16(d);
-    if (p.splits > 1 && (!workspace || workspace_bytes < emadapt_conv_wgrad_bf16_workspace_bytes(d)))
-        return EMADAPT_ERR_WORKSPACE;
+    // workspace: [splits][K][N] partial filter gradients (splits > 1), then [splits][tiles_k][N] partial bias gradients (more than one row)
+    const long long w_floats = p.splits > 1 ? (long long)p.splits * KN : 0;
+    const int b_rows = db ? p.splits * p.tiles_k : 0;
+    const long long b_floats = b_rows > 1 ? (long long)b_rows * d->Cout : 0;
+    if (w_floats + b_floats > 0 && (!workspace || workspace_bytes < (size_t)(w_floats + b_floats) * sizeof(float))) return EMADAPT_ERR_WORKSPACE;
     WgradBf16Args a;
     a.x = static_cast<const float *>(x); a.dy = static_cast<const float *>(dy);
     a.out = p.splits > 1 ? static_cast<float *>(workspace) : dw;
+    a.bias_out = !db ? nullptr : b_rows > 1 ? static_cast<float *>(workspace) + w_floats : db;
     a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.N = d->Cout; a.KW = d->KW; a.dil = d->dil;
     a.pad_h = conv_pad_before(d->KH, d->dil); a.pad_w = conv_pad_before(d->KW, d->dil);
     a.M = d->B * d->H * d->W; a.ntaps = d->KH * d->KW; a.K = a.ntaps * d->Cin;
@@ -1014,8 +1067,38 @@ int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dty
     rc = x_dtype ? (dy_dtype ? launch_wgrad_bf16_plan<true, true>(p, a, stream) : launch_wgrad_bf16_plan<true, false>(p, a, stream))
                  : (dy_dtype ? launch_wgrad_bf16_plan<false, true>(p, a, stream) : launch_wgrad_bf16_plan<false, false>(p, a, stream));
     if (rc) return rc;
-    if (p.splits > 1) rc = launch_slab_sum(static_cast<const float *>(workspace), p.splits, KN, dw, stream);
-    return rc;
+    // one second-stage launch finishes both gradients (each in a fixed order)
+    return launch_slab_sum2(static_cast<const float *>(workspace), p.splits, p.splits > 1 ? KN : 0, dw,
+                            static_cast<const float *>(workspace) + w_floats, b_rows, b_floats ? d->Cout : 0, db, stream);
+}
+
+int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
+                            float *dw, void *workspace, size_t workspace_bytes, void *stream_) {
+    return wgrad_bf16_impl(d, x, x_dtype, dy, dy_dtype, dw, nullptr, workspace, workspace_bytes, stream_);
+}
+
+int emadapt_conv_wgrad_bias_bf16_fused(const emadapt_conv_desc *d, int x_dtype, int dy_dtype) {
+    if (check_desc_wgrad(d) != EMADAPT_OK || ((x_dtype | dy_dtype) & ~1)) return 0;
+    if (tune(TUNE_WGRAD_BIAS) == 1) return 0;
+    return dy_dtype == EMADAPT_DT_BF16 && d->Cout % 8 == 0 && (!x_dtype || d->Cin % 8 == 0) ? 1 : 0;
+}
+
+size_t emadapt_conv_wgrad_bias_bf16_workspace_bytes(const emadapt_conv_desc *d) {
+    if (check_desc_wgrad(d) != EMADAPT_OK || d->B == 0) return 0;
+    const PlanW p = make_plan_bf16(d);
+    const size_t w_floats = p.splits > 1 ? (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout : 0;
+    const size_t b_rows = (size_t)p.splits * p.tiles_k;
+    return (w_floats + (b_rows > 1 ? b_rows * d->Cout : 0)) * sizeof(float);
+}
+
+int emadapt_conv_wgrad_bias_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
+                                 float *dw, float *db, void *workspace, size_t workspace_bytes, void *stream_) {
+    if (!db) return EMADAPT_ERR_INVALID;
+    if (!emadapt_conv_wgrad_bias_bf16_fused(d, x_dtype, dy_dtype)) {
+        const int rc = check_desc_wgrad(d);
+        return rc ? rc : EMADAPT_ERR_UNSUPPORTED;
+    }
+    return wgrad_bf16_impl(d, x, x_dtype, dy, dy_dtype, dw, db, workspace, workspace_bytes, stream_);
 }
 
 /* ---- LDS-DMA kernel on bf16-stored activations and a TILED filter image (igemm_b16t.h) ---- */

@@ -287,40 +287,53 @@ __global__ void __launch_bounds__(256) bias_grad_partial_kernel(const T *__restr
 // stage 2 (also used by the conv filter-gradient): out[i] = sum_s slab[s][i].
 // block = 64 float4 columns x 4 slab lanes; lane g adds slabs g, g+4, g+8, .. (4 independent loads in flight per
 // step), then the four lane sums are combined as ((l0+l1)+(l2+l3)): a fixed tree -> bitwise reproducible.
-__global__ void __launch_bounds__(256) slab_sum_kernel(const float *__restrict__ slab, int nslab, long long n4,
-                                                     float *__restrict__ out) {
+// Two independent segments in one launch (a filter gradient's slabs + the bias-gradient partial rows of the same launch,
+// conv_bf16.hip): float4 index i < n4a belongs to segment a, the rest to segment b (its own slab count and row length n4b).
+struct SlabSumSeg {
+    const float *slab;
+    float *out;
+    long long n4;
+    int nslab;
+};
+
+__global__ void __launch_bounds__(256) slab_sum_kernel(SlabSumSeg sa, SlabSumSeg sb) {
     __shared__ float4 sh[4][64];
     const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long long n4 = sa.n4 + sb.n4;
     for (long long i0 = (long long)blockIdx.x * 64; i0 < n4; i0 += (long long)gridDim.x * 64) {
-        const long long i = i0 + tx;
+        const long long ig = i0 + tx;
+        const bool second = ig >= sa.n4;
+        const float *slab = second ? sb.slab : sa.slab;
+        const long long sn4 = second ? sb.n4 : sa.n4, i = second ? ig - sa.n4 : ig;
+        const int nslab = second ? sb.nslab : sa.nslab;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n4) {
+        if (ig < n4) {
             int k = g;
             for (; k + 12 < nslab; k += 16) {
-                const float4 v0 = ld4(slab + ((long long)k * n4 + i) * 4);
-                const float4 v1 = ld4(slab + ((long long)(k + 4) * n4 + i) * 4);
-                const float4 v2 = ld4(slab + ((long long)(k + 8) * n4 + i) * 4);
-                const float4 v3 = ld4(slab + ((long long)(k + 12) * n4 + i) * 4);
+                const float4 v0 = ld4(slab + ((long long)k * sn4 + i) * 4);
+                const float4 v1 = ld4(slab + ((long long)(k + 4) * sn4 + i) * 4);
+                const float4 v2 = ld4(slab + ((long long)(k + 8) * sn4 + i) * 4);
+                const float4 v3 = ld4(slab + ((long long)(k + 12) * sn4 + i) * 4);
                 s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
                 s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
                 s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
                 s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
             }
             for (; k < nslab; k += 4) {
-                const float4 v = ld4(slab + ((long long)k * n4 + i) * 4);
+                const float4 v = ld4(slab + ((long long)k * sn4 + i) * 4);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
         }
         sh[g][tx] = s;
         __syncthreads();
-        if (g == 0 && i < n4) {
+        if (g == 0 && ig < n4) {
             const float4 a = sh[0][tx], b = sh[1][tx], c = sh[2][tx], d = sh[3][tx];
             float4 r;
             r.x = (a.x + b.x) + (c.x + d.x);
             r.y = (a.y + b.y) + (c.y + d.y);
             r.z = (a.z + b.z) + (c.z + d.z);
             r.w = (a.w + b.w) + (c.w + d.w);
-            st4(out + i * 4, r);
+            st4((second ? sb.out : sa.out) + i * 4, r);
         }
         __syncthreads();
     }
@@ -621,7 +634,17 @@ namespace emadapt {
 // used by conv_wgrad.hip
 int launch_slab_sum(const float *slab, int nslab, long long n, float *out, hipStream_t stream) {
     if (n % 4 != 0) return EMADAPT_ERR_INVALID;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 64, 4096)), dim3(256), 0, stream, slab, nslab, n / 4, out);
+    const SlabSumSeg sa = {slab, out, n / 4, nslab}, sb = {nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 64, 4096)), dim3(256), 0, stream, sa, sb);
+    return launch_status();
+}
+// two independent sums in one launch: out_a[i] = sum over nslab_a slabs of n_a floats, out_b likewise (either may be empty: n = 0)
+int launch_slab_sum2(const float *slab_a, int nslab_a, long long n_a, float *out_a, const float *slab_b, int nslab_b, long long n_b,
+                     float *out_b, hipStream_t stream) {
+    if (n_a % 4 != 0 || n_b % 4 != 0) return EMADAPT_ERR_INVALID;
+    if (n_a + n_b == 0) return EMADAPT_OK;
+    const SlabSumSeg sa = {slab_a, out_a, n_a / 4, nslab_a}, sb = {slab_b, out_b, n_b / 4, nslab_b};
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for((n_a + n_b) / 4, 64, 4096)), dim3(256), 0, stream, sa, sb);
     return launch_status();
 }
 }  // namespace emadapt

@@ -98,6 +98,31 @@ __global__ void __launch_bounds__(WT_THREADS, 3) wgrad_b16t_kernel(WgradBf16Args
             yok[j] = n0 + c * 8 < a.N;
         }
         const int x_shift = (dh * a.W + dw) * a.Cin * 2;   // bytes from a pixel to the pixel its tap reads
+        // BiasAddGrad rides along: the DMA waves add up the dy stage that has just landed -- wave lw owns the 16-byte chunks 8 lw ..
+        // 8 lw + 7 (64 columns), lane -> chunk lane & 7 and the pixels 4 (lane >> 3) + r of the step (four ds_read_b128).  The DMA
+        // waves are NOT idle enough to do that every step (measured: the launch 15 % slower when the workgroups of the first k tile
+        // did it alone -- the MFMA waves wait for them at the barrier), so the workgroups that share a pixel range and columns, one
+        // per k tile, divide the steps: step st belongs to k tile st % tiles_k, a workgroup's partial sums go to row (split, tile_k)
+        const bool do_bias = a.bias_out != nullptr;
+        int bias_st = tile_k;
+        const int bchunk = lw * 8 + (lane & 7), bpg = lane >> 3;
+        float bs[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) bs[e] = 0.f;
+        auto bias_step = [&](int off) {
+            const char *ys = ldsb + off + OPER + (4 * bpg) * 512;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pos = bchunk ^ (((2 * bpg + (r >> 1)) & 7) << 1);   // (the stage's unit swizzle: pair index (P >> 1) & 7)
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(ys + r * 512 + pos * 16);
+                const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    bs[2 * e] += __uint_as_float(w4[e] << 16);
+                    bs[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+                }
+            }
+        };
         auto fill = [&](int off, int st) {
             const int mb = m_begin + st * WT_PX;
             char *xs = ldsb + off + lw * (IPW * 1024), *ys = ldsb + off + OPER + lw * (IPW * 1024);
@@ -122,14 +147,32 @@ __global__ void __launch_bounds__(WT_THREADS, 3) wgrad_b16t_kernel(WgradBf16Args
         for (int s = 0; s < AHEAD; s++) fill(s * STAGE, s);   // (steps past the end: every pixel >= m_end -> zeros)
         wait_vmcnt<(AHEAD - 1) * 2 * IPW>();
         __builtin_amdgcn_s_barrier();   // step 0 has landed
-        int dst = AHEAD * STAGE;
+        int dst = AHEAD * STAGE, cur = 0;
         for (int st = 0; st < nsteps; st++) {
             fill(dst, st + AHEAD);
+            if (do_bias && st == bias_st) {   // (stage st landed before the previous barrier; its slot is refilled two iterations from now)
+                asm volatile("" ::: "memory");
+                bias_step(cur);
+                bias_st += a.tiles_k;
+            }
             wait_vmcnt<(AHEAD - 1) * 2 * IPW>();   // step st + 1 has landed
             __builtin_amdgcn_s_barrier();
             dst = dst == (NBUF - 1) * STAGE ? 0 : dst + STAGE;
+            cur = cur == (NBUF - 1) * STAGE ? 0 : cur + STAGE;
         }
         wait_vmcnt<0>();
+        if (do_bias) {   // the eight pixel groups of the wave (lane bits 3 .. 5), in a fixed order
+#pragma unroll
+            for (int sft = 8; sft < 64; sft <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; e++) bs[e] += __shfl_xor(bs[e], sft);
+            const int col = n0 + bchunk * 8;
+            if (lane < 8 && col < a.N) {
+                float *bo = a.bias_out + ((long long)split * a.tiles_k + tile_k) * a.N + col;
+                *reinterpret_cast<float4 *>(bo) = make_float4(bs[0], bs[1], bs[2], bs[3]);
+                *reinterpret_cast<float4 *>(bo + 4) = make_float4(bs[4], bs[5], bs[6], bs[7]);
+            }
+        }
         return;
     }
 

@@ -680,8 +680,8 @@ class ADAPT(Network):
             if op.kind == "conv":
                 x_in = bufs["act"][prev.name] if prev is not None else bufs["x_in"]
                 if bf16:
-                    ops.conv_wgrad_bf16(x_in, d, op.k, op.k, op.rate, out=op.gw_pad)
-                    ops.bias_grad(d, out=op.gb_pad)
+                    # (the bias gradient rides in the filter-gradient launch: its loader waves see every dy piece anyway)
+                    ops.conv_wgrad_bf16(x_in, d, op.k, op.k, op.rate, out=op.gw_pad, bias_out=op.gb_pad)
                 elif x6:
                     e = bufs["xp"][op.name]
                     if e["wgrad"] or (e["dgrad"] and prev is not None):

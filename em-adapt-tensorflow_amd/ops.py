@@ -208,14 +208,27 @@ def conv_dgrad_bf16(dy, wd, ksize, dil=1, gate=None, gate_scale=1.0, out=None, o
     return dx
 
 
-def conv_wgrad_bf16(x, dy, KH, KW, dil=1, out=None):
-    """conv_wgrad with bf16 operands / fp32 accumulation (f32 HWIO result); x and dy stored f32 or bf16."""
+def conv_wgrad_bf16(x, dy, KH, KW, dil=1, out=None, bias_out=None):
+    """conv_wgrad with bf16 operands / fp32 accumulation (f32 HWIO result); x and dy stored f32 or bf16.  bias_out (f32 [Cout]):
+    also BiasAddGrad -- in the same launch where the library fuses it (dy stored bf16: emadapt_conv_wgrad_bias_bf16), else by the
+    separate kernel (bias_grad)."""
     xdt = _act(x, "x"); ddt = _act(dy, "dy")
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     d = conv_desc(B, H, W, Cin, Cout, KH, KW, dil)
     dw = out if out is not None else torch.empty((KH, KW, Cin, Cout), dtype=torch.float32, device=x.device)
     _check(dw, name="out")
+    if bias_out is not None:
+        _check(bias_out, name="bias_out")
+        if bias_out.numel() != Cout:
+            raise ValueError("bias_out has %d elements, the gradient %d channels" % (bias_out.numel(), Cout))
+        if _lib.load().emadapt_conv_wgrad_bias_bf16_fused(ctypes.byref(d), xdt, ddt) and bias_out.data_ptr() % 16 == 0:
+            nbytes = _lib.load().emadapt_conv_wgrad_bias_bf16_workspace_bytes(ctypes.byref(d))
+            ws = _WS.get(nbytes, x.device)
+            _lib.call("emadapt_conv_wgrad_bias_bf16", ctypes.byref(d), _p(x), xdt, _p(dy), ddt, _p(dw), _p(bias_out), _p(ws), ws.numel(),
+                      _stream())
+            return dw
+        bias_grad(dy, out=bias_out)
     nbytes = _lib.load().emadapt_conv_wgrad_bf16_workspace_bytes(ctypes.byref(d))
     ws = _WS.get(nbytes, x.device)
     _lib.call("emadapt_conv_wgrad_bf16", ctypes.byref(d), _p(x), xdt, _p(dy), ddt, _p(dw), _p(ws), ws.numel(), _stream())

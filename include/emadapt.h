@@ -54,8 +54,10 @@ extern "C" {
  *        there (the tile is also poisoned with NaNs, which the fused ReLU / ReLU-gradient gate now PROPAGATE like
  *        tf.nn.relu), and emadapt_sgd_momentum / emadapt_sgd_momentum_payload leave weights, momentum and accumulators
  *        untouched while the word is non-zero.  Added: the gradient-exchange staging entries (emadapt_grad_pack,
- *        emadapt_grad_owner_sum, emadapt_sgd_momentum_payload), emadapt_sgd_accumulate_momentum. */
-#define EMADAPT_ABI_VERSION 203
+ *        emadapt_grad_owner_sum, emadapt_sgd_momentum_payload), emadapt_sgd_accumulate_momentum.
+ *   204  round 5, added: emadapt_conv_wgrad_bias_bf16 (+ _fused, _workspace_bytes): bf16 filter gradient and bias gradient in one
+ *        launch (and one second-stage launch for both); emadapt_conv_bf16t_pays; tune "bf16t_sk". */
+#define EMADAPT_ABI_VERSION 204
 int emadapt_version(void);
 const char *emadapt_strerror(int code);
 int emadapt_last_hip_error(void);          /* hipError_t of the last failing HIP call on this thread */
@@ -257,6 +259,16 @@ int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const void *dy, int dy_d
 size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_wgrad_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
                             float *dw, void *workspace, size_t workspace_bytes, void *stream);
+/* Filter gradient AND BiasAddGrad (db[n] = sum over pixels of dy[m][n], f32 [Cout], 16-byte aligned) in one launch: the loader
+ * waves add up dy pieces that pass through them anyway -- the workgroups that stream the same pixels and columns (one per filter-row
+ * tile) divide the K steps among them -- and the same second-stage launch that sums the split-M partial filter gradients sums the
+ * partial bias rows (fixed order: bit-reproducible; the separate emadapt_bias_grad_dt costs two launches and one more pass over dy
+ * per layer).  Needs dy stored bf16: emadapt_conv_wgrad_bias_bf16_fused() answers 1 where it applies (else 0 and the entry returns
+ * EMADAPT_ERR_UNSUPPORTED; tune "wgrad_bias" = 1 makes it answer 0 everywhere).  (ABI 204) */
+int emadapt_conv_wgrad_bias_bf16_fused(const emadapt_conv_desc *d, int x_dtype, int dy_dtype);
+size_t emadapt_conv_wgrad_bias_bf16_workspace_bytes(const emadapt_conv_desc *d);
+int emadapt_conv_wgrad_bias_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
+                                 float *dw, float *db, void *workspace, size_t workspace_bytes, void *stream);
 /* The plan a bf16 launch will take for this shape (kind 0 forward, 1 data gradient, 2 filter gradient): plan[0] x plan[1] = the
  * output tile (forward / data gradient: pixels x channels, 256 x 256 or 128 x 128; filter gradient: filter rows x columns),
  * plan[2] = split-K / split-M factor.  The parity tests assert through it that the benchmark shapes run the big tiles.  (ABI 200)

@@ -293,6 +293,51 @@ def test_bf16_wgrad_on_lds_dma(env, shape, cus):
     assert _rel(new.cpu(), old.cpu()) < 2e-5
 
 
+# the bias gradient inside the filter-gradient launch (emadapt_conv_wgrad_bias_bf16): both kernel families, one split and many, column
+# tails, the narrow tiles whose loader lanes share columns (64 / 128 wide), fc8's 24 columns
+WGRAD_BIAS = WGRAD_T + [
+    ((2, 33, 31, 8, 64, 3, 1), 256),        # conv1_1: 128 x 64 tiles
+    ((1, 40, 40, 64, 64, 3, 1), 256),       # conv1_2
+    ((2, 21, 21, 64, 128, 3, 1), 7),        # 128 x 128 tiles
+    ((1, 21, 21, 128, 136, 3, 1), 256),     # a second n tile 8 wide
+    ((2, 9, 9, 512, 24, 1, 1), 256),        # fc8
+    ((1, 3, 3, 256, 256, 1, 1), 256),       # 9 pixels: one split, one step
+]
+
+
+@pytest.mark.parametrize("shape,cus", WGRAD_BIAS)
+def test_bf16_wgrad_carries_the_bias_gradient(env, shape, cus):
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    rng = np.random.default_rng(hash(shape) % (1 << 31))
+    xg = _t(torch, rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)).bfloat16()
+    dyg = _t(torch, rng.normal(0.3, 1, (B, H, W, Cout)).astype(np.float32)).bfloat16()
+    want = dyg.double().sum(dim=(0, 1, 2)).cpu()
+    d = ops.conv_desc(B, H, W, Cin, Cout, k, k, dil)
+    from em_adapt_tensorflow_amd import _lib
+    for gen in (0, 1):
+        with ops.tuned(plan_cus=cus, wgrad_gen=gen):
+            assert _lib.load().emadapt_conv_wgrad_bias_bf16_fused(d, 1, 1) == 1
+            plain = ops.conv_wgrad_bf16(xg, dyg, k, k, dil)
+            db = torch.full((Cout,), float("nan"), device=xg.device)
+            dw = ops.conv_wgrad_bf16(xg, dyg, k, k, dil, bias_out=db)
+            assert torch.equal(dw, plain), "the filter gradient does not change when the bias gradient rides along"
+            assert _rel(db.cpu().double(), want) < 1e-5
+            db2 = torch.zeros_like(db)
+            ops.conv_wgrad_bf16(xg, dyg, k, k, dil, bias_out=db2)
+            assert torch.equal(db, db2), "bias gradient must be bitwise reproducible"
+            with ops.tuned(wgrad_bias=1):     # the separate kernel (what f32-stored dy gets)
+                assert _lib.load().emadapt_conv_wgrad_bias_bf16_fused(d, 1, 1) == 0
+                db3 = torch.zeros_like(db)
+                assert torch.equal(ops.conv_wgrad_bf16(xg, dyg, k, k, dil, bias_out=db3), plain)
+            assert _rel(db3.cpu().double(), want) < 1e-5
+    # f32-stored dy: not fused, same call
+    assert _lib.load().emadapt_conv_wgrad_bias_bf16_fused(d, 1, 0) == 0
+    db4 = torch.zeros_like(db)
+    ops.conv_wgrad_bf16(xg, dyg.float(), k, k, dil, bias_out=db4)
+    assert _rel(db4.cpu().double(), want) < 1e-5
+
+
 def test_bf16_dropout_epilogue_matches_fp32_kernel_mask(env):
     """The counter-based dropout mask depends only on (seed, element index): the bf16 and fp32 kernels drop the same
     elements, and kept values are relu(conv)/keep."""
