@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_t_kernel(IgemmArgs a) {
 
 #include "igemm_b16t.h"   // the LDS-DMA kernel for bf16-stored activations (uses epilogue_t / cvt4 / splitk_epilogue_t_kernel above)
 #include "conv_p3.h"      // the patch kernel for the 3 x 3 layers with 128 and fewer output columns
+#include "conv_d64.h"     // direct 3 x 3 convolution, 64 -> 64 channels, the filter in registers (conv1_2)
 
 namespace {
 
@@ -442,6 +443,13 @@ int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace
     // step it is 0.5 % behind the implicit-GEMM kernels it would replace (profiles/r05_p3_patch_kernel.txt: per layer 9 - 11 % ahead in
     // isolation, but a K step of these layers is 16 - 32 MFMAs and the step-wise barrier of eight waves, the DMA issue rate and the
     // per-tile epilogue each cost as much as the MFMAs)
+    if constexpr (XBF && YBF) {   // conv1_2 (64 -> 64 channels, 3 x 3): the direct kernel, unless a tile is forced
+        if (tune(TUNE_BF16_TILE) == 0 && d64_shape_ok(a) && !(a.epi == EMADAPT_EPI_BIAS_RELU && (a.keep < 1.0f || a.mask))) {
+            a.m_begin = 0;
+            a.m_end = a.M;
+            return launch_d64(a, a.sign < 0, stream);
+        }
+    }
     if constexpr (XBF) {
         const int force = tune(TUNE_BF16_TILE);
         if (force == 3 && p3_ok(a, true)) {
@@ -948,6 +956,10 @@ int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]) {
     IgemmArgs a;
     int Cxp;
     fill_geometry_bf16(a, Cxp, d, kind == 1);
+    if (tune(TUNE_BF16_TILE) == 0 && d->B > 0 && d64_shape_ok(a)) {   // (bf16-stored tensors assumed: what the model keeps)
+        plan[0] = 4; plan[1] = 16; plan[2] = 16;
+        return EMADAPT_OK;
+    }
     if (tune(TUNE_BF16_TILE) == 3 && d->B > 0 && p3_ok(a, true)) {   // (opt-in; bf16-stored activations assumed: what the model keeps)
         P3Geo g;
         p3_geometry(d->B, d->H, d->W, d->dil, g);

@@ -276,7 +276,10 @@ int emadapt_conv_wgrad_bias_bf16(const emadapt_conv_desc *d, const void *x, int 
  * filters, rate 1 or 2, at most 128 output columns, gathered channels a multiple of 32, bf16-stored activations -- conv1_2, conv2_x
  * and the data gradients into 64 / 128 channels): the input patch of a plan[1] x plan[2]-pixel output tile is staged in LDS once per
  * 32 channels and read by all nine taps (the implicit-GEMM kernels fetch every activation nine times); same arithmetic model, same
- * epilogues, bitwise reproducible.  Not the default: it ties the implicit-GEMM kernels in the step. */
+ * epilogues, bitwise reproducible.  Not the default: it ties the implicit-GEMM kernels in the step.
+ * ABI 204: plan[0] == 4 (forward / data gradient, automatic -- any forced "bf16_tile" switches it off) = the DIRECT kernel
+ * (csrc/conv_d64.h) for 3 x 3, rate 1, 64 -> 64 channels on bf16-stored tensors without dropout (conv1_2): plan[1] x plan[2] = its
+ * output tile in pixels; the filter stays in registers / LDS for the whole launch, the input patch of a tile is fetched once. */
 int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]);
 
 /* ---- bf16 forward / data gradient on LDS-DMA (csrc/igemm_b16t.h; round 5: 8 MFMA wavefronts on v_mfma_f32_16x16x32_bf16 + 4 DMA

@@ -255,6 +255,78 @@ def test_bf16_patch_kernel(env, shape, cus):
             assert torch.equal(ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=gg, gate_scale=2.0), g32.bfloat16())
 
 
+# (B, H, W), plan_cus: the direct kernel for 3 x 3, 64 -> 64 channels on bf16-stored tensors (csrc/conv_d64.h: conv1_2) -- maps smaller than
+# a 16 x 16 tile, ragged tile rows / columns, several tiles per workgroup (plan_cus small: both patch buffers, the persistent loop), one
+# workgroup with an odd number of tiles, more workgroups than tiles never happens (the grid is min(tiles, CUs))
+D64 = [
+    ((1, 5, 7), 256),
+    ((2, 16, 16), 256),
+    ((1, 33, 47), 3),
+    ((3, 17, 50), 2),
+    ((1, 70, 9), 1),
+    ((2, 40, 40), 5),
+]
+
+
+@pytest.mark.parametrize("shape,cus", D64)
+def test_bf16_direct_kernel_64_to_64(env, shape, cus):
+    ops, do, torch = env
+    B, H, W = shape
+    k, C = 3, 64
+    rng = np.random.default_rng(hash(shape) % (1 << 31))
+    x = torch.tensor(rng.normal(0, 1, (B, H, W, C)).astype(np.float32)).bfloat16()
+    w = torch.tensor(rng.normal(0, 0.2, (k, k, C, C)).astype(np.float32))
+    b = torch.tensor(rng.normal(0, 0.5, (C,)).astype(np.float32))
+    xr = x.double().requires_grad_(True)
+    y = do.conv_same(xr, w.bfloat16().double(), b.double(), 1)
+    xg, wg, bg = x.cuda(), w.cuda(), b.cuda()
+    wf, wd = ops.weights_to_bf16(wg)
+
+    def close(got, want, tol=2.0 ** -8):   # a bf16 result against the exact one: rounding (half an ulp <= 2^-9 relative) + the fp32 sums' noise
+        got, want = got.double().cpu(), want.double()
+        err = (got - want).abs()
+        return bool((err <= want.abs() * tol + 3e-5).all())   # (+ the fp32 sums' absolute noise where the terms cancel)
+
+    with ops.tuned(plan_cus=cus):
+        assert ops.conv_bf16_plan(B, H, W, C, C, k, 1) == (4, 16, 16)
+        got = ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=False, out_dtype=torch.bfloat16)
+        assert close(got, y.detach())
+        assert torch.equal(got, ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=False, out_dtype=torch.bfloat16)), "bitwise reproducible"
+        assert close(ops.conv_fwd_bf16(xg, wf, (k, k), None, 1, out_dtype=torch.bfloat16), (y - b.double()).detach())
+        got = ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=True, out_dtype=torch.bfloat16)
+        assert close(got, torch.relu(y.detach()))
+        with ops.tuned(bf16_tile=128):   # the implicit-GEMM kernel: the same function, another order of the fp32 sums
+            assert ops.conv_bf16_plan(B, H, W, C, C, k, 1)[0] == 128
+            old = ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=True, out_dtype=torch.bfloat16)
+        same = (got == old).float().mean().item()
+        assert same > 0.98 and close(got, old.double().cpu(), 2.0 ** -7), same   # (two bf16 roundings of sums that differ in their last bits: one ulp)
+        # a NaN in the input reaches every output its taps touch and nothing else; the ReLU lets it through
+        xn = xg.clone()
+        xn[0, H // 2, W // 2, 5] = float("nan")
+        yn = ops.conv_fwd_bf16(xn, wf, (k, k), bg, 1, relu=True, out_dtype=torch.bfloat16)
+        bad = torch.isnan(yn).any(dim=3)
+        assert int(bad.sum()) == len(range(max(H // 2 - 1, 0), min(H // 2 + 2, H))) * len(range(max(W // 2 - 1, 0), min(W // 2 + 2, W)))
+        # data gradient + gate
+        dy = torch.tensor(rng.normal(0, 1, (B, H, W, C)).astype(np.float32)).bfloat16()
+        gate = torch.tensor(rng.normal(0, 1, (B, H, W, C)).astype(np.float32)).bfloat16()
+        y.backward(dy.double())
+        dyg, gg = dy.cuda(), gate.cuda()
+        assert ops.conv_bf16_plan(B, H, W, C, C, k, 1, "dgrad") == (4, 16, 16)
+        got = ops.conv_dgrad_bf16(dyg, wd, (k, k), 1, out_dtype=torch.bfloat16)
+        assert close(got, xr.grad)
+        want = torch.where(gate.double() > 0, xr.grad * 2.0, torch.zeros((), dtype=torch.float64))
+        gb = ops.conv_dgrad_bf16(dyg, wd, (k, k), 1, gate=gg, gate_scale=2.0)
+        assert gb.dtype == torch.bfloat16 and close(gb, want)
+        assert torch.equal(gb, ops.conv_dgrad_bf16(dyg, wd, (k, k), 1, gate=gg, gate_scale=2.0))
+        with ops.tuned(bf16_tile=128):
+            old = ops.conv_dgrad_bf16(dyg, wd, (k, k), 1, gate=gg, gate_scale=2.0)
+        assert (gb == old).float().mean().item() > 0.98 and close(gb, old.double().cpu(), 2.0 ** -7)
+        # dropout in the epilogue is not the direct kernel's: the call takes the implicit-GEMM kernel and still answers
+        mask = torch.tensor((rng.random((B, H, W, C)) < 0.5).astype(np.uint8)).cuda()
+        got = ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=True, keep_prob=0.5, drop_mask=mask, out_dtype=torch.bfloat16)
+        assert close(got, torch.relu(y.detach()) * 2.0 * mask.cpu().double())
+
+
 # (B, H, W, Cin, Cout, k, dil), plan_cus: the LDS-DMA filter-gradient kernel (csrc/wgrad_b16t.h) takes bf16-stored tensors with
 # Cin % 256 == 0 where the plan uses 256 x 256 filter tiles: M tails inside a 32-pixel step, splits that end inside a step's pairs,
 # one to many K steps (all three bodies of the fragment rotation), Cout tails, every tap geometry of the model (1x1, 3x3 rate 1 / 2,

@@ -32,6 +32,15 @@ def _rel(got, want):
 
 
 @pytest.fixture
+def implicit_gemm_kernel():
+    """tune bf16_tile = 128: conv1_2 on the implicit-GEMM kernel (what it ran on before the direct kernel, and still runs on with f32 tensors)."""
+    import em_adapt_tensorflow_amd.ops as ops
+    ops.tune_set("bf16_tile", 128)
+    yield
+    ops.tune_set("bf16_tile", 0)
+
+
+@pytest.fixture
 def patch_kernel():
     """tune bf16_tile = 3: the 3 x 3 layers with <= 128 output columns on the opt-in patch kernel (csrc/conv_p3.h)."""
     import em_adapt_tensorflow_amd.ops as ops
@@ -46,7 +55,8 @@ FULL = [
     ("fc7", (16, 41, 41, 4096, 4096, 1, 1), 256, (256, 256), True),     # deeplab.py:95,147
     ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 256, (256, 256), False),
     ("conv3_2", (16, 81, 81, 256, 256, 3, 1), 256, (256, 256), False),
-    ("conv1_2", (16, 321, 321, 64, 64, 3, 1), 128, (128, 64), False),   # 12,881 workgroups; 1.65 M pixels
+    ("conv1_2", (16, 321, 321, 64, 64, 3, 1), 128, (128, 64), False),   # 12,881 workgroups; 1.65 M pixels (forced: tune bf16_tile = 128)
+    ("conv1_2 direct", (16, 321, 321, 64, 64, 3, 1), 4, (128, 64), False),    # the automatic plan: the direct kernel (csrc/conv_d64.h), 7,056 tiles of 16 x 16
     ("conv1_2 patch", (16, 321, 321, 64, 64, 3, 1), 3, (128, 64), False),     # the opt-in patch kernel (csrc/conv_p3.h): 18 x 14 tiles
     ("conv2_2 patch", (16, 161, 161, 128, 128, 3, 1), 3, (128, 128), False),  # 128 columns: 8 B fragments per step, 4 channel groups
 ]
@@ -58,8 +68,10 @@ def test_bf16_benchmark_shape_against_fp64_oracle_on_rounded_operands(env, reque
     B, H, W, Cin, Cout, k, dil = shape
     if tile == 3:
         request.getfixturevalue("patch_kernel")
+    if name == "conv1_2":
+        request.getfixturevalue("implicit_gemm_kernel")
     pf, pd, pw = (ops.conv_bf16_plan(B, H, W, Cin, Cout, k, dil, kind) for kind in ("fwd", "dgrad", "wgrad"))
-    assert pf[0] == tile and pd[0] == tile and pw[:2] == wtile, (pf, pd, pw)
+    assert pf[0] == tile and pd[0] == tile and (pw[:2] == wtile or name == "conv1_2"), (pf, pd, pw)   # (a forced 128 keeps the filter gradient's 128-wide tile)
     if name == "fc6":
         assert pd[2] > 1, pd          # 212 tiles of a 65536-long reduction: split-K slabs
 
@@ -91,6 +103,25 @@ def test_bf16_benchmark_shape_against_fp64_oracle_on_rounded_operands(env, reque
     wf, wd = ops.weights_to_bf16(wg)
     kw = dict(relu=True, keep_prob=0.5 if drop else 1.0, drop_mask=mg)
 
+    if tile == 4:
+        # the direct kernel takes bf16-stored x, y and gate (what the model keeps); every other storage combination runs the implicit-GEMM
+        # kernel -- the same function, another order of the fp32 sums: one bf16 ulp apart at most
+        def close(got, want, tol):
+            err = (got.double().cpu() - want.double().cpu()).abs()
+            return bool((err <= want.double().cpu().abs() * tol + 3e-5).all())
+        yb = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, out_dtype=torch.bfloat16, **kw)
+        assert close(yb, want_y, 2.0 ** -8)
+        assert torch.equal(yb, ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, out_dtype=torch.bfloat16, **kw)), "forward must repeat bitwise"
+        y32 = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, **kw)   # f32 output: the implicit-GEMM kernel
+        assert _rel(y32.cpu(), want_y) < 2e-5 and close(yb, y32.bfloat16(), 2.0 ** -7) and (yb == y32.bfloat16()).float().mean().item() > 0.99
+        del yb, y32
+        dxb = ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg, gate_scale=scale)
+        assert dxb.dtype == torch.bfloat16 and close(dxb, want_dx, 2.0 ** -8)
+        assert torch.equal(dxb, ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg, gate_scale=scale))
+        dx32 = ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg.float(), gate_scale=scale)
+        assert _rel(dx32.cpu(), want_dx) < 2e-5 and close(dxb, dx32.bfloat16(), 2.0 ** -7) and (dxb == dx32.bfloat16()).float().mean().item() > 0.99
+        del dxb, dx32
+        return
     # forward: bf16-stored input -> f32 output
     y1 = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, **kw)
     assert _rel(y1.cpu(), want_y) < 2e-5

@@ -371,7 +371,12 @@ def test_executed_fraction_and_new_plan_queries_without_a_device():
         assert f(16, 41, 41, 512, 4096, 4, 4, "fwd") == 1.0 and f(16, 41, 41, 512, 4096, 4, 4, "wgrad") == 1.0
     # bf16 plans at the benchmark shapes: 256 x 256 tiles for the wide layers, 128 x 64 for the 64-column ones (round 4)
     assert ops.conv_bf16_plan(16, 41, 41, 4096, 4096, 1, 1)[:2] == (256, 256)
-    assert ops.conv_bf16_plan(16, 321, 321, 64, 64, 3, 1)[:2] == (128, 64) and ops.conv_bf16_plan(16, 161, 161, 128, 64, 3, 1, "dgrad")[:2] == (128, 128)
+    # (round 5: conv1_2 -- 3 x 3, 64 -> 64 channels -- on the direct kernel, 16 x 16-pixel tiles; any forced tile switches it off)
+    assert ops.conv_bf16_plan(16, 321, 321, 64, 64, 3, 1) == (4, 16, 16) and ops.conv_bf16_plan(16, 321, 321, 64, 64, 3, 1, "dgrad") == (4, 16, 16)
+    with ops.tuned(bf16_tile=128):
+        assert ops.conv_bf16_plan(16, 321, 321, 64, 64, 3, 1)[0] == 128
+    assert ops.conv_bf16_plan(16, 321, 321, 64, 64, 3, 2)[:2] == (128, 64)
+    assert ops.conv_bf16_plan(16, 161, 161, 128, 64, 3, 1, "dgrad")[:2] == (128, 128)
     assert ops.conv_bf16_plan(16, 161, 161, 64, 128, 3, 1, "dgrad")[:2] == (128, 64)   # the data gradient's columns are Cin
     # LDS-DMA bf16 kernels: gathered channels % 32, stream-K where the tiles are not whole rounds
     d = ops.conv_desc(16, 41, 41, 512, 512, 3, 3, 1)
