@@ -704,6 +704,72 @@ __global__ void __launch_bounds__(kThreads, 2) estep_kernel(EstepArgs a) {   // 
         }
         __syncthreads();
     }
+    // Round 5: the LDS-resident geometries walk a FLAT visit list (slot of the class | 0x100 for class 0, built once by wave 0 behind the
+    // compacted rows) and keep the visited class image in registers.  What a visit used to put in front of its selection -- order entry
+    // -> class -> slot -> channel values, then the values again for the update: five dependent LDS round trips, 1.2 us of the 3 us per
+    // visit with nothing to overlap them (scripts/estep_ablate.py) -- is now one list entry and one class image fetched a visit ahead,
+    // while the current selection runs (another class's image does not depend on it; the same class twice in a row takes the updated
+    // registers).
+    const int nper = a.num_iter * (C - 1);
+    const bool fast = compact && full && nper + a.num_iter * C <= kPermCap;
+    if (fast) {
+        unsigned short *vis = l.perm + nper;
+        if (tid < 64) {
+            const int s0 = l.slot[0];
+            int base = 0;
+            for (int it = 0; it < a.num_iter; it++) {
+                const int n = l.stk[it];
+                const unsigned short *row = l.perm + it * (C - 1);
+                if (s0 >= 0 && tid == 0) vis[base] = (unsigned short)(s0 | 0x100);   // class 0 first (estep.py:64)
+                const int b1 = base + (s0 >= 0 ? 1 : 0);
+                for (int q = tid; q < n; q += 64) {
+                    const int j = row[q];
+                    vis[b1 + q] = (unsigned short)(l.slot[j] | (j == 0 ? 0x100 : 0));
+                }
+                base = b1 + n;
+            }
+            if (tid == 0) l.sel[3] = base;
+        }
+        __syncthreads();
+        const int nv = l.sel[3];
+        int ii[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) ii[e] = min(tid + e * kThreads, HW - 1);   // (loads unconditional; pixels past the end re-read the last one)
+        float chv[EPT], chn[EPT];
+        int cur = nv > 0 ? (int)vis[0] : 0;
+        int nxt = nv > 1 ? (int)vis[1] : cur;
+        if (nv > 0) {
+            const float *ch = l.chan + (size_t)(cur & 0xff) * hwp;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) chv[e] = ch[ii[e]];
+        }
+        for (int n = 0; n < nv; n++) {
+            const int nxt2 = (n + 2 < nv) ? (int)vis[n + 2] : nxt;   // (the list entry two visits ahead: the class image one visit ahead needs no dependent read)
+            const int k = (cur & 0x100) ? a.k_bg : a.k_fg;
+            unsigned key[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) key[e] = (tid + e * kThreads < HW) ? __float_as_uint(mx[e] - chv[e]) : 0xFFFFFFFFu;  // >= +0: raw bits are order-preserving
+            {
+                const float *chx = l.chan + (size_t)(nxt & 0xff) * hwp;   // the next visit's class image: in flight during this selection
+#pragma unroll
+                for (int e = 0; e < EPT; e++) chn[e] = chx[ii[e]];
+            }
+            const float t = __uint_as_float(radix_select<EPT>(key, k, l, tid, lane, a.stop_after));  // np.partition(d, k)[k]
+            float *ch = l.chan + (size_t)(cur & 0xff) * hwp;
+            const bool same = (nxt & 0xff) == (cur & 0xff);
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const float v = chv[e] + t;
+                if (tid + e * kThreads < HW) {
+                    ch[ii[e]] = v;
+                    mx[e] = (v > mx[e]) ? v : mx[e];
+                }
+                chv[e] = same ? v : chn[e];
+            }
+            cur = nxt;
+            nxt = nxt2;
+        }
+    } else
     for (int it = 0; it < a.num_iter; it++) {
         const int nvis = compact ? l.stk[it] : C - 1;
         for (int q = -1; q < nvis; q++) {   // class 0 first (estep.py:64), then the (compacted) order
