@@ -20,7 +20,9 @@
 //     calls follow NumPy's pairwise summation tree (its leaf / combine program is built on the host: it depends on
 //     H*W alone), so label maps AND float maps are bit-identical;
 //   * the class visiting order (random.shuffle in the reference) is an input; it is staged in LDS and compacted to
-//     the classes present in the image before the sweeps.
+//     the classes present in the image before the sweeps; for the LDS-resident geometries (round 5) it is flattened into ONE
+//     visit list, read two visits ahead, and the visited class image stays in registers from the key to the update while
+//     the next one is fetched during the current selection (86.5 -> 78.8 us: profiles/r05_estep_bench.txt).
 //
 // Round 3 (profiles/r03_estep_bench.txt): 192 -> 90 us at 16 x 41x41x21, 685 -> 232 us at 10 x 65x65x41 (there the classes
 // that do not fit in LDS live class-major in the workspace, not in the NHWC float map).  What the
