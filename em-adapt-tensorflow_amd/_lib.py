@@ -146,6 +146,7 @@ PROTOTYPES = {
     "emadapt_conv_bf16t_pays": (c_int, [POINTER(ConvDesc), c_int, c_int]),
     "emadapt_filter_tiles_bf16_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "emadapt_filter_tiles_bf16": (c_int, [POINTER(ConvDesc), _vp, _vp, c_int, _vp]),
+    "emadapt_filter_tiles_bf16_both": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "emadapt_conv_bf16t_workspace_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "emadapt_conv_bf16t_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
     "emadapt_conv_fwd_bf16t": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_int, c_int, c_float, _vp, c_uint64, _vp, c_size_t, _vp]),

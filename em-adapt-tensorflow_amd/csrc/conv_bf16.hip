@@ -1171,6 +1171,27 @@ int emadapt_filter_tiles_bf16(const emadapt_conv_desc *d, const float *w, void *
     return launch_status();
 }
 
+int emadapt_filter_tiles_bf16_both(const emadapt_conv_desc *d, const float *w, void *tiles_fwd, void *tiles_dgrad, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!w || !tiles_fwd || !tiles_dgrad || !aligned16(w) || !aligned16(tiles_fwd) || !aligned16(tiles_dgrad)) return EMADAPT_ERR_INVALID;
+    if (d->Cin % BT_BK != 0 || d->Cout % BT_BK != 0) return EMADAPT_ERR_UNSUPPORTED;
+    if (d->Cin % 256 != 0 || d->Cout % 64 != 0) {   // (padding rows of the data-gradient image, or a ragged row block: the two single-image kernels)
+        rc = emadapt_filter_tiles_bf16(d, w, tiles_fwd, 0, stream_);
+        return rc ? rc : emadapt_filter_tiles_bf16(d, w, tiles_dgrad, 1, stream_);
+    }
+    const int rows_pad_f = (int)(ceil_div(d->Cout, 256) * 256), taps = d->KH * d->KW;
+    if (rows_pad_f != d->Cout) {   // the forward image's padding rows (Cout % 256 != 0) are zeros: written by the single-image kernel only
+        rc = emadapt_filter_tiles_bf16(d, w, tiles_fwd, 0, stream_);
+        return rc ? rc : emadapt_filter_tiles_bf16(d, w, tiles_dgrad, 1, stream_);
+    }
+    const long long g = (long long)taps * (d->Cin / BT_BK) * (d->Cout / 64);
+    if (g > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(filter_tiles_b16_both_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream_), w, reinterpret_cast<uint4 *>(tiles_fwd),
+                       reinterpret_cast<uint4 *>(tiles_dgrad), d->Cin, d->Cout, rows_pad_f);
+    return launch_status();
+}
+
 size_t emadapt_conv_bf16t_workspace_bytes(const emadapt_conv_desc *d, int kind) {
     if (kind < 0 || kind > 1 || !bt_ok(d, kind == 1, 0) || d->B == 0) return 0;
     IgemmArgs a;

@@ -118,6 +118,46 @@ __global__ void __launch_bounds__(256) filter_tiles_b16_fwd_kernel(const float *
     out[(((long long)tap * G + g) * rows_pad + row) * 4 + slot] = *reinterpret_cast<uint4 *>(&v);
 }
 
+// Both images from ONE pass over the f32 filter (a layer whose forward and data gradient both run on this kernel refreshes both every
+// optimizer step: the two kernels above read the 260 MB of filters twice).  The [32 ci][64 co] piece a block holds in LDS for the
+// forward image's transpose is also 32 rows x 2 k groups x 4 slots of the data-gradient image (rows = ci, k = co): one more 16-byte
+// slot per thread, straight out of the LDS rows.  Needs Cin % 256 == 0 (the data-gradient image then has no padding rows to zero)
+// and Cout % 64 == 0.
+__global__ void __launch_bounds__(256) filter_tiles_b16_both_kernel(const float *__restrict__ w, uint4 *__restrict__ out_f, uint4 *__restrict__ out_d,
+                                                                    int Cin, int Cout, int rows_pad_f) {
+    __shared__ float t[32][65];
+    const int G = Cin / BT_BK, RB = Cout / 64, GD = Cout / BT_BK;
+    int bid = blockIdx.x;
+    const int rb = bid % RB;
+    bid /= RB;
+    const int g = bid % G, tap = bid / G;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int k = ty + 4 * r;
+        t[k][tx] = w[((long long)tap * Cin + g * BT_BK + k) * Cout + rb * 64 + tx];
+    }
+    __syncthreads();
+    {   // forward image: row = co, k = ci (filter_tiles_b16_fwd_kernel's second half)
+        const int row_l = threadIdx.x >> 2, slot = threadIdx.x & 3;
+        const int row = rb * 64 + row_l;
+        const int chunk = slot ^ bt_swz(row);
+        bt_bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (__bf16)t[chunk * 8 + e][row_l];
+        out_f[(((long long)tap * G + g) * rows_pad_f + row) * 4 + slot] = *reinterpret_cast<uint4 *>(&v);
+    }
+    {   // data-gradient image: row = ci, k = co -- thread -> (ci of the piece, k group of the piece's 64 co, slot)
+        const int slot = threadIdx.x & 3, gl = (threadIdx.x >> 2) & 1, ci_l = threadIdx.x >> 3;
+        const int row = g * BT_BK + ci_l;
+        const int chunk = slot ^ bt_swz(row);
+        bt_bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = (__bf16)t[ci_l][gl * 32 + chunk * 8 + e];
+        out_d[(((long long)tap * GD + rb * 2 + gl) * Cin + row) * 4 + slot] = *reinterpret_cast<uint4 *>(&v);   // (rows_pad == Cin)
+    }
+}
+
 // Tile epilogue of a 64 x 128 block held as 4 x 8 accumulator tiles of the 16 x 16 MFMA (C/D layout: column = lane & 15, row =
 // 4 (lane >> 4) + r): 16 rows at a time through the wave's private LDS slab ([16][128 + 4] floats), read back as 8 consecutive
 // columns per lane -- then exactly store_acc_tile's arithmetic (igemm_common.h: bias / ReLU / dropout / gate on 8 values, 16-byte

@@ -488,9 +488,11 @@ class ADAPT(Network):
                     if not (e["fwd"] and e["dgrad"]):
                         ops.weights_to_bf16(op.w_pad, None if e["fwd"] else op.seg["wf16"], None if e["dgrad"] else op.seg["wd16"],
                                             want_fwd=not e["fwd"], want_dgrad=not e["dgrad"])
-                    if e["fwd"]:
+                    if e["fwd"] and e["dgrad"]:
+                        ops.filter_tiles_bf16_both(op.w_pad, op.seg["wt16"], op.seg["wtd16"])   # (one pass over the f32 filter)
+                    elif e["fwd"]:
                         ops.filter_tiles_bf16(op.w_pad, dgrad=False, out=op.seg["wt16"])
-                    if e["dgrad"]:
+                    elif e["dgrad"]:
                         ops.filter_tiles_bf16(op.w_pad, dgrad=True, out=op.seg["wtd16"])
                 else:
                     if op.seg["kmajor"] or not self._plane_fwd.get(op.name, True):

@@ -269,6 +269,20 @@ def filter_tiles_bf16(w, dgrad=False, out=None):
     return t
 
 
+def filter_tiles_bf16_both(w, out_fwd, out_dgrad):
+    """Both tiled bf16 images of an f32 HWIO filter in one pass (the model's refresh where a layer's forward AND data gradient run on the
+    LDS-DMA kernel)."""
+    _check(w, name="w")
+    KH, KW, Cin, Cout = w.shape
+    d = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+    for t, dg in ((out_fwd, 0), (out_dgrad, 1)):
+        n = _lib.load().emadapt_filter_tiles_bf16_bytes(ctypes.byref(d), dg)
+        if n == 0 or t.dtype != torch.bfloat16 or t.numel() * 2 != n:
+            raise ValueError("tiled image buffer does not match the filter")
+    _lib.call("emadapt_filter_tiles_bf16_both", ctypes.byref(d), _p(w), _p(out_fwd), _p(out_dgrad), _stream())
+    return out_fwd, out_dgrad
+
+
 def conv_fwd_bf16t(x, wt, ksize, Cout, bias=None, dil=1, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None,
                    out_dtype=None):
     """conv_fwd_bf16 on the LDS-DMA kernel: x stored bf16, wt = filter_tiles_bf16(w); output bf16 unless out / out_dtype say f32."""

@@ -304,6 +304,8 @@ int emadapt_conv_bf16t_supported(const emadapt_conv_desc *d, int kind, int y_dty
 int emadapt_conv_bf16t_pays(const emadapt_conv_desc *d, int kind, int y_dtype);
 size_t emadapt_filter_tiles_bf16_bytes(const emadapt_conv_desc *d, int dgrad);
 int emadapt_filter_tiles_bf16(const emadapt_conv_desc *d, const float *w, void *tiles, int dgrad, void *stream);
+/* both images from one pass over the f32 filter (ABI 204; one kernel where Cin % 256 == 0 and Cout % 256 == 0, else the two calls above) */
+int emadapt_filter_tiles_bf16_both(const emadapt_conv_desc *d, const float *w, void *tiles_fwd, void *tiles_dgrad, void *stream);
 size_t emadapt_conv_bf16t_workspace_bytes(const emadapt_conv_desc *d, int kind);
 int emadapt_conv_bf16t_plan(const emadapt_conv_desc *d, int kind, int plan[4]);
 int emadapt_conv_fwd_bf16t(const emadapt_conv_desc *d, const void *x_bf16, const void *w_tiles, const float *bias, void *y,

@@ -119,6 +119,22 @@ def test_b16t_small_shapes_every_layout(env, shape, cus):
             assert torch.equal(ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=gg, gate_scale=2.0), g32.bfloat16())
 
 
+@pytest.mark.parametrize("shape", [(3, 256, 256), (1, 512, 4096), (4, 256, 512), (3, 512, 320), (1, 64, 96), (3, 288, 256)],
+                         ids=lambda s: "k%d_%dto%d" % s)
+def test_both_tiled_images_in_one_pass(env, shape):
+    """emadapt_filter_tiles_bf16_both: one kernel where Cin % 256 == 0 and Cout % 256 == 0 (the model's layers), the two single-image
+    kernels elsewhere -- the same bytes as two calls either way."""
+    ops, do, torch = env
+    k, Cin, Cout = shape
+    g = torch.Generator().manual_seed(k * 1000 + Cin + Cout)
+    w = torch.randn((k, k, Cin, Cout), generator=g).to("cuda:0")
+    f0, d0 = ops.filter_tiles_bf16(w), ops.filter_tiles_bf16(w, dgrad=True)
+    f1 = torch.full_like(f0, float("nan"))
+    d1 = torch.full_like(d0, float("nan"))
+    ops.filter_tiles_bf16_both(w, f1, d1)
+    assert torch.equal(f0.view(torch.int16), f1.view(torch.int16)) and torch.equal(d0.view(torch.int16), d1.view(torch.int16))
+
+
 def test_b16t_layout_coverage_of_the_small_shapes(env):
     """The forced layouts above really are the three kinds the benchmark uses."""
     ops, do, torch = env
