@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_t_kernel(IgemmArgs a) {
 #include "igemm_b16t.h"   // the LDS-DMA kernel for bf16-stored activations (uses epilogue_t / cvt4 / splitk_epilogue_t_kernel above)
 #include "conv_p3.h"      // the patch kernel for the 3 x 3 layers with 128 and fewer output columns
 #include "conv_d64.h"     // direct 3 x 3 convolution, 64 -> 64 channels, the filter in registers (conv1_2)
+#include "conv_d4.h"      // direct 3 x 3 convolution of the 4-channel f32 image into 64 bf16 channels (conv1_1 forward)
 
 namespace {
 
@@ -449,6 +450,9 @@ int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace
             a.m_end = a.M;
             return launch_d64(a, a.sign < 0, stream);
         }
+    }
+    if constexpr (!XBF && YBF) {   // conv1_1 (the 4-channel f32 image -> 64 bf16 channels, 3 x 3): the direct kernel, unless a tile is forced
+        if (tune(TUNE_BF16_TILE) == 0 && d4_shape_ok(a) && !a.gate && !(a.epi == EMADAPT_EPI_BIAS_RELU && (a.keep < 1.0f || a.mask))) return launch_d4(a, stream);
     }
     if constexpr (XBF) {
         const int force = tune(TUNE_BF16_TILE);
@@ -958,6 +962,10 @@ int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]) {
     fill_geometry_bf16(a, Cxp, d, kind == 1);
     if (tune(TUNE_BF16_TILE) == 0 && d->B > 0 && d64_shape_ok(a)) {   // (bf16-stored tensors assumed: what the model keeps)
         plan[0] = 4; plan[1] = 16; plan[2] = 16;
+        return EMADAPT_OK;
+    }
+    if (tune(TUNE_BF16_TILE) == 0 && d->B > 0 && kind == 0 && d4_shape_ok(a)) {   // (the f32 image in, bf16 out: conv1_1 as the model runs it)
+        plan[0] = 5; plan[1] = 16; plan[2] = 16;
         return EMADAPT_OK;
     }
     if (tune(TUNE_BF16_TILE) == 3 && d->B > 0 && p3_ok(a, true)) {   // (opt-in; bf16-stored activations assumed: what the model keeps)

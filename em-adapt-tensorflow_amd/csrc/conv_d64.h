@@ -67,7 +67,8 @@ struct D64Geo {
 inline bool d64_shape_ok(const IgemmArgs &a) {   // (plus, at the launch: x, y and the gate stored bf16, no dropout)
     if (a.ntaps != 9 || a.KW != 3 || a.dil != 1 || a.Cx != 64 || a.N != 64) return false;
     if (a.M <= 0 || a.M % (a.H * a.W) != 0 || (long long)a.M * 128 >= (1LL << 31) || a.H > 16384 || a.W > 16384) return false;
-    return true;
+    const long long per_img = (long long)((a.W + 15) / 16) * ((a.H + 15) / 16), tiles = (long long)(a.M / (a.H * a.W)) * per_img;
+    return (tiles + 2 * 1024) * per_img < (1LL << 32);   // (the tile -> image division by multiply-high, tiles past the end included)
 }
 
 // ABLM (diagnostic library only, tune "ablate"): parts COMPILED out -- 1 no patch DMAs behind the first, 2 no MFMAs, 4 no output stores,

@@ -279,7 +279,9 @@ int emadapt_conv_wgrad_bias_bf16(const emadapt_conv_desc *d, const void *x, int 
  * epilogues, bitwise reproducible.  Not the default: it ties the implicit-GEMM kernels in the step.
  * ABI 204: plan[0] == 4 (forward / data gradient, automatic -- any forced "bf16_tile" switches it off) = the DIRECT kernel
  * (csrc/conv_d64.h) for 3 x 3, rate 1, 64 -> 64 channels on bf16-stored tensors without dropout (conv1_2): plan[1] x plan[2] = its
- * output tile in pixels; the filter stays in registers / LDS for the whole launch, the input patch of a tile is fetched once. */
+ * output tile in pixels; the filter stays in registers / LDS for the whole launch, the input patch of a tile is fetched once.
+ * plan[0] == 5 (forward, automatic): the direct kernel for 3 x 3, rate 1, 4 -> 64 channels from an f32-stored input into a bf16-stored
+ * output without dropout (csrc/conv_d4.h: conv1_1 on the 3 + 1-channel image). */
 int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]);
 
 /* ---- bf16 forward / data gradient on LDS-DMA (csrc/igemm_b16t.h; round 5: 8 MFMA wavefronts on v_mfma_f32_16x16x32_bf16 + 4 DMA

@@ -327,6 +327,42 @@ def test_bf16_direct_kernel_64_to_64(env, shape, cus):
         assert close(got, torch.relu(y.detach()) * 2.0 * mask.cpu().double())
 
 
+@pytest.mark.parametrize("shape", [(1, 5, 7), (2, 16, 16), (1, 33, 47), (3, 17, 50), (1, 70, 9)], ids=lambda s: "%dx%dx%d" % s)
+def test_bf16_direct_kernel_image_to_64(env, shape):
+    """conv1_1 as the model runs it: the 4-channel f32 image -> 64 bf16 channels, 3 x 3 (csrc/conv_d4.h; one workgroup per 16 x 16 tile)."""
+    ops, do, torch = env
+    B, H, W = shape
+    k, Cin, C = 3, 4, 64
+    rng = np.random.default_rng(hash(shape) % (1 << 31))
+    x = torch.tensor(rng.normal(0, 50, (B, H, W, Cin)).astype(np.float32))
+    x[..., 3] = 0                                                     # (the pad channel, as copy_pad_channels leaves it)
+    w = torch.tensor(rng.normal(0, 0.05, (k, k, Cin, C)).astype(np.float32))
+    b = torch.tensor(rng.normal(0, 0.5, (C,)).astype(np.float32))
+    y = do.conv_same(x.bfloat16().double(), w.bfloat16().double(), b.double(), 1)
+    xg, wg, bg = x.cuda(), w.cuda(), b.cuda()
+    wf, _ = ops.weights_to_bf16(wg, want_dgrad=False)
+
+    def close(got, want, tol=2.0 ** -8):
+        err = (got.double().cpu() - want.double()).abs()
+        return bool((err <= want.double().abs() * tol + 1e-3).all())   # (sums of terms up to 150 * 0.15: the fp32 noise floor is ~1e-4)
+
+    assert ops.conv_bf16_plan(B, H, W, Cin, C, k, 1) == (5, 16, 16)
+    got = ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=True, out_dtype=torch.bfloat16)
+    assert close(got, torch.relu(y))
+    assert torch.equal(got, ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=True, out_dtype=torch.bfloat16)), "bitwise reproducible"
+    assert close(ops.conv_fwd_bf16(xg, wf, (k, k), None, 1, out_dtype=torch.bfloat16), y - b.double())
+    with ops.tuned(bf16_tile=128):   # the implicit-GEMM kernel: the same function, another order of the fp32 sums
+        assert ops.conv_bf16_plan(B, H, W, Cin, C, k, 1)[0] == 128
+        old = ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=True, out_dtype=torch.bfloat16)
+    assert (got == old).float().mean().item() > 0.98 and close(got, old.double().cpu(), 2.0 ** -7)
+    # an f32 output, or dropout in the epilogue, is not this kernel's: the call takes the implicit-GEMM kernel and still answers
+    y32 = ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=True, out_dtype=torch.float32)
+    assert _rel(y32.cpu(), torch.relu(y)) < 2e-5
+    mask = torch.tensor((rng.random((B, H, W, C)) < 0.5).astype(np.uint8)).cuda()
+    got = ops.conv_fwd_bf16(xg, wf, (k, k), bg, 1, relu=True, keep_prob=0.5, drop_mask=mask, out_dtype=torch.bfloat16)
+    assert close(got, torch.relu(y) * 2.0 * mask.cpu().double())
+
+
 # (B, H, W, Cin, Cout, k, dil), plan_cus: the LDS-DMA filter-gradient kernel (csrc/wgrad_b16t.h) takes bf16-stored tensors with
 # Cin % 256 == 0 where the plan uses 256 x 256 filter tiles: M tails inside a 32-pixel step, splits that end inside a step's pairs,
 # one to many K steps (all three bodies of the fragment rotation), Cout tails, every tap geometry of the model (1x1, 3x3 rate 1 / 2,
