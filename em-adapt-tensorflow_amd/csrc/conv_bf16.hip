@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(256) splitk_epilogue_t_kernel(IgemmArgs a) {
 #include "conv_p3.h"      // the patch kernel for the 3 x 3 layers with 128 and fewer output columns
 #include "conv_d64.h"     // direct 3 x 3 convolution, 64 -> 64 channels, the filter in registers (conv1_2)
 #include "conv_d4.h"      // direct 3 x 3 convolution of the 4-channel f32 image into 64 bf16 channels (conv1_1 forward)
+#include "conv_k32.h"     // 1 x 1 convolution with at most 32 gathered channels, operands straight from memory (fc8's data gradient)
 
 namespace {
 
@@ -444,6 +445,9 @@ int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace
     // step it is 0.5 % behind the implicit-GEMM kernels it would replace (profiles/r05_p3_patch_kernel.txt: per layer 9 - 11 % ahead in
     // isolation, but a K step of these layers is 16 - 32 MFMAs and the step-wise barrier of eight waves, the DMA issue rate and the
     // per-tile epilogue each cost as much as the MFMAs)
+    if constexpr (XBF && YBF) {   // fc8's data gradient (1 x 1, 24 gathered channels): one MFMA step, nothing staged
+        if (tune(TUNE_BF16_TILE) == 0 && k32_shape_ok(a) && !a.bias && a.epi == EMADAPT_EPI_NONE) return launch_k32(a, stream);
+    }
     if constexpr (XBF && YBF) {   // conv1_2 (64 -> 64 channels, 3 x 3): the direct kernel, unless a tile is forced
         if (tune(TUNE_BF16_TILE) == 0 && d64_shape_ok(a) && !(a.epi == EMADAPT_EPI_BIAS_RELU && (a.keep < 1.0f || a.mask))) {
             a.m_begin = 0;
@@ -962,6 +966,10 @@ int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]) {
     fill_geometry_bf16(a, Cxp, d, kind == 1);
     if (tune(TUNE_BF16_TILE) == 0 && d->B > 0 && d64_shape_ok(a)) {   // (bf16-stored tensors assumed: what the model keeps)
         plan[0] = 4; plan[1] = 16; plan[2] = 16;
+        return EMADAPT_OK;
+    }
+    if (tune(TUNE_BF16_TILE) == 0 && d->B > 0 && kind == 1 && k32_shape_ok(a)) {   // (bf16-stored tensors assumed; the forward has a bias)
+        plan[0] = 6; plan[1] = 64; plan[2] = 256;
         return EMADAPT_OK;
     }
     if (tune(TUNE_BF16_TILE) == 0 && d->B > 0 && kind == 0 && d4_shape_ok(a)) {   // (the f32 image in, bf16 out: conv1_1 as the model runs it)

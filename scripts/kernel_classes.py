@@ -11,7 +11,7 @@ import re
 
 # position of the direction flag BT in each fp32 kernel's template argument list (csrc/conv_igemm.hip, igemm_v2.h)
 _BT_POS = {"igemm2_kernel": 6, "igemm_kernel": 4, "igemm_ws_kernel": 0, "conv_d64_kernel": 0}
-_CONV = re.compile(r"\b((?:igemm|wgrad|conv_d64|conv_d4)\w*_kernel)\b(?:<([^>]*)>)?")   # (conv_d64_kernel<DG>, conv_d4_kernel: the direct conv1_2 / conv1_1 kernels, round 5)
+_CONV = re.compile(r"\b((?:igemm|wgrad|conv_d64|conv_d4|conv_k32)\w*_kernel)\b(?:<([^>]*)>)?")   # (conv_d64_kernel<DG>, conv_d4_kernel, conv_k32_kernel: the direct conv1_2 / conv1_1 / fc8-dgrad kernels, round 5)
 _SECOND_STAGE = ("streamk_fixup", "splitk_epilogue", "slab_sum", "rowmap")   # (streamk_fixup: profiles of rounds 2-3 and the opt-in bf16t kernels)
 
 

@@ -50,7 +50,7 @@ out = ["# rocprofv3 --pmc passes over `bench.py --steps 1 --warmup 1` (kernel-tr
 agg = collections.OrderedDict()
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
     rows = load(newest("%s/%s/runc/*_counter_collection.csv" % (SRC, sub)))
-    conv = [r for r in rows if re.search(r"igemm|wgrad|conv_d64|conv_d4", r["name"])]
+    conv = [r for r in rows if re.search(r"igemm|wgrad|conv_d64|conv_d4|conv_k32", r["name"])]
     conv = conv[len(conv) // 2:]  # second (timed) step
     for r in conv:
         a = agg.setdefault(r["name"], collections.defaultdict(float))

@@ -363,6 +363,43 @@ def test_bf16_direct_kernel_image_to_64(env, shape):
     assert close(got, torch.relu(y) * 2.0 * mask.cpu().double())
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 3, 24, 256), (2, 9, 7, 24, 512), (1, 41, 41, 24, 1024), (3, 5, 5, 8, 256), (1, 13, 11, 32, 768)],
+                         ids=lambda s: "%dx%dx%d_%dto%d" % s)
+def test_bf16_short_reduction_data_gradient(env, shape):
+    """fc8's data gradient as the model runs it: 1 x 1, 24 gathered channels (the padded classes) -> fc7's channels, bf16-stored dy / dx / gate
+    (csrc/conv_k32.h: one MFMA step, operands straight from memory); pixel tails inside a 64-pixel tile, 8 - 32 gathered channels."""
+    ops, do, torch = env
+    B, H, W, Cout, Cin = shape     # (the layer's forward is Cin -> Cout; its data gradient gathers the Cout channels of dy)
+    rng = np.random.default_rng(hash(shape) % (1 << 31))
+    w = torch.tensor(rng.normal(0, 0.2, (1, 1, Cin, Cout)).astype(np.float32))
+    dy = torch.tensor(rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)).bfloat16()
+    gate = torch.tensor(rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)).bfloat16()
+    want = torch.einsum("bhwo,io->bhwi", dy.double(), w[0, 0].bfloat16().double())
+    wg, dyg, gg = w.cuda(), dy.cuda(), gate.cuda()
+    _, wd = ops.weights_to_bf16(wg, want_fwd=False)
+
+    def close(got, want, tol=2.0 ** -8):
+        err = (got.double().cpu() - want.double()).abs()
+        return bool((err <= want.double().abs() * tol + 3e-5).all())
+
+    assert ops.conv_bf16_plan(B, H, W, Cin, Cout, 1, 1, "dgrad") == (6, 64, 256)
+    got = ops.conv_dgrad_bf16(dyg, wd, (1, 1), 1, out_dtype=torch.bfloat16)
+    assert close(got, want)
+    wantg = torch.where(gate.double() > 0, want * 2.0, torch.zeros((), dtype=torch.float64))
+    gb = ops.conv_dgrad_bf16(dyg, wd, (1, 1), 1, gate=gg, gate_scale=2.0)
+    assert gb.dtype == torch.bfloat16 and close(gb, wantg)
+    assert torch.equal(gb, ops.conv_dgrad_bf16(dyg, wd, (1, 1), 1, gate=gg, gate_scale=2.0)), "bitwise reproducible"
+    with ops.tuned(bf16_tile=128):
+        assert ops.conv_bf16_plan(B, H, W, Cin, Cout, 1, 1, "dgrad")[0] != 6
+        old = ops.conv_dgrad_bf16(dyg, wd, (1, 1), 1, gate=gg, gate_scale=2.0)
+    assert (gb == old).float().mean().item() > 0.98 and close(gb, old.double().cpu(), 2.0 ** -7)
+    # a NaN gradient passes the gate on either branch
+    dyn = dyg.clone()
+    dyn[0, 0, 0, 3] = float("nan")
+    gn = ops.conv_dgrad_bf16(dyn, wd, (1, 1), 1, gate=gg, gate_scale=2.0)
+    assert bool(torch.isnan(gn[0, 0, 0]).all()) and int(torch.isnan(gn).sum()) == Cin
+
+
 # (B, H, W, Cin, Cout, k, dil), plan_cus: the LDS-DMA filter-gradient kernel (csrc/wgrad_b16t.h) takes bf16-stored tensors with
 # Cin % 256 == 0 where the plan uses 256 x 256 filter tiles: M tails inside a 32-pixel step, splits that end inside a step's pairs,
 # one to many K steps (all three bodies of the fragment rotation), Cout tails, every tap geometry of the model (1x1, 3x3 rate 1 / 2,
