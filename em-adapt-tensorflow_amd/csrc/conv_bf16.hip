@@ -817,6 +817,7 @@ int launch_wgrad_bf16(const WgradBf16Args &a, hipStream_t stream) {
 }  // namespace
 
 #include "wgrad_b16t.h"   // the LDS-DMA filter-gradient kernel for bf16-stored tensors (uses WgradBf16Args, the bt_* vector types)
+#include "wgrad_d64.h"    // direct filter gradient for 3 x 3, 64 -> 64 channels (conv1_2): the whole gradient in registers, operands fetched once
 
 namespace {
 
@@ -952,13 +953,15 @@ int emadapt_weights_to_bf16(const emadapt_conv_desc *d, const float *w, void *w_
     return launch_status();
 }
 
+static PlanW plan_wgrad_bf16(const emadapt_conv_desc *d, int x_dtype, int dy_dtype);
+
 int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]) {
     if (!plan || kind < 0 || kind > 2) return EMADAPT_ERR_INVALID;
     int rc = kind == 2 ? check_desc_wgrad(d) : check_desc(d);
     if (rc) return rc;
     if (kind == 2) {
-        const PlanW p = make_plan_bf16(d);
-        plan[0] = p.bko; plan[1] = p.bn; plan[2] = p.splits;
+        const PlanW p = plan_wgrad_bf16(d, 1, 1);   // (bf16-stored tensors assumed: what the model keeps)
+        plan[0] = p.bko ? p.bko : 4; plan[1] = p.bko ? p.bn : 16; plan[2] = p.splits;   // (4 x 16: the direct kernel, 16 x 16-pixel tiles, plan[2] slabs)
         return EMADAPT_OK;
     }
     IgemmArgs a;
@@ -1052,11 +1055,32 @@ int emadapt_conv_dgrad_bf16(const emadapt_conv_desc *d, const void *dy, int dy_d
     return dispatch_igemm_bf16_dt(a, Cxp, dy_dtype, dx_dtype, workspace, workspace_bytes, stream);
 }
 
+// The plan of a filter-gradient launch given the storage types: the direct kernel (wgrad_d64.h; bko == 0 marks it, one slab per workgroup)
+// where it applies, else make_plan_bf16's.  tune "wgrad_gen" = 1 or any forced "bf16_tile" keep the split-M kernels.
+static PlanW plan_wgrad_bf16(const emadapt_conv_desc *d, int x_dtype, int dy_dtype) {
+    PlanW p = make_plan_bf16(d);
+    if (wgrad_d64_shape_ok(d, x_dtype, dy_dtype) && tune(TUNE_WGRAD_GEN) != 1 && tune(TUNE_BF16_TILE) == 0) {
+        p.bko = 0; p.bn = 64; p.tiles_k = 1; p.tiles_n = 1; p.splits = wgrad_d64_groups(d); p.rows_per_split = 0;
+    }
+    return p;
+}
+
+// (the queries do not know the storage types: the larger of the two plans' needs where the direct kernel could be chosen)
+static size_t wgrad_bf16_ws_floats(const emadapt_conv_desc *d, bool bias) {
+    size_t need = 0;
+    for (int direct = 0; direct < 2; direct++) {
+        const PlanW p = direct ? plan_wgrad_bf16(d, 1, 1) : make_plan_bf16(d);
+        const size_t w_floats = p.splits > 1 ? (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout : 0;
+        const size_t b_rows = bias ? (size_t)p.splits * p.tiles_k : 0;
+        const size_t n = w_floats + (b_rows > 1 ? b_rows * d->Cout : 0);
+        if (n > need) need = n;
+    }
+    return need;
+}
+
 size_t emadapt_conv_wgrad_bf16_workspace_bytes(const emadapt_conv_desc *d) {
     if (check_desc_wgrad(d) != EMADAPT_OK || d->B == 0) return 0;
-    const PlanW p = make_plan_bf16(d);
-    if (p.splits <= 1) return 0;
-    return (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+    return wgrad_bf16_ws_floats(d, false) * sizeof(float);
 }
 
 static int wgrad_bf16_impl(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,
@@ -1074,7 +1098,7 @@ static int wgrad_bf16_impl(const emadapt_conv_desc *d, const void *x, int x_dtyp
         if (db) EMADAPT_HIP_TRY(hipMemsetAsync(db, 0, (size_t)d->Cout * sizeof(float), stream));
         return EMADAPT_OK;
     }
-    const PlanW p = make_plan_bf16(d);
+    const PlanW p = plan_wgrad_bf16(d, x_dtype, dy_dtype);
     // workspace: [splits][K][N] partial filter gradients (splits > 1), then [splits][tiles_k][N] partial bias gradients (more than one row)
     const long long w_floats = p.splits > 1 ? (long long)p.splits * KN : 0;
     const int b_rows = db ? p.splits * p.tiles_k : 0;
@@ -1092,6 +1116,8 @@ static int wgrad_bf16_impl(const emadapt_conv_desc *d, const void *x, int x_dtyp
     a.y_bytes = (unsigned)((long long)a.M * d->Cout * (dy_dtype ? 2 : 4));
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, (double)a.x_bytes + (double)a.y_bytes + 4.0 * a.K * a.N, stream);
+    if (p.bko == 0) rc = launch_wgrad_d64(a, stream);
+    else
     rc = x_dtype ? (dy_dtype ? launch_wgrad_bf16_plan<true, true>(p, a, stream) : launch_wgrad_bf16_plan<true, false>(p, a, stream))
                  : (dy_dtype ? launch_wgrad_bf16_plan<false, true>(p, a, stream) : launch_wgrad_bf16_plan<false, false>(p, a, stream));
     if (rc) return rc;
@@ -1113,10 +1139,7 @@ int emadapt_conv_wgrad_bias_bf16_fused(const emadapt_conv_desc *d, int x_dtype, 
 
 size_t emadapt_conv_wgrad_bias_bf16_workspace_bytes(const emadapt_conv_desc *d) {
     if (check_desc_wgrad(d) != EMADAPT_OK || d->B == 0) return 0;
-    const PlanW p = make_plan_bf16(d);
-    const size_t w_floats = p.splits > 1 ? (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout : 0;
-    const size_t b_rows = (size_t)p.splits * p.tiles_k;
-    return (w_floats + (b_rows > 1 ? b_rows * d->Cout : 0)) * sizeof(float);
+    return wgrad_bf16_ws_floats(d, true) * sizeof(float);
 }
 
 int emadapt_conv_wgrad_bias_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *dy, int dy_dtype,

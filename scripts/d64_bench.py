@@ -42,9 +42,13 @@ y = torch.empty((B, H, H, C), dtype=torch.bfloat16, device="cuda")
 dx = torch.empty_like(y)
 fl = 2.0 * B * H * H * k * k * C * C
 nbytes = {"fwd": 2 * x.numel() * 2, "dgrad": 3 * x.numel() * 2}
+dwo = torch.empty((k, k, C, C), device="cuda")
+dbo = torch.empty((C,), device="cuda")
+nbytes["wgrad"] = 2 * x.numel() * 2
 print("%-6s %10s %7s %9s   %10s %7s %9s" % ("kind", "igemm ms", "% peak", "GB/s", "direct ms", "% peak", "GB/s"))
 for kind, fn in (("fwd", lambda: ops.conv_fwd_bf16(x, wf, (k, k), b, 1, relu=True, out=y)),
-                 ("dgrad", lambda: ops.conv_dgrad_bf16(dy, wd, (k, k), 1, gate=x, out=dx))):
+                 ("dgrad", lambda: ops.conv_dgrad_bf16(dy, wd, (k, k), 1, gate=x, out=dx)),
+                 ("wgrad", lambda: ops.conv_wgrad_bf16(x, dy, k, k, 1, out=dwo, bias_out=dbo))):   # (with the bias gradient, as the model calls it)
     with ops.tuned(bf16_tile=1):
         t_old = timed(fn)
     assert ops.conv_bf16_plan(B, H, H, C, C, k, 1, kind)[0] == 4

@@ -42,7 +42,7 @@ def layers(size=321, C=21, preset="ref", width=64):
 
 
 def short(name):
-    m = re.search(r"(igemm_ws_kernel<\w+>|wgrad_ws_kernel<\d+>|igemm2?_kernel<[^>]*>|wgrad2_kernel(?:<\w+>)?|wgrad_kernel<[^>]*>|igemm_bf16\w*_kernel|igemm_b16t_kernel<\w+|conv_d64_kernel<\w+|conv_d4_kernel|conv_k32_kernel|wgrad_bf16_kernel<\d+>|wgrad_b16t_kernel"
+    m = re.search(r"(igemm_ws_kernel<\w+>|wgrad_ws_kernel<\d+>|igemm2?_kernel<[^>]*>|wgrad2_kernel(?:<\w+>)?|wgrad_kernel<[^>]*>|igemm_bf16\w*_kernel|igemm_b16t_kernel<\w+|conv_d64_kernel<\w+|conv_d4_kernel|conv_k32_kernel|wgrad_bf16_kernel<\d+>|wgrad_b16t_kernel|wgrad_d64_kernel"
                   r"|igemm_x6p?_kernel<[^>]*>|wgrad_x6p?_kernel<[^>]*>)", name)
     return m.group(1) if m else name[:40]
 
@@ -54,7 +54,7 @@ def main():
     C = int(sys.argv[4]) if len(sys.argv) > 4 else 21
     preset = sys.argv[5] if len(sys.argv) > 5 else "ref"
     L = layers(size, C, preset)
-    rows = [r for r in csv.DictReader(open(path)) if re.search(r"igemm(_ws|_bf16\w*|_b16t|2|_x6p?)?_kernel|conv_d64_kernel|conv_d4_kernel|conv_k32_kernel|wgrad(_ws|_bf16|_b16t|2|_x6p?)?_kernel", r["Kernel_Name"])]
+    rows = [r for r in csv.DictReader(open(path)) if re.search(r"igemm(_ws|_bf16\w*|_b16t|2|_x6p?)?_kernel|conv_d64_kernel|conv_d4_kernel|conv_k32_kernel|wgrad(_ws|_bf16|_b16t|_d64|2|_x6p?)?_kernel", r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))   # (the trace file is not always in launch order)
     global PEAK
     if any("_x6" in r["Kernel_Name"] for r in rows):

@@ -400,6 +400,38 @@ def test_bf16_short_reduction_data_gradient(env, shape):
     assert bool(torch.isnan(gn[0, 0, 0]).all()) and int(torch.isnan(gn).sum()) == Cin
 
 
+@pytest.mark.parametrize("shape,cus", D64)
+def test_bf16_direct_filter_gradient_64_to_64(env, shape, cus):
+    """conv1_2's filter gradient on the direct kernel (csrc/wgrad_d64.h): the whole 9 x 64 x 64 gradient of a workgroup's tiles in registers,
+    one slab per workgroup; the bias gradient as one more MFMA tile.  Same shapes as the forward's direct kernel."""
+    ops, do, torch = env
+    B, H, W = shape
+    k, C = 3, 64
+    rng = np.random.default_rng(hash(shape) % (1 << 31) + 1)
+    x = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+    dy = rng.normal(0.2, 1, (B, H, W, C)).astype(np.float32)
+    wt = torch.zeros((k, k, C, C), dtype=torch.float64, requires_grad=True)
+    y = do.conv_same(_bf(torch, x), wt, torch.zeros(C, dtype=torch.float64), 1)
+    y.backward(_bf(torch, dy))
+    xg, dyg = _t(torch, x).bfloat16(), _t(torch, dy).bfloat16()
+    want_b = dyg.double().sum(dim=(0, 1, 2)).cpu()
+    with ops.tuned(plan_cus=cus):
+        plan = ops.conv_bf16_plan(B, H, W, C, C, k, 1, "wgrad")
+        assert plan[:2] == (4, 16) and plan[2] == min(cus, B * ((H + 15) // 16) * ((W + 15) // 16))
+        new = ops.conv_wgrad_bf16(xg, dyg, k, k, 1)
+        assert _rel(new.cpu(), wt.grad) < 2e-5
+        assert torch.equal(new, ops.conv_wgrad_bf16(xg, dyg, k, k, 1)), "filter gradient must be bitwise reproducible"
+        db = torch.full((C,), float("nan"), device=xg.device)
+        assert torch.equal(ops.conv_wgrad_bf16(xg, dyg, k, k, 1, bias_out=db), new)
+        assert _rel(db.cpu().double(), want_b) < 1e-5
+        with ops.tuned(wgrad_gen=1):
+            assert ops.conv_bf16_plan(B, H, W, C, C, k, 1, "wgrad")[:2] == (128, 64)
+            old = ops.conv_wgrad_bf16(xg, dyg, k, k, 1)        # the split-M kernel
+        assert _rel(new.cpu(), old.cpu()) < 2e-5
+        # f32-stored operands are not the direct kernel's: the same call answers through the split-M kernel
+        assert _rel(ops.conv_wgrad_bf16(xg.float(), dyg, k, k, 1).cpu(), wt.grad) < 2e-5
+
+
 # (B, H, W, Cin, Cout, k, dil), plan_cus: the LDS-DMA filter-gradient kernel (csrc/wgrad_b16t.h) takes bf16-stored tensors with
 # Cin % 256 == 0 where the plan uses 256 x 256 filter tiles: M tails inside a 32-pixel step, splits that end inside a step's pairs,
 # one to many K steps (all three bodies of the fragment rotation), Cout tails, every tap geometry of the model (1x1, 3x3 rate 1 / 2,

@@ -56,7 +56,7 @@ FULL = [
     ("conv4_2", (16, 41, 41, 512, 512, 3, 1), 256, (256, 256), False),
     ("conv3_2", (16, 81, 81, 256, 256, 3, 1), 256, (256, 256), False),
     ("conv1_2", (16, 321, 321, 64, 64, 3, 1), 128, (128, 64), False),   # 12,881 workgroups; 1.65 M pixels (forced: tune bf16_tile = 128)
-    ("conv1_2 direct", (16, 321, 321, 64, 64, 3, 1), 4, (128, 64), False),    # the automatic plan: the direct kernel (csrc/conv_d64.h), 7,056 tiles of 16 x 16
+    ("conv1_2 direct", (16, 321, 321, 64, 64, 3, 1), 4, (4, 16), False),    # the automatic plan: the direct kernel (csrc/conv_d64.h), 7,056 tiles of 16 x 16
     ("conv1_2 patch", (16, 321, 321, 64, 64, 3, 1), 3, (128, 64), False),     # the opt-in patch kernel (csrc/conv_p3.h): 18 x 14 tiles
     ("conv2_2 patch", (16, 161, 161, 128, 128, 3, 1), 3, (128, 128), False),  # 128 columns: 8 B fragments per step, 4 channel groups
 ]
@@ -121,6 +121,14 @@ def test_bf16_benchmark_shape_against_fp64_oracle_on_rounded_operands(env, reque
         dx32 = ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg.float(), gate_scale=scale)
         assert _rel(dx32.cpu(), want_dx) < 2e-5 and close(dxb, dx32.bfloat16(), 2.0 ** -7) and (dxb == dx32.bfloat16()).float().mean().item() > 0.99
         del dxb, dx32
+        # the filter gradient on its direct kernel (csrc/wgrad_d64.h: 256 slabs of 9 x 64 x 64 + the bias row)
+        dw1 = ops.conv_wgrad_bf16(xg, dyg, k, k, dil)
+        assert _rel(dw1.cpu(), want_dw) < 2e-5
+        assert torch.equal(dw1, ops.conv_wgrad_bf16(xg, dyg, k, k, dil)), "filter gradient must repeat bitwise"
+        db = torch.empty((Cout,), device=dev)
+        assert torch.equal(ops.conv_wgrad_bf16(xg, dyg, k, k, dil, bias_out=db), dw1)
+        assert _rel(db.cpu().double(), dy.double().sum(dim=(0, 1, 2))) < 1e-5
+        assert _rel(ops.conv_wgrad_bf16(xg.float(), dyg.float(), k, k, dil).cpu(), dw1.cpu()) < 2e-5   # (f32-stored operands: the split-M kernel)
         return
     # forward: bf16-stored input -> f32 output
     y1 = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, **kw)
