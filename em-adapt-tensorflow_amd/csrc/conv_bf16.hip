@@ -873,6 +873,10 @@ PlanBT plan_b16t(const IgemmArgs &a) {
     // one round that fills at least three quarters of the CUs (conv4_x / conv5_x: 212 tiles): plain tiles -- stream-K's second
     // prologue, published and combined accumulator image per CU cost more than the idle quarter (0.107 against 0.119 ms on conv4_2)
     if (t <= cus && 4 * t >= 3LL * cus) return p;
+    // four and more rounds (fc6 / fc7: 6.6): plain tiles all the way -- the last round's idle CUs (a sixth of one round in seven) cost less than
+    // the second launch, its prologue and the combined tiles of a stream-K tail: fc7 forward 0.697 -> 0.667 ms, data gradient 0.760 -> 0.727,
+    // fc6 forward 1.201 -> 1.193 (same process, same tensors, A/B/A/B).  Fewer rounds keep whole rounds + stream-K tail below.
+    if (t >= 4LL * cus && tune(TUNE_BF16T_SK) == 0) return p;
     if (a.N <= 1024 || t < cus || tune(TUNE_BF16T_SK) == 1) {
         p.main_sk = 1;
         p.main_levels = streamk_levels(t, nk, cus);

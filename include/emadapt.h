@@ -468,9 +468,9 @@ int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *p
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
  *   "bf16_tile"  128 | 256 (emadapt_conv_*_bf16: 128 also keeps the 128-wide tile where 128 x 64 would be chosen); 3: the patch kernel
  *                (csrc/conv_p3.h) for the 3 x 3 layers with at most 128 output columns on bf16-stored activations, automatic elsewhere
- *   "bf16t_sk"   1: the tiled-filter bf16 launches (emadapt_conv_*_bf16t) run ALL their tiles as one stream-K launch instead of whole
- *                rounds of plain tiles + a stream-K launch over the last partial round (A/B aid: measured slower on fc6 / fc7,
- *                profiles/r05_bf16t_bench.txt)
+ *   "bf16t_sk"   1: the tiled-filter bf16 launches (emadapt_conv_*_bf16t) run ALL their tiles as one stream-K launch (A/B aid: measured
+ *                slower on fc6 / fc7, profiles/r05_bf16t_bench.txt) | 2: four and more rounds of tiles as whole rounds of plain tiles +
+ *                a stream-K launch over the last partial round (rounds 4-5; the default is plain tiles all the way there: fc7 -4 %)
  *   "x6_tile"    128 | 256
  *   "plan_cus"  number of CUs the launch plans are laid out for (default 256: MI355X)
  *   "fp32_loader" 1: the 256x256 fp32 kernels' loader waves compute their offsets per K step (works for any tap count);

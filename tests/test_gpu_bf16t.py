@@ -60,7 +60,8 @@ SMALL = [
     ((2, 13, 11, 64, 40, 3, 2), 256),
     ((2, 19, 17, 32, 264, 1, 1), 3),       # two N tiles; 3 "CUs": stream-K pieces across tiles
     ((3, 21, 20, 96, 520, 3, 1), 4),       # 6 x 3 tiles on 4 CUs
-    ((1, 41, 41, 64, 1032, 1, 1), 2),      # N > 1024: whole rounds as plain tiles + a stream-K tail
+    ((1, 41, 41, 1024, 1032, 1, 1), 10),   # N > 1024, 3.5 rounds of tiles: whole rounds as plain tiles + a stream-K tail (four and more rounds: plain)
+    ((1, 41, 41, 64, 1032, 1, 1), 2),      # .. the same on 2 "CUs": 17.5 rounds, plain tiles all the way
     ((2, 16, 16, 128, 256, 4, 4), 5),      # 4x4 rate 4 (fc6's filter), 16 taps
     ((1, 25, 25, 32, 48, 3, 12), 256),     # rate 12 reaches far outside the map
     ((2, 30, 18, 160, 288, 3, 1), 7),

@@ -391,7 +391,9 @@ def test_executed_fraction_and_new_plan_queries_without_a_device():
     assert ops.conv_bf16t_pays(ops.conv_desc(16, 41, 41, 512, 4096, 4, 4, 4), "dgrad")   # fc6's data gradient: 1696 K steps per CU
     assert not ops.conv_bf16t_pays(ops.conv_desc(16, 161, 161, 128, 128, 3, 3, 1), "fwd")   # narrower than a tile
     rows, sk, levels, tail = ops.conv_bf16t_plan(16, 41, 41, 4096, 4096, 1, 1)
-    assert rows == 24576 and sk == 0 and tail >= 1                                     # 6 whole rounds + a stream-K tail
+    assert rows == 16 * 41 * 41 and sk == 0 and levels == 0                             # 6.6 rounds: plain tiles all the way (round 5; rounds 4-5: + a stream-K tail)
+    rows, sk, levels, tail = ops.conv_bf16t_plan(6, 41, 41, 4096, 4096, 1, 1)
+    assert rows == 8192 and sk == 0 and tail >= 1                                      # 2.5 rounds: 2 whole rounds + a stream-K tail
     # tensors of 2 GiB and more: one launch is refused by the 32-bit offsets, the entries slice the batch; workspace = the largest slice's
     big = ops.conv_desc(129, 256, 256, 32, 64, 3, 3, 1)
     one = ops.conv_desc(127, 256, 256, 32, 64, 3, 3, 1)
