@@ -56,7 +56,12 @@ extern "C" {
  *        untouched while the word is non-zero.  Added: the gradient-exchange staging entries (emadapt_grad_pack,
  *        emadapt_grad_owner_sum, emadapt_sgd_momentum_payload), emadapt_sgd_accumulate_momentum.
  *   204  round 5, added: emadapt_conv_wgrad_bias_bf16 (+ _fused, _workspace_bytes): bf16 filter gradient and bias gradient in one
- *        launch (and one second-stage launch for both); emadapt_conv_bf16t_pays; tune "bf16t_sk". */
+ *        launch (and one second-stage launch for both); emadapt_conv_bf16t_pays; emadapt_filter_tiles_bf16_both; tune "bf16t_sk".  No
+ *        signature changed, but launch plans did: emadapt_conv_{fwd,dgrad}_bf16 take 3 x 3, 64 -> 64 channels on bf16-stored tensors
+ *        to a direct kernel (emadapt_conv_bf16_plan: plan[0] == 4), the forward of 3 x 3, 4 (f32-stored) -> 64 (bf16-stored) channels
+ *        to another (5), a 1 x 1 data gradient with at most 32 gathered channels to a third (6); emadapt_conv_wgrad[_bias]_bf16 take
+ *        3 x 3, 64 -> 64 channels on bf16-stored tensors to a direct kernel whose workspace is one slab per workgroup (re-query
+ *        emadapt_conv_wgrad[_bias]_bf16_workspace_bytes: 37.8 MB for conv1_2 at batch 16 where the split-M plan needed 15 MB). */
 #define EMADAPT_ABI_VERSION 204
 int emadapt_version(void);
 const char *emadapt_strerror(int code);
