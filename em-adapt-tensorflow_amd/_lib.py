@@ -130,6 +130,7 @@ PROTOTYPES = {
     "emadapt_sgd_momentum": (c_int, [_vp, _vp, _vp, c_int64, c_float, c_float, c_float, _vp]),
     "emadapt_sgd_accumulate_momentum": (c_int, [_vp, _vp, _vp, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float, _vp]),
     "emadapt_sgd_momentum_payload": (c_int, [_vp, _vp, _vp, _vp, c_int, c_int64, c_float, c_float, c_float, _vp]),
+    "emadapt_sgd_accumulate_pack": (c_int, [_vp, _vp, c_int64, c_int64, c_float, c_float, _vp, c_int, _vp]),
     "emadapt_grad_pack": (c_int, [_vp, c_int64, _vp, c_int, c_int64, _vp]),
     "emadapt_grad_owner_sum": (c_int, [_vp, c_int, c_int, c_int64, _vp, _vp]),
     "emadapt_status_word": (c_int, [POINTER(_vp)]),

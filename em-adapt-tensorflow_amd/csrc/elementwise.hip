@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(256) sgd_momentum_payload_kernel(float *__rest
             wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
             st4(v + o, vi);
             st4(w + o, wi);
-            st4(accum + o, make_float4(0.f, 0.f, 0.f, 0.f));
+            if (accum) st4(accum + o, make_float4(0.f, 0.f, 0.f, 0.f));   // (null: the exchange was fed without an accumulator, sgd_accumulate_pack)
         }
     }
 }
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(256) sgd_momentum_payload_tail_kernel(float *_
         const float vi = opt_velocity(mu, v[i], (float)payload[i], ascale);
         v[i] = vi;
         w[i] = opt_step(w[i], lr, vi);
-        accum[i] = 0.f;
+        if (accum) accum[i] = 0.f;
     }
 }
 
@@ -545,6 +545,39 @@ __global__ void __launch_bounds__(256) sgd_accumulate_momentum_kernel(float *__r
 }
 
 // ------------------------------------------------------------------------------------------
+// accumulate + pack for accum_num == 1 in a data-parallel job: payload[i] = P(0 + (g + wd w) scale) -- what emadapt_sgd_accumulate would leave
+// in a zeroed accumulator and emadapt_grad_pack would then round, operation for operation, without the accumulator's write, read and
+// clean (12 of the 44 bytes the exchange path moved per parameter) and without the pack pass.
+template <typename P>
+__global__ void __launch_bounds__(256) sgd_accumulate_pack_kernel(const float *__restrict__ g, const float *__restrict__ w, long long nv,
+                                                                long long n_decay, float wd, float scale, P *__restrict__ dst) {
+    constexpr int VN = VW<P>::N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        float x[VN];
+#pragma unroll
+        for (int q = 0; q < VN / 4; q++) {
+            const long long o = i * VN + q * 4;
+            float4 gi = ld4(g + o);
+            if (o < n_decay) {   // (n_decay % 4 == 0: checked by the host)
+                const float4 wi = ld4(w + o);
+                gi.x = opt_decay(gi.x, wd, wi.x); gi.y = opt_decay(gi.y, wd, wi.y); gi.z = opt_decay(gi.z, wd, wi.z); gi.w = opt_decay(gi.w, wd, wi.w);
+            }
+            x[q * 4 + 0] = opt_accum(0.f, gi.x, scale); x[q * 4 + 1] = opt_accum(0.f, gi.y, scale);
+            x[q * 4 + 2] = opt_accum(0.f, gi.z, scale); x[q * 4 + 3] = opt_accum(0.f, gi.w, scale);
+        }
+        stv(dst + i * VN, x);
+    }
+}
+template <typename P>
+__global__ void __launch_bounds__(256) sgd_accumulate_pack_scalar_kernel(const float *__restrict__ g, const float *__restrict__ w, long long i0,
+                                                                       long long n, long long n_decay, float wd, float scale, P *__restrict__ dst) {
+    for (long long i = i0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        if (i < n_decay) gi = opt_decay(gi, wd, w[i]);
+        dst[i] = (P)opt_accum(0.f, gi, scale);
+    }
+}
+
 // Staging of the data-parallel gradient exchange (dist.py, algo "direct": reduce-scatter + all-gather as two all-to-all steps).
 // The exchange maps the reference's micro-batches to ranks (deeplab.py:202: accum += g / accum_num); these kernels are the only
 // arithmetic on that path and replace round 4's torch copy_/add_ sequences (6 + W launches and ~8 passes per bucket) by one pass each.
@@ -871,6 +904,32 @@ int emadapt_sgd_accumulate(float *accum, const float *g, const float *w, int64_t
     return launch_status();
 }
 
+int emadapt_sgd_accumulate_pack(const float *g, const float *w, int64_t n, int64_t n_decay, float weight_decay, float scale,
+                                void *dst, int dst_dtype, void *stream_) {
+    if (!g || !dst || n < 0 || n_decay < 0 || n_decay > n || (dst_dtype != EMADAPT_DT_F32 && dst_dtype != EMADAPT_DT_BF16)) return EMADAPT_ERR_INVALID;
+    if (n_decay > 0 && !w) return EMADAPT_ERR_INVALID;
+    if (n == 0) return EMADAPT_OK;
+    hipStream_t stream = as_stream(stream_);
+    const bool bf = dst_dtype == EMADAPT_DT_BF16;
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * (4.0 + (bf ? 2.0 : 4.0)) + (double)n_decay * 4.0, stream);
+    const int vn = bf ? 8 : 4;
+    const bool vec = aligned16(g) && aligned16(dst) && (!w || aligned16(w)) && n_decay % 4 == 0;
+    const int64_t nvec = vec ? n / vn : 0;
+    if (nvec > 0) {
+        if (bf) hipLaunchKernelGGL(sgd_accumulate_pack_kernel<__bf16>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, stream, g, w, (long long)nvec,
+                                   (long long)n_decay, weight_decay, scale, static_cast<__bf16 *>(dst));
+        else hipLaunchKernelGGL(sgd_accumulate_pack_kernel<float>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, stream, g, w, (long long)nvec,
+                                (long long)n_decay, weight_decay, scale, static_cast<float *>(dst));
+    }
+    if (nvec * vn < n) {
+        if (bf) hipLaunchKernelGGL(sgd_accumulate_pack_scalar_kernel<__bf16>, dim3(grid_for(n - nvec * vn, 256, 4096)), dim3(256), 0, stream, g, w,
+                                   (long long)(nvec * vn), (long long)n, (long long)n_decay, weight_decay, scale, static_cast<__bf16 *>(dst));
+        else hipLaunchKernelGGL(sgd_accumulate_pack_scalar_kernel<float>, dim3(grid_for(n - nvec * vn, 256, 4096)), dim3(256), 0, stream, g, w,
+                                (long long)(nvec * vn), (long long)n, (long long)n_decay, weight_decay, scale, static_cast<float *>(dst));
+    }
+    return launch_status();
+}
+
 int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, float momentum, float accum_scale,
                          void *stream_) {
     if (!w || !v || !accum || n < 0) return EMADAPT_ERR_INVALID;
@@ -890,15 +949,15 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
 
 int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *payload, int payload_dtype, int64_t n, float lr,
                                  float momentum, float scale, void *stream_) {
-    if (!w || !v || !accum || !payload || n < 0 || (payload_dtype != EMADAPT_DT_F32 && payload_dtype != EMADAPT_DT_BF16))
+    if (!w || !v || !payload || n < 0 || (payload_dtype != EMADAPT_DT_F32 && payload_dtype != EMADAPT_DT_BF16))   // (accum may be NULL: nothing to clean)
         return EMADAPT_ERR_INVALID;
     if (n == 0) return EMADAPT_OK;
     hipStream_t stream = as_stream(stream_);
     const unsigned *status = status_word();
     const bool bf = payload_dtype == EMADAPT_DT_BF16;
-    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * (20.0 + (bf ? 2.0 : 4.0)), stream);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * ((accum ? 20.0 : 16.0) + (bf ? 2.0 : 4.0)), stream);
     const int vn = bf ? 8 : 4;
-    const bool vec = aligned16(w) && aligned16(v) && aligned16(accum) && aligned16(payload);
+    const bool vec = aligned16(w) && aligned16(v) && (!accum || aligned16(accum)) && aligned16(payload);
     const int64_t nvec = vec ? n / vn : 0;
     if (nvec > 0) {
         if (bf)

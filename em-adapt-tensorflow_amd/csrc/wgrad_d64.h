@@ -133,7 +133,6 @@ __global__ void __launch_bounds__(256, 1) wgrad_d64_kernel(WgradBf16Args a, D64G
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     for (int ti = 0; ti < my_tiles; ti++) {
         const int buf = ti & 1;
         stage_tile(ti + 1);

@@ -637,9 +637,13 @@ class ADAPT(Network):
             grad_dtype = str(self.config.get("grad_dtype", "fp32"))
             algo = str(self.config.get("allreduce_algo", "direct" if grad_dtype == "bf16" else "allreduce"))
             # (direct exchange: the summed gradients stay in GradSync.gathered, which apply_update's Momentum kernel reads in place)
+            # accum_num == 1 with the direct exchange: backward packs (g + wd w) / accum_num straight into the exchange's send buffer
+            # (ops.sgd_accumulate_pack) -- no accumulate pass, no accumulator traffic, no pack pass (config "dp_prepack": False = the
+            # accumulator path, what accum_num > 1 always takes)
+            prepack = self.accum_num == 1 and algo == "direct" and bool(self.config.get("dp_prepack", True))
             self._gradsync = GradSync(self._flat["accum"], [(s["start"], s["end"]) for s in self._bucket_order()],
                                       bucket_bytes=int(self.config.get("bucket_mb", 32)) << 20, algo=algo, payload=grad_dtype,
-                                      writeback=False)
+                                      writeback=False, prepacked=prepack)
 
     def _bucket_order(self):
         return [self._segments[op.name] for op in reversed(self._plan) if op.kind == "conv"]
@@ -701,7 +705,10 @@ class ADAPT(Network):
                     ops.conv_wgrad(x_in, d, op.k, op.k, op.rate, out=op.gw_pad, bias_out=op.gb_pad)
                 seg = op.seg
                 s, n = seg["start"], seg["nw"] + seg["nb"]
-                if not fused:
+                if sync is not None and sync.prepacked:
+                    ops.sgd_accumulate_pack(self._flat["grads"][s:s + n], self._flat["params"][s:s + n], seg["nw"], self._weight_decay,
+                                            inv_accum, out=sync.sendfull[s:s + n])
+                elif not fused:
                     ops.sgd_accumulate(self._flat["accum"][s:s + n], self._flat["grads"][s:s + n],
                                        self._flat["params"][s:s + n], seg["nw"], self._weight_decay, inv_accum)
                 if last_micro and self._gradsync is not None:
@@ -761,7 +768,8 @@ class ADAPT(Network):
             self._pending_fused = False
         elif gs is not None and not gs.writeback:
             # the exchanged sum lives in the gathered payload (f32 or bf16); the accumulator is only zeroed (the clean op)
-            ops.sgd_momentum_payload(f["params"], f["momentum"], f["accum"], gs.gathered, self.net["lr"], self._momentum, scale)
+            ops.sgd_momentum_payload(f["params"], f["momentum"], None if gs.prepacked else f["accum"], gs.gathered, self.net["lr"],
+                                     self._momentum, scale)
         else:
             ops.sgd_momentum(f["params"], f["momentum"], f["accum"], self.net["lr"], self._momentum, scale)
         self._w16_seen = None  # the master weights moved: the bf16 images are refreshed by the next forward

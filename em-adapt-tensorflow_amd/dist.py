@@ -63,7 +63,7 @@ def _ops():
 
 
 class GradSync:
-    def __init__(self, flat, segments, bucket_bytes=64 << 20, group=None, algo="allreduce", payload="fp32", writeback=True):
+    def __init__(self, flat, segments, bucket_bytes=64 << 20, group=None, algo="allreduce", payload="fp32", writeback=True, prepacked=False):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("torch.distributed is not initialised")
         if algo not in ("allreduce", "direct") or payload not in ("fp32", "bf16"):
@@ -80,6 +80,11 @@ class GradSync:
         # direct exchange only: False = the summed gradients stay in `gathered` (payload type) and flat[...] keeps the LOCAL values --
         # the optimiser reads `gathered` (ops.sgd_momentum_payload); True = they are also copied back into flat
         self.writeback = bool(writeback) or algo != "direct"
+        # direct exchange without write-back only: True = the CALLER fills `sendfull` (payload type, laid out like `gathered`) with this
+        # rank's contribution before segment_ready() -- ops.sgd_accumulate_pack does, when accum_num == 1 -- and flat is never read: the
+        # accumulate pass, the accumulator's traffic and the pack pass of the exchange disappear; the sums come out as with the pack
+        self.prepacked = bool(prepacked) and algo == "direct" and not self.writeback
+        self.sendfull = None
         self.gathered = None
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -116,6 +121,8 @@ class GradSync:
             # [s, e) lives at [s, s + npad)): what the optimiser reads when nothing is written back
             s_last, e_last = self.buckets[-1]
             self.gathered = torch.zeros(s_last + -(-(e_last - s_last) // W) * W, dtype=pdt, device=flat.device)
+            if self.prepacked:
+                self.sendfull = torch.zeros_like(self.gathered)   # (the padding behind the last bucket stays zero: nobody writes it)
             if flat.is_cuda:
                 self._side = torch.cuda.Stream(device=flat.device)
         self.wire_bytes_per_update = self._wire_bytes()
@@ -136,7 +143,9 @@ class GradSync:
         sh = npad // W
         recv, gath = self._recv[:npad], self.gathered[s:s + npad]
         hip = self.flat.is_cuda
-        if self.payload != "bf16" and npad == n:
+        if self.prepacked:
+            send = self.sendfull[s:s + npad]         # filled by the caller, already in the payload type
+        elif self.payload != "bf16" and npad == n:
             send = self.flat[s:e]                    # whole fp32 shards: sent as they lie in the accumulator
         else:
             send = self._send[:npad]

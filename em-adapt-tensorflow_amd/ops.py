@@ -672,9 +672,23 @@ def _payload_dt(t, name):
     raise TypeError("%s must be float32 or bfloat16, got %s" % (name, t.dtype))
 
 
+def sgd_accumulate_pack(g, w, n_decay, weight_decay, scale, out):
+    """out[i] = payload type of 0 + (g[i] + weight_decay * w[i] (i < n_decay)) * scale: accumulate + pack without an accumulator (accum_num == 1,
+    data-parallel exchange fed `prepacked`: dist.py)."""
+    _check(g, name="g"); _check(w, name="w")
+    dt = _payload_dt(out, "out")
+    if out.numel() != g.numel() or w.numel() != g.numel():
+        raise ValueError("g, w and out must have the same length")
+    _lib.call("emadapt_sgd_accumulate_pack", _p(g), _p(w), g.numel(), int(n_decay), float(weight_decay), float(scale), _p(out), dt, _stream())
+    return out
+
+
 def sgd_momentum_payload(w, v, accum, payload, lr, momentum, scale=1.0):
-    """Momentum reading the summed gradient from the gathered payload of the gradient exchange (f32 or bf16); accum is zeroed."""
-    _check(w, name="w"); _check(v, name="v"); _check(accum, name="accum")
+    """Momentum reading the summed gradient from the gathered payload of the gradient exchange (f32 or bf16); accum is zeroed (None: there is
+    no accumulator to zero)."""
+    _check(w, name="w"); _check(v, name="v")
+    if accum is not None:
+        _check(accum, name="accum")
     dt = _payload_dt(payload, "payload")
     if payload.numel() < w.numel():
         raise ValueError("payload holds %d elements, the parameters %d" % (payload.numel(), w.numel()))

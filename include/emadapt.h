@@ -456,7 +456,11 @@ int emadapt_sgd_accumulate_momentum(float *w, float *v, const float *g, int64_t 
 int emadapt_grad_pack(const float *src, int64_t n, void *dst, int dst_dtype, int64_t npad, void *stream);
 int emadapt_grad_owner_sum(const void *recv, int dtype, int world, int64_t shard, void *out, void *stream);
 int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *payload, int payload_dtype, int64_t n,
-                                 float lr, float momentum, float scale, void *stream);
+                                 float lr, float momentum, float scale, void *stream);   /* accum may be NULL (ABI 204): nothing to zero */
+/* accum_num == 1 in a data-parallel job (ABI 204): dst[i] = payload type of 0 + (g[i] + weight_decay w[i] (i < n_decay)) scale -- exactly what
+ * emadapt_sgd_accumulate leaves in a zeroed accumulator and emadapt_grad_pack then rounds, without the accumulator (dist.py `prepacked`). */
+int emadapt_sgd_accumulate_pack(const float *g, const float *w, int64_t n, int64_t n_decay, float weight_decay, float scale,
+                                void *dst, int dst_dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Launch-plan overrides.  Every convolution picks a kernel variant and a split factor from its shape; these

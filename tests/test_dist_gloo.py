@@ -180,6 +180,17 @@ def _direct_worker(rank, world, port, out_dir):
         gs2.wait()
         assert np.array_equal(flat.numpy(), mine.numpy())
         assert np.array_equal(gs2.gathered[:total].float().numpy(), np.load(os.path.join(out_dir, "%s_%d.npy" % (payload, rank))))
+        # prepacked (accum_num == 1: backward writes this rank's contribution, already in the payload type, into `sendfull`; the
+        # accumulator is never read): the same sums, bit for bit -- flat may hold anything
+        flat.fill_(float("nan"))
+        gs3 = GradSync(flat, segs, bucket_bytes=2048 * 4, algo="direct", payload=payload, writeback=False, prepacked=True)
+        assert gs3.prepacked and gs3.sendfull.dtype == gs3.gathered.dtype and gs3.sendfull.numel() == gs3.gathered.numel()
+        for s, e in segs:
+            gs3.sendfull[s:e].copy_(mine[s:e])          # (the HIP path: ops.sgd_accumulate_pack writes it)
+            gs3.segment_ready(s, e)
+        gs3.wait()
+        assert np.array_equal(gs3.gathered[:total].float().numpy(), np.load(os.path.join(out_dir, "%s_%d.npy" % (payload, rank))))
+        assert not GradSync(flat, segs, algo="allreduce", prepacked=True).prepacked      # (only the direct exchange without write-back)
     np.save(os.path.join(out_dir, "mine%d.npy" % rank), mine.numpy())
     dist.barrier()
     dist.destroy_process_group()

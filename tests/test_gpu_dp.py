@@ -125,3 +125,19 @@ def test_direct_exchange_and_bf16_gradient_payload(tmp_path, dtype, exchange, ba
     want = a._flat["params"].cpu().numpy()
     err = np.abs(p0 - want).max() / np.abs(want).max()
     assert err < bar, err
+
+
+@pytest.mark.parametrize("dtype,exchange", [("fp32", {"allreduce_algo": "direct"}), ("bf16", {"grad_dtype": "bf16"})])
+def test_prepacked_exchange_is_the_accumulator_path_bit_for_bit(tmp_path, dtype, exchange):
+    """accum_num == 1 with the direct exchange: backward packs (g + wd w) / accum_num straight into the exchange's send buffer
+    (ops.sgd_accumulate_pack, GradSync(prepacked=True): no accumulate pass, no accumulator, no pack pass) -- the weights after two updates
+    are the accumulator path's (config dp_prepack = False), bit for bit, on both ranks."""
+    import torch.multiprocessing as mp
+    got = {}
+    for pre in (True, False):
+        d = tmp_path / ("pre%d" % pre)
+        d.mkdir()
+        mp.spawn(_worker, args=(2, _free_port(), str(d), dtype, dict(exchange, dp_prepack=pre)), nprocs=2, join=True)
+        got[pre] = [np.load(d / ("params%d.npy" % r)) for r in range(2)]
+        assert np.array_equal(got[pre][0], got[pre][1]), "ranks diverged"
+    assert np.array_equal(got[True][0], got[False][0])

@@ -282,6 +282,34 @@ def test_fused_accumulate_momentum_is_the_two_kernels_bit_for_bit(env, n, n_deca
         assert torch.equal(w1, w2) and torch.equal(v1.view(torch.int32), v2.view(torch.int32)), (gscale, ascale)
 
 
+@pytest.mark.parametrize("n,n_decay", [(64 * 1024 + 512, 64 * 1024), (1027, 1001), (8, 8), (4096, 0), (4099, 4096)])
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_accumulate_pack_is_accumulate_then_pack_bit_for_bit(env, n, n_decay, payload):
+    """emadapt_sgd_accumulate_pack (accum_num == 1 in a data-parallel job: backward feeds the exchange without an accumulator) must produce
+    exactly what emadapt_sgd_accumulate leaves in a zeroed accumulator and emadapt_grad_pack then rounds; and emadapt_sgd_momentum_payload
+    without an accumulator must update weights and momentum exactly as with one."""
+    ops, do, torch = env
+    pdt = torch.bfloat16 if payload == "bf16" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(n + 17)
+    w = torch.randn(n, device="cuda", generator=g)
+    v = torch.randn(n, device="cuda", generator=g) * 0.1
+    grad = torch.randn(n, device="cuda", generator=g) * torch.exp(torch.randn(n, device="cuda", generator=g) * 2) * 1e-2
+    grad[::7] = -0.0
+    grad[3::11] = 0.0
+    for gscale in (1.0, 0.125, 1.0 / 3.0):
+        acc = torch.zeros(n, device="cuda")
+        ops.sgd_accumulate(acc, grad, w, n_decay, 5e-4, gscale)
+        want = ops.grad_pack(acc, torch.empty(n, dtype=pdt, device="cuda"))
+        got = ops.sgd_accumulate_pack(grad, w, n_decay, 5e-4, gscale, torch.full((n,), float("nan"), dtype=pdt, device="cuda"))
+        bits = torch.int16 if payload == "bf16" else torch.int32
+        assert torch.equal(got.view(bits), want.view(bits)), gscale
+        w1, v1 = w.clone(), v.clone()
+        ops.sgd_momentum_payload(w1, v1, acc, want, 1e-3, 0.9, 0.5)
+        w2, v2 = w.clone(), v.clone()
+        ops.sgd_momentum_payload(w2, v2, None, got, 1e-3, 0.9, 0.5)
+        assert torch.equal(w1, w2) and torch.equal(v1.view(torch.int32), v2.view(torch.int32)) and not bool(acc.any())
+
+
 @pytest.mark.parametrize("world,n", [(2, 4096), (3, 4099), (8, 1476), (8, 32768 + 8), (8, 65536), (5, 7)])
 @pytest.mark.parametrize("payload", ["fp32", "bf16"])
 def test_gradient_exchange_staging_kernels(env, world, n, payload):
