@@ -75,8 +75,11 @@ def test_six_ranks_share_the_gpu_with_the_all_links_exchange_and_the_bf16_payloa
     padding in tests/test_dist_gloo.py) with configs[2] / [3]'s exchange -- bf16 compute, bf16 gradient payload, direct
     (reduce-scatter + all-gather as two all-to-all steps), staging by the HIP kernels, Momentum on the gathered payload -- one line,
     n_gpus and allreduce.ranks from the communicator, the exchange's overhead measured in the same process."""
+    import torch
+    # (the pool's limit counts THIS process too once an earlier test has opened the card in it: five workers then)
+    W = 5 if torch.cuda.is_initialized() else 6
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--backend", "gloo", "--size", "65", "--classes", "5",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(W), "--backend", "gloo", "--size", "65", "--classes", "5",
                         "--width", "16", "--batch", "2", "--steps", "3", "--warmup", "1", "--dtype", "bf16", "--grad-dtype", "bf16",
                         "--launch-timeout", "500"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
@@ -84,12 +87,12 @@ def test_six_ranks_share_the_gpu_with_the_all_links_exchange_and_the_bf16_payloa
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 6 and d["config"]["global_batch"] == 12 and d["config"]["parallelism"] == "dp6" and d["dtype"] == "bf16"
+    assert d["n_gpus"] == W and d["config"]["global_batch"] == 2 * W and d["config"]["parallelism"] == "dp%d" % W and d["dtype"] == "bf16"
     a = d["allreduce"]
-    assert a["ranks"] == 6 and a["algo"] == "direct" and a["grad_dtype"] == "bf16" and a["staging"].startswith("HIP kernels")
-    assert a["wire_bytes_per_rank_per_update"] == int(2 * 5 / 6 * (a["bytes_per_update"] // 4) * 2)
+    assert a["ranks"] == W and a["algo"] == "direct" and a["grad_dtype"] == "bf16" and a["staging"].startswith("HIP kernels")
+    assert a["wire_bytes_per_rank_per_update"] == int(2 * (W - 1) / W * (a["bytes_per_update"] // 4) * 2)
     assert a["overhead_ms_per_step"] is not None and a["ms_per_step_without_exchange"] > 0
-    assert d["ms_per_step_ranks"]["n"] == 6 and np.isfinite(d["final_loss"])
+    assert d["ms_per_step_ranks"]["n"] == W and np.isfinite(d["final_loss"])
 
 
 def test_gpus_2_rccl_on_one_gpu_fails_fast_with_a_reason():
