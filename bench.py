@@ -97,6 +97,9 @@ def parse():
                     help="run accumulate / Momentum / clean as the reference's three ops (deeplab.py:202-205) instead of one pass per "
                          "layer (config fused_update: what ADAPT.train switches on for accum_num 1 without a gradient exchange; same "
                          "weights bit for bit)")
+    ap.add_argument("--pool-gate-tensor", action="store_true",
+                    help="A/B: the max-pool gradients read the pooled tensor as their ReluGrad gate (config pool_gate_idx = False) "
+                         "instead of the bit the forward pool left in its index bytes; same gradients bit for bit")
     ap.add_argument("--bf16t", default="auto", choices=["auto", "always", "never"],
                     help="--dtype bf16: which layers run forward / data gradient on the LDS-DMA kernel (csrc/igemm_b16t.h)")
     ap.add_argument("--overhead-steps", type=int, default=-1,
@@ -340,7 +343,8 @@ def main():
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
            "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb,
            "allreduce_release_at": None if args.release_at == "none" else args.release_at, "grad_dtype": args.grad_dtype, "x6_planes": args.x6_planes,
-           "fused_update": not args.no_fused_update, "bf16t": args.bf16t}
+           "fused_update": not args.no_fused_update, "bf16t": args.bf16t,
+           "pool_gate_idx": not args.pool_gate_tensor}
     if args.allreduce_algo != "auto":
         cfg["allreduce_algo"] = args.allreduce_algo
     for kv in filter(None, args.tune.split(",")):

@@ -102,6 +102,7 @@ PROTOTYPES = {
     "emadapt_conv_wgrad_x6p": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_size_t, _vp]),
     "emadapt_maxpool_fwd_dt": (c_int, [_vp, c_int, c_int, c_int, c_int, c_int, c_int, _vp, _vp, _vp]),
     "emadapt_maxpool_bwd_dt": (c_int, [_vp, _vp, _vp, c_int, c_int, c_int, c_int, c_int, c_int, _vp, _vp]),
+    "emadapt_maxpool_fwd_gated": (c_int, [_vp, c_int, c_int, c_int, c_int, c_int, c_int, _vp, _vp, c_int, _vp]),
     "emadapt_bias_grad_dt": (c_int, [_vp, c_int, c_int64, c_int, _vp, _vp, c_size_t, _vp]),
     "emadapt_softmax_ce_dt": (c_int, [_vp, c_int64, _vp, c_int64, c_int, c_float, _vp, c_int, _vp, _vp, c_size_t, _vp]),
     "emadapt_weights_bf16_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),

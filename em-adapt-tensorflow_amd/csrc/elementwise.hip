@@ -59,7 +59,11 @@ template <> struct ByteVec<8> { typedef unsigned long long type; };
 // I = index type: unsigned when the element count fits 31 bits (always, for DeepLab's maps), else long long -- the
 // decomposition of the linear index costs four divisions by run-time divisors per thread, and 64-bit ones are ~10x the
 // instructions of 32-bit ones on this hardware.
-template <typename T, typename I>
+// GATED: the index byte also carries kPoolClosed when the winner is not > 0 -- the ReluGrad gate of the layer that produced x, which
+// the backward kernels then apply without reading x again (the gate only matters at a pixel that wins a window, and there it is
+// the window's maximum).
+constexpr unsigned kPoolClosed = 0x10u;
+template <typename T, typename I, bool GATED>
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ x, int B, int H, int W, int CV,
                                                         int stride, int OH, int OW, int pt, int pl,
                                                         T *__restrict__ y, unsigned char *__restrict__ idx) {
@@ -96,7 +100,11 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T *__restrict__ 
         if (idx) {
             typename ByteVec<N>::type pk = 0;
 #pragma unroll
-            for (int e = 0; e < N; e++) pk |= (typename ByteVec<N>::type)(unsigned char)bi[e] << (8 * e);
+            for (int e = 0; e < N; e++) {
+                unsigned byte = (unsigned)bi[e] & 0xffu;
+                if (GATED) byte |= best[e] > 0.f ? 0u : kPoolClosed;
+                pk |= (typename ByteVec<N>::type)byte << (8 * e);
+            }
             *reinterpret_cast<typename ByteVec<N>::type *>(idx + (long long)t * N) = pk;
         }
     }
@@ -119,8 +127,9 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ 
         const int h = (int)(r % (I)H);
         const int b = (int)(r / (I)H);
         float acc[N];
+        unsigned won[N];   // index byte of a window this pixel won (they all carry the same gate bit: it is this pixel's)
 #pragma unroll
-        for (int e = 0; e < N; e++) acc[e] = 0.f;
+        for (int e = 0; e < N; e++) { acc[e] = 0.f; won[e] = 0u; }
 #pragma unroll
         for (int kh = 0; kh < 3; kh++) {
             const int th = h + pt - kh;
@@ -139,10 +148,14 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T *__restrict__ 
                 ldv(dy + o, g);
                 const unsigned tap = kh * 3 + kw;
 #pragma unroll
-                for (int e = 0; e < N; e++)
-                    if (((unsigned)(id >> (8 * e)) & 0xffu) == tap) acc[e] += g[e];
+                for (int e = 0; e < N; e++) {
+                    const unsigned byte = (unsigned)(id >> (8 * e)) & 0xffu;
+                    if ((byte & 0xfu) == tap) { acc[e] += g[e]; won[e] = byte; }
+                }
             }
         }
+#pragma unroll
+        for (int e = 0; e < N; e++) acc[e] = gate_keep_nan((won[e] & kPoolClosed) ? 0.f : 1.f, acc[e]);
         if (gate) {
             float a[N];
             ldv(gate + (long long)t * N, a);
@@ -182,8 +195,9 @@ __global__ void __launch_bounds__(256) maxpool_bwd_rows_kernel(const T *__restri
         const int w = (int)div_magic((unsigned)t, cv_magic);
         const int cv = t - w * CV;
         float acc[N];
+        unsigned won[N];
 #pragma unroll
-        for (int e = 0; e < N; e++) acc[e] = 0.f;
+        for (int e = 0; e < N; e++) { acc[e] = 0.f; won[e] = 0u; }
 #pragma unroll
         for (int a = 0; a < NC; a++) {
             if (r_oh[a] < 0) continue;   // uniform over the block
@@ -200,10 +214,14 @@ __global__ void __launch_bounds__(256) maxpool_bwd_rows_kernel(const T *__restri
                 ldv(dy + o, g);
                 const unsigned tap = r_kh[a] * 3 + kw;
 #pragma unroll
-                for (int e = 0; e < N; e++)
-                    if (((unsigned)(id >> (8 * e)) & 0xffu) == tap) acc[e] += g[e];
+                for (int e = 0; e < N; e++) {
+                    const unsigned byte = (unsigned)(id >> (8 * e)) & 0xffu;
+                    if ((byte & 0xfu) == tap) { acc[e] += g[e]; won[e] = byte; }
+                }
             }
         }
+#pragma unroll
+        for (int e = 0; e < N; e++) acc[e] = gate_keep_nan((won[e] & kPoolClosed) ? 0.f : 1.f, acc[e]);
         const long long xo = (row_base + t) * N;
         if (gate) {
             float g[N];
@@ -212,6 +230,78 @@ __global__ void __launch_bounds__(256) maxpool_bwd_rows_kernel(const T *__restri
             for (int e = 0; e < N; e++) acc[e] = gate_keep_nan(g[e], acc[e]);
         }
         stv(dx + xo, acc);
+    }
+}
+
+// Stride 2 by QUADS: one thread = the 2 x 2 input pixels (2a, 2a+1) x (2b, 2b+1) of the padded grid (hs = h + pt, ws = w + pl) x N
+// channels.  The four pixels lie in the same four windows -- rows a (taps kh = hs - 2a: 0, 1) and a - 1 (tap 2), columns likewise --
+// so a thread loads (index, dy) of 4 windows once and serves the 9 (pixel, window) pairs they form: the row form above loads and
+// widens 4 / 2 / 2 / 1 windows for the same four pixels and runs both column parities through every wave (the kernel is bound by
+// its vector ALU, not by memory: ~200 instructions per 16 bytes written there, ~130 here).  Every pixel adds its windows in the row
+// form's order (kh, then kw, ascending), so the sums round identically.
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_quad_kernel(const T *__restrict__ dy, const unsigned char *__restrict__ idx,
+                                                             const T *__restrict__ gate, int H, int W, int CV, int OH, int OW,
+                                                             int pt, int pl, int NA, int NB, unsigned cv_magic, T *__restrict__ dx) {
+    constexpr int N = VW<T>::N;
+    typedef typename ByteVec<N>::type IdT;
+    const int ba = blockIdx.x;
+    const int b = ba / NA, a = ba - b * NA;
+    const int h0 = 2 * a - pt;   // the quad's pixel rows: h0, h0 + 1
+    const bool hok[2] = {h0 >= 0 && h0 < H, h0 + 1 >= 0 && h0 + 1 < H};
+    const int oh_q[2] = {a, a - 1};
+    const bool ohok[2] = {a < OH, a - 1 >= 0 && a - 1 < OH};
+    const int row_n = NB * CV;
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < row_n; t += gridDim.y * 256) {
+        const int bq = (int)div_magic((unsigned)t, cv_magic);
+        const int cv = t - bq * CV;
+        const int w0 = 2 * bq - pl;
+        const bool wok[2] = {w0 >= 0 && w0 < W, w0 + 1 >= 0 && w0 + 1 < W};
+        const bool owok[2] = {bq < OW, bq - 1 >= 0 && bq - 1 < OW};
+        // window q = 2 * (row: 0 = a, 1 = a - 1) + (column: 0 = bq, 1 = bq - 1); a missing window matches no tap (low nibble 15)
+        float g[4][N];
+        IdT id[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            id[q] = ~(IdT)0;
+#pragma unroll
+            for (int e = 0; e < N; e++) g[q][e] = 0.f;
+            if (ohok[q >> 1] && owok[q & 1]) {
+                const long long o = ((((long long)b * OH + oh_q[q >> 1]) * OW + (bq - (q & 1))) * CV + cv) * N;
+                id[q] = *reinterpret_cast<const IdT *>(idx + o);
+                ldv(dy + o, g[q]);
+            }
+        }
+        float acc[4][N];     // pixel p = 2 * (row h0 + (p >> 1)) + (column w0 + (p & 1))
+        unsigned won[4][N];
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+#pragma unroll
+            for (int e = 0; e < N; e++) { acc[p][e] = 0.f; won[p][e] = 0u; }
+#define EMADAPT_POOL_PAIR(P, Q, TAP)                                                  \
+        _Pragma("unroll") for (int e = 0; e < N; e++) {                                \
+            const unsigned byte = (unsigned)(id[Q] >> (8 * e)) & 0xffu;                \
+            if ((byte & 0xfu) == (TAP)) { acc[P][e] += g[Q][e]; won[P][e] = byte; }    \
+        }
+        EMADAPT_POOL_PAIR(0, 0, 0u) EMADAPT_POOL_PAIR(0, 1, 2u) EMADAPT_POOL_PAIR(0, 2, 6u) EMADAPT_POOL_PAIR(0, 3, 8u)
+        EMADAPT_POOL_PAIR(1, 0, 1u) EMADAPT_POOL_PAIR(1, 2, 7u)
+        EMADAPT_POOL_PAIR(2, 0, 3u) EMADAPT_POOL_PAIR(2, 1, 5u)
+        EMADAPT_POOL_PAIR(3, 0, 4u)
+#undef EMADAPT_POOL_PAIR
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            if (!hok[p >> 1] || !wok[p & 1]) continue;
+            const long long xo = ((((long long)b * H + (h0 + (p >> 1))) * W + (w0 + (p & 1))) * CV + cv) * N;
+#pragma unroll
+            for (int e = 0; e < N; e++) acc[p][e] = gate_keep_nan((won[p][e] & kPoolClosed) ? 0.f : 1.f, acc[p][e]);
+            if (gate) {
+                float gt[N];
+                ldv(gate + xo, gt);
+#pragma unroll
+                for (int e = 0; e < N; e++) acc[p][e] = gate_keep_nan(gt[e], acc[p][e]);
+            }
+            stv(dx + xo, acc[p]);
+        }
     }
 }
 
@@ -685,7 +775,7 @@ int launch_slab_sum2(const float *slab_a, int nslab_a, long long n_a, float *out
 namespace {
 
 template <typename T>
-int maxpool_fwd_t(const T *x, int B, int H, int W, int C, int stride, T *y, uint8_t *idx, void *stream_) {
+int maxpool_fwd_t(const T *x, int B, int H, int W, int C, int stride, T *y, uint8_t *idx, bool gated, void *stream_) {
     if (!x || !y || B < 0 || H <= 0 || W <= 0 || C <= 0) return EMADAPT_ERR_INVALID;
     constexpr int N = VW<T>::N;
     if (C % N != 0 || (stride != 1 && stride != 2)) return EMADAPT_ERR_UNSUPPORTED;
@@ -697,12 +787,17 @@ int maxpool_fwd_t(const T *x, int B, int H, int W, int C, int stride, T *y, uint
     const long long n = (long long)B * OH * OW * (C / N);
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)B * H * W * C * sizeof(T) + (double)n * N * (sizeof(T) + 1.0), stream);
-    if (n < (1LL << 31) - (1LL << 23) && (long long)B * H * W * (C / N) < (1LL << 31))
-        hipLaunchKernelGGL((maxpool_fwd_kernel<T, unsigned>), dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W,
-                           C / N, stride, OH, OW, pt, pl, y, idx);
+    if (gated && !idx) return EMADAPT_ERR_INVALID;
+    const dim3 grid(grid_for(n, 256, 16384));
+    const bool narrow = n < (1LL << 31) - (1LL << 23) && (long long)B * H * W * (C / N) < (1LL << 31);
+    if (narrow && gated)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<T, unsigned, true>), grid, dim3(256), 0, stream, x, B, H, W, C / N, stride, OH, OW, pt, pl, y, idx);
+    else if (narrow)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<T, unsigned, false>), grid, dim3(256), 0, stream, x, B, H, W, C / N, stride, OH, OW, pt, pl, y, idx);
+    else if (gated)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<T, long long, true>), grid, dim3(256), 0, stream, x, B, H, W, C / N, stride, OH, OW, pt, pl, y, idx);
     else
-        hipLaunchKernelGGL((maxpool_fwd_kernel<T, long long>), dim3(grid_for(n, 256, 16384)), dim3(256), 0, stream, x, B, H, W,
-                           C / N, stride, OH, OW, pt, pl, y, idx);
+        hipLaunchKernelGGL((maxpool_fwd_kernel<T, long long, false>), grid, dim3(256), 0, stream, x, B, H, W, C / N, stride, OH, OW, pt, pl, y, idx);
     return launch_status();
 }
 
@@ -725,7 +820,15 @@ int maxpool_bwd_t(const T *dy, const uint8_t *idx, const T *gate, int B, int H, 
         const long long want = ceil_div(16384, rows);          // ~16 K blocks; rows of wide maps are walked in a loop
         if (chunks > want) chunks = want;
         const dim3 grid((unsigned)rows, (unsigned)chunks);
-        if (stride == 2)
+        if (stride == 2 && tune(TUNE_POOL_ROWS) == 0) {   // by quads (tune "pool_rows" = 1: the row form, the A/B)
+            const int NA = (H + pt + 1) >> 1, NB = (W + pl + 1) >> 1;
+            const long long qrows = (long long)B * NA, qrow_n = (long long)NB * (C / N);
+            long long qchunks = ceil_div(qrow_n, 256);
+            const long long qwant = ceil_div(16384, qrows);
+            if (qchunks > qwant) qchunks = qwant;
+            hipLaunchKernelGGL((maxpool_bwd_quad_kernel<T>), dim3((unsigned)qrows, (unsigned)qchunks), dim3(256), 0, stream, dy, idx, gate, H, W,
+                               C / N, OH, OW, pt, pl, NA, NB, magic_u32(C / N), dx);
+        } else if (stride == 2)
             hipLaunchKernelGGL((maxpool_bwd_rows_kernel<T, 2>), grid, dim3(256), 0, stream, dy, idx, gate, H, W, C / N, OH, OW,
                                pt, pl, magic_u32(C / N), dx);
         else
@@ -744,7 +847,7 @@ extern "C" {
 
 int emadapt_maxpool_fwd(const float *x, int B, int H, int W, int C, int stride, float *y, uint8_t *idx,
                         void *stream_) {
-    return maxpool_fwd_t<float>(x, B, H, W, C, stride, y, idx, stream_);
+    return maxpool_fwd_t<float>(x, B, H, W, C, stride, y, idx, false, stream_);
 }
 
 int emadapt_maxpool_bwd(const float *dy, const uint8_t *idx, const float *gate, int B, int H, int W, int C,
@@ -754,10 +857,15 @@ int emadapt_maxpool_bwd(const float *dy, const uint8_t *idx, const float *gate, 
 
 int emadapt_maxpool_fwd_dt(const void *x, int dtype, int B, int H, int W, int C, int stride, void *y, uint8_t *idx,
                            void *stream_) {
+    return emadapt_maxpool_fwd_gated(x, dtype, B, H, W, C, stride, y, idx, 0, stream_);
+}
+
+int emadapt_maxpool_fwd_gated(const void *x, int dtype, int B, int H, int W, int C, int stride, void *y, uint8_t *idx, int relu_gate,
+                              void *stream_) {
     if (dtype == EMADAPT_DT_F32)
-        return maxpool_fwd_t<float>(static_cast<const float *>(x), B, H, W, C, stride, static_cast<float *>(y), idx, stream_);
+        return maxpool_fwd_t<float>(static_cast<const float *>(x), B, H, W, C, stride, static_cast<float *>(y), idx, relu_gate != 0, stream_);
     if (dtype == EMADAPT_DT_BF16)
-        return maxpool_fwd_t<__bf16>(static_cast<const __bf16 *>(x), B, H, W, C, stride, static_cast<__bf16 *>(y), idx, stream_);
+        return maxpool_fwd_t<__bf16>(static_cast<const __bf16 *>(x), B, H, W, C, stride, static_cast<__bf16 *>(y), idx, relu_gate != 0, stream_);
     return EMADAPT_ERR_INVALID;
 }
 

@@ -503,6 +503,11 @@ class ADAPT(Network):
                         ops.filter_tiles(op.w_pad, True, out=op.seg["wp6"])
         self._w16_seen = ver
 
+    def _pool_gate_in_idx(self, before):
+        """A max-pool behind a ReLU layer keeps that layer's ReluGrad gate in its index bytes (ops.maxpool_fwd relu_gate; config
+        "pool_gate_idx": False = the gradient reads the pooled tensor as the gate, the A/B)."""
+        return bool(before is not None and before.kind == "conv" and before.relu and self.config.get("pool_gate_idx", True))
+
     def forward(self, images, keep_prob=1.0, drop_masks=None, for_backward=False):
         """The conv stack (deeplab.py:35-49). images [B,H,W,3]; returns the fc8 logits view [B,S,S,C].  for_backward: the pass is
         followed by backward() (micro_step): bf16x6 then also splits the inputs of the layers whose FILTER GRADIENT alone runs on
@@ -520,8 +525,10 @@ class ADAPT(Network):
         else:
             x = ops.copy_pad_channels(images, bufs["x4"].shape[3], out=bufs["x4"])
         bufs["x_in"] = x
+        prev = None
         for op in self._plan:
             out = bufs["act"][op.name]
+            prev, before = op, prev
             if op.kind == "conv":
                 kp = keep_prob if op.drop else 1.0
                 mask = None
@@ -553,7 +560,8 @@ class ADAPT(Network):
                     ops.conv_fwd(x, op.w_pad, op.b_pad, op.rate, relu=op.relu, keep_prob=kp, drop_mask=mask,
                                  drop_seed=seed, out=out)
             else:
-                ops.maxpool_fwd(x, op.stride, out=out, idx=bufs["idx"][op.name])
+                # (the index carries the ReluGrad gate of the pooled tensor: backward() then never reads that tensor again)
+                ops.maxpool_fwd(x, op.stride, out=out, idx=bufs["idx"][op.name], relu_gate=self._pool_gate_in_idx(before))
             x = out
         bufs["keep_prob"] = keep_prob
         return self.net["output"]
@@ -735,7 +743,7 @@ class ADAPT(Network):
                     d = ops.conv_dgrad(d, op.w_pad, op.rate, gate=gate, gate_scale=scale, out=out)
             else:
                 x_in = bufs["act"][prev.name]
-                gate = x_in if (prev.kind == "conv" and prev.relu) else None
+                gate = x_in if (prev.kind == "conv" and prev.relu and not self._pool_gate_in_idx(prev)) else None
                 out = other[:x_in.numel()].view(x_in.shape)
                 d = ops.maxpool_bwd(d, bufs["idx"][op.name], tuple(x_in.shape), op.stride, gate=gate, out=out)
             cur, other = other, cur

@@ -492,8 +492,12 @@ def pool_out_size(n, stride):
     return (n + stride - 1) // stride
 
 
-def maxpool_fwd(x, stride, out=None, idx=None):
-    """3x3 max-pool, SAME (deeplab.py:77,82). Returns (y, idx) with idx the winning tap (uint8)."""
+POOL_CLOSED = 0x10   # bit of a gated max-pool index: the window's winner is not > 0 (include/emadapt.h emadapt_maxpool_fwd_gated)
+
+
+def maxpool_fwd(x, stride, out=None, idx=None, relu_gate=False):
+    """3x3 max-pool, SAME (deeplab.py:77,82). Returns (y, idx) with idx the winning tap (uint8).  relu_gate: the index also carries
+    the ReluGrad gate of x (POOL_CLOSED), and maxpool_bwd on it needs no gate tensor."""
     dt = _act(x, "x")
     B, H, W, C = x.shape
     OH, OW = pool_out_size(H, stride), pool_out_size(W, stride)
@@ -502,7 +506,9 @@ def maxpool_fwd(x, stride, out=None, idx=None):
         raise TypeError("max-pool input and output must have the same storage type")
     if idx is None:
         idx = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=x.device)
-    if dt == DT_F32:
+    if relu_gate:
+        _lib.call("emadapt_maxpool_fwd_gated", _p(x), dt, B, H, W, C, int(stride), _p(y), _p(idx), 1, _stream())
+    elif dt == DT_F32:
         _lib.call("emadapt_maxpool_fwd", _p(x), B, H, W, C, int(stride), _p(y), _p(idx), _stream())
     else:
         _lib.call("emadapt_maxpool_fwd_dt", _p(x), dt, B, H, W, C, int(stride), _p(y), _p(idx), _stream())

@@ -61,8 +61,11 @@ extern "C" {
  *        to a direct kernel (emadapt_conv_bf16_plan: plan[0] == 4), the forward of 3 x 3, 4 (f32-stored) -> 64 (bf16-stored) channels
  *        to another (5), a 1 x 1 data gradient with at most 32 gathered channels to a third (6); emadapt_conv_wgrad[_bias]_bf16 take
  *        3 x 3, 64 -> 64 channels on bf16-stored tensors to a direct kernel whose workspace is one slab per workgroup (re-query
- *        emadapt_conv_wgrad[_bias]_bf16_workspace_bytes: 37.8 MB for conv1_2 at batch 16 where the split-M plan needed 15 MB). */
-#define EMADAPT_ABI_VERSION 204
+ *        emadapt_conv_wgrad[_bias]_bf16_workspace_bytes: 37.8 MB for conv1_2 at batch 16 where the split-M plan needed 15 MB).
+ *   205  round 5, added: emadapt_maxpool_fwd_gated (the index byte carries the ReluGrad gate of the pooled tensor; the backward entries
+ *        decode it, so the model's max-pool gradients no longer read the gate tensor); tune "pool_rows".  The stride-2 max-pool
+ *        gradient runs by 2 x 2 pixel quads (same results). */
+#define EMADAPT_ABI_VERSION 205
 int emadapt_version(void);
 const char *emadapt_strerror(int code);
 int emadapt_last_hip_error(void);          /* hipError_t of the last failing HIP call on this thread */
@@ -385,6 +388,14 @@ int emadapt_maxpool_fwd_dt(const void *x, int dtype, int B, int H, int W, int C,
                            void *stream);
 int emadapt_maxpool_bwd_dt(const void *dy, const uint8_t *idx, const void *gate, int dtype, int B, int H, int W,
                            int C, int stride, void *dx, void *stream);
+/* emadapt_maxpool_fwd_dt whose index byte also carries the ReluGrad gate of x when relu_gate != 0 (ABI 205): bit 4 (0x10) is set
+ * where the window's winner is not > 0.  ReluGrad of the layer that produced x only matters at a pixel that wins a window, and
+ * there x IS the window's maximum -- so emadapt_maxpool_bwd[_dt] on such an index with gate = NULL returns exactly what it
+ * returns on a plain index with gate = x (a NaN gradient passes a closed gate either way), without reading x: 211 of the 502 MB
+ * of pool1's gradient at batch 16.  The backward entries decode bit 4 of every index they are given (a plain index never has it
+ * set); an explicit gate is applied on top.  idx must not be NULL when relu_gate != 0. */
+int emadapt_maxpool_fwd_gated(const void *x, int dtype, int B, int H, int W, int C, int stride, void *y, uint8_t *idx,
+                              int relu_gate, void *stream);
 int emadapt_bias_grad_dt(const void *dy, int dtype, int64_t M, int N, float *db, void *workspace,
                          size_t workspace_bytes, void *stream);
 int emadapt_softmax_ce_dt(const float *logits, int64_t ldl, const int64_t *labels, int64_t M, int C,
@@ -402,7 +413,8 @@ int emadapt_bias_grad(const float *dy, int64_t M, int N, float *db, void *worksp
 int emadapt_maxpool_fwd(const float *x, int B, int H, int W, int C, int stride, float *y, uint8_t *idx,
                         void *stream);
 /* MaxPoolGrad fused with the ReluGrad of the layer below: dx[p] = sum over windows whose winner is p
- * of dy, then dx = gate>0 ? dx : 0 when gate (f32 [B,H,W,C], = the pool input) is non-NULL. */
+ * of dy, then dx = gate>0 ? dx : 0 when gate (f32 [B,H,W,C], = the pool input) is non-NULL -- or, with an index written by
+ * emadapt_maxpool_fwd_gated(relu_gate = 1), the same from the index alone (gate = NULL). */
 int emadapt_maxpool_bwd(const float *dy, const uint8_t *idx, const float *gate, int B, int H, int W,
                         int C, int stride, float *dx, void *stream);
 
@@ -481,6 +493,8 @@ int emadapt_sgd_accumulate_pack(const float *g, const float *w, int64_t n, int64
  *                slower on fc6 / fc7, profiles/r05_bf16t_bench.txt) | 2: four and more rounds of tiles as whole rounds of plain tiles +
  *                a stream-K launch over the last partial round (rounds 4-5; the default is plain tiles all the way there: fc7 -4 %)
  *   "x6_tile"    128 | 256
+ *   "pool_rows"  1: emadapt_maxpool_bwd[_dt] at stride 2 runs its row form (one thread per pixel) instead of 2 x 2 pixel quads
+ *                (ABI 205; same results bit for bit)
  *   "plan_cus"  number of CUs the launch plans are laid out for (default 256: MI355X)
  *   "fp32_loader" 1: the 256x256 fp32 kernels' loader waves compute their offsets per K step (works for any tap count);
  *                0: loaders specialised for 1x1 / 3x3 / 4x4 filters where the filter has that many taps, and the

@@ -42,14 +42,19 @@ def main():
         idx = torch.empty((B, O, O, C), dtype=torch.uint8, device="cuda")
         dy = torch.randn((B, O, O, C), device="cuda").to(dt)
         dx = torch.empty_like(x)
+        x.relu_()
         t_f = timed(lambda: ops.maxpool_fwd(x, stride, out=y, idx=idx))
         t_b = timed(lambda: ops.maxpool_bwd(dy, idx, tuple(x.shape), stride, gate=x, out=dx))
+        # the model's form: the ReluGrad gate rides in the index bytes, the gradient reads no gate tensor
+        t_fg = timed(lambda: ops.maxpool_fwd(x, stride, out=y, idx=idx, relu_gate=True))
+        t_bg = timed(lambda: ops.maxpool_bwd(dy, idx, tuple(x.shape), stride, out=dx))
         by_f = x.numel() * es + y.numel() * (es + 1)
         by_b = 2 * x.numel() * es + y.numel() * (es + 1)
-        tot["fwd"] += t_f
-        tot["bwd"] += t_b
-        print("  %-6s %3dx%-3d C=%-4d s%d  fwd %7.1f us %6.0f GB/s   bwd(+gate) %7.1f us %6.0f GB/s" % (
-            name, S, S, C, stride, t_f, by_f / t_f / 1e3, t_b, by_b / t_b / 1e3))
+        by_bg = x.numel() * es + y.numel() * (es + 1)
+        tot["fwd"] += t_fg
+        tot["bwd"] += t_bg
+        print("  %-6s %3dx%-3d C=%-4d s%d  fwd %6.1f us %5.0f GB/s  bwd(+gate tensor) %6.1f us %5.0f GB/s | gate in idx: fwd %6.1f us %5.0f GB/s  bwd %6.1f us %5.0f GB/s" % (
+            name, S, S, C, stride, t_f, by_f / t_f / 1e3, t_b, by_b / t_b / 1e3, t_fg, by_f / t_fg / 1e3, t_bg, by_bg / t_bg / 1e3))
     for name, S, C in BIAS:
         Cp = (C + 7) // 8 * 8
         dy = torch.randn((B, S, S, Cp), device="cuda").to(dt)
@@ -57,7 +62,7 @@ def main():
         t = timed(lambda: ops.bias_grad(dy, out=db))
         tot["bias"] += t
         print("  bias gradient %-8s M=%-8d N=%-5d %7.1f us %6.0f GB/s" % (name, B * S * S, Cp, t, dy.numel() * es / t / 1e3))
-    print("  sums: pool fwd %.1f us, pool bwd %.1f us, bias (one layer per shape) %.1f us" % (tot["fwd"], tot["bwd"], tot["bias"]))
+    print("  sums (pools: gate in idx): pool fwd %.1f us, pool bwd %.1f us, bias (one layer per shape) %.1f us" % (tot["fwd"], tot["bwd"], tot["bias"]))
 
 
 if __name__ == "__main__":

@@ -208,6 +208,55 @@ def test_maxpool(env, shape):
     assert _rel(gated.cpu(), np.where(x > 0, xt.grad.numpy(), 0)) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 21, 21, 8, 2), (2, 11, 11, 16, 1), (2, 40, 50, 64, 2), (3, 1, 9, 8, 2), (3, 9, 1, 8, 2), (2, 1, 1, 8, 2),
+                                   (2, 2, 2, 8, 2), (1, 41, 41, 64, 1), (20, 420, 40, 32, 2), (1, 3, 70, 32768, 2)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_maxpool_gate_in_the_index(env, shape, dtype):
+    """emadapt_maxpool_fwd_gated: same y, same winner, bit 4 of the index byte = the winner is not > 0; the gradient on that index with
+    no gate tensor is BITWISE the gradient on the plain index gated by the pooled tensor -- also where gradients are NaN / infinite
+    (a NaN passes a closed gate either way) and where the input holds zeros of both signs and NaNs."""
+    ops, do, torch = env
+    B, H, W, C, stride = shape
+    rng = np.random.default_rng(sum(shape) + 5)
+    x = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+    x[rng.random(x.shape) < 0.3] = 0.0            # post-ReLU zeros: whole windows of them
+    x[rng.random(x.shape) < 0.02] = -0.0
+    x[rng.random(x.shape) < 0.01] = np.nan
+    xg = _t(torch, x)
+    if dtype == "bf16":
+        xg = xg.bfloat16()
+    y0, idx0 = ops.maxpool_fwd(xg, stride)
+    y1, idx1 = ops.maxpool_fwd(xg, stride, relu_gate=True)
+    assert torch.equal(y0.view(torch.int16 if dtype == "bf16" else torch.int32), y1.view(torch.int16 if dtype == "bf16" else torch.int32))
+    assert torch.equal(idx1 & 0xF, idx0) and int(idx0.max()) <= 8
+    closed = ~(y0.float() > 0)
+    assert torch.equal((idx1 & ops.POOL_CLOSED) != 0, closed) and int((idx1 & 0xE0).max()) == 0
+    dy = rng.normal(0, 1, tuple(y0.shape)).astype(np.float32)
+    dy[rng.random(dy.shape) < 0.02] = np.nan
+    dy[rng.random(dy.shape) < 0.02] = np.inf
+    dy[rng.random(dy.shape) < 0.02] = -np.inf
+    dyg = _t(torch, dy)
+    if dtype == "bf16":
+        dyg = dyg.bfloat16()
+    want = ops.maxpool_bwd(dyg, idx0, (B, H, W, C), stride, gate=xg)
+    got = ops.maxpool_bwd(dyg, idx1, (B, H, W, C), stride)
+    it = torch.int16 if dtype == "bf16" else torch.int32
+    nan_w, nan_g = torch.isnan(want), torch.isnan(got)
+    assert torch.equal(nan_w, nan_g) and (want.numel() < 4096 or bool(nan_w.any()))
+    assert torch.equal(torch.where(nan_w, torch.zeros_like(want), want).view(it), torch.where(nan_g, torch.zeros_like(got), got).view(it))
+    if stride == 2:   # the quad form (default) against the row form
+        with ops.tuned(pool_rows=1):
+            rows_w = ops.maxpool_bwd(dyg, idx0, (B, H, W, C), stride, gate=xg)
+            rows_g = ops.maxpool_bwd(dyg, idx1, (B, H, W, C), stride)
+        for r in (rows_w, rows_g):
+            assert torch.equal(torch.isnan(r), nan_w)
+            assert torch.equal(torch.where(nan_w, torch.zeros_like(r), r).view(it), torch.where(nan_w, torch.zeros_like(want), want).view(it))
+    # an explicit gate on top of a gated index changes nothing
+    both = ops.maxpool_bwd(dyg, idx1, (B, H, W, C), stride, gate=xg)
+    assert torch.equal(torch.isnan(both), nan_w) and torch.equal(torch.where(nan_w, torch.zeros_like(both), both).view(it),
+                                                                 torch.where(nan_w, torch.zeros_like(want), want).view(it))
+
+
 def test_maxpool_ties_go_to_first_maximum(env):
     ops, do, torch = env
     x = np.zeros((1, 5, 5, 4), np.float32)  # all equal (post-ReLU zeros)
