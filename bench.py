@@ -97,6 +97,12 @@ def parse():
                     help="run accumulate / Momentum / clean as the reference's three ops (deeplab.py:202-205) instead of one pass per "
                          "layer (config fused_update: what ADAPT.train switches on for accum_num 1 without a gradient exchange; same "
                          "weights bit for bit)")
+    ap.add_argument("--no-fused-tiles", action="store_true",
+                    help="A/B (bf16): the optimizer pass does not write the tiled bf16 filter images of the LDS-DMA layers; the next "
+                         "forward's refresh pass builds them from a second read of the weights (config fused_tiles = False; same bits)")
+    ap.add_argument("--no-fused-multi", action="store_true",
+                    help="A/B: the fused update runs one optimizer launch per layer instead of one launch over all the layers without a "
+                         "pass of their own (config fused_update_multi = False; same bits)")
     ap.add_argument("--pool-gate-tensor", action="store_true",
                     help="A/B: the max-pool gradients read the pooled tensor as their ReluGrad gate (config pool_gate_idx = False) "
                          "instead of the bit the forward pool left in its index bytes; same gradients bit for bit")
@@ -344,7 +350,8 @@ def main():
            "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb,
            "allreduce_release_at": None if args.release_at == "none" else args.release_at, "grad_dtype": args.grad_dtype, "x6_planes": args.x6_planes,
            "fused_update": not args.no_fused_update, "bf16t": args.bf16t,
-           "pool_gate_idx": not args.pool_gate_tensor}
+           "pool_gate_idx": not args.pool_gate_tensor, "fused_tiles": not args.no_fused_tiles,
+           "fused_update_multi": not args.no_fused_multi}
     if args.allreduce_algo != "auto":
         cfg["allreduce_algo"] = args.allreduce_algo
     for kv in filter(None, args.tune.split(",")):

@@ -34,6 +34,27 @@ inline int launch_status() {
 // the library's code object -- no allocation, no stream operation, safe under graph capture.  nullptr when HIP cannot resolve it.
 unsigned *status_word();
 
+// ---- optimiser arithmetic (deeplab.py:202-205), shared by elementwise.hip and conv_bf16.hip's fused update ----
+// The optimiser's arithmetic, PINNED.  hipcc contracts `mu * v + a * s` into an fma around EITHER product by its own heuristics: two
+// kernels with the same source expression (Momentum on a loaded accumulator / on one computed in registers) came out 1 ulp apart on
+// 28 % of the elements.  These spell out what the round-1..4 vector kernels compiled to (the values every checkpoint and test since
+// round 1 were produced with): the decay and accumulate steps are fmas, Momentum rounds mu * v and fuses the gradient term, the
+// weight step is an fma.  (HIP's default -ffp-contract=fast-honor-pragmas honours the pragma in mul_rn.)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float opt_decay(float g, float wd, float w) { return __builtin_fmaf(wd, w, g); }                       // g + wd w
+__device__ __forceinline__ float opt_accum(float a, float g, float scale) { return __builtin_fmaf(g, scale, a); }                  // a + g scale
+__device__ __forceinline__ float opt_velocity(float mu, float v, float a, float s) { return __builtin_fmaf(a, s, mul_rn(mu, v)); }  // mu v + a s
+__device__ __forceinline__ float opt_step(float w, float lr, float v) { return __builtin_fmaf(-lr, v, w); }                        // w - lr v
+
+
+// The device status word (include/emadapt.h, emadapt_status_poll): while a kernel has a failure recorded there the optimiser
+// kernels return at once, on the device -- a gradient with a poisoned tile never reaches weights, momentum or accumulators, and no
+// host synchronisation is needed for that (the word is read once per wave: a scalar load).
+__device__ __forceinline__ bool status_raised(const unsigned *status) { return status && __builtin_nontemporal_load(status) != 0u; }
+
 // ---- per-kernel event timing (bench.py roofline; see emadapt_prof_* in emadapt.h) ----
 struct ProfScope {
     ProfScope(int kind, double flops, double bytes, hipStream_t stream);

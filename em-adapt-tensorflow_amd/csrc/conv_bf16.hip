@@ -1235,6 +1235,33 @@ int emadapt_filter_tiles_bf16_both(const emadapt_conv_desc *d, const float *w, v
     return launch_status();
 }
 
+int emadapt_sgd_accumulate_momentum_tiles_supported(const emadapt_conv_desc *d) {
+    if (check_desc(d)) return 0;
+    const long long g = (long long)d->KH * d->KW * (d->Cin / BT_BK) * (d->Cout / 64) + ceil_div(d->Cout, 256);
+    return d->Cin % 256 == 0 && d->Cout % 256 == 0 && g <= 0x7fffffffLL ? 1 : 0;
+}
+
+int emadapt_sgd_accumulate_momentum_tiles(const emadapt_conv_desc *d, float *w, float *v, const float *g, int64_t n_bias, float weight_decay,
+                                          float gscale, float lr, float momentum, float ascale, void *tiles_fwd, void *tiles_dgrad,
+                                          void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!w || !v || !g || !tiles_fwd || !tiles_dgrad || n_bias < 0 || !aligned16(w) || !aligned16(v) || !aligned16(g) || !aligned16(tiles_fwd) ||
+        !aligned16(tiles_dgrad))
+        return EMADAPT_ERR_INVALID;
+    if (!emadapt_sgd_accumulate_momentum_tiles_supported(d)) return EMADAPT_ERR_UNSUPPORTED;
+    const int taps = d->KH * d->KW;
+    const long long pieces = (long long)taps * (d->Cin / BT_BK) * (d->Cout / 64), nw = (long long)taps * d->Cin * d->Cout;
+    const long long blocks = pieces + ceil_div((long long)n_bias, 256);
+    if (blocks > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)nw * 24.0 + (double)n_bias * 20.0, stream);
+    hipLaunchKernelGGL(sgd_tiles_b16_both_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, w, v, g, reinterpret_cast<uint4 *>(tiles_fwd),
+                       reinterpret_cast<uint4 *>(tiles_dgrad), d->Cin, d->Cout, d->Cout, (int)pieces, nw, (long long)n_bias, weight_decay, gscale, lr,
+                       momentum, ascale, status_word());
+    return launch_status();
+}
+
 size_t emadapt_conv_bf16t_workspace_bytes(const emadapt_conv_desc *d, int kind) {
     if (kind < 0 || kind > 1 || !bt_ok(d, kind == 1, 0) || d->B == 0) return 0;
     IgemmArgs a;

@@ -477,19 +477,7 @@ __global__ void __launch_bounds__(256) l2_partial_kernel(const float *__restrict
 // ------------------------------------------------------------------------------------------
 // optimiser (deeplab.py:202-205)
 // ------------------------------------------------------------------------------------------
-// The optimiser's arithmetic, PINNED.  hipcc contracts `mu * v + a * s` into an fma around EITHER product by its own heuristics: two
-// kernels with the same source expression (Momentum on a loaded accumulator / on one computed in registers) came out 1 ulp apart on
-// 28 % of the elements.  These spell out what the round-1..4 vector kernels compiled to (the values every checkpoint and test since
-// round 1 were produced with): the decay and accumulate steps are fmas, Momentum rounds mu * v and fuses the gradient term, the
-// weight step is an fma.  (HIP's default -ffp-contract=fast-honor-pragmas honours the pragma in mul_rn.)
-__device__ __forceinline__ float mul_rn(float a, float b) {
-#pragma clang fp contract(off)
-    return a * b;
-}
-__device__ __forceinline__ float opt_decay(float g, float wd, float w) { return __builtin_fmaf(wd, w, g); }                       // g + wd w
-__device__ __forceinline__ float opt_accum(float a, float g, float scale) { return __builtin_fmaf(g, scale, a); }                  // a + g scale
-__device__ __forceinline__ float opt_velocity(float mu, float v, float a, float s) { return __builtin_fmaf(a, s, mul_rn(mu, v)); }  // mu v + a s
-__device__ __forceinline__ float opt_step(float w, float lr, float v) { return __builtin_fmaf(-lr, v, w); }                        // w - lr v
+// (the pinned arithmetic -- mul_rn, opt_decay / opt_accum / opt_velocity / opt_step -- lives in common.h: conv_bf16.hip's fused update shares it)
 
 __global__ void __launch_bounds__(256) sgd_accumulate_kernel(float *__restrict__ accum, const float *__restrict__ g,
                                                            const float *__restrict__ w, long long n,
@@ -519,11 +507,7 @@ __global__ void __launch_bounds__(256) sgd_accumulate_kernel_v4(float *__restric
     }
 }
 
-// The device status word (include/emadapt.h, emadapt_status_poll): while a kernel has a failure recorded there the optimiser
-// kernels return at once, on the device -- a gradient with a poisoned tile never reaches weights, momentum or accumulators, and no
-// host synchronisation is needed for that (the word is read once per wave: a scalar load).
-__device__ __forceinline__ bool status_raised(const unsigned *status) { return status && __builtin_nontemporal_load(status) != 0u; }
-
+// (status_raised: common.h)
 __global__ void __launch_bounds__(256) sgd_momentum_kernel(float *__restrict__ w, float *__restrict__ v,
                                                          float *__restrict__ accum, long long n, float lr, float mu,
                                                          float ascale, const unsigned *__restrict__ status) {
@@ -616,6 +600,37 @@ __global__ void __launch_bounds__(256) sgd_accumulate_momentum_kernel_v4(float *
         wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
         st4(v + i * 4, vi);
         st4(w + i * 4, wi);
+    }
+}
+// The same pass over SEVERAL layers' segments of the flat buffers in one launch (the small layers' launches are all ramp and tail:
+// 8 of them cost 35 us for 1.7 M parameters).  first4[k] = the segment's first float4 in the launch's index space (first4[count] =
+// the total), at4[k] = where it starts in w / v / g, decay4[k] = its decayed float4s.
+constexpr int kSgdMaxSegs = 16;
+struct SgdSegs {
+    long long first4[kSgdMaxSegs + 1], at4[kSgdMaxSegs], decay4[kSgdMaxSegs];
+    int count;
+};
+__global__ void __launch_bounds__(256) sgd_accumulate_momentum_multi_kernel(float *__restrict__ w, float *__restrict__ v,
+                                                                          const float *__restrict__ g, SgdSegs sg, float wd, float gscale,
+                                                                          float lr, float mu, float ascale,
+                                                                          const unsigned *__restrict__ status) {
+    if (status_raised(status)) return;
+    const long long n4 = sg.first4[sg.count];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < kSgdMaxSegs; q++) k += (q < sg.count && i >= sg.first4[q]) ? 1 : 0;
+        const long long r = i - sg.first4[k], o = (sg.at4[k] + r) * 4;
+        float4 gi = ld4(g + o);
+        float4 wi = ld4(w + o);
+        float4 vi = ld4(v + o);
+        if (r < sg.decay4[k]) { gi.x = opt_decay(gi.x, wd, wi.x); gi.y = opt_decay(gi.y, wd, wi.y); gi.z = opt_decay(gi.z, wd, wi.z); gi.w = opt_decay(gi.w, wd, wi.w); }
+        const float4 a = make_float4(opt_accum(0.f, gi.x, gscale), opt_accum(0.f, gi.y, gscale), opt_accum(0.f, gi.z, gscale), opt_accum(0.f, gi.w, gscale));
+        vi.x = opt_velocity(mu, vi.x, a.x, ascale); vi.y = opt_velocity(mu, vi.y, a.y, ascale);
+        vi.z = opt_velocity(mu, vi.z, a.z, ascale); vi.w = opt_velocity(mu, vi.w, a.w, ascale);
+        wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
+        st4(v + o, vi);
+        st4(w + o, wi);
     }
 }
 __global__ void __launch_bounds__(256) sgd_accumulate_momentum_kernel(float *__restrict__ w, float *__restrict__ v,
@@ -1103,6 +1118,34 @@ int emadapt_sgd_accumulate_momentum(float *w, float *v, const float *g, int64_t 
         hipLaunchKernelGGL(sgd_accumulate_momentum_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, w, v, g, (long long)n,
                            (long long)n_decay, weight_decay, gscale, lr, momentum, ascale, status);
     }
+    return launch_status();
+}
+
+int emadapt_sgd_accumulate_momentum_multi(float *w, float *v, const float *g, int nseg, const int64_t *start, const int64_t *n,
+                                          const int64_t *n_decay, float weight_decay, float gscale, float lr, float momentum, float ascale,
+                                          void *stream_) {
+    if (!w || !v || !g || nseg < 0 || nseg > kSgdMaxSegs || (nseg && (!start || !n || !n_decay))) return EMADAPT_ERR_INVALID;
+    if (!aligned16(w) || !aligned16(v) || !aligned16(g)) return EMADAPT_ERR_INVALID;
+    SgdSegs sg;
+    long long tot = 0;
+    sg.count = 0;
+    for (int k = 0; k < nseg; k++) {
+        if (start[k] < 0 || n[k] < 0 || n_decay[k] < 0 || n_decay[k] > n[k]) return EMADAPT_ERR_INVALID;
+        if (start[k] % 4 != 0 || n[k] % 4 != 0 || n_decay[k] % 4 != 0) return EMADAPT_ERR_UNSUPPORTED;   // (whole float4s: the caller takes such a segment to the one-segment entry)
+        for (int j = 0; j < k; j++)
+            if (start[k] < start[j] + n[j] && start[j] < start[k] + n[k]) return EMADAPT_ERR_INVALID;   // overlapping segments
+        if (n[k] == 0) continue;
+        sg.first4[sg.count] = tot; sg.at4[sg.count] = start[k] / 4; sg.decay4[sg.count] = n_decay[k] / 4;
+        tot += n[k] / 4;
+        sg.count++;
+    }
+    for (int k = sg.count; k <= kSgdMaxSegs; k++) sg.first4[k] = tot;
+    for (int k = sg.count; k < kSgdMaxSegs; k++) { sg.at4[k] = 0; sg.decay4[k] = 0; }
+    if (tot == 0) return EMADAPT_OK;
+    hipStream_t stream = as_stream(stream_);
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)tot * 80.0, stream);
+    hipLaunchKernelGGL(sgd_accumulate_momentum_multi_kernel, dim3(grid_for(tot, 256, 4096)), dim3(256), 0, stream, w, v, g, sg, weight_decay, gscale, lr,
+                       momentum, ascale, status_word());
     return launch_status();
 }
 

@@ -158,6 +158,72 @@ __global__ void __launch_bounds__(256) filter_tiles_b16_both_kernel(const float 
     }
 }
 
+// The optimizer step of a layer AND both images, one pass (round 5): accumulate + Momentum + clean of one micro-batch on the block's
+// [32 ci][64 co] piece of (w, v, g) -- emadapt_sgd_accumulate_momentum's arithmetic, operation for operation (common.h opt_*) -- the new
+// weights go to memory and to the LDS piece the two image writers of the kernel above read.  The refresh pass re-read every filter the
+// optimizer had just written: 4 of the 28 bytes per parameter the two passes moved.  The blocks behind the last piece update the
+// biases (no decay).  A raised status word leaves weights, momentum and images alone, like the plain optimizer kernels.
+__global__ void __launch_bounds__(256) sgd_tiles_b16_both_kernel(float *__restrict__ w, float *__restrict__ v, const float *__restrict__ g,
+                                                                 uint4 *__restrict__ out_f, uint4 *__restrict__ out_d, int Cin, int Cout, int rows_pad_f,
+                                                                 int pieces, long long nw, long long nb, float wd, float gscale, float lr, float mu,
+                                                                 float ascale, const unsigned *__restrict__ status) {
+    __shared__ float t[32][65];
+    if (status_raised(status)) return;
+    if ((int)blockIdx.x >= pieces) {   // biases
+        const long long i = ((long long)blockIdx.x - pieces) * 256 + threadIdx.x;
+        if (i < nb) {
+            const float a = opt_accum(0.f, g[nw + i], gscale);
+            const float vi = opt_velocity(mu, v[nw + i], a, ascale);
+            v[nw + i] = vi;
+            w[nw + i] = opt_step(w[nw + i], lr, vi);
+        }
+        return;
+    }
+    const int G = Cin / BT_BK, RB = Cout / 64, GD = Cout / BT_BK;
+    int bid = blockIdx.x;
+    const int rb = bid % RB;
+    bid /= RB;
+    const int gk = bid % G, tap = bid / G;
+    {
+        const int c4 = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int k = ty + 16 * r;
+            const long long o = ((long long)tap * Cin + gk * BT_BK + k) * Cout + rb * 64 + c4 * 4;
+            float4 gi = *reinterpret_cast<const float4 *>(g + o);
+            float4 wi = *reinterpret_cast<const float4 *>(w + o);
+            float4 vi = *reinterpret_cast<const float4 *>(v + o);
+            gi.x = opt_decay(gi.x, wd, wi.x); gi.y = opt_decay(gi.y, wd, wi.y); gi.z = opt_decay(gi.z, wd, wi.z); gi.w = opt_decay(gi.w, wd, wi.w);
+            const float4 a = make_float4(opt_accum(0.f, gi.x, gscale), opt_accum(0.f, gi.y, gscale), opt_accum(0.f, gi.z, gscale), opt_accum(0.f, gi.w, gscale));
+            vi.x = opt_velocity(mu, vi.x, a.x, ascale); vi.y = opt_velocity(mu, vi.y, a.y, ascale);
+            vi.z = opt_velocity(mu, vi.z, a.z, ascale); vi.w = opt_velocity(mu, vi.w, a.w, ascale);
+            wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
+            *reinterpret_cast<float4 *>(v + o) = vi;
+            *reinterpret_cast<float4 *>(w + o) = wi;
+            t[k][c4 * 4 + 0] = wi.x; t[k][c4 * 4 + 1] = wi.y; t[k][c4 * 4 + 2] = wi.z; t[k][c4 * 4 + 3] = wi.w;
+        }
+    }
+    __syncthreads();
+    {   // forward image: row = co, k = ci
+        const int row_l = threadIdx.x >> 2, slot = threadIdx.x & 3;
+        const int row = rb * 64 + row_l;
+        const int chunk = slot ^ bt_swz(row);
+        bt_bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (__bf16)t[chunk * 8 + e][row_l];
+        out_f[(((long long)tap * G + gk) * rows_pad_f + row) * 4 + slot] = *reinterpret_cast<uint4 *>(&o);
+    }
+    {   // data-gradient image: row = ci, k = co
+        const int slot = threadIdx.x & 3, gl = (threadIdx.x >> 2) & 1, ci_l = threadIdx.x >> 3;
+        const int row = gk * BT_BK + ci_l;
+        const int chunk = slot ^ bt_swz(row);
+        bt_bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (__bf16)t[ci_l][gl * 32 + chunk * 8 + e];
+        out_d[(((long long)tap * GD + rb * 2 + gl) * Cin + row) * 4 + slot] = *reinterpret_cast<uint4 *>(&o);   // (rows_pad == Cin)
+    }
+}
+
 // Tile epilogue of a 64 x 128 block held as 4 x 8 accumulator tiles of the 16 x 16 MFMA (C/D layout: column = lane & 15, row =
 // 4 (lane >> 4) + r): 16 rows at a time through the wave's private LDS slab ([16][128 + 4] floats), read back as 8 consecutive
 // columns per lane -- then exactly store_acc_tile's arithmetic (igemm_common.h: bias / ReLU / dropout / gate on 8 values, 16-byte

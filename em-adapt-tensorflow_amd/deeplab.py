@@ -100,6 +100,7 @@ class ADAPT(Network):
         self._fused = bool(self.config.get("fused_update", False))
         self._pending_fused = False
         self._bt = {}
+        self._tiles_fresh, self._tiles_fresh_ver = set(), None   # layers whose tiled bf16 images the optimizer pass wrote (apply_update)
         self._perm_pool = None
         self._perm_pos = 0
         self.init_model = None
@@ -481,6 +482,8 @@ class ADAPT(Network):
         ver = self._flat["params"]._version
         if not force and self._w16_seen == ver:
             return
+        # (layers whose two tiled images the optimizer pass itself wrote from the weights as they are now: apply_update)
+        fresh = self._tiles_fresh if (not force and self._tiles_fresh_ver == ver) else ()
         for op in self._plan:
             if op.kind == "conv":
                 if self.compute_dtype == "bf16":
@@ -488,7 +491,9 @@ class ADAPT(Network):
                     if not (e["fwd"] and e["dgrad"]):
                         ops.weights_to_bf16(op.w_pad, None if e["fwd"] else op.seg["wf16"], None if e["dgrad"] else op.seg["wd16"],
                                             want_fwd=not e["fwd"], want_dgrad=not e["dgrad"])
-                    if e["fwd"] and e["dgrad"]:
+                    if e["fwd"] and e["dgrad"] and op.name in fresh:
+                        pass
+                    elif e["fwd"] and e["dgrad"]:
                         ops.filter_tiles_bf16_both(op.w_pad, op.seg["wt16"], op.seg["wtd16"])   # (one pass over the f32 filter)
                     elif e["fwd"]:
                         ops.filter_tiles_bf16(op.w_pad, dgrad=False, out=op.seg["wt16"])
@@ -502,6 +507,7 @@ class ADAPT(Network):
                     if self._plane_dgrad.get(op.name, False):
                         ops.filter_tiles(op.w_pad, True, out=op.seg["wp6"])
         self._w16_seen = ver
+        self._tiles_fresh, self._tiles_fresh_ver = set(), None
 
     def _pool_gate_in_idx(self, before):
         """A max-pool behind a ReLU layer keeps that layer's ReluGrad gate in its index bytes (ops.maxpool_fwd relu_gate; config
@@ -767,12 +773,29 @@ class ADAPT(Network):
         if gs is not None:
             gs.wait()
             scale = 1.0 / gs.world_size
+        fresh = set()
         if self._pending_fused:
-            for op in self._plan:   # accumulate + apply_gradients + clean of the one micro-batch, one pass per layer
+            tiles = self.compute_dtype == "bf16" and self.config.get("fused_tiles", True)
+            rest = []   # (start, n, n_decay) of the layers without a pass of their own: one launch for all of them
+            for op in self._plan:   # accumulate + apply_gradients + clean of the one micro-batch
                 if op.kind == "conv":
                     s, n = op.seg["start"], op.seg["nw"] + op.seg["nb"]
-                    ops.sgd_accumulate_momentum(f["params"][s:s + n], f["momentum"][s:s + n], f["grads"][s:s + n], op.seg["nw"],
-                                                self._weight_decay, 1.0 / float(self.accum_num), self.net["lr"], self._momentum, scale)
+                    e = self._bt.get(op.name, {"fwd": False, "dgrad": False})
+                    if (tiles and e["fwd"] and e["dgrad"] and op.seg.get("wt16") is not None and op.seg.get("wtd16") is not None
+                            and ops.sgd_accumulate_momentum_tiles_supported(*op.seg["pshape"])):
+                        # (the pass also writes the layer's two tiled bf16 images: the next forward's refresh skips them)
+                        ops.sgd_accumulate_momentum_tiles(f["params"][s:s + n], f["momentum"][s:s + n], f["grads"][s:s + n], tuple(op.seg["pshape"]),
+                                                          self._weight_decay, 1.0 / float(self.accum_num), self.net["lr"], self._momentum, scale,
+                                                          op.seg["wt16"], op.seg["wtd16"])
+                        fresh.add(op.name)
+                    elif s % 4 == 0 and n % 4 == 0 and op.seg["nw"] % 4 == 0 and self.config.get("fused_update_multi", True):
+                        rest.append((s, n, op.seg["nw"]))
+                    else:
+                        ops.sgd_accumulate_momentum(f["params"][s:s + n], f["momentum"][s:s + n], f["grads"][s:s + n], op.seg["nw"],
+                                                    self._weight_decay, 1.0 / float(self.accum_num), self.net["lr"], self._momentum, scale)
+            for i in range(0, len(rest), ops.SGD_MAX_SEGS):
+                ops.sgd_accumulate_momentum_multi(f["params"], f["momentum"], f["grads"], rest[i:i + ops.SGD_MAX_SEGS], self._weight_decay,
+                                                  1.0 / float(self.accum_num), self.net["lr"], self._momentum, scale)
             self._pending_fused = False
         elif gs is not None and not gs.writeback:
             # the exchanged sum lives in the gathered payload (f32 or bf16); the accumulator is only zeroed (the clean op)
@@ -781,6 +804,7 @@ class ADAPT(Network):
         else:
             ops.sgd_momentum(f["params"], f["momentum"], f["accum"], self.net["lr"], self._momentum, scale)
         self._w16_seen = None  # the master weights moved: the bf16 images are refreshed by the next forward
+        self._tiles_fresh, self._tiles_fresh_ver = fresh, f["params"]._version
         self._step += 1
 
     def eval_loss(self, images, labels, keep_prob=0.5, perms=None, drop_masks=None):

@@ -668,6 +668,44 @@ def sgd_accumulate_momentum(w, v, g, n_decay, weight_decay, gscale, lr, momentum
               float(lr), float(momentum), float(ascale), _stream())
 
 
+SGD_MAX_SEGS = 16
+
+
+def sgd_accumulate_momentum_multi(w, v, g, segs, weight_decay, gscale, lr, momentum, ascale=1.0):
+    """sgd_accumulate_momentum over several segments (start, n, n_decay) of the flat buffers in one launch (at most SGD_MAX_SEGS,
+    multiples of 4 each): bit-identical to one call per segment."""
+    _check(w, name="w"); _check(v, name="v"); _check(g, name="g")
+    k = len(segs)
+    arr = ctypes.c_int64 * max(k, 1)
+    st, nn, nd = arr(*[int(s[0]) for s in segs]), arr(*[int(s[1]) for s in segs]), arr(*[int(s[2]) for s in segs])
+    if any(s[0] + s[1] > w.numel() for s in segs) or v.numel() != w.numel() or g.numel() != w.numel():
+        raise ValueError("segment outside the buffers")
+    _lib.call("emadapt_sgd_accumulate_momentum_multi", _p(w), _p(v), _p(g), k, st, nn, nd, float(weight_decay), float(gscale), float(lr),
+              float(momentum), float(ascale), _stream())
+
+
+def sgd_accumulate_momentum_tiles_supported(KH, KW, Cin, Cout):
+    d = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+    return bool(_lib.load().emadapt_sgd_accumulate_momentum_tiles_supported(ctypes.byref(d)))
+
+
+def sgd_accumulate_momentum_tiles(w, v, g, filter_shape, weight_decay, gscale, lr, momentum, ascale, out_fwd, out_dgrad):
+    """sgd_accumulate_momentum on one layer's [filter | biases] segment that also writes both tiled bf16 images of the new filter
+    (filter_tiles_bf16_both): bit-identical weights, momentum and images, without the refresh pass's second read of the weights."""
+    _check(w, name="w"); _check(v, name="v"); _check(g, name="g")
+    KH, KW, Cin, Cout = filter_shape
+    nw = KH * KW * Cin * Cout
+    if w.numel() < nw or v.numel() != w.numel() or g.numel() != w.numel():
+        raise ValueError("w / v / g must hold the %d filter elements followed by the biases" % nw)
+    d = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+    for t, dg in ((out_fwd, 0), (out_dgrad, 1)):
+        n = _lib.load().emadapt_filter_tiles_bf16_bytes(ctypes.byref(d), dg)
+        if n == 0 or t.dtype != torch.bfloat16 or t.numel() * 2 != n or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("tiled image buffer does not match the filter")
+    _lib.call("emadapt_sgd_accumulate_momentum_tiles", ctypes.byref(d), _p(w), _p(v), _p(g), w.numel() - nw, float(weight_decay),
+              float(gscale), float(lr), float(momentum), float(ascale), _p(out_fwd), _p(out_dgrad), _stream())
+
+
 def _payload_dt(t, name):
     if not t.is_cuda or not t.is_contiguous():
         raise ValueError("%s must be a contiguous GPU tensor" % name)

@@ -64,7 +64,9 @@ extern "C" {
  *        emadapt_conv_wgrad[_bias]_bf16_workspace_bytes: 37.8 MB for conv1_2 at batch 16 where the split-M plan needed 15 MB).
  *   205  round 5, added: emadapt_maxpool_fwd_gated (the index byte carries the ReluGrad gate of the pooled tensor; the backward entries
  *        decode it, so the model's max-pool gradients no longer read the gate tensor); tune "pool_rows".  The stride-2 max-pool
- *        gradient runs by 2 x 2 pixel quads (same results). */
+ *        gradient runs by 2 x 2 pixel quads (same results).  emadapt_sgd_accumulate_momentum_tiles (+ _supported): the optimizer
+ *        pass of a layer that also writes the layer's two tiled bf16 filter images; emadapt_sgd_accumulate_momentum_multi: the pass
+ *        over several layers' segments in one launch. */
 #define EMADAPT_ABI_VERSION 205
 int emadapt_version(void);
 const char *emadapt_strerror(int code);
@@ -455,6 +457,23 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
  * bit-identical (tests/test_gpu_kernels.py); 20 bytes per parameter instead of 40.  (ABI 203) */
 int emadapt_sgd_accumulate_momentum(float *w, float *v, const float *g, int64_t n, int64_t n_decay, float weight_decay,
                                     float gscale, float lr, float momentum, float ascale, void *stream);
+/* The same pass over up to 16 disjoint segments [start[k], start[k] + n[k]) of w / v / g in ONE launch (ABI 205), the first
+ * n_decay[k] elements of each decayed: the small layers' launches are all ramp and tail.  start, n, n_decay are HOST arrays of
+ * multiples of 4 (else EMADAPT_ERR_UNSUPPORTED: take such a segment to the one-segment entry); bit-identical results. */
+int emadapt_sgd_accumulate_momentum_multi(float *w, float *v, const float *g, int nseg, const int64_t *start, const int64_t *n,
+                                          const int64_t *n_decay, float weight_decay, float gscale, float lr, float momentum,
+                                          float ascale, void *stream);
+/* The same pass for ONE layer whose forward and data gradient both run on the LDS-DMA bf16 kernel (ABI 205): w / v / g hold the
+ * layer's KH*KW*Cin*Cout filter (HWIO, all of it decayed) followed by n_bias biases (not decayed); the kernel also writes both
+ * tiled bf16 images of the NEW filter (emadapt_filter_tiles_bf16_both), which the refresh pass would otherwise build from a second
+ * read of the weights.  Weights and momentum come out bit for bit as from emadapt_sgd_accumulate_momentum, the images as from
+ * emadapt_filter_tiles_bf16_both on those weights.  _supported: Cin % 256 == 0 and Cout % 256 == 0 (the shapes the one-pass image
+ * kernel takes); elsewhere the entry returns EMADAPT_ERR_UNSUPPORTED.  A raised status word leaves weights, momentum AND images
+ * untouched. */
+int emadapt_sgd_accumulate_momentum_tiles_supported(const emadapt_conv_desc *d);
+int emadapt_sgd_accumulate_momentum_tiles(const emadapt_conv_desc *d, float *w, float *v, const float *g, int64_t n_bias,
+                                          float weight_decay, float gscale, float lr, float momentum, float ascale,
+                                          void *tiles_fwd, void *tiles_dgrad, void *stream);
 
 /* ---- staging of the data-parallel gradient exchange (dist.py; the reference's accum += g/accum_num, deeplab.py:202, with
  * micro-batches mapped to ranks).  The exchange is reduce-scatter + all-gather written as two all-to-all steps over all xGMI

@@ -331,6 +331,63 @@ def test_fused_accumulate_momentum_is_the_two_kernels_bit_for_bit(env, n, n_deca
         assert torch.equal(w1, w2) and torch.equal(v1.view(torch.int32), v2.view(torch.int32)), (gscale, ascale)
 
 
+def test_optimizer_pass_over_several_segments_in_one_launch(env):
+    """emadapt_sgd_accumulate_momentum_multi: bit for bit one emadapt_sgd_accumulate_momentum call per segment; what lies between the
+    segments is not touched; ragged or overlapping segments are refused."""
+    ops, do, torch = env
+    n = 300000
+    g = torch.Generator(device="cuda").manual_seed(77)
+    w = torch.randn(n, device="cuda", generator=g)
+    v = torch.randn(n, device="cuda", generator=g) * 0.1
+    grad = torch.randn(n, device="cuda", generator=g) * 1e-2
+    grad[::5] = -0.0
+    segs = [(0, 1728 + 64, 1728), (4096, 36864 + 64, 36864), (50000, 8, 4), (60000, 0, 0), (100000, 150000, 149996), (290000, 4, 0)]
+    segs += [(260000 + 16 * k, 8, 8) for k in range(10)]          # 16 segments in all
+    assert len(segs) == ops.SGD_MAX_SEGS
+    w1, v1 = w.clone(), v.clone()
+    for s, m, nd in segs:
+        if m:
+            ops.sgd_accumulate_momentum(w1[s:s + m], v1[s:s + m], grad[s:s + m], nd, 5e-4, 0.5, 1e-3, 0.9, 0.25)
+    w2, v2 = w.clone(), v.clone()
+    ops.sgd_accumulate_momentum_multi(w2, v2, grad, segs, 5e-4, 0.5, 1e-3, 0.9, 0.25)
+    assert torch.equal(w1.view(torch.int32), w2.view(torch.int32)) and torch.equal(v1.view(torch.int32), v2.view(torch.int32))
+    assert not torch.equal(w2, w) and torch.equal(w2[2000:4096], w[2000:4096])
+    for bad in ([(0, 10, 8)], [(2, 8, 8)], [(0, 8, 6)], [(0, 64, 64), (32, 64, 64)], [(0, 8, 12)], [(8 * k, 8, 8) for k in range(17)]):
+        with pytest.raises(Exception):
+            ops.sgd_accumulate_momentum_multi(w2, v2, grad, bad, 5e-4, 0.5, 1e-3, 0.9, 0.25)
+    assert torch.equal(w1.view(torch.int32), w2.view(torch.int32))
+
+
+@pytest.mark.parametrize("shape,nb", [((1, 1, 256, 256), 256), ((3, 3, 256, 512), 512), ((2, 2, 512, 256), 264), ((1, 1, 256, 768), 0)])
+def test_optimizer_pass_that_writes_the_tiled_images(env, shape, nb):
+    """emadapt_sgd_accumulate_momentum_tiles: weights and momentum bit for bit emadapt_sgd_accumulate_momentum's (filter decayed, biases
+    not), both tiled bf16 images bit for bit emadapt_filter_tiles_bf16_both's on the new weights; unsupported shapes are refused."""
+    ops, do, torch = env
+    KH, KW, Cin, Cout = shape
+    assert ops.sgd_accumulate_momentum_tiles_supported(*shape)
+    assert not ops.sgd_accumulate_momentum_tiles_supported(3, 3, 128, 256) and not ops.sgd_accumulate_momentum_tiles_supported(3, 3, 256, 320)
+    nw = KH * KW * Cin * Cout
+    n = nw + nb
+    g = torch.Generator(device="cuda").manual_seed(n)
+    w = torch.randn(n, device="cuda", generator=g) * 0.05
+    v = torch.randn(n, device="cuda", generator=g) * 0.01
+    grad = torch.randn(n, device="cuda", generator=g) * 1e-2
+    grad[::7] = -0.0
+    for gscale, ascale in ((1.0, 1.0), (0.25, 0.5)):
+        w1, v1 = w.clone(), v.clone()
+        ops.sgd_accumulate_momentum(w1, v1, grad, nw, 5e-4, gscale, 1e-3, 0.9, ascale)
+        tf1 = ops.filter_tiles_bf16(w1[:nw].view(shape))
+        td1 = ops.filter_tiles_bf16(w1[:nw].view(shape), dgrad=True)
+        w2, v2 = w.clone(), v.clone()
+        tf2, td2 = torch.full_like(tf1, 7.0), torch.full_like(td1, 7.0)
+        ops.sgd_accumulate_momentum_tiles(w2, v2, grad, shape, 5e-4, gscale, 1e-3, 0.9, ascale, tf2, td2)
+        assert torch.equal(w1.view(torch.int32), w2.view(torch.int32)) and torch.equal(v1.view(torch.int32), v2.view(torch.int32))
+        assert torch.equal(tf1.view(torch.int16), tf2.view(torch.int16)) and torch.equal(td1.view(torch.int16), td2.view(torch.int16))
+    with pytest.raises(Exception):
+        ops.sgd_accumulate_momentum_tiles(w[:3 * 3 * 128 * 256], v[:3 * 3 * 128 * 256], grad[:3 * 3 * 128 * 256], (3, 3, 128, 256), 5e-4, 1.0, 1e-3, 0.9,
+                                          1.0, tf2, td2)
+
+
 @pytest.mark.parametrize("n,n_decay", [(64 * 1024 + 512, 64 * 1024), (1027, 1001), (8, 8), (4096, 0), (4099, 4096)])
 @pytest.mark.parametrize("payload", ["fp32", "bf16"])
 def test_accumulate_pack_is_accumulate_then_pack_bit_for_bit(env, n, n_decay, payload):

@@ -210,3 +210,39 @@ def test_fused_update_leaves_the_same_weights_bit_for_bit(env, dtype):
         flats.append((adapt._flat["params"].clone(), adapt._flat["momentum"].clone()))
     assert torch.equal(flats[0][0], flats[1][0]) and torch.equal(flats[0][1], flats[1][1])
     assert float(flats[0][1].abs().max()) > 0
+
+
+def test_optimizer_pass_writes_the_tiled_images_the_refresh_would(env):
+    """config "fused_tiles" (bf16, fused update): the optimizer pass of a layer whose forward and data gradient run on the LDS-DMA kernel
+    also writes the layer's two tiled bf16 images and the next forward's refresh skips them.  Full-width net (so that layers with
+    Cin % 256 == 0 and Cout % 256 == 0 exist), the LDS-DMA kernel forced onto every layer it supports: after three steps weights,
+    momentum, images and the loss of a further forward must be bit-identical to the path whose refresh rebuilds the images."""
+    ADAPT, do, eo, torch = env
+    B, size, C = 1, 65, 5
+    images, labels = do.synthetic_batch(B, size, C, seed=3)
+    images = (images / 50.0).astype(np.float32)
+    perms = eo.draw_perms(5, C, seed=7)
+    outs = []
+    for tiles in (False, True):
+        adapt = ADAPT({"input_size": (size, size), "category_num": C, "accum_num": 1, "batch_size": B, "compute_dtype": "bf16",
+                       "fused_update": True, "fused_tiles": tiles, "bf16t": "always", "seed": 5})
+        adapt.build()
+        adapt.pre_train(base_lr=1e-2, weight_decay=1e-3, momentum=0.9, batch_size=B)
+        took = 0
+        for _ in range(3):
+            adapt.micro_step(images, labels, keep_prob=0.5, perms=perms)
+            adapt.apply_update()
+            took = max(took, len(adapt._tiles_fresh))
+        assert (took > 0) == tiles
+        loss = adapt.eval_loss(images, labels, keep_prob=1.0, perms=perms)   # (its forward refreshes what is not fresh)
+        assert len(adapt._tiles_fresh) == 0
+        torch.cuda.synchronize()
+        imgs = [op.seg[k].clone() for op in adapt._plan if op.kind == "conv" for k in ("wt16", "wtd16") if op.seg.get(k) is not None]
+        outs.append((adapt._flat["params"].clone(), adapt._flat["momentum"].clone(), imgs, loss))
+        del adapt
+        torch.cuda.empty_cache()
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[3] == b[3] and np.isfinite(a[3])
+    assert len(a[2]) == len(b[2]) > 0
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16))
