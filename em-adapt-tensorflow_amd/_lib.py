@@ -107,6 +107,7 @@ PROTOTYPES = {
     "emadapt_softmax_ce_dt": (c_int, [_vp, c_int64, _vp, c_int64, c_int, c_float, _vp, c_int, _vp, _vp, c_size_t, _vp]),
     "emadapt_weights_bf16_bytes": (c_size_t, [POINTER(ConvDesc), c_int]),
     "emadapt_weights_to_bf16": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "emadapt_weights_to_bf16_multi": (c_int, [c_int, _vp, _vp, _vp, _vp, _vp]),
     "emadapt_conv_fwd_bf16_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "emadapt_conv_fwd_bf16": (c_int, [POINTER(ConvDesc), _vp, c_int, _vp, _vp, _vp, c_int, c_int, c_float, _vp, c_uint64,
                                       _vp, c_size_t, _vp]),

@@ -52,11 +52,9 @@ __device__ __forceinline__ uint2 cvt4(float4 v) {
 // ------------------------------------------------------------------------------------------------------------------
 // Filter conversion: fp32 HWIO -> the two bf16 images.  One 32x32 (ci, co) tile per workgroup, transposed through LDS.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) weights_to_bf16_kernel(const float *__restrict__ w, __bf16 *__restrict__ wf,
-                                                              __bf16 *__restrict__ wd, int Cin, int Cout, int Cip,
-                                                              int Cop, int tiles_ci, int tiles_co) {
+__device__ __forceinline__ void weights_to_bf16_block(int bid, const float *__restrict__ w, __bf16 *__restrict__ wf, __bf16 *__restrict__ wd, int Cin,
+                                                      int Cout, int Cip, int Cop, int tiles_ci, int tiles_co) {
     __shared__ float tile[32][33];
-    int bid = blockIdx.x;
     const int tco = bid % tiles_co;
     bid /= tiles_co;
     const int tci = bid % tiles_ci;
@@ -77,6 +75,27 @@ __global__ void __launch_bounds__(256) weights_to_bf16_kernel(const float *__res
         const int co = co0 + ty + 8 * r, ci = ci0 + tx;
         if (co < Cout && ci < Cip) wf[((long long)tap * Cout + co) * Cip + ci] = (__bf16)tile[tx][ty + 8 * r];
     }
+}
+__global__ void __launch_bounds__(256) weights_to_bf16_kernel(const float *__restrict__ w, __bf16 *__restrict__ wf,
+                                                              __bf16 *__restrict__ wd, int Cin, int Cout, int Cip,
+                                                              int Cop, int tiles_ci, int tiles_co) {
+    weights_to_bf16_block((int)blockIdx.x, w, wf, wd, Cin, Cout, Cip, Cop, tiles_ci, tiles_co);
+}
+// Several filters in one launch (the small layers' refresh launches are all ramp and tail): layer k owns blocks [first[k], first[k + 1]).
+constexpr int kW16MaxLayers = 16;
+struct W16Layers {
+    const float *w[kW16MaxLayers];
+    __bf16 *wf[kW16MaxLayers], *wd[kW16MaxLayers];
+    int Cin[kW16MaxLayers], Cout[kW16MaxLayers], tiles_ci[kW16MaxLayers], tiles_co[kW16MaxLayers], first[kW16MaxLayers + 1];
+    int count;
+};
+__global__ void __launch_bounds__(256) weights_to_bf16_multi_kernel(W16Layers L) {
+    const int bid = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < kW16MaxLayers; q++) k += (q < L.count && bid >= L.first[q]) ? 1 : 0;
+    weights_to_bf16_block(bid - L.first[k], L.w[k], L.wf[k], L.wd[k], L.Cin[k], L.Cout[k], (L.Cin[k] + 7) & ~7, (L.Cout[k] + 7) & ~7, L.tiles_ci[k],
+                          L.tiles_co[k]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -954,6 +973,32 @@ int emadapt_weights_to_bf16(const emadapt_conv_desc *d, const float *w, void *w_
     hipLaunchKernelGGL(weights_to_bf16_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream_), w,
                        static_cast<__bf16 *>(w_fwd_bf16), static_cast<__bf16 *>(w_dgrad_bf16), d->Cin, d->Cout, Cip,
                        Cop, tiles_ci, tiles_co);
+    return launch_status();
+}
+
+int emadapt_weights_to_bf16_multi(int n, const emadapt_conv_desc *const *d, const float *const *w, void *const *w_fwd_bf16,
+                                  void *const *w_dgrad_bf16, void *stream_) {
+    if (n < 0 || n > kW16MaxLayers || (n && (!d || !w || !w_fwd_bf16 || !w_dgrad_bf16))) return EMADAPT_ERR_INVALID;
+    W16Layers L;
+    long long tot = 0;
+    L.count = 0;
+    for (int k = 0; k < n; k++) {
+        int rc = check_desc(d[k]);
+        if (rc) return rc;
+        if (!w[k] || (!w_fwd_bf16[k] && !w_dgrad_bf16[k]) || !aligned16(w[k]) || !aligned16(w_fwd_bf16[k]) || !aligned16(w_dgrad_bf16[k]))
+            return EMADAPT_ERR_INVALID;
+        const int c = L.count++;
+        L.w[c] = w[k]; L.wf[c] = static_cast<__bf16 *>(w_fwd_bf16[k]); L.wd[c] = static_cast<__bf16 *>(w_dgrad_bf16[k]);
+        L.Cin[c] = d[k]->Cin; L.Cout[c] = d[k]->Cout;
+        L.tiles_ci[c] = (int)ceil_div(round_up8(d[k]->Cin), 32); L.tiles_co[c] = (int)ceil_div(round_up8(d[k]->Cout), 32);
+        L.first[c] = (int)tot;
+        tot += (long long)d[k]->KH * d[k]->KW * L.tiles_ci[c] * L.tiles_co[c];
+        if (tot > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    }
+    for (int k = L.count; k <= kW16MaxLayers; k++) L.first[k] = (int)tot;
+    for (int k = L.count; k < kW16MaxLayers; k++) { L.w[k] = nullptr; L.wf[k] = nullptr; L.wd[k] = nullptr; L.Cin[k] = L.Cout[k] = L.tiles_ci[k] = L.tiles_co[k] = 0; }
+    if (tot == 0) return EMADAPT_OK;
+    hipLaunchKernelGGL(weights_to_bf16_multi_kernel, dim3((unsigned)tot), dim3(256), 0, as_stream(stream_), L);
     return launch_status();
 }
 

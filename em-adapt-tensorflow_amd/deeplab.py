@@ -484,13 +484,13 @@ class ADAPT(Network):
             return
         # (layers whose two tiled images the optimizer pass itself wrote from the weights as they are now: apply_update)
         fresh = self._tiles_fresh if (not force and self._tiles_fresh_ver == ver) else ()
+        plain = []   # (filter, forward image, data-gradient image) of the layers on the register-staged kernel: one launch for all
         for op in self._plan:
             if op.kind == "conv":
                 if self.compute_dtype == "bf16":
                     e = self._bt.get(op.name, {"fwd": False, "dgrad": False})
                     if not (e["fwd"] and e["dgrad"]):
-                        ops.weights_to_bf16(op.w_pad, None if e["fwd"] else op.seg["wf16"], None if e["dgrad"] else op.seg["wd16"],
-                                            want_fwd=not e["fwd"], want_dgrad=not e["dgrad"])
+                        plain.append((op.w_pad, None if e["fwd"] else op.seg["wf16"], None if e["dgrad"] else op.seg["wd16"]))
                     if e["fwd"] and e["dgrad"] and op.name in fresh:
                         pass
                     elif e["fwd"] and e["dgrad"]:
@@ -506,6 +506,8 @@ class ADAPT(Network):
                         ops.filter_tiles(op.w_pad, False, out=op.seg["wkp"])
                     if self._plane_dgrad.get(op.name, False):
                         ops.filter_tiles(op.w_pad, True, out=op.seg["wp6"])
+        for i in range(0, len(plain), ops.W16_MAX_LAYERS):
+            ops.weights_to_bf16_multi(plain[i:i + ops.W16_MAX_LAYERS])
         self._w16_seen = ver
         self._tiles_fresh, self._tiles_fresh_ver = set(), None
 

@@ -163,6 +163,37 @@ def weights_to_bf16(w, fwd_out=None, dgrad_out=None, want_fwd=True, want_dgrad=T
     return wf, wd
 
 
+W16_MAX_LAYERS = 16
+
+
+def weights_to_bf16_multi(items):
+    """weights_to_bf16 of several filters in one launch: items = [(w, fwd_out or None, dgrad_out or None)], at most W16_MAX_LAYERS;
+    the images must exist (sizes as weights_to_bf16 allocates them)."""
+    n = len(items)
+    if n == 0:
+        return
+    descs = (ConvDesc * n)()
+    ws, wfs, wds = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+    dps = (ctypes.c_void_p * n)()
+    for k, (w, wf, wd) in enumerate(items):
+        _check(w, name="w")
+        KH, KW, Cin, Cout = w.shape
+        if wf is None and wd is None:
+            raise ValueError("a layer needs at least one image")
+        if wf is not None:
+            _check(wf, torch.bfloat16, "fwd_out")
+            if wf.numel() != KH * KW * Cout * _round8(Cin):
+                raise ValueError("fwd_out has the wrong size")
+        if wd is not None:
+            _check(wd, torch.bfloat16, "dgrad_out")
+            if wd.numel() != KH * KW * Cin * _round8(Cout):
+                raise ValueError("dgrad_out has the wrong size")
+        descs[k] = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+        dps[k] = ctypes.addressof(descs[k])
+        ws[k], wfs[k], wds[k] = w.data_ptr(), (None if wf is None else wf.data_ptr()), (None if wd is None else wd.data_ptr())
+    _lib.call("emadapt_weights_to_bf16_multi", n, dps, ws, wfs, wds, _stream())
+
+
 def conv_fwd_bf16(x, wf, ksize, bias=None, dil=1, relu=True, keep_prob=1.0, drop_mask=None, drop_seed=0, out=None,
                   out_dtype=None):
     """conv_fwd with bf16 operands / fp32 accumulation; wf = forward image of weights_to_bf16, ksize = (KH, KW).

@@ -66,7 +66,7 @@ extern "C" {
  *        decode it, so the model's max-pool gradients no longer read the gate tensor); tune "pool_rows".  The stride-2 max-pool
  *        gradient runs by 2 x 2 pixel quads (same results).  emadapt_sgd_accumulate_momentum_tiles (+ _supported): the optimizer
  *        pass of a layer that also writes the layer's two tiled bf16 filter images; emadapt_sgd_accumulate_momentum_multi: the pass
- *        over several layers' segments in one launch. */
+ *        over several layers' segments in one launch; emadapt_weights_to_bf16_multi: several filters' bf16 images in one launch. */
 #define EMADAPT_ABI_VERSION 205
 int emadapt_version(void);
 const char *emadapt_strerror(int code);
@@ -255,7 +255,11 @@ int emadapt_conv_wgrad_bias(const emadapt_conv_desc *d, const float *x, const fl
 #define EMADAPT_DT_BF16 1
 size_t emadapt_weights_bf16_bytes(const emadapt_conv_desc *d, int which);
 int emadapt_weights_to_bf16(const emadapt_conv_desc *d, const float *w, void *w_fwd_bf16, void *w_dgrad_bf16,
-                            void *stream); /* either image pointer may be NULL */
+                            void *stream);
+/* emadapt_weights_to_bf16 of up to 16 filters in one launch (ABI 205): arrays of n descriptors, filters and image pointers (an
+ * image pointer may be NULL as above, not both of a layer). */
+int emadapt_weights_to_bf16_multi(int n, const emadapt_conv_desc *const *d, const float *const *w, void *const *w_fwd_bf16,
+                                  void *const *w_dgrad_bf16, void *stream); /* either image pointer may be NULL */
 size_t emadapt_conv_fwd_bf16_workspace_bytes(const emadapt_conv_desc *d);
 int emadapt_conv_fwd_bf16(const emadapt_conv_desc *d, const void *x, int x_dtype, const void *w_fwd_bf16,
                           const float *bias, void *y, int y_dtype, int epilogue, float keep_prob,

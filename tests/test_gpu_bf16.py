@@ -660,3 +660,27 @@ def test_bf16_training_tracks_fp32_training():
     assert h[-10:].mean() < 0.7 * h[:4].mean(), "bf16 run did not learn: %s" % h[::8]
     assert abs(h[0] - f[0]) / f[0] < 2e-2                       # same start (one bf16 forward of difference)
     assert abs(h[-10:].mean() - f[-10:].mean()) / f[-10:].mean() < 0.25, (f[::8], h[::8])
+
+
+def test_weights_to_bf16_of_several_filters_in_one_launch(env):
+    """emadapt_weights_to_bf16_multi: every image bit for bit the single-filter entry's, either image optional per layer, 16 layers."""
+    ops, do, torch = env
+    rng = np.random.default_rng(5)
+    shapes = [(3, 3, 4, 64), (3, 3, 64, 64), (3, 3, 64, 128), (1, 1, 4096, 24), (3, 3, 136, 72), (1, 1, 8, 8), (4, 4, 40, 136), (3, 3, 256, 256)]
+    shapes = shapes + shapes
+    items, want = [], []
+    for k, shp in enumerate(shapes):
+        w = _t(torch, rng.normal(0, 0.1, shp).astype(np.float32))
+        wf0, wd0 = ops.weights_to_bf16(w)
+        wf = torch.full_like(wf0, 3.0) if k % 3 != 1 else None
+        wd = torch.full_like(wd0, 3.0) if k % 3 != 2 else None
+        items.append((w, wf, wd))
+        want.append((wf0, wd0))
+    ops.weights_to_bf16_multi(items)
+    for (w, wf, wd), (wf0, wd0) in zip(items, want):
+        assert wf is None or torch.equal(wf.view(torch.int16), wf0.view(torch.int16))
+        assert wd is None or torch.equal(wd.view(torch.int16), wd0.view(torch.int16))
+    with pytest.raises(Exception):
+        ops.weights_to_bf16_multi(items + items[:1])
+    with pytest.raises(Exception):
+        ops.weights_to_bf16_multi([(items[0][0], None, None)])
