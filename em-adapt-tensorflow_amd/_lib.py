@@ -132,6 +132,7 @@ PROTOTYPES = {
     "emadapt_sgd_momentum": (c_int, [_vp, _vp, _vp, c_int64, c_float, c_float, c_float, _vp]),
     "emadapt_sgd_accumulate_momentum": (c_int, [_vp, _vp, _vp, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float, _vp]),
     "emadapt_sgd_accumulate_momentum_multi": (c_int, [_vp, _vp, _vp, c_int, _vp, _vp, _vp, c_float, c_float, c_float, c_float, c_float, _vp]),
+    "emadapt_sgd_momentum_payload_tiles": (c_int, [_vp, _vp, _vp, _vp, _vp, c_int, c_int64, c_float, c_float, c_float, _vp, _vp, _vp]),
     "emadapt_sgd_accumulate_momentum_tiles_supported": (c_int, [_vp]),
     "emadapt_sgd_accumulate_momentum_tiles": (c_int, [_vp, _vp, _vp, _vp, c_int64, c_float, c_float, c_float, c_float, c_float, _vp, _vp, _vp]),
     "emadapt_sgd_momentum_payload": (c_int, [_vp, _vp, _vp, _vp, c_int, c_int64, c_float, c_float, c_float, _vp]),

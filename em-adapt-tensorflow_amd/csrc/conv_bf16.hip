@@ -1307,6 +1307,34 @@ int emadapt_sgd_accumulate_momentum_tiles(const emadapt_conv_desc *d, float *w, 
     return launch_status();
 }
 
+int emadapt_sgd_momentum_payload_tiles(const emadapt_conv_desc *d, float *w, float *v, float *accum, const void *payload, int payload_dtype,
+                                       int64_t n_bias, float lr, float momentum, float scale, void *tiles_fwd, void *tiles_dgrad, void *stream_) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (!w || !v || !payload || !tiles_fwd || !tiles_dgrad || n_bias < 0 || (payload_dtype != EMADAPT_DT_F32 && payload_dtype != EMADAPT_DT_BF16))
+        return EMADAPT_ERR_INVALID;
+    if (!aligned16(w) || !aligned16(v) || !aligned16(accum) || !aligned16(tiles_fwd) || !aligned16(tiles_dgrad) ||
+        reinterpret_cast<uintptr_t>(payload) % (payload_dtype == EMADAPT_DT_BF16 ? 8 : 16) != 0)
+        return EMADAPT_ERR_INVALID;
+    if (!emadapt_sgd_accumulate_momentum_tiles_supported(d)) return EMADAPT_ERR_UNSUPPORTED;
+    const int taps = d->KH * d->KW;
+    const long long pieces = (long long)taps * (d->Cin / BT_BK) * (d->Cout / 64), nw = (long long)taps * d->Cin * d->Cout;
+    const long long blocks = pieces + ceil_div((long long)n_bias, 256);
+    if (blocks > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
+    hipStream_t stream = as_stream(stream_);
+    const bool bf = payload_dtype == EMADAPT_DT_BF16;
+    ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)(nw + n_bias) * ((accum ? 24.0 : 20.0) + (bf ? 2.0 : 4.0)), stream);
+    if (bf)
+        hipLaunchKernelGGL(sgd_payload_tiles_b16_both_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, w, v, accum,
+                           static_cast<const __bf16 *>(payload), reinterpret_cast<uint4 *>(tiles_fwd), reinterpret_cast<uint4 *>(tiles_dgrad), d->Cin,
+                           d->Cout, d->Cout, (int)pieces, nw, (long long)n_bias, lr, momentum, scale, status_word());
+    else
+        hipLaunchKernelGGL(sgd_payload_tiles_b16_both_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, w, v, accum,
+                           static_cast<const float *>(payload), reinterpret_cast<uint4 *>(tiles_fwd), reinterpret_cast<uint4 *>(tiles_dgrad), d->Cin,
+                           d->Cout, d->Cout, (int)pieces, nw, (long long)n_bias, lr, momentum, scale, status_word());
+    return launch_status();
+}
+
 size_t emadapt_conv_bf16t_workspace_bytes(const emadapt_conv_desc *d, int kind) {
     if (kind < 0 || kind > 1 || !bt_ok(d, kind == 1, 0) || d->B == 0) return 0;
     IgemmArgs a;

@@ -224,6 +224,79 @@ __global__ void __launch_bounds__(256) sgd_tiles_b16_both_kernel(float *__restri
     }
 }
 
+// The same for the data-parallel job's Momentum pass (emadapt_sgd_momentum_payload: the summed gradient arrives as the exchange's
+// gathered payload, f32 or bf16, decay and 1 / accum_num already inside): v = mu v + payload ascale, w -= lr v, accum = 0 where there
+// is an accumulator -- on the block's piece, then both images.
+template <typename P>
+__global__ void __launch_bounds__(256) sgd_payload_tiles_b16_both_kernel(float *__restrict__ w, float *__restrict__ v, float *__restrict__ accum,
+                                                                         const P *__restrict__ payload, uint4 *__restrict__ out_f,
+                                                                         uint4 *__restrict__ out_d, int Cin, int Cout, int rows_pad_f, int pieces,
+                                                                         long long nw, long long nb, float lr, float mu, float ascale,
+                                                                         const unsigned *__restrict__ status) {
+    __shared__ float t[32][65];
+    if (status_raised(status)) return;
+    if ((int)blockIdx.x >= pieces) {   // biases
+        const long long i = ((long long)blockIdx.x - pieces) * 256 + threadIdx.x;
+        if (i < nb) {
+            const float vi = opt_velocity(mu, v[nw + i], (float)payload[nw + i], ascale);
+            v[nw + i] = vi;
+            w[nw + i] = opt_step(w[nw + i], lr, vi);
+            if (accum) accum[nw + i] = 0.f;
+        }
+        return;
+    }
+    const int G = Cin / BT_BK, RB = Cout / 64, GD = Cout / BT_BK;
+    int bid = blockIdx.x;
+    const int rb = bid % RB;
+    bid /= RB;
+    const int gk = bid % G, tap = bid / G;
+    {
+        const int c4 = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int k = ty + 16 * r;
+            const long long o = ((long long)tap * Cin + gk * BT_BK + k) * Cout + rb * 64 + c4 * 4;
+            float a[4];
+            if constexpr (sizeof(P) == 4) {
+                const float4 pv = *reinterpret_cast<const float4 *>(payload + o);
+                a[0] = pv.x; a[1] = pv.y; a[2] = pv.z; a[3] = pv.w;
+            } else {
+                typedef __bf16 pk_bf16x4 __attribute__((ext_vector_type(4)));
+                const pk_bf16x4 pv = *reinterpret_cast<const pk_bf16x4 *>(payload + o);
+                a[0] = (float)pv[0]; a[1] = (float)pv[1]; a[2] = (float)pv[2]; a[3] = (float)pv[3];
+            }
+            float4 wi = *reinterpret_cast<const float4 *>(w + o);
+            float4 vi = *reinterpret_cast<const float4 *>(v + o);
+            vi.x = opt_velocity(mu, vi.x, a[0], ascale); vi.y = opt_velocity(mu, vi.y, a[1], ascale);
+            vi.z = opt_velocity(mu, vi.z, a[2], ascale); vi.w = opt_velocity(mu, vi.w, a[3], ascale);
+            wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
+            *reinterpret_cast<float4 *>(v + o) = vi;
+            *reinterpret_cast<float4 *>(w + o) = wi;
+            if (accum) *reinterpret_cast<float4 *>(accum + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+            t[k][c4 * 4 + 0] = wi.x; t[k][c4 * 4 + 1] = wi.y; t[k][c4 * 4 + 2] = wi.z; t[k][c4 * 4 + 3] = wi.w;
+        }
+    }
+    __syncthreads();
+    {   // forward image: row = co, k = ci
+        const int row_l = threadIdx.x >> 2, slot = threadIdx.x & 3;
+        const int row = rb * 64 + row_l;
+        const int chunk = slot ^ bt_swz(row);
+        bt_bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (__bf16)t[chunk * 8 + e][row_l];
+        out_f[(((long long)tap * G + gk) * rows_pad_f + row) * 4 + slot] = *reinterpret_cast<uint4 *>(&o);
+    }
+    {   // data-gradient image: row = ci, k = co
+        const int slot = threadIdx.x & 3, gl = (threadIdx.x >> 2) & 1, ci_l = threadIdx.x >> 3;
+        const int row = gk * BT_BK + ci_l;
+        const int chunk = slot ^ bt_swz(row);
+        bt_bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (__bf16)t[ci_l][gl * 32 + chunk * 8 + e];
+        out_d[(((long long)tap * GD + rb * 2 + gl) * Cin + row) * 4 + slot] = *reinterpret_cast<uint4 *>(&o);   // (rows_pad == Cin)
+    }
+}
+
 // Tile epilogue of a 64 x 128 block held as 4 x 8 accumulator tiles of the 16 x 16 MFMA (C/D layout: column = lane & 15, row =
 // 4 (lane >> 4) + r): 16 rows at a time through the wave's private LDS slab ([16][128 + 4] floats), read back as 8 consecutive
 // columns per lane -- then exactly store_acc_tile's arithmetic (igemm_common.h: bias / ReLU / dropout / gate on 8 values, 16-byte

@@ -801,8 +801,31 @@ class ADAPT(Network):
             self._pending_fused = False
         elif gs is not None and not gs.writeback:
             # the exchanged sum lives in the gathered payload (f32 or bf16); the accumulator is only zeroed (the clean op)
-            ops.sgd_momentum_payload(f["params"], f["momentum"], None if gs.prepacked else f["accum"], gs.gathered, self.net["lr"],
-                                     self._momentum, scale)
+            acc = None if gs.prepacked else f["accum"]
+            tiled = []   # layers whose pass also writes their two tiled bf16 images (as in the fused update above)
+            if self.compute_dtype == "bf16" and self.config.get("fused_tiles", True):
+                for op in self._plan:
+                    if op.kind == "conv":
+                        e = self._bt.get(op.name, {"fwd": False, "dgrad": False})
+                        if (e["fwd"] and e["dgrad"] and op.seg.get("wt16") is not None and op.seg.get("wtd16") is not None
+                                and ops.sgd_accumulate_momentum_tiles_supported(*op.seg["pshape"])):
+                            tiled.append(op)
+            if not tiled:
+                ops.sgd_momentum_payload(f["params"], f["momentum"], acc, gs.gathered, self.net["lr"], self._momentum, scale)
+            else:
+                at = 0   # the flat buffer in order: a tiled layer's own pass, one plain pass per run of other layers in between
+                for op in sorted(tiled, key=lambda o: o.seg["start"]) + [None]:
+                    s = f["total"] if op is None else op.seg["start"]
+                    if s > at:
+                        ops.sgd_momentum_payload(f["params"][at:s], f["momentum"][at:s], None if acc is None else acc[at:s], gs.gathered[at:s],
+                                                 self.net["lr"], self._momentum, scale)
+                    if op is not None:
+                        n = op.seg["nw"] + op.seg["nb"]
+                        ops.sgd_momentum_payload_tiles(f["params"][s:s + n], f["momentum"][s:s + n], None if acc is None else acc[s:s + n],
+                                                       gs.gathered[s:s + n], tuple(op.seg["pshape"]), self.net["lr"], self._momentum, scale,
+                                                       op.seg["wt16"], op.seg["wtd16"])
+                        fresh.add(op.name)
+                        at = s + n
         else:
             ops.sgd_momentum(f["params"], f["momentum"], f["accum"], self.net["lr"], self._momentum, scale)
         self._w16_seen = None  # the master weights moved: the bf16 images are refreshed by the next forward

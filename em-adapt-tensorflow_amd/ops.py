@@ -737,6 +737,23 @@ def sgd_accumulate_momentum_tiles(w, v, g, filter_shape, weight_decay, gscale, l
               float(gscale), float(lr), float(momentum), float(ascale), _p(out_fwd), _p(out_dgrad), _stream())
 
 
+def sgd_momentum_payload_tiles(w, v, accum, payload, filter_shape, lr, momentum, scale, out_fwd, out_dgrad):
+    """sgd_momentum_payload on one layer's [filter | biases] segment that also writes both tiled bf16 images of the new filter."""
+    _check(w, name="w"); _check(v, name="v"); _check(accum, name="accum")
+    pdt = _payload_dt(payload, "payload")
+    KH, KW, Cin, Cout = filter_shape
+    nw = KH * KW * Cin * Cout
+    if w.numel() < nw or v.numel() != w.numel() or payload.numel() != w.numel() or (accum is not None and accum.numel() != w.numel()):
+        raise ValueError("w / v / accum / payload must hold the %d filter elements followed by the biases" % nw)
+    d = conv_desc(1, 1, 1, Cin, Cout, KH, KW, 1)
+    for t, dg in ((out_fwd, 0), (out_dgrad, 1)):
+        n = _lib.load().emadapt_filter_tiles_bf16_bytes(ctypes.byref(d), dg)
+        if n == 0 or t.dtype != torch.bfloat16 or t.numel() * 2 != n or not t.is_cuda or not t.is_contiguous():
+            raise ValueError("tiled image buffer does not match the filter")
+    _lib.call("emadapt_sgd_momentum_payload_tiles", ctypes.byref(d), _p(w), _p(v), _p(accum), _p(payload), pdt, w.numel() - nw, float(lr),
+              float(momentum), float(scale), _p(out_fwd), _p(out_dgrad), _stream())
+
+
 def _payload_dt(t, name):
     if not t.is_cuda or not t.is_contiguous():
         raise ValueError("%s must be a contiguous GPU tensor" % name)

@@ -64,8 +64,8 @@ extern "C" {
  *        emadapt_conv_wgrad[_bias]_bf16_workspace_bytes: 37.8 MB for conv1_2 at batch 16 where the split-M plan needed 15 MB).
  *   205  round 5, added: emadapt_maxpool_fwd_gated (the index byte carries the ReluGrad gate of the pooled tensor; the backward entries
  *        decode it, so the model's max-pool gradients no longer read the gate tensor); tune "pool_rows".  The stride-2 max-pool
- *        gradient runs by 2 x 2 pixel quads (same results).  emadapt_sgd_accumulate_momentum_tiles (+ _supported): the optimizer
- *        pass of a layer that also writes the layer's two tiled bf16 filter images; emadapt_sgd_accumulate_momentum_multi: the pass
+ *        gradient runs by 2 x 2 pixel quads (same results).  emadapt_sgd_accumulate_momentum_tiles (+ _supported) and
+ *        emadapt_sgd_momentum_payload_tiles: the optimizer pass of a layer that also writes the layer's two tiled bf16 filter images; emadapt_sgd_accumulate_momentum_multi: the pass
  *        over several layers' segments in one launch; emadapt_weights_to_bf16_multi: several filters' bf16 images in one launch. */
 #define EMADAPT_ABI_VERSION 205
 int emadapt_version(void);
@@ -478,6 +478,12 @@ int emadapt_sgd_accumulate_momentum_tiles_supported(const emadapt_conv_desc *d);
 int emadapt_sgd_accumulate_momentum_tiles(const emadapt_conv_desc *d, float *w, float *v, const float *g, int64_t n_bias,
                                           float weight_decay, float gscale, float lr, float momentum, float ascale,
                                           void *tiles_fwd, void *tiles_dgrad, void *stream);
+/* ... and the data-parallel job's Momentum pass on the exchange's gathered payload (emadapt_sgd_momentum_payload below) for such a
+ * layer, with both images (ABI 205): w / v / accum (may be NULL) / payload point at the layer's [filter | biases] segment; same
+ * shapes as _tiles_supported; weights, momentum and accumulator bit for bit emadapt_sgd_momentum_payload's. */
+int emadapt_sgd_momentum_payload_tiles(const emadapt_conv_desc *d, float *w, float *v, float *accum, const void *payload,
+                                       int payload_dtype, int64_t n_bias, float lr, float momentum, float scale,
+                                       void *tiles_fwd, void *tiles_dgrad, void *stream);
 
 /* ---- staging of the data-parallel gradient exchange (dist.py; the reference's accum += g/accum_num, deeplab.py:202, with
  * micro-batches mapped to ranks).  The exchange is reduce-scatter + all-gather written as two all-to-all steps over all xGMI

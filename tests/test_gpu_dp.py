@@ -141,3 +141,61 @@ def test_prepacked_exchange_is_the_accumulator_path_bit_for_bit(tmp_path, dtype,
         got[pre] = [np.load(d / ("params%d.npy" % r)) for r in range(2)]
         assert np.array_equal(got[pre][0], got[pre][1]), "ranks diverged"
     assert np.array_equal(got[True][0], got[False][0])
+
+
+def _worker_full_width(rank, world, port, out_dir, tiles, prepack):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from oracle import deeplab_oracle as do
+    from oracle import estep_oracle as eo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, size, C = 1, 65, 5
+    images, labels = do.synthetic_batch(B * world, size, C, seed=3)
+    images = (images / 50.0).astype(np.float32)
+    perms = eo.draw_perms(5, C, seed=7)
+    a = ADAPT({"input_size": (size, size), "category_num": C, "accum_num": 1, "batch_size": B, "compute_dtype": "bf16", "device": "cuda:0",
+               "bf16t": "always", "fused_tiles": tiles, "grad_dtype": "bf16", "dp_prepack": prepack, "force_gradsync": True, "seed": 5,
+               "bucket_mb": 32})
+    a.build()
+    a.pre_train(base_lr=1e-2, weight_decay=1e-3, momentum=0.9, batch_size=B)
+    assert a._gradsync is not None and a._gradsync.algo == "direct" and not a._gradsync.writeback and a._gradsync.prepacked == prepack
+    sl = slice(rank * B, (rank + 1) * B)
+    took = 0
+    for _ in range(3):
+        a.micro_step(images[sl], labels[sl], keep_prob=0.5, perms=perms)
+        a.apply_update()
+        took = max(took, len(a._tiles_fresh))
+    assert (took > 0) == tiles
+    loss = a.eval_loss(images[sl], labels[sl], keep_prob=1.0, perms=perms)
+    torch.cuda.synchronize()
+    assert float(a._flat["accum"].abs().max()) == 0.0
+    imgs = [op.seg[k].view(torch.int16).cpu().numpy() for op in a._plan if op.kind == "conv" for k in ("wt16", "wtd16") if op.seg.get(k) is not None]
+    np.savez(os.path.join(out_dir, "full%d.npz" % rank), params=a._flat["params"].cpu().numpy(), momentum=a._flat["momentum"].cpu().numpy(),
+             loss=np.float64(loss), **{"img%d" % i: t for i, t in enumerate(imgs)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("prepack", [True, False])
+def test_momentum_on_the_payload_writes_the_tiled_images_the_refresh_would(tmp_path, prepack):
+    """The data-parallel job's update (Momentum on the exchange's gathered bf16 payload) on a full-width bf16 net with the LDS-DMA kernel
+    forced onto every layer it supports: the layers whose pass also writes their tiled bf16 images (emadapt_sgd_momentum_payload_tiles,
+    config fused_tiles) come out with the weights, momentum, images and loss of the path that runs ONE Momentum pass over the flat
+    buffer and lets the next forward rebuild the images -- bit for bit, with and without the accumulator (dp_prepack)."""
+    import torch.multiprocessing as mp
+    got = {}
+    for tiles in (True, False):
+        d = tmp_path / ("tiles%d" % tiles)
+        d.mkdir()
+        mp.spawn(_worker_full_width, args=(1, _free_port(), str(d), tiles, prepack), nprocs=1, join=True)
+        got[tiles] = dict(np.load(d / "full0.npz"))
+    assert set(got[True]) == set(got[False]) and len(got[True]) > 4
+    for k in got[True]:
+        assert np.array_equal(got[True][k], got[False][k]), k
+    assert np.isfinite(float(got[True]["loss"]))

@@ -331,6 +331,34 @@ def test_fused_accumulate_momentum_is_the_two_kernels_bit_for_bit(env, n, n_deca
         assert torch.equal(w1, w2) and torch.equal(v1.view(torch.int32), v2.view(torch.int32)), (gscale, ascale)
 
 
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+@pytest.mark.parametrize("with_accum", [True, False])
+def test_momentum_on_the_payload_that_writes_the_tiled_images(env, payload, with_accum):
+    """emadapt_sgd_momentum_payload_tiles: weights, momentum and accumulator bit for bit emadapt_sgd_momentum_payload's, the images
+    emadapt_filter_tiles_bf16's on the new weights."""
+    ops, do, torch = env
+    pdt = torch.bfloat16 if payload == "bf16" else torch.float32
+    for shape, nb in (((3, 3, 256, 256), 256), ((1, 1, 512, 768), 776)):
+        nw = shape[0] * shape[1] * shape[2] * shape[3]
+        n = nw + nb
+        g = torch.Generator(device="cuda").manual_seed(n + 3)
+        w = torch.randn(n, device="cuda", generator=g) * 0.05
+        v = torch.randn(n, device="cuda", generator=g) * 0.01
+        pay = (torch.randn(n, device="cuda", generator=g) * 1e-2).to(pdt)
+        pay[::9] = -0.0
+        w1, v1, a1 = w.clone(), v.clone(), (torch.ones(n, device="cuda") if with_accum else None)
+        ops.sgd_momentum_payload(w1, v1, a1, pay, 1e-3, 0.9, 0.5)
+        tf1 = ops.filter_tiles_bf16(w1[:nw].view(shape))
+        td1 = ops.filter_tiles_bf16(w1[:nw].view(shape), dgrad=True)
+        w2, v2, a2 = w.clone(), v.clone(), (torch.ones(n, device="cuda") if with_accum else None)
+        tf2, td2 = torch.full_like(tf1, 7.0), torch.full_like(td1, 7.0)
+        ops.sgd_momentum_payload_tiles(w2, v2, a2, pay, shape, 1e-3, 0.9, 0.5, tf2, td2)
+        assert torch.equal(w1.view(torch.int32), w2.view(torch.int32)) and torch.equal(v1.view(torch.int32), v2.view(torch.int32))
+        assert torch.equal(tf1.view(torch.int16), tf2.view(torch.int16)) and torch.equal(td1.view(torch.int16), td2.view(torch.int16))
+        if with_accum:
+            assert float(a2.abs().max()) == 0.0 and float(a1.abs().max()) == 0.0
+
+
 def test_optimizer_pass_over_several_segments_in_one_launch(env):
     """emadapt_sgd_accumulate_momentum_multi: bit for bit one emadapt_sgd_accumulate_momentum call per segment; what lies between the
     segments is not touched; ragged or overlapping segments are refused."""
