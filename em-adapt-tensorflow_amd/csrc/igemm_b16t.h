@@ -383,8 +383,8 @@ __device__ __forceinline__ void store_acc_tile16(const IgemmArgs &a, const bt_f3
     }
 }
 
-// ABLM (diagnostic library only, tune "ablate"): parts of the K loop COMPILED out -- 1 no DMAs (every stage filled once), 2 no
-// fragment reads, 8 no MFMAs; results are garbage, scripts/bf16t_ablate.py reads the time.
+// ABLM (diagnostic library only, tune "ablate"): parts of the kernel COMPILED out -- 1 no DMAs (every stage filled once), 2 no
+// fragment reads, 4 no epilogue, 8 no MFMAs; results are garbage, scripts/bf16t_ablate.py reads the time.
 template <bool SK, bool YBF, int ABLM = 0>
 __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) {
     constexpr int BM = 256, BN = 256, BK = BT_BK, NBUF = BT_NBUF, AHEAD = BT_AHEAD, STAGE = BT_STAGE, OPER = BT_OPER, IPW = BT_IPW;
@@ -674,7 +674,8 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
         float *slab_ = !SK && lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;   // (split-K levels of the plain launches)
         float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (128 + 4));
         static_assert(BT_MWAVES * 16 * (128 + 4) * 4 <= BT_LDS, "epilogue slabs must fit in the ring");
-        store_acc_tile16<YBF>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+        if (!(ABLM & 4) || a.m_end < -1)   // (ablation 4: a condition that is never true at run time keeps the accumulators alive)
+            store_acc_tile16<YBF>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
     }
     if constexpr (SK) {
         __syncthreads();   // every wave's slab stores were drained ahead of this barrier
@@ -695,7 +696,7 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
     if constexpr (ABLM == 0 && YBF) {
         switch (tune(TUNE_ABLATE)) {
 #define EMADAPT_ABL_CASE(m) case m: return launch_igemm_b16t<SK, YBF, m>(a, stream);
-            EMADAPT_ABL_CASE(1) EMADAPT_ABL_CASE(2) EMADAPT_ABL_CASE(3) EMADAPT_ABL_CASE(8) EMADAPT_ABL_CASE(9) EMADAPT_ABL_CASE(10)
+            EMADAPT_ABL_CASE(1) EMADAPT_ABL_CASE(2) EMADAPT_ABL_CASE(3) EMADAPT_ABL_CASE(4) EMADAPT_ABL_CASE(8) EMADAPT_ABL_CASE(9) EMADAPT_ABL_CASE(10)
 #undef EMADAPT_ABL_CASE
             default: break;
         }
