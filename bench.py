@@ -62,9 +62,10 @@ def parse():
                          "/ narrow workloads then run on the native fp32 kernels); always = wherever they can run (tests)")
     ap.add_argument("--tune", default="", help="launch-plan overrides for A/B runs, e.g. fp32_loader=2,plan_cus=256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="images per CPU-baseline step (BASELINE.md section 4: 16)")
-    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (median is reported)")
-    ap.add_argument("--cpu-warmup", type=int, default=1)
+    ap.add_argument("--cpu-batch", default="16,1",
+                    help="images per CPU-baseline step, one leg per value (BASELINE.md section 4: batch 16 and config 1's single image)")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline steps per leg (median is reported; BASELINE.md section 4: >= 5)")
+    ap.add_argument("--cpu-warmup", type=int, default=2, help="untimed CPU-baseline steps per leg (BASELINE.md section 4: 2)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = cgroup quota / affinity")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--prof-every", type=int, default=4,
@@ -148,7 +149,22 @@ def cpu_model():
 
 
 def cpu_baseline(args):
-    """Time the CPU oracle on a bounded sample of the same workload (test infrastructure used as a baseline)."""
+    """Time the CPU oracle on a bounded sample of the same workload (test infrastructure used as a baseline), the way BASELINE.md
+    section 4 prescribes: the step of deeplab.py:265-270 at batch 16 AND at config 1's single image, all host cores, 2 warm-up + 5 timed
+    steps each, medians.  The top-level value is the batch-16 leg (the batch the metric is quoted on)."""
+    legs = {}
+    for b in [int(x) for x in str(args.cpu_batch).split(",") if x.strip()]:
+        legs["b%d" % b] = cpu_baseline_leg(args, b)
+    first = legs["b16"] if "b16" in legs else next(iter(legs.values()))
+    out = dict(first)
+    out["protocol"] = "BASELINE.md section 4: %d warm-up + %d timed steps per leg, median; legs: %s" % (
+        args.cpu_warmup, max(args.cpu_steps, 1), ", ".join(legs))
+    for k, v in legs.items():
+        out[k] = {kk: v[kk] for kk in ("value", "unit", "batch", "ms_per_step", "estep_share", "timed_seconds")}
+    return out
+
+
+def cpu_baseline_leg(args, B):
     import numpy as np
     import torch
     from oracle import deeplab_oracle as do
@@ -156,7 +172,6 @@ def cpu_baseline(args):
 
     cores = args.cpu_threads or host_cores()
     torch.set_num_threads(cores)
-    B = args.cpu_batch
     oracle = do.DeepLabOracle(category_num=args.classes, preset=args.preset, width=args.width, dtype=torch.float32)
     params = do.init_params(oracle.specs, seed=2, std=0.01)
     plist = {k: [w.copy(), b.copy()] for k, (w, b) in params.items()}
@@ -192,11 +207,205 @@ def cpu_baseline(args):
         "cpu_model": cpu_model(),
         "kind": "port",
         "batch": B,
+        "ms_per_step": round(med * 1e3, 1),
+        "timed_seconds": round(sum(times), 1),
         "estep_share": round(sorted(shares)[len(shares) // 2], 4),
         "sample": "median of %d timed steps of %d images (after %d warm-up) of the same step: %dx%d, %d classes, preset %s, "
                   "fp32, PyTorch-CPU convs + NumPy E-step oracle (stand-in for the reference's TF-CPU path); %.1f s timed" % (
                       len(times), B, args.cpu_warmup, args.size, args.size, args.classes, args.preset, sum(times)),
     }
+
+
+def _traffic_profiles(key):
+    """Committed PMC summaries (profiles/r*_traffic*.json, newest first) taken on exactly this workload AND on the kernel sources that
+    are running: (path relative to the repository, parsed json) pairs, plus a note when only stale ones exist."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    from em_adapt_tensorflow_amd import _build
+    lib_hash = _build.source_hash()
+    found, note = [], "none: no committed counter profile of this workload"
+    for tpath in sorted(glob.glob(os.path.join(here, "profiles", "r*_traffic*.json")), reverse=True):
+        try:
+            tj = json.load(open(tpath))
+        except (OSError, ValueError):
+            continue
+        if tj.get("key") != key:
+            continue
+        if tj.get("source_hash") != lib_hash:
+            # the profile was taken on other kernel sources: a number carried forward would be a stale claim
+            if not found:
+                note = "stale: %s was taken on kernel sources %s, these are %s (re-run scripts/make_profiles.sh)" % (
+                    os.path.relpath(tpath, here), tj.get("source_hash"), lib_hash)
+            continue
+        found.append((os.path.relpath(tpath, here), tj))
+    return found, note
+
+
+def roofline_object(prof, prof_steps, steps, every, dtype, ms, fb_flops, batch, key):
+    """The `roofline` object of a line (or of a side leg) from the library's per-class HIP-event sums."""
+    conv = {k: prof[k] for k in ("igemm_fwd", "igemm_dgrad", "igemm_wgrad")}
+    dom = max(conv, key=lambda k: conv[k]["ms"])
+    d = conv[dom]
+    tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    tf_exec = d["flops_executed"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    all_flops = sum(v["flops"] for v in conv.values())
+    all_exec = sum(v["flops_executed"] for v in conv.values())
+    all_ms = sum(v["ms"] for v in conv.values())
+    peak = {"fp32": PEAK_FP32_MATRIX_TFLOPS, "bf16": PEAK_BF16_MATRIX_TFLOPS, "bf16x6": round(PEAK_BF16_MATRIX_TFLOPS / 6, 1)}[dtype]
+    r = {
+        "bound": "mfma",
+        "kernel": dom,
+        "achieved": round(tf, 2),
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": round(tf / peak, 4),
+        # MFMA utilisation proper: the FLOPs the launches ISSUED (the library's count: algorithmic minus the products
+        # with a dilated filter's zero padding that the kernels skip) / time / peak.  `frac` is what the caller gets
+        # (SURVEY 8d's algorithmic FLOPs), `frac_executed` how busy the matrix pipe was; both never above 1 together
+        "frac_executed": round(tf_exec / peak, 4),
+        "achieved_executed": round(tf_exec, 2),
+        "executed_over_algorithmic": round(d["flops_executed"] / d["flops"], 4) if d["flops"] > 0 else None,
+        "traffic": None,   # filled below from the committed PMC passes when they cover this workload
+        "algorithmic_bytes": round(d["bytes"] / max(d["launches"], 1)),   # per launch: every operand and the output once
+        "traffic_over_algorithmic": None,
+        "launches": d["launches"],
+        "timed_steps_with_events": "%d of %d (every %d%s)" % (prof_steps, steps, every, "th" if every > 3 else ""),
+        "fractions_taken_on": "the event-timed steps (HIP events bracket every kernel of those steps on the launch stream)",
+        "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
+        "flop_per_launch": d["flops"] / max(d["launches"], 1),
+        "flop_accounting": "frac / achieved / flop_per_launch: algorithmic (2*M*K*N per launch, zero-padding products "
+                           "included: SURVEY 8d); frac_executed / achieved_executed: the products the kernels really "
+                           "issue (packed pixel classes and per-tap pixel boxes skip a dilated filter's padding)",
+        "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None,
+        "all_conv_tflops_executed": round(all_exec / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None,
+        "all_conv_frac": round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4) if all_ms > 0 else None,
+        "all_conv_frac_executed": round(all_exec / (all_ms * 1e-3) / 1e12 / peak, 4) if all_ms > 0 else None,
+        "step_tflops": round(fb_flops * batch / (ms * 1e-3) / 1e12, 2),
+    }
+    # HBM (L2-miss) bytes per launch of the dominant class: PMC counters need their own rocprofv3 passes
+    # (scripts/make_profiles.sh); their per-class summary is committed under profiles/ and used when it was taken
+    # on exactly this workload (matched on its structured key, not on prose) and on these kernel sources
+    found, note = _traffic_profiles(key)
+    r["traffic_source"] = note
+    for rel, tj in found:
+        try:
+            per_step = tj["per_step"][dom]
+        except KeyError:
+            continue
+        calls = d["launches"] / max(prof_steps, 1)
+        r["traffic_source"] = rel
+        r["traffic"] = round((per_step["read_bytes"] + per_step["write_bytes"]) / max(calls, 1))
+        r["traffic_unit"] = "bytes per launch (HBM-side reads + writes, %s)" % rel
+        if d["bytes"] > 0:
+            r["traffic_over_algorithmic"] = round(r["traffic"] / (d["bytes"] / d["launches"]), 2)
+        break
+    return r
+
+
+def estep_object(prof, key):
+    e = prof["estep"]
+    if e["ms"] <= 0:
+        return None
+    out = {"ms": round(e["ms"] / max(e["launches"], 1), 4),
+           "achieved_GBps": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 2), "bound": "hbm",
+           "peak_GBps": 8000, "algorithmic_bytes": round(e["bytes"] / max(e["launches"], 1)),
+           "traffic": None}
+    # counter-based HBM bytes of the E-step's kernels per call (FETCH_SIZE x 2 + WRITE_SIZE: the same passes and the
+    # same staleness rule as roofline.traffic)
+    for rel, tj in _traffic_profiles(key)[0]:
+        if "estep" in tj:
+            es = tj["estep"]
+            out["traffic"] = round(es["read_bytes"] + es["write_bytes"])
+            out["traffic_GBps"] = round((es["read_bytes"] + es["write_bytes"]) / (e["ms"] / max(e["launches"], 1) * 1e-3) / 1e9, 2)
+            out["traffic_over_algorithmic"] = round(out["traffic"] / max(out["algorithmic_bytes"], 1), 2)
+            out["l2_hit_rate"] = es.get("l2_hit_rate")
+            out["traffic_source"] = rel
+            break
+    return out
+
+
+def side_leg(what, base_cfg, args, device, fence, steps, warmup, every, dtype=None, preset=None, size=None, classes=None, batch=None, accum=1):
+    """One more measurement of the same step in the same process, reported BESIDE the headline (never as it): its own model, data,
+    visiting orders and warm-up, `steps` timed steps bracketed like the headline's.  With accum > 1 a step is `accum` micro-batches
+    and one update (the reference's own recipe: deeplab.py:288,293)."""
+    import random
+    import numpy as np
+    import torch
+    from em_adapt_tensorflow_amd import ops
+    from em_adapt_tensorflow_amd.data import SyntheticData
+    from em_adapt_tensorflow_amd.deeplab import ADAPT
+    from em_adapt_tensorflow_amd.estep import draw_perms
+
+    dtype, preset = dtype or args.dtype, preset or args.preset
+    size, classes, batch = size or args.size, classes or args.classes, batch or args.batch
+    key = {"dtype": dtype, "preset": preset, "size": size, "classes": classes, "batch": batch, "width": args.width}
+    cfg = dict(base_cfg, input_size=(size, size), category_num=classes, batch_size=batch, preset=preset, compute_dtype=dtype,
+               accum_num=accum, force_gradsync=False)
+    leg = None
+    try:
+        data = SyntheticData(dict(cfg, seed=0, unique_batches=2))
+        leg = ADAPT(dict(cfg, data=data))
+        leg.build()
+        leg.pre_train(base_lr=1e-3, weight_decay=1e-5, momentum=0.9, batch_size=batch)
+        batches = data.next_batch("train", batch)
+        pool = [next(batches) for _ in range(2)]
+        rng = random.Random(3)
+        host = np.stack([draw_perms(5, classes, rng=rng) for _ in range((warmup + steps) * accum)])
+        leg._perm_pool, leg._perm_pos = torch.as_tensor(host).to(device), 0
+
+        def step(i):
+            for m in range(accum):
+                x, y = pool[(i * accum + m) % len(pool)]
+                leg.micro_step(x, y, keep_prob=args.keep_prob)
+            leg.apply_update()
+
+        for i in range(warmup):
+            step(i)
+        fence()
+        ops.prof_reset()
+        prof_steps = 0
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ops.prof_enable(i % every == 0)
+            prof_steps += i % every == 0
+            step(warmup + i)
+        fence()
+        dt = time.perf_counter() - t0
+        ops.prof_enable(False)
+        prof = ops.prof_collect()
+        ops.prof_reset()
+        loss = float(leg.loss["norm"].cpu())
+        ms = dt / max(steps, 1) * 1e3
+        _, fb_flops = leg.flops_per_image()
+        r = roofline_object(prof, prof_steps, steps, every, dtype, ms / accum, fb_flops, batch, key)
+        out = {
+            "what": what,
+            "value": round(batch * accum * steps / dt, 3), "unit": "images/s",
+            "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+            "images_per_step": batch * accum,
+            "workload_key": dict(key, accum_num=accum),
+            "dtype": dtype,
+            "final_loss": round(loss, 5) if np.isfinite(loss) else None,
+            "gflop_per_image_fwd_bwd": round(fb_flops / 1e9, 1),
+            "roofline": {k: r[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "frac_executed", "all_conv_tflops", "all_conv_frac",
+                                           "all_conv_frac_executed", "traffic", "algorithmic_bytes", "traffic_over_algorithmic",
+                                           "traffic_source", "avg_launch_ms", "launches", "timed_steps_with_events")},
+        }
+        es = estep_object(prof, key)
+        if es is not None:
+            out["estep_ms"] = es["ms"]
+        if not np.isfinite(loss):
+            out["error"] = "non-finite loss"
+        return out
+    except Exception as e:   # a side measurement must never cost the headline line
+        return {"what": what, "error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        del leg
+        try:
+            ops.prof_enable(False)
+            ops.prof_reset()
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
 
 
 def launch_workers(n, worker_cmd, timeout=None, env=None, out=None):
@@ -365,7 +574,7 @@ def main():
     # E-step visiting orders for every step, drawn like the reference does and parked in HBM
     random.seed(3 + rank)
     total_steps = args.warmup + args.steps
-    n_extra = 2 + (args.steps if args.overhead_steps < 0 else args.overhead_steps)   # (the exchange-overhead leg, when there is one)
+    n_extra = 2 * (2 + (args.steps if args.overhead_steps < 0 else args.overhead_steps))   # (the two exchange-overhead legs, when there are any)
     host = np.stack([draw_perms(5, args.classes, rng=random) for _ in range(max(total_steps, 1) + n_extra)])
     adapt._perm_pool = torch.as_tensor(host).to(device)
     adapt._perm_pos = 0
@@ -409,20 +618,34 @@ def main():
         ops.prof_reset()
     gs_stats = adapt._gradsync.stats() if adapt._gradsync is not None else None
     rank_ms = [(t_local - t0) / max(args.steps, 1) * 1e3]
-    ms_without_exchange = None
+    ms_without_exchange = ms_without_exchange_unfused = None
     n_over = args.steps if args.overhead_steps < 0 else args.overhead_steps
     if adapt._gradsync is not None and n_over > 0:
         # the same steps with the exchange switched off (same process, same buffers; the ranks' weights drift apart from here on,
-        # which nothing below depends on): what the exchange COSTS the step, hidden or not
+        # which nothing below depends on): what the exchange COSTS the step, hidden or not.  Two legs (advisor finding, round 5):
+        # without a gradient exchange the step runs the FUSED update (accumulate + Momentum + clean, one pass per layer) -- the
+        # single-GPU job's step, so `overhead_ms_per_step` is what data parallelism costs all told, the loss of that fusion included;
+        # the second leg switches the fusion off too (accumulate, then Momentum, as separate passes), so that
+        # `overhead_vs_unfused_ms_per_step` is the exchange's launches, staging passes and contention alone
         gs_keep, adapt._gradsync = adapt._gradsync, None
-        for i in range(2):
-            step(total_steps + i)
-        fence()
-        t1 = time.perf_counter()
-        for i in range(n_over):
-            step(total_steps + 2 + i)
-        fence()
-        ms_without_exchange = (time.perf_counter() - t1) / n_over * 1e3
+        fused_keep = adapt._fused
+        at = total_steps
+        for unfused in (False, True):
+            adapt._fused = fused_keep and not unfused
+            for i in range(2):
+                step(at + i)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(n_over):
+                step(at + 2 + i)
+            fence()
+            t_leg = (time.perf_counter() - t1) / n_over * 1e3
+            at += 2 + n_over
+            if unfused:
+                ms_without_exchange_unfused = t_leg
+            else:
+                ms_without_exchange = t_leg
+        adapt._fused = fused_keep
         adapt._gradsync = gs_keep
     if distributed:
         from em_adapt_tensorflow_amd.dist import all_reduce_max
@@ -434,6 +657,7 @@ def main():
         dt = all_reduce_max(dt, device)
         if ms_without_exchange is not None:
             ms_without_exchange = all_reduce_max(ms_without_exchange, device)
+            ms_without_exchange_unfused = all_reduce_max(ms_without_exchange_unfused, device)
         if gs_stats is not None and gs_stats["exposed_ms"] is not None:
             gs_stats["exposed_ms_max_over_ranks"] = all_reduce_max(gs_stats["exposed_ms"], device)
     loss = float(adapt.loss["norm"].cpu())
@@ -476,95 +700,16 @@ def main():
             "final_loss": round(loss, 5),
         }
         if prof is not None:
-            conv = {k: prof[k] for k in ("igemm_fwd", "igemm_dgrad", "igemm_wgrad")}
-            dom = max(conv, key=lambda k: conv[k]["ms"])
-            d = conv[dom]
-            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-            tf_exec = d["flops_executed"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-            all_flops = sum(v["flops"] for v in conv.values())
-            all_exec = sum(v["flops_executed"] for v in conv.values())
-            all_ms = sum(v["ms"] for v in conv.values())
-            peak = {"fp32": PEAK_FP32_MATRIX_TFLOPS, "bf16": PEAK_BF16_MATRIX_TFLOPS,
-                    "bf16x6": round(PEAK_BF16_MATRIX_TFLOPS / 6, 1)}[args.dtype]
-            out["roofline"] = {
-                "bound": "mfma",
-                "kernel": dom,
-                "achieved": round(tf, 2),
-                "peak": peak,
-                "unit": "TFLOP/s",
-                "frac": round(tf / peak, 4),
-                # MFMA utilisation proper: the FLOPs the launches ISSUED (the library's count: algorithmic minus the products
-                # with a dilated filter's zero padding that the kernels skip) / time / peak.  `frac` is what the caller gets
-                # (SURVEY 8d's algorithmic FLOPs), `frac_executed` how busy the matrix pipe was; both never above 1 together
-                "frac_executed": round(tf_exec / peak, 4),
-                "achieved_executed": round(tf_exec, 2),
-                "executed_over_algorithmic": round(d["flops_executed"] / d["flops"], 4) if d["flops"] > 0 else None,
-                "traffic": None,   # filled below from the committed PMC passes when they cover this workload
-                "algorithmic_bytes": round(d["bytes"] / max(d["launches"], 1)),   # per launch: every operand and the output once
-                "traffic_over_algorithmic": None,
-                "launches": d["launches"],
-                "timed_steps_with_events": "%d of %d (every %d%s)" % (prof_steps, args.steps, every, "th" if every > 3 else ""),
-                "avg_launch_ms": round(d["ms"] / max(d["launches"], 1), 4),
-                "flop_per_launch": d["flops"] / max(d["launches"], 1),
-                "flop_accounting": "frac / achieved / flop_per_launch: algorithmic (2*M*K*N per launch, zero-padding products "
-                                   "included: SURVEY 8d); frac_executed / achieved_executed: the products the kernels really "
-                                   "issue (packed pixel classes and per-tap pixel boxes skip a dilated filter's padding)",
-                "all_conv_tflops": round(all_flops / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None,
-                "all_conv_tflops_executed": round(all_exec / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else None,
-                "all_conv_frac_executed": round(all_exec / (all_ms * 1e-3) / 1e12 / peak, 4) if all_ms > 0 else None,
-                "step_tflops": round(fb_flops * args.batch / (ms * 1e-3) / 1e12, 2),
-            }
-            # HBM (L2-miss) bytes per launch of the dominant class: PMC counters need their own rocprofv3 passes
-            # (scripts/make_profiles.sh); their per-class summary is committed under profiles/ and used when it was taken
-            # on exactly this workload (matched on its structured key, not on prose)
-            key = workload_key(args)
-            here = os.path.dirname(os.path.abspath(__file__))
-            from em_adapt_tensorflow_amd import _build
-            lib_hash = _build.source_hash()
-            out["roofline"]["traffic_source"] = "none: no committed counter profile of this workload"
-            for tpath in sorted(glob.glob(os.path.join(here, "profiles", "r*_traffic*.json")), reverse=True):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("key") != key:
-                        continue
-                    if tj.get("source_hash") != lib_hash:
-                        # the profile was taken on other kernel sources: a number carried forward would be a stale claim
-                        out["roofline"]["traffic_source"] = "stale: %s was taken on kernel sources %s, these are %s (re-run scripts/make_profiles.sh)" % (
-                            os.path.relpath(tpath, here), tj.get("source_hash"), lib_hash)
-                        continue
-                    out["roofline"]["traffic_source"] = os.path.relpath(tpath, here)
-                    per_step = tj["per_step"][dom]
-                    calls = d["launches"] / max(prof_steps, 1)
-                    out["roofline"]["traffic"] = round((per_step["read_bytes"] + per_step["write_bytes"]) / max(calls, 1))
-                    out["roofline"]["traffic_unit"] = "bytes per launch (HBM-side reads + writes, %s)" % os.path.relpath(tpath, here)
-                    if d["bytes"] > 0:
-                        out["roofline"]["traffic_over_algorithmic"] = round(out["roofline"]["traffic"] / (d["bytes"] / d["launches"]), 2)
-                    break
-                except (OSError, KeyError, ValueError):
-                    continue
-            # per event-timed step: those steps carry two marker packets per launch, so they run a little slower than
-            # the un-timed ones that dominate ms_per_step
+            out["roofline"] = roofline_object(prof, prof_steps, args.steps, every, args.dtype, ms, fb_flops, args.batch, workload_key(args))
+            # per event-timed step: those steps carry two marker packets per launch, so they run a little slower than the un-timed
+            # ones that dominate ms_per_step -- the class sums below (and every fraction in `roofline`) are taken on the EVENT-TIMED
+            # steps and may add up to more than ms_per_step, which averages all steps
             out["kernel_ms_per_step"] = {k: round(v["ms"] / max(prof_steps, 1), 3) for k, v in prof.items()}
-            e = prof["estep"]
-            if e["ms"] > 0:
-                out["estep"] = {"ms": round(e["ms"] / max(e["launches"], 1), 4),
-                                "achieved_GBps": round(e["bytes"] / (e["ms"] * 1e-3) / 1e9, 2), "bound": "hbm",
-                                "peak_GBps": 8000, "algorithmic_bytes": round(e["bytes"] / max(e["launches"], 1)),
-                                "traffic": None}
-                # counter-based HBM bytes of the E-step's kernels per call (FETCH_SIZE x 2 + WRITE_SIZE: the same passes and the
-                # same staleness rule as roofline.traffic)
-                for tpath in sorted(glob.glob(os.path.join(here, "profiles", "r*_traffic*.json")), reverse=True):
-                    try:
-                        tj = json.load(open(tpath))
-                        if tj.get("key") == key and tj.get("source_hash") == lib_hash and "estep" in tj:
-                            es = tj["estep"]
-                            out["estep"]["traffic"] = round(es["read_bytes"] + es["write_bytes"])
-                            out["estep"]["traffic_GBps"] = round((es["read_bytes"] + es["write_bytes"]) / (e["ms"] / max(e["launches"], 1) * 1e-3) / 1e9, 2)
-                            out["estep"]["l2_hit_rate"] = es.get("l2_hit_rate")
-                            out["estep"]["traffic_source"] = os.path.relpath(tpath, here)
-                            break
-                    except (OSError, KeyError, ValueError):
-                        continue
+            out["kernel_ms_per_step_basis"] = "event-timed steps only (%s); ms_per_step averages all %d steps" % (
+                out["roofline"]["timed_steps_with_events"], args.steps)
+            es = estep_object(prof, workload_key(args))
+            if es is not None:
+                out["estep"] = es
         if gs_stats is not None:
             # data-parallel evidence: how much of the gradient all-reduce was NOT hidden under backward
             out["allreduce"] = {
@@ -581,54 +726,42 @@ def main():
                 # step time with the exchange - the same steps without it, same process (MAX over ranks each): contention included
                 "overhead_ms_per_step": None if ms_without_exchange is None else round(ms - ms_without_exchange, 3),
                 "ms_per_step_without_exchange": None if ms_without_exchange is None else round(ms_without_exchange, 3),
+                # ... and against the same steps with the fused update switched off as well: the exchange alone
+                "overhead_vs_unfused_ms_per_step": None if ms_without_exchange_unfused is None else round(ms - ms_without_exchange_unfused, 3),
+                "ms_per_step_without_exchange_unfused": None if ms_without_exchange_unfused is None else round(ms_without_exchange_unfused, 3),
+                "overhead_note": "overhead_ms_per_step compares with the single-GPU step (fused accumulate + Momentum pass, which an exchange "
+                                 "rules out): it includes the loss of that fusion; overhead_vs_unfused_ms_per_step does not",
                 "staging": "HIP kernels (emadapt_grad_pack / _owner_sum / emadapt_sgd_momentum_payload)" if gs_stats["algo"] == "direct" else "none (RCCL all-reduce in place)",
             }
             if "trace" in gs_stats:
                 out["allreduce"]["trace_last_update"] = gs_stats["trace"]
         if world == 1 and args.dtype == "fp32" and not args.no_alt:
-            # The same step with compute_dtype "bf16x6" (DESIGN 4.4): every tensor fp32, conv products as six bf16 MFMAs over the
-            # exact 3-way split -- held to the native path's parity bars (tests/test_gpu_x6p.py).  Reported beside the headline,
-            # never as it: same weights, batches and visiting orders, its own warm-up, the same number of timed steps.
-            try:
-                alt = ADAPT(dict(cfg, data=data, compute_dtype="bf16x6"))
-                alt.build()
-                alt.pre_train(base_lr=1e-3, weight_decay=1e-5, momentum=0.9, batch_size=args.batch)
-                alt._perm_pool, alt._perm_pos = adapt._perm_pool, 0
-
-                def alt_step(i):
-                    x, y = pool[i % len(pool)]
-                    alt.micro_step(x, y, keep_prob=args.keep_prob)
-                    alt.apply_update()
-
-                for i in range(args.warmup):
-                    alt_step(i)
-                fence()
-                ops.prof_reset()
-                ta = time.perf_counter()
-                for i in range(args.steps):
-                    ops.prof_enable(i % every == 0)
-                    alt_step(args.warmup + i)
-                fence()
-                dta = time.perf_counter() - ta
-                ops.prof_enable(False)
-                aprof = ops.prof_collect()
-                ops.prof_reset()
-                aconv = [aprof[k] for k in ("igemm_fwd", "igemm_dgrad", "igemm_wgrad")]
-                a_ms, a_fl = sum(v["ms"] for v in aconv), sum(v["flops"] for v in aconv)
-                a_peak = round(PEAK_BF16_MATRIX_TFLOPS / 6, 1)
-                a_tf = a_fl / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0
-                out["bf16x6"] = {
-                    "what": "the same step with compute_dtype bf16x6: fp32 tensors, every conv product as six bf16 MFMAs over the exact "
-                            "3-way bf16 split of both operands, fp32 accumulation (fp32-grade: same parity bars as the native path); "
-                            "python bench.py --dtype bf16x6 prints it as a line of its own",
-                    "value": round(args.batch * args.steps / dta, 3), "unit": "images/s",
-                    "ms_per_step": round(dta / max(args.steps, 1) * 1e3, 3),
-                    "final_loss": round(float(alt.loss["norm"].cpu()), 5),
-                    "all_conv_tflops": round(a_tf, 2), "peak": a_peak, "frac": round(a_tf / a_peak, 4),
-                }
-                del alt
-            except Exception as e:   # the side measurement must never cost the headline line
-                out["bf16x6"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # Side legs, reported beside the headline and never as it (each with its own model, data and warm-up; the same number of
+            # timed steps; `python bench.py --dtype ... --preset ... --size ...` prints any of them as a line of its own):
+            #   bf16x6  -- DESIGN 4.4: every tensor fp32, conv products as six bf16 MFMAs over the exact 3-way split (fp32-grade)
+            #   bf16    -- BASELINE configs[2] / [3]'s per-GPU arithmetic at batch 16 (bf16 operands, fp32 accumulate)
+            #   configs -- BASELINE configs[4]'s geometry (513 x 513, 41 classes: `ref` at batch 10, and the LargeFOV preset it names
+            #              through "atrous rate=12"), the LargeFOV preset at 321 x 321, and the reference's own recipe shape
+            #              (micro-batch 6 x accum_num 5, deeplab.py:288,293), all fp32
+            n_leg = max(args.steps, 1)
+            out["bf16x6"] = side_leg("the same step with compute_dtype bf16x6: fp32 tensors, every conv product as six bf16 MFMAs over the exact "
+                                     "3-way bf16 split of both operands, fp32 accumulation (fp32-grade: same parity bars as the native path)",
+                                     cfg, args, device, fence, n_leg, args.warmup, every, dtype="bf16x6")
+            out["bf16"] = side_leg("the same step with compute_dtype bf16 (BASELINE configs[2] / [3] per GPU): bf16 conv operands / fp32 "
+                                   "accumulate, fp32 master weights, bf16 activation storage", cfg, args, device, fence, n_leg, args.warmup,
+                                   every, dtype="bf16")
+            out["configs"] = {
+                "largefov_321_fp32": side_leg("LargeFOV preset (fc6 3x3 rate 12 -> 1024), 321x321, 21 classes, batch 16, fp32",
+                                              cfg, args, device, fence, n_leg, args.warmup, every, preset="largefov"),
+                "ref_513_c41_b10_fp32": side_leg("BASELINE configs[4] geometry on the network as written: 513x513, 41 classes, batch 10, fp32",
+                                                 cfg, args, device, fence, max(n_leg // 2, 3), 2, every, size=513, classes=41, batch=10),
+                "largefov_513_c41_b10_fp32": side_leg("BASELINE configs[4]: 513x513, 41 classes, fc6 3x3 rate 12, batch 10, fp32",
+                                                      cfg, args, device, fence, max(n_leg // 2, 3), 2, every, preset="largefov", size=513,
+                                                      classes=41, batch=10),
+                "ref_321_recipe_b6_accum5_fp32": side_leg("the reference's recipe shape (deeplab.py:288,293): micro-batch 6 x accum_num 5 = 30 images "
+                                                          "per update, 321x321, 21 classes, fp32; a step = 5 micro-batches + one update",
+                                                          cfg, args, device, fence, max(n_leg // 2, 3), 1, every, batch=6, accum=5),
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -37,6 +37,7 @@ class EmadaptDeviceError(EmadaptError):
 
 
 STATUS_STREAMK_TIMEOUT = 1
+STATUS_NAN_GRADIENT = 2
 
 
 class ConvDesc(ctypes.Structure):
@@ -141,6 +142,8 @@ PROTOTYPES = {
     "emadapt_grad_owner_sum": (c_int, [_vp, c_int, c_int, c_int64, _vp, _vp]),
     "emadapt_status_word": (c_int, [POINTER(_vp)]),
     "emadapt_status_poll": (c_int, [POINTER(ctypes.c_uint), c_int, _vp]),
+    "emadapt_status_collective": (c_int, [c_int]),
+    "emadapt_status_raise": (c_int, [ctypes.c_uint, _vp]),
     "emadapt_conv_plan": (c_int, [POINTER(ConvDesc), c_int, POINTER(c_int)]),
     "emadapt_tune_set": (c_int, [ctypes.c_char_p, c_int]),
     "emadapt_tune_get": (c_int, [ctypes.c_char_p, POINTER(c_int)]),

@@ -33,6 +33,8 @@ inline int launch_status() {
 // Device address of the status word of the current device (include/emadapt.h, emadapt_status_poll): a __device__ variable of
 // the library's code object -- no allocation, no stream operation, safe under graph capture.  nullptr when HIP cannot resolve it.
 unsigned *status_word();
+// 1 while emadapt_status_collective(1) is in force (process-wide, like the tune keys): see "Collective mode" below
+int status_collective();
 
 // ---- optimiser arithmetic (deeplab.py:202-205), shared by elementwise.hip and conv_bf16.hip's fused update ----
 // The optimiser's arithmetic, PINNED.  hipcc contracts `mu * v + a * s` into an fma around EITHER product by its own heuristics: two
@@ -54,6 +56,25 @@ __device__ __forceinline__ float opt_step(float w, float lr, float v) { return _
 // kernels return at once, on the device -- a gradient with a poisoned tile never reaches weights, momentum or accumulators, and no
 // host synchronisation is needed for that (the word is read once per wave: a scalar load).
 __device__ __forceinline__ bool status_raised(const unsigned *status) { return status && __builtin_nontemporal_load(status) != 0u; }
+
+// Collective mode of the status word (emadapt_status_collective(1): data-parallel jobs, where "this rank's word is raised" must not
+// decide anything a peer decides differently).  The failure TRAVELS WITH THE GRADIENT instead: the kernels that feed the exchange
+// (accumulate, accumulate + pack, pack) emit NaN for everything while the local word is raised, sums over ranks keep a NaN, and the
+// optimiser kernels -- which then ignore the local word -- leave an element whose summed gradient is NaN alone (weight and momentum
+// kept, accumulator still zeroed) and raise EMADAPT_STATUS_NAN_GRADIENT on their own device.  Every rank reads the same summed
+// gradient, so every rank skips the same elements and every rank's next poll reports the failure.
+__device__ __forceinline__ float poison_nan() { return __builtin_nanf(""); }
+__device__ __forceinline__ void opt_update(float &w, float &v, float a, float lr, float mu, float ascale, bool coll, bool &bad) {
+    const float vn = opt_velocity(mu, v, a, ascale);
+    const float wn = opt_step(w, lr, vn);
+    const bool nan = coll && a != a;
+    v = nan ? v : vn;
+    w = nan ? w : wn;
+    bad = bad || nan;
+}
+__device__ __forceinline__ void status_raise(unsigned *status, unsigned bits) {
+    if (status) __hip_atomic_fetch_or(status, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- per-kernel event timing (bench.py roofline; see emadapt_prof_* in emadapt.h) ----
 struct ProfScope {

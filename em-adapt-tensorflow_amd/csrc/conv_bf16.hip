@@ -1327,11 +1327,11 @@ int emadapt_sgd_momentum_payload_tiles(const emadapt_conv_desc *d, float *w, flo
     if (bf)
         hipLaunchKernelGGL(sgd_payload_tiles_b16_both_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, w, v, accum,
                            static_cast<const __bf16 *>(payload), reinterpret_cast<uint4 *>(tiles_fwd), reinterpret_cast<uint4 *>(tiles_dgrad), d->Cin,
-                           d->Cout, d->Cout, (int)pieces, nw, (long long)n_bias, lr, momentum, scale, status_word());
+                           d->Cout, d->Cout, (int)pieces, nw, (long long)n_bias, lr, momentum, scale, status_word(), status_collective());
     else
         hipLaunchKernelGGL(sgd_payload_tiles_b16_both_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, w, v, accum,
                            static_cast<const float *>(payload), reinterpret_cast<uint4 *>(tiles_fwd), reinterpret_cast<uint4 *>(tiles_dgrad), d->Cin,
-                           d->Cout, d->Cout, (int)pieces, nw, (long long)n_bias, lr, momentum, scale, status_word());
+                           d->Cout, d->Cout, (int)pieces, nw, (long long)n_bias, lr, momentum, scale, status_word(), status_collective());
     return launch_status();
 }
 

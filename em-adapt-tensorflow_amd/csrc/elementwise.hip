@@ -481,19 +481,21 @@ __global__ void __launch_bounds__(256) l2_partial_kernel(const float *__restrict
 
 __global__ void __launch_bounds__(256) sgd_accumulate_kernel(float *__restrict__ accum, const float *__restrict__ g,
                                                            const float *__restrict__ w, long long n,
-                                                           long long n_decay, float wd, float scale) {
+                                                           long long n_decay, float wd, float scale, const unsigned *__restrict__ poison) {
+    const bool bad = status_raised(poison);   // (collective mode only: common.h -- the failure travels with the gradient)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         float gi = g[i];
         if (i < n_decay) gi = opt_decay(gi, wd, w[i]);
-        accum[i] = opt_accum(accum[i], gi, scale);
+        accum[i] = bad ? poison_nan() : opt_accum(accum[i], gi, scale);
     }
 }
 
 __global__ void __launch_bounds__(256) sgd_accumulate_kernel_v4(float *__restrict__ accum,
                                                               const float *__restrict__ g,
                                                               const float *__restrict__ w, long long n4,
-                                                              long long n_decay4, float wd, float scale) {
+                                                              long long n_decay4, float wd, float scale, const unsigned *__restrict__ poison) {
+    const bool bad = status_raised(poison);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         float4 gi = ld4(g + i * 4);
@@ -503,6 +505,7 @@ __global__ void __launch_bounds__(256) sgd_accumulate_kernel_v4(float *__restric
         }
         float4 a = ld4(accum + i * 4);
         a.x = opt_accum(a.x, gi.x, scale); a.y = opt_accum(a.y, gi.y, scale); a.z = opt_accum(a.z, gi.z, scale); a.w = opt_accum(a.w, gi.w, scale);
+        if (bad) a = make_float4(poison_nan(), poison_nan(), poison_nan(), poison_nan());
         st4(accum + i * 4, a);
     }
 }
@@ -510,33 +513,37 @@ __global__ void __launch_bounds__(256) sgd_accumulate_kernel_v4(float *__restric
 // (status_raised: common.h)
 __global__ void __launch_bounds__(256) sgd_momentum_kernel(float *__restrict__ w, float *__restrict__ v,
                                                          float *__restrict__ accum, long long n, float lr, float mu,
-                                                         float ascale, const unsigned *__restrict__ status) {
-    if (status_raised(status)) return;
+                                                         float ascale, unsigned *__restrict__ status, int coll) {
+    if (!coll && status_raised(status)) return;
+    bool bad = false;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        const float vi = opt_velocity(mu, v[i], accum[i], ascale);
+        float vi = v[i], wi = w[i];
+        opt_update(wi, vi, accum[i], lr, mu, ascale, coll, bad);
         v[i] = vi;
-        w[i] = opt_step(w[i], lr, vi);
+        w[i] = wi;
         accum[i] = 0.f;
     }
+    if (bad) status_raise(status, EMADAPT_STATUS_NAN_GRADIENT);
 }
 
 __global__ void __launch_bounds__(256) sgd_momentum_kernel_v4(float *__restrict__ w, float *__restrict__ v,
                                                             float *__restrict__ accum, long long n4, float lr,
-                                                            float mu, float ascale, const unsigned *__restrict__ status) {
-    if (status_raised(status)) return;
+                                                            float mu, float ascale, unsigned *__restrict__ status, int coll) {
+    if (!coll && status_raised(status)) return;
+    bool bad = false;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
         const float4 a = ld4(accum + i * 4);
         float4 vi = ld4(v + i * 4);
         float4 wi = ld4(w + i * 4);
-        vi.x = opt_velocity(mu, vi.x, a.x, ascale); vi.y = opt_velocity(mu, vi.y, a.y, ascale);
-        vi.z = opt_velocity(mu, vi.z, a.z, ascale); vi.w = opt_velocity(mu, vi.w, a.w, ascale);
-        wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
+        opt_update(wi.x, vi.x, a.x, lr, mu, ascale, coll, bad); opt_update(wi.y, vi.y, a.y, lr, mu, ascale, coll, bad);
+        opt_update(wi.z, vi.z, a.z, lr, mu, ascale, coll, bad); opt_update(wi.w, vi.w, a.w, lr, mu, ascale, coll, bad);
         st4(v + i * 4, vi);
         st4(w + i * 4, wi);
         st4(accum + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
     }
+    if (bad) status_raise(status, EMADAPT_STATUS_NAN_GRADIENT);
 }
 
 // The same update reading the SUMMED GRADIENT from the gathered payload of the data-parallel exchange (f32 or bf16, dist.py)
@@ -546,9 +553,10 @@ template <typename P>
 __global__ void __launch_bounds__(256) sgd_momentum_payload_kernel(float *__restrict__ w, float *__restrict__ v,
                                                                  float *__restrict__ accum, const P *__restrict__ payload,
                                                                  long long nv, float lr, float mu, float ascale,
-                                                                 const unsigned *__restrict__ status) {
+                                                                 unsigned *__restrict__ status, int coll) {
     constexpr int VN = VW<P>::N;
-    if (status_raised(status)) return;
+    if (!coll && status_raised(status)) return;
+    bool bad = false;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
         float g[VN];
         ldv(payload + i * VN, g);
@@ -557,27 +565,30 @@ __global__ void __launch_bounds__(256) sgd_momentum_payload_kernel(float *__rest
             const long long o = i * VN + q * 4;
             float4 vi = ld4(v + o);
             float4 wi = ld4(w + o);
-            vi.x = opt_velocity(mu, vi.x, g[q * 4 + 0], ascale); vi.y = opt_velocity(mu, vi.y, g[q * 4 + 1], ascale);
-            vi.z = opt_velocity(mu, vi.z, g[q * 4 + 2], ascale); vi.w = opt_velocity(mu, vi.w, g[q * 4 + 3], ascale);
-            wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
+            opt_update(wi.x, vi.x, g[q * 4 + 0], lr, mu, ascale, coll, bad); opt_update(wi.y, vi.y, g[q * 4 + 1], lr, mu, ascale, coll, bad);
+            opt_update(wi.z, vi.z, g[q * 4 + 2], lr, mu, ascale, coll, bad); opt_update(wi.w, vi.w, g[q * 4 + 3], lr, mu, ascale, coll, bad);
             st4(v + o, vi);
             st4(w + o, wi);
             if (accum) st4(accum + o, make_float4(0.f, 0.f, 0.f, 0.f));   // (null: the exchange was fed without an accumulator, sgd_accumulate_pack)
         }
     }
+    if (bad) status_raise(status, EMADAPT_STATUS_NAN_GRADIENT);
 }
 template <typename P>
 __global__ void __launch_bounds__(256) sgd_momentum_payload_tail_kernel(float *__restrict__ w, float *__restrict__ v,
                                                                       float *__restrict__ accum, const P *__restrict__ payload,
                                                                       long long i0, long long n, float lr, float mu, float ascale,
-                                                                      const unsigned *__restrict__ status) {
-    if (status_raised(status)) return;
+                                                                      unsigned *__restrict__ status, int coll) {
+    if (!coll && status_raised(status)) return;
+    bool bad = false;
     for (long long i = i0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float vi = opt_velocity(mu, v[i], (float)payload[i], ascale);
+        float vi = v[i], wi = w[i];
+        opt_update(wi, vi, (float)payload[i], lr, mu, ascale, coll, bad);
         v[i] = vi;
-        w[i] = opt_step(w[i], lr, vi);
+        w[i] = wi;
         if (accum) accum[i] = 0.f;
     }
+    if (bad) status_raise(status, EMADAPT_STATUS_NAN_GRADIENT);
 }
 
 // accumulate (deeplab.py:202) + apply_gradients (:204-205) + clean (:203) of ONE micro-batch in one pass, for accum_num == 1
@@ -655,8 +666,10 @@ __global__ void __launch_bounds__(256) sgd_accumulate_momentum_kernel(float *__r
 // clean (12 of the 44 bytes the exchange path moved per parameter) and without the pack pass.
 template <typename P>
 __global__ void __launch_bounds__(256) sgd_accumulate_pack_kernel(const float *__restrict__ g, const float *__restrict__ w, long long nv,
-                                                                long long n_decay, float wd, float scale, P *__restrict__ dst) {
+                                                                long long n_decay, float wd, float scale, P *__restrict__ dst,
+                                                                const unsigned *__restrict__ poison) {
     constexpr int VN = VW<P>::N;
+    const bool bad = status_raised(poison);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
         float x[VN];
 #pragma unroll
@@ -670,16 +683,22 @@ __global__ void __launch_bounds__(256) sgd_accumulate_pack_kernel(const float *_
             x[q * 4 + 0] = opt_accum(0.f, gi.x, scale); x[q * 4 + 1] = opt_accum(0.f, gi.y, scale);
             x[q * 4 + 2] = opt_accum(0.f, gi.z, scale); x[q * 4 + 3] = opt_accum(0.f, gi.w, scale);
         }
+        if (bad) {
+#pragma unroll
+            for (int e = 0; e < VN; e++) x[e] = poison_nan();
+        }
         stv(dst + i * VN, x);
     }
 }
 template <typename P>
 __global__ void __launch_bounds__(256) sgd_accumulate_pack_scalar_kernel(const float *__restrict__ g, const float *__restrict__ w, long long i0,
-                                                                       long long n, long long n_decay, float wd, float scale, P *__restrict__ dst) {
+                                                                       long long n, long long n_decay, float wd, float scale, P *__restrict__ dst,
+                                                                       const unsigned *__restrict__ poison) {
+    const bool bad = status_raised(poison);
     for (long long i = i0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float gi = g[i];
         if (i < n_decay) gi = opt_decay(gi, wd, w[i]);
-        dst[i] = (P)opt_accum(0.f, gi, scale);
+        dst[i] = (P)(bad ? poison_nan() : opt_accum(0.f, gi, scale));
     }
 }
 
@@ -689,8 +708,10 @@ __global__ void __launch_bounds__(256) sgd_accumulate_pack_scalar_kernel(const f
 // ------------------------------------------------------------------------------------------
 // pack: send[0:n] = P(accum[0:n]) (bf16: round to nearest even, once), send[n:npad] = 0 (whole shards for every rank)
 template <typename P>
-__global__ void __launch_bounds__(256) grad_pack_kernel(const float *__restrict__ src, long long n, P *__restrict__ dst, long long npad) {
+__global__ void __launch_bounds__(256) grad_pack_kernel(const float *__restrict__ src, long long n, P *__restrict__ dst, long long npad,
+                                                        const unsigned *__restrict__ poison) {
     constexpr int VN = VW<P>::N;
+    const bool bad = status_raised(poison);
     const long long nv = npad / VN;   // (npad % VN == 0 and both pointers 16-byte aligned: checked by the host, else the scalar kernel)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
         float x[VN];
@@ -702,13 +723,19 @@ __global__ void __launch_bounds__(256) grad_pack_kernel(const float *__restrict_
             else if (o < n) { t.x = src[o]; if (o + 1 < n) t.y = src[o + 1]; if (o + 2 < n) t.z = src[o + 2]; }
             x[q * 4 + 0] = t.x; x[q * 4 + 1] = t.y; x[q * 4 + 2] = t.z; x[q * 4 + 3] = t.w;
         }
+        if (bad) {
+#pragma unroll
+            for (int e = 0; e < VN; e++) x[e] = poison_nan();   // (the padding too: nobody applies it)
+        }
         stv(dst + i * VN, x);
     }
 }
 template <typename P>
-__global__ void __launch_bounds__(256) grad_pack_scalar_kernel(const float *__restrict__ src, long long n, P *__restrict__ dst, long long npad) {
+__global__ void __launch_bounds__(256) grad_pack_scalar_kernel(const float *__restrict__ src, long long n, P *__restrict__ dst, long long npad,
+                                                               const unsigned *__restrict__ poison) {
+    const bool bad = status_raised(poison);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += (long long)gridDim.x * blockDim.x)
-        dst[i] = (P)(i < n ? src[i] : 0.f);
+        dst[i] = (P)(bad ? poison_nan() : (i < n ? src[i] : 0.f));
 }
 // owner sum: out[i] = P( fp32(recv[0][i]) + fp32(recv[1][i]) + ... + fp32(recv[W-1][i]) ), the adds in fp32 in RANK ORDER (every
 // element is summed exactly once, by its owner: all ranks end up with the same bits), the sum rounded once.  recv = [W][shard].
@@ -1017,12 +1044,13 @@ int emadapt_sgd_accumulate(float *accum, const float *g, const float *w, int64_t
     if (n == 0) return EMADAPT_OK;
     hipStream_t stream = as_stream(stream_);
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 12.0 + (double)n_decay * 4.0, stream);
+    const unsigned *poison = status_collective() ? status_word() : nullptr;   // (collective mode: a raised word turns the output into NaNs, common.h)
     if (n % 4 == 0 && n_decay % 4 == 0 && aligned16(accum) && aligned16(g) && (!w || aligned16(w))) {
         hipLaunchKernelGGL(sgd_accumulate_kernel_v4, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, accum, g,
-                           w, (long long)(n / 4), (long long)(n_decay / 4), weight_decay, scale);
+                           w, (long long)(n / 4), (long long)(n_decay / 4), weight_decay, scale, poison);
     } else {
         hipLaunchKernelGGL(sgd_accumulate_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, accum, g, w,
-                           (long long)n, (long long)n_decay, weight_decay, scale);
+                           (long long)n, (long long)n_decay, weight_decay, scale, poison);
     }
     return launch_status();
 }
@@ -1035,20 +1063,21 @@ int emadapt_sgd_accumulate_pack(const float *g, const float *w, int64_t n, int64
     hipStream_t stream = as_stream(stream_);
     const bool bf = dst_dtype == EMADAPT_DT_BF16;
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * (4.0 + (bf ? 2.0 : 4.0)) + (double)n_decay * 4.0, stream);
+    const unsigned *poison = status_collective() ? status_word() : nullptr;
     const int vn = bf ? 8 : 4;
     const bool vec = aligned16(g) && aligned16(dst) && (!w || aligned16(w)) && n_decay % 4 == 0;
     const int64_t nvec = vec ? n / vn : 0;
     if (nvec > 0) {
         if (bf) hipLaunchKernelGGL(sgd_accumulate_pack_kernel<__bf16>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, stream, g, w, (long long)nvec,
-                                   (long long)n_decay, weight_decay, scale, static_cast<__bf16 *>(dst));
+                                   (long long)n_decay, weight_decay, scale, static_cast<__bf16 *>(dst), poison);
         else hipLaunchKernelGGL(sgd_accumulate_pack_kernel<float>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, stream, g, w, (long long)nvec,
-                                (long long)n_decay, weight_decay, scale, static_cast<float *>(dst));
+                                (long long)n_decay, weight_decay, scale, static_cast<float *>(dst), poison);
     }
     if (nvec * vn < n) {
         if (bf) hipLaunchKernelGGL(sgd_accumulate_pack_scalar_kernel<__bf16>, dim3(grid_for(n - nvec * vn, 256, 4096)), dim3(256), 0, stream, g, w,
-                                   (long long)(nvec * vn), (long long)n, (long long)n_decay, weight_decay, scale, static_cast<__bf16 *>(dst));
+                                   (long long)(nvec * vn), (long long)n, (long long)n_decay, weight_decay, scale, static_cast<__bf16 *>(dst), poison);
         else hipLaunchKernelGGL(sgd_accumulate_pack_scalar_kernel<float>, dim3(grid_for(n - nvec * vn, 256, 4096)), dim3(256), 0, stream, g, w,
-                                (long long)(nvec * vn), (long long)n, (long long)n_decay, weight_decay, scale, static_cast<float *>(dst));
+                                (long long)(nvec * vn), (long long)n, (long long)n_decay, weight_decay, scale, static_cast<float *>(dst), poison);
     }
     return launch_status();
 }
@@ -1058,14 +1087,15 @@ int emadapt_sgd_momentum(float *w, float *v, float *accum, int64_t n, float lr, 
     if (!w || !v || !accum || n < 0) return EMADAPT_ERR_INVALID;
     if (n == 0) return EMADAPT_OK;
     hipStream_t stream = as_stream(stream_);
-    const unsigned *status = status_word();
+    unsigned *status = status_word();
+    const int coll = status_collective();
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 24.0, stream);
     if (n % 4 == 0 && aligned16(w) && aligned16(v) && aligned16(accum)) {
         hipLaunchKernelGGL(sgd_momentum_kernel_v4, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, stream, w, v, accum,
-                           (long long)(n / 4), lr, momentum, accum_scale, status);
+                           (long long)(n / 4), lr, momentum, accum_scale, status, coll);
     } else {
         hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, stream, w, v, accum,
-                           (long long)n, lr, momentum, accum_scale, status);
+                           (long long)n, lr, momentum, accum_scale, status, coll);
     }
     return launch_status();
 }
@@ -1076,7 +1106,8 @@ int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *p
         return EMADAPT_ERR_INVALID;
     if (n == 0) return EMADAPT_OK;
     hipStream_t stream = as_stream(stream_);
-    const unsigned *status = status_word();
+    unsigned *status = status_word();
+    const int coll = status_collective();
     const bool bf = payload_dtype == EMADAPT_DT_BF16;
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * ((accum ? 20.0 : 16.0) + (bf ? 2.0 : 4.0)), stream);
     const int vn = bf ? 8 : 4;
@@ -1085,20 +1116,20 @@ int emadapt_sgd_momentum_payload(float *w, float *v, float *accum, const void *p
     if (nvec > 0) {
         if (bf)
             hipLaunchKernelGGL(sgd_momentum_payload_kernel<__bf16>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, stream, w, v, accum,
-                               static_cast<const __bf16 *>(payload), (long long)nvec, lr, momentum, scale, status);
+                               static_cast<const __bf16 *>(payload), (long long)nvec, lr, momentum, scale, status, coll);
         else
             hipLaunchKernelGGL(sgd_momentum_payload_kernel<float>, dim3(grid_for(nvec, 256, 4096)), dim3(256), 0, stream, w, v, accum,
-                               static_cast<const float *>(payload), (long long)nvec, lr, momentum, scale, status);
+                               static_cast<const float *>(payload), (long long)nvec, lr, momentum, scale, status, coll);
         int rc = launch_status();
         if (rc) return rc;
     }
     if (nvec * vn < n) {
         if (bf)
             hipLaunchKernelGGL(sgd_momentum_payload_tail_kernel<__bf16>, dim3(grid_for(n - nvec * vn, 256, 4096)), dim3(256), 0, stream, w, v,
-                               accum, static_cast<const __bf16 *>(payload), (long long)(nvec * vn), (long long)n, lr, momentum, scale, status);
+                               accum, static_cast<const __bf16 *>(payload), (long long)(nvec * vn), (long long)n, lr, momentum, scale, status, coll);
         else
             hipLaunchKernelGGL(sgd_momentum_payload_tail_kernel<float>, dim3(grid_for(n - nvec * vn, 256, 4096)), dim3(256), 0, stream, w, v,
-                               accum, static_cast<const float *>(payload), (long long)(nvec * vn), (long long)n, lr, momentum, scale, status);
+                               accum, static_cast<const float *>(payload), (long long)(nvec * vn), (long long)n, lr, momentum, scale, status, coll);
         return launch_status();
     }
     return EMADAPT_OK;
@@ -1155,16 +1186,17 @@ int emadapt_grad_pack(const float *src, int64_t n, void *dst, int dst_dtype, int
     hipStream_t stream = as_stream(stream_);
     const bool bf = dst_dtype == EMADAPT_DT_BF16;
     ProfScope prof(EMADAPT_K_OTHER, 0.0, (double)n * 4.0 + (double)npad * (bf ? 2.0 : 4.0), stream);
+    const unsigned *poison = status_collective() ? status_word() : nullptr;
     const int vn = bf ? 8 : 4;
     const bool vec = npad % vn == 0 && aligned16(src) && aligned16(dst);
     if (bf) {
         __bf16 *d = static_cast<__bf16 *>(dst);
-        if (vec) hipLaunchKernelGGL(grad_pack_kernel<__bf16>, dim3(grid_for(npad / vn, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad);
-        else hipLaunchKernelGGL(grad_pack_scalar_kernel<__bf16>, dim3(grid_for(npad, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad);
+        if (vec) hipLaunchKernelGGL(grad_pack_kernel<__bf16>, dim3(grid_for(npad / vn, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad, poison);
+        else hipLaunchKernelGGL(grad_pack_scalar_kernel<__bf16>, dim3(grid_for(npad, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad, poison);
     } else {
         float *d = static_cast<float *>(dst);
-        if (vec) hipLaunchKernelGGL(grad_pack_kernel<float>, dim3(grid_for(npad / vn, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad);
-        else hipLaunchKernelGGL(grad_pack_scalar_kernel<float>, dim3(grid_for(npad, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad);
+        if (vec) hipLaunchKernelGGL(grad_pack_kernel<float>, dim3(grid_for(npad / vn, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad, poison);
+        else hipLaunchKernelGGL(grad_pack_scalar_kernel<float>, dim3(grid_for(npad, 256, 4096)), dim3(256), 0, stream, src, (long long)n, d, (long long)npad, poison);
     }
     return launch_status();
 }

@@ -232,17 +232,20 @@ __global__ void __launch_bounds__(256) sgd_payload_tiles_b16_both_kernel(float *
                                                                          const P *__restrict__ payload, uint4 *__restrict__ out_f,
                                                                          uint4 *__restrict__ out_d, int Cin, int Cout, int rows_pad_f, int pieces,
                                                                          long long nw, long long nb, float lr, float mu, float ascale,
-                                                                         const unsigned *__restrict__ status) {
+                                                                         unsigned *__restrict__ status, int coll) {
     __shared__ float t[32][65];
-    if (status_raised(status)) return;
+    if (!coll && status_raised(status)) return;
+    bool bad = false;   // (collective mode, common.h: an element whose summed gradient is NaN is left alone, on every rank alike)
     if ((int)blockIdx.x >= pieces) {   // biases
         const long long i = ((long long)blockIdx.x - pieces) * 256 + threadIdx.x;
         if (i < nb) {
-            const float vi = opt_velocity(mu, v[nw + i], (float)payload[nw + i], ascale);
+            float vi = v[nw + i], wi = w[nw + i];
+            opt_update(wi, vi, (float)payload[nw + i], lr, mu, ascale, coll, bad);
             v[nw + i] = vi;
-            w[nw + i] = opt_step(w[nw + i], lr, vi);
+            w[nw + i] = wi;
             if (accum) accum[nw + i] = 0.f;
         }
+        if (bad) status_raise(status, EMADAPT_STATUS_NAN_GRADIENT);
         return;
     }
     const int G = Cin / BT_BK, RB = Cout / 64, GD = Cout / BT_BK;
@@ -267,15 +270,15 @@ __global__ void __launch_bounds__(256) sgd_payload_tiles_b16_both_kernel(float *
             }
             float4 wi = *reinterpret_cast<const float4 *>(w + o);
             float4 vi = *reinterpret_cast<const float4 *>(v + o);
-            vi.x = opt_velocity(mu, vi.x, a[0], ascale); vi.y = opt_velocity(mu, vi.y, a[1], ascale);
-            vi.z = opt_velocity(mu, vi.z, a[2], ascale); vi.w = opt_velocity(mu, vi.w, a[3], ascale);
-            wi.x = opt_step(wi.x, lr, vi.x); wi.y = opt_step(wi.y, lr, vi.y); wi.z = opt_step(wi.z, lr, vi.z); wi.w = opt_step(wi.w, lr, vi.w);
+            opt_update(wi.x, vi.x, a[0], lr, mu, ascale, coll, bad); opt_update(wi.y, vi.y, a[1], lr, mu, ascale, coll, bad);
+            opt_update(wi.z, vi.z, a[2], lr, mu, ascale, coll, bad); opt_update(wi.w, vi.w, a[3], lr, mu, ascale, coll, bad);
             *reinterpret_cast<float4 *>(v + o) = vi;
             *reinterpret_cast<float4 *>(w + o) = wi;
             if (accum) *reinterpret_cast<float4 *>(accum + o) = make_float4(0.f, 0.f, 0.f, 0.f);
             t[k][c4 * 4 + 0] = wi.x; t[k][c4 * 4 + 1] = wi.y; t[k][c4 * 4 + 2] = wi.z; t[k][c4 * 4 + 3] = wi.w;
         }
     }
+    if (bad) status_raise(status, EMADAPT_STATUS_NAN_GRADIENT);
     __syncthreads();
     {   // forward image: row = co, k = ci
         const int row_l = threadIdx.x >> 2, slot = threadIdx.x & 3;

@@ -32,6 +32,11 @@ std::mutex g_attr_mu;
 
 int tune(TuneKey key) { return g_tune[key].load(std::memory_order_relaxed); }
 
+namespace {
+std::atomic<int> g_status_collective{0};
+}
+int status_collective() { return g_status_collective.load(std::memory_order_relaxed); }
+
 // The status word: one per device, living in the code object (a module is loaded per device, so the symbol has an address per
 // device); its address is looked up once per device and cached.
 __device__ unsigned g_device_status[4];   // [0] the flags; the rest pads the word onto a line of its own use
@@ -141,6 +146,23 @@ int emadapt_status_poll(unsigned *flags, int clear, void *stream_) {
     EMADAPT_HIP_TRY(hipStreamSynchronize(stream));
     if (flags) *flags = host;
     return host ? EMADAPT_ERR_DEVICE_STATUS : EMADAPT_OK;
+}
+
+namespace {
+__global__ void status_raise_kernel(unsigned *word, unsigned bits) { __hip_atomic_fetch_or(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}  // namespace
+
+int emadapt_status_raise(unsigned bits, void *stream_) {
+    unsigned *word = status_word();
+    if (!word) return EMADAPT_ERR_HIP;
+    if (!bits) return EMADAPT_OK;
+    hipLaunchKernelGGL(status_raise_kernel, dim3(1), dim3(1), 0, as_stream(stream_), word, bits);
+    return launch_status();
+}
+
+int emadapt_status_collective(int on) {
+    const int old = g_status_collective.exchange(on ? 1 : 0, std::memory_order_relaxed);
+    return old;
 }
 
 int emadapt_tune_set(const char *key, int value) {

@@ -660,6 +660,10 @@ class ADAPT(Network):
             self._gradsync = GradSync(self._flat["accum"], [(s["start"], s["end"]) for s in self._bucket_order()],
                                       bucket_bytes=int(self.config.get("bucket_mb", 32)) << 20, algo=algo, payload=grad_dtype,
                                       writeback=False, prepacked=prepack)
+            # a failure recorded in ONE rank's device status word must not make that rank alone skip its update: the producers of the
+            # exchange turn it into NaNs that travel with the gradient, and every rank's optimiser pass leaves the same elements alone
+            # and raises its own word (include/emadapt.h, emadapt_status_collective)
+            ops.status_collective(True)
 
     def _bucket_order(self):
         return [self._segments[op.name] for op in reversed(self._plan) if op.kind == "conv"]
@@ -825,7 +829,10 @@ class ADAPT(Network):
                                                        gs.gathered[s:s + n], tuple(op.seg["pshape"]), self.net["lr"], self._momentum, scale,
                                                        op.seg["wt16"], op.seg["wtd16"])
                         fresh.add(op.name)
-                        at = s + n
+                        # the next plain run starts at the segment's aligned end, not at s + n: the gap is padding nobody's gradient
+                        # touches, and a run that started inside it would lose the 16-byte alignment of its bf16 payload pointer
+                        # and fall back to the scalar kernel without a word (advisor finding, round 5)
+                        at = op.seg["end"]
         else:
             ops.sgd_momentum(f["params"], f["momentum"], f["accum"], self.net["lr"], self._momentum, scale)
         self._w16_seen = None  # the master weights moved: the bf16 images are refreshed by the next forward
@@ -880,6 +887,9 @@ class ADAPT(Network):
         saver_dir = self.config.get("saver_path", "saver")
 
         def save(which, name, step):
+            # never write a checkpoint behind a recorded device failure (the optimiser kernels have been skipping updates since it was
+            # raised; in a data-parallel job every rank's word is raised by then -- emadapt_status_collective -- so every rank raises here)
+            ops.status_poll(clear=True, raise_on_error=True)
             path = self.saver[which].save(None, os.path.join(saver_dir, name), global_step=step)
             if world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
                 torch.distributed.barrier()   # (rank / world given by the config alone: nothing to meet at)
@@ -914,7 +924,7 @@ class ADAPT(Network):
             i += 1
             epoch = i / iterations_per_epoch_train
         torch.cuda.synchronize(self.device)
-        ops.status_poll(clear=True, raise_on_error=True)   # (before anything is saved)
+        ops.status_poll(clear=True, raise_on_error=True)   # (whether or not anything is saved)
         if self.config.get("save_final", True):
             save("norm", "norm", i)
         end_time = time.time()

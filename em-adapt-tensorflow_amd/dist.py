@@ -120,11 +120,16 @@ class GradSync:
             # the gathered payload of EVERY bucket, each at its own offset (all buckets but the last are whole shards, so bucket
             # [s, e) lives at [s, s + npad)): what the optimiser reads when nothing is written back
             s_last, e_last = self.buckets[-1]
+            # the optimiser reads gathered[i] as the summed gradient of flat[i] (ops.sgd_momentum_payload over the whole flat buffer, or
+            # slices of both at the same offsets): that holds because every bucket but the last is a whole number of shards, so its
+            # gathered image is exactly as long as the bucket itself
+            assert all((e - s) % W == 0 for s, e in self.buckets[:-1]), "buckets before the last must be whole shards"
             self.gathered = torch.zeros(s_last + -(-(e_last - s_last) // W) * W, dtype=pdt, device=flat.device)
             if self.prepacked:
                 self.sendfull = torch.zeros_like(self.gathered)   # (the padding behind the last bucket stays zero: nobody writes it)
             if flat.is_cuda:
                 self._side = torch.cuda.Stream(device=flat.device)
+            assert self.gathered.numel() >= self.total and (self.sendfull is None or self.sendfull.numel() == self.gathered.numel())
         self.wire_bytes_per_update = self._wire_bytes()
 
     def _wire_bytes(self):

@@ -826,6 +826,21 @@ def status_poll(clear=True, raise_on_error=True):
     return flags.value
 
 
+def status_collective(on):
+    """Collective mode of the status word for data-parallel jobs (include/emadapt.h, emadapt_status_collective): the failure travels
+    with the exchanged gradient (NaN) instead of being decided from each rank's own word.  Returns the previous setting."""
+    return bool(_lib.load().emadapt_status_collective(1 if on else 0))
+
+
+def status_raise(bits):
+    """Raise bits of the device status word from the host, in stream order (include/emadapt.h, emadapt_status_raise)."""
+    _lib.call("emadapt_status_raise", int(bits), _stream())
+
+
+STATUS_STREAMK_TIMEOUT = _lib.STATUS_STREAMK_TIMEOUT
+STATUS_NAN_GRADIENT = _lib.STATUS_NAN_GRADIENT
+
+
 def conv_plan(B, H, W, Cin, Cout, k, dil=1, dgrad=False):
     """(tile variant, main rows, main split-K factor / for stream-K the most workgroups sharing a tile, tail split-K -- or, for a stream-K launch that skips
     the zero padding of a dilated filter, its number of pixel classes) of the fp32 forward / data-gradient launch plan."""

@@ -66,8 +66,10 @@ extern "C" {
  *        decode it, so the model's max-pool gradients no longer read the gate tensor); tune "pool_rows".  The stride-2 max-pool
  *        gradient runs by 2 x 2 pixel quads (same results).  emadapt_sgd_accumulate_momentum_tiles (+ _supported) and
  *        emadapt_sgd_momentum_payload_tiles: the optimizer pass of a layer that also writes the layer's two tiled bf16 filter images; emadapt_sgd_accumulate_momentum_multi: the pass
- *        over several layers' segments in one launch; emadapt_weights_to_bf16_multi: several filters' bf16 images in one launch. */
-#define EMADAPT_ABI_VERSION 205
+ *        over several layers' segments in one launch; emadapt_weights_to_bf16_multi: several filters' bf16 images in one launch.
+ *   206  round 6, added: emadapt_status_raise; emadapt_status_collective (data-parallel jobs: the failure travels with the exchanged gradient instead of
+ *        being decided from each rank's own word), EMADAPT_STATUS_NAN_GRADIENT. */
+#define EMADAPT_ABI_VERSION 206
 int emadapt_version(void);
 const char *emadapt_strerror(int code);
 int emadapt_last_hip_error(void);          /* hipError_t of the last failing HIP call on this thread */
@@ -86,8 +88,22 @@ int emadapt_device_count(void);            /* does not initialise a context */
  * synchronisation is acceptable (the reference's loop logs every 500 iterations, deeplab.py:273).  emadapt_status_word returns
  * the device address (tests, graph captures).  Replaces nothing in the reference: TF raises from session.run. */
 #define EMADAPT_STATUS_STREAMK_TIMEOUT 1u
+#define EMADAPT_STATUS_NAN_GRADIENT 2u   /* collective mode: an optimiser entry met a NaN in the summed gradient and left that element alone */
 int emadapt_status_word(void **device_ptr);
 int emadapt_status_poll(unsigned *flags, int clear, void *stream);
+/* Collective mode (ABI 206; process-wide, returns the previous setting; off by default).  In a data-parallel job "my word is raised"
+ * must not decide anything a peer decides differently: a rank whose stream-K wait ran out would skip its update while its NaN tile
+ * travels through the exchange and the peers, whose words are clean, apply it -- the ranks diverge.  With the mode on the failure
+ * TRAVELS WITH THE GRADIENT: while the local word is raised emadapt_sgd_accumulate, emadapt_sgd_accumulate_pack and
+ * emadapt_grad_pack write NaN for every element they produce (sums over ranks keep it); emadapt_sgd_momentum,
+ * emadapt_sgd_momentum_payload and emadapt_sgd_momentum_payload_tiles no longer look at the local word but leave every element
+ * whose summed gradient is NaN alone (weight and momentum kept, accumulator zeroed) and raise EMADAPT_STATUS_NAN_GRADIENT on their
+ * own device.  All ranks read the same summed gradient, so all skip the same elements and all report the failure at their next
+ * emadapt_status_poll.  The entries without an exchange (emadapt_sgd_accumulate_momentum*) are not affected. */
+int emadapt_status_collective(int on);
+/* Raise bits of the word from the host, in stream order (ABI 206): a caller that found a failure of its own (a non-finite loss, a
+ * failed read) and wants the optimiser entries -- and, in collective mode, its peers -- to see it; the tests. */
+int emadapt_status_raise(unsigned bits, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * E-step (weak-label assignment)

@@ -199,3 +199,62 @@ def test_momentum_on_the_payload_writes_the_tiled_images_the_refresh_would(tmp_p
     for k in got[True]:
         assert np.array_equal(got[True][k], got[False][k]), k
     assert np.isfinite(float(got[True]["loss"]))
+
+
+def _worker_status(rank, world, port, out_dir, dtype, exchange):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from em_adapt_tensorflow_amd import ops
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    images, labels, params, perms = _inputs()
+    B = CFG["B"]
+    a = _build(torch, params, B, dtype, exchange)
+    sl = slice(rank * B, (rank + 1) * B)
+    a.micro_step(images[sl], labels[sl], keep_prob=1.0, perms=perms)
+    a.apply_update()
+    torch.cuda.synchronize()
+    assert ops.status_poll(clear=False, raise_on_error=False) == 0
+    after_one = a._flat["params"].clone()
+    mom_one = a._flat["momentum"].clone()
+    if rank == 1:
+        ops.status_raise(ops.STATUS_STREAMK_TIMEOUT)   # what a stream-K head whose wait ran out leaves behind, on ONE rank
+    for _ in range(2):
+        a.micro_step(images[sl], labels[sl], keep_prob=1.0, perms=perms)
+        a.apply_update()
+    torch.cuda.synchronize()
+    flags = ops.status_poll(clear=True, raise_on_error=False)
+    assert flags & ops.STATUS_NAN_GRADIENT, "rank %d never learnt of the failure (flags 0x%x)" % (rank, flags)
+    assert torch.equal(a._flat["params"], after_one) and torch.equal(a._flat["momentum"], mom_one), "rank %d applied an update" % rank
+    if a._gradsync.algo != "allreduce":
+        assert float(a._flat["accum"].abs().max()) == 0.0
+    np.save(os.path.join(out_dir, "params%d.npy" % rank), a._flat["params"].cpu().numpy())
+    # after the poll cleared every rank's word the job steps again, together
+    a.micro_step(images[sl], labels[sl], keep_prob=1.0, perms=perms)
+    a.apply_update()
+    torch.cuda.synchronize()
+    assert ops.status_poll(clear=True, raise_on_error=False) == 0
+    assert not torch.equal(a._flat["params"], after_one) and bool(torch.isfinite(a._flat["params"]).all())
+    np.save(os.path.join(out_dir, "params_next%d.npy" % rank), a._flat["params"].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,exchange", [("fp32", None), ("fp32", {"allreduce_algo": "direct"}), ("bf16", {"grad_dtype": "bf16"}),
+                                            ("fp32", {"allreduce_algo": "direct", "dp_prepack": False})])
+def test_a_failure_on_one_rank_stops_every_rank_the_same_way(tmp_path, dtype, exchange):
+    """Round-5 advisor finding: only the optimiser kernels looked at the device status word, each at its own.  A rank with a raised word
+    skipped its update while its poisoned gradient travelled through the exchange and the clean ranks applied it -- the ranks diverged and
+    rank 0 could save NaN weights.  Now (emadapt_status_collective) the rank's contribution to the exchange is NaN while its word is
+    raised, every rank's Momentum pass leaves NaN elements alone and raises its OWN word: no rank moves, every rank's poll reports, and
+    once the words are cleared the ranks step on together, bit-identical.  Ring all-reduce, the direct exchange with and without the
+    accumulator, and the bf16 payload."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_status, args=(2, _free_port(), str(tmp_path), dtype, exchange), nprocs=2, join=True)
+    for name in ("params", "params_next"):
+        p0, p1 = np.load(tmp_path / (name + "0.npy")), np.load(tmp_path / (name + "1.npy"))
+        assert np.array_equal(p0, p1) and np.isfinite(p0).all(), name

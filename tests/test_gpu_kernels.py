@@ -482,6 +482,91 @@ def test_gradient_exchange_staging_kernels(env, world, n, payload):
     assert torch.equal(w1, w2) and torch.equal(v1, v2) and float(a2.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_collective_status_mode_travels_with_the_gradient(env, payload):
+    """emadapt_status_collective(1), the data-parallel rule (round-5 advisor finding: a rank whose word is raised skipped its update alone
+    while its NaN tile went through the exchange and the clean ranks applied it): (a) while the LOCAL word is raised the producers of the
+    exchange -- accumulate, accumulate + pack, pack -- emit NaN for everything; (b) the optimiser entries ignore the local word, leave an
+    element whose summed gradient is NaN alone (weight and momentum kept, accumulator zeroed), update every other element exactly as
+    before and raise STATUS_NAN_GRADIENT; (c) with the mode off nothing changes."""
+    ops, do, torch = env
+    pdt = torch.bfloat16 if payload == "bf16" else torch.float32
+    n, nd = 4096 + 5, 2048   # (vector body + scalar tail)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    grad = torch.randn(n, device="cuda", generator=g)
+    w = torch.randn(n, device="cuda", generator=g)
+    v = torch.randn(n, device="cuda", generator=g) * 0.1
+    assert ops.status_poll(clear=True, raise_on_error=False) == 0
+    assert ops.status_collective(True) is False
+    try:
+        # (b) clean word, NaNs at a few elements of the summed gradient
+        pay = (torch.randn(n, device="cuda", generator=g) * 1e-2).to(pdt)
+        bad = torch.tensor([0, 3, 1000, 4095, 4097, n - 1], device="cuda")
+        payn = pay.clone()
+        payn[bad] = float("nan")
+        w0, v0, a0 = w.clone(), v.clone(), torch.ones(n, device="cuda")
+        ops.sgd_momentum_payload(w0, v0, a0, pay, 1e-3, 0.9, 0.5)
+        assert ops.status_poll(clear=True, raise_on_error=False) == 0
+        w1, v1, a1 = w.clone(), v.clone(), torch.ones(n, device="cuda")
+        ops.sgd_momentum_payload(w1, v1, a1, payn, 1e-3, 0.9, 0.5)
+        keep = torch.ones(n, dtype=torch.bool, device="cuda")
+        keep[bad] = False
+        assert torch.equal(w1[keep], w0[keep]) and torch.equal(v1[keep], v0[keep]) and float(a1.abs().max()) == 0.0
+        assert torch.equal(w1[bad], w[bad]) and torch.equal(v1[bad], v[bad])
+        assert ops.status_poll(clear=True, raise_on_error=False) == ops.STATUS_NAN_GRADIENT
+        # ... the accumulator form (the ring all-reduce path) alike
+        acc = pay.float().clone()
+        acc[bad] = float("nan")
+        w2, v2 = w.clone(), v.clone()
+        ops.sgd_momentum(w2, v2, acc, 1e-3, 0.9, 0.5)
+        assert torch.equal(w2, w1) and torch.equal(v2, v1) and float(acc.abs().max()) == 0.0
+        assert ops.status_poll(clear=True, raise_on_error=False) == ops.STATUS_NAN_GRADIENT
+        # ... and the pass that also writes the tiled images
+        shape, nb = (1, 1, 256, 256), 256
+        nw = 256 * 256
+        pt = (torch.randn(nw + nb, device="cuda", generator=g) * 1e-2).to(pdt)
+        pt[5] = float("nan"); pt[nw + 7] = float("nan")
+        wt, vt = torch.randn(nw + nb, device="cuda", generator=g), torch.zeros(nw + nb, device="cuda")
+        w3, v3, w4, v4 = wt.clone(), vt.clone(), wt.clone(), vt.clone()
+        ops.sgd_momentum_payload(w3, v3, None, pt, 1e-3, 0.9, 0.5)
+        tf = torch.empty_like(ops.filter_tiles_bf16(w3[:nw].view(shape)))
+        td = torch.empty_like(ops.filter_tiles_bf16(w3[:nw].view(shape), dgrad=True))
+        ops.sgd_momentum_payload_tiles(w4, v4, None, pt, shape, 1e-3, 0.9, 0.5, tf, td)
+        assert torch.equal(w3, w4) and torch.equal(v3, v4) and float(w4[5]) == float(wt[5]) and float(w4[nw + 7]) == float(wt[nw + 7])
+        assert torch.equal(tf.view(torch.int16), ops.filter_tiles_bf16(w4[:nw].view(shape)).view(torch.int16))
+        assert ops.status_poll(clear=True, raise_on_error=False) == ops.STATUS_NAN_GRADIENT
+        # (a) raised word: everything the producers emit is NaN; the consumers do NOT look at the local word
+        ops.status_raise(ops.STATUS_STREAMK_TIMEOUT)
+        accum = torch.zeros(n, device="cuda")
+        ops.sgd_accumulate(accum, grad, w, nd, 1e-3, 1.0)
+        assert bool(torch.isnan(accum).all())
+        out = torch.zeros(n, dtype=pdt, device="cuda")
+        ops.sgd_accumulate_pack(grad, w, nd, 1e-3, 1.0, out)
+        assert bool(torch.isnan(out.float()).all())
+        send = torch.zeros(n + 3, dtype=pdt, device="cuda")
+        ops.grad_pack(grad, send)
+        assert bool(torch.isnan(send[:n].float()).all())
+        w5, v5 = w.clone(), v.clone()
+        ops.sgd_momentum_payload(w5, v5, None, pay, 1e-3, 0.9, 0.5)   # a finite summed gradient is applied whatever the local word says
+        assert torch.equal(w5, w0) and torch.equal(v5, v0)
+        w6, v6 = w.clone(), v.clone()
+        ops.sgd_momentum_payload(w6, v6, None, out, 1e-3, 0.9, 0.5)   # an all-NaN one leaves everything alone
+        assert torch.equal(w6, w) and torch.equal(v6, v)
+        assert ops.status_poll(clear=True, raise_on_error=False) == ops.STATUS_STREAMK_TIMEOUT | ops.STATUS_NAN_GRADIENT
+    finally:
+        assert ops.status_collective(False) is True
+        ops.status_poll(clear=True, raise_on_error=False)
+    # (c) mode off: the producers ignore the word, the consumers skip everything while it is raised (the single-process rule)
+    ops.status_raise(ops.STATUS_STREAMK_TIMEOUT)
+    accum = torch.zeros(n, device="cuda")
+    ops.sgd_accumulate(accum, grad, w, nd, 1e-3, 1.0)
+    assert bool(torch.isfinite(accum).all())
+    w7, v7 = w.clone(), v.clone()
+    ops.sgd_momentum_payload(w7, v7, None, pay, 1e-3, 0.9, 0.5)
+    assert torch.equal(w7, w) and torch.equal(v7, v)
+    assert ops.status_poll(clear=True, raise_on_error=False) == ops.STATUS_STREAMK_TIMEOUT
+
+
 def test_profiler_counts_launches(env):
     ops, do, torch = env
     ops.prof_reset()
