@@ -232,7 +232,7 @@ def _traffic_profiles(key):
             continue
         if tj.get("source_hash") != lib_hash:
             # the profile was taken on other kernel sources: a number carried forward would be a stale claim
-            if not found:
+            if not found and not note.startswith("stale"):   # (newest first: name the newest stale one)
                 note = "stale: %s was taken on kernel sources %s, these are %s (re-run scripts/make_profiles.sh)" % (
                     os.path.relpath(tpath, here), tj.get("source_hash"), lib_hash)
             continue
