@@ -40,6 +40,12 @@ STATUS_STREAMK_TIMEOUT = 1
 STATUS_NAN_GRADIENT = 2
 
 
+class VocSample(ctypes.Structure):
+    """Mirror of emadapt_voc_sample (include/emadapt.h)."""
+    _fields_ = [("img_off", ctypes.c_int64), ("lab_off", ctypes.c_int64), ("h0", ctypes.c_int32), ("w0", ctypes.c_int32),
+                ("h1", ctypes.c_int32), ("w1", ctypes.c_int32), ("flip", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class ConvDesc(ctypes.Structure):
     """Mirror of emadapt_conv_desc (include/emadapt.h)."""
 
@@ -71,6 +77,10 @@ PROTOTYPES = {
     "emadapt_pred_bilinear_argmax": (c_int, [_vp, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _vp, _vp, _vp]),
     "emadapt_bgr_mean_flip": (c_int, [_vp, _vp, c_int, c_int, c_int, POINTER(c_float), _vp, _vp, _vp, _vp]),
     "emadapt_resize_nearest": (c_int, [_vp, c_int, c_int, c_int, _vp, c_int, c_int, _vp]),
+    "emadapt_host_register": (c_int, [_vp, c_size_t]),
+    "emadapt_host_unregister": (c_int, [_vp]),
+    "emadapt_memcpy_h2d_async": (c_int, [_vp, _vp, c_size_t, _vp]),
+    "emadapt_voc_preprocess": (c_int, [_vp, c_int64, POINTER(VocSample), c_int, c_int, c_int, POINTER(c_float), _vp, _vp, _vp]),
     "emadapt_conv_fwd_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "emadapt_conv_fwd": (c_int, [POINTER(ConvDesc), _vp, _vp, _vp, _vp, c_int, c_float, _vp, c_uint64, _vp, c_size_t,
                                  _vp]),

@@ -160,6 +160,27 @@ int emadapt_status_raise(unsigned bits, void *stream_) {
     return launch_status();
 }
 
+// ---- pinned staging for the input pipeline (data.py): the decode workers are separate processes that write into a shared-memory
+// block; registering it with the runtime makes the batch's one host-to-device copy a true asynchronous DMA
+int emadapt_host_register(void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return EMADAPT_ERR_INVALID;
+    EMADAPT_HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return EMADAPT_OK;
+}
+
+int emadapt_host_unregister(void *ptr) {
+    if (!ptr) return EMADAPT_ERR_INVALID;
+    EMADAPT_HIP_TRY(hipHostUnregister(ptr));
+    return EMADAPT_OK;
+}
+
+int emadapt_memcpy_h2d_async(void *dst_device, const void *src_host, size_t bytes, void *stream_) {
+    if (!bytes) return EMADAPT_OK;
+    if (!dst_device || !src_host) return EMADAPT_ERR_INVALID;
+    EMADAPT_HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream_)));
+    return EMADAPT_OK;
+}
+
 int emadapt_status_collective(int on) {
     const int old = g_status_collective.exchange(on ? 1 : 0, std::memory_order_relaxed);
     return old;

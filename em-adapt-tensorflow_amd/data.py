@@ -118,8 +118,10 @@ class dataset:
         ``(images f32 [B,H,W,3] BGR-mean, labels f32 [B,H,W,1], ids)`` device tensors: shuffled every epoch, ``epoches``
         passes (-1 = endless), "train" samples get the random scale U[0.75,1.25) and the coin-toss flip
         (dataset.py:125-126), other categories neither; a short final batch is yielded as is (tf.data ``batch``);
-      * JPEG/PNG decoding runs in a small host thread pool one batch ahead of the consumer; scaling, resizing, channel
-        swap, mean subtraction and flip are the HIP kernels behind ``image_preprocess``.
+      * JPEG/PNG decoding runs in ``decode_workers`` worker PROCESSES (config ``decode_mode``: "process" | "thread"),
+        ``prefetch_batches`` (2) batches ahead of the consumer, straight into a pinned staging ring; scaling, resizing, channel
+        swap, mean subtraction and flip of a whole batch are ONE kernel on a side stream (``ops.voc_preprocess``:
+        bit for bit the op-by-op ``image_preprocess`` below, which stays as the single-sample entry).
     ``ADAPT.train`` accepts it as ``config["data"]`` (it ignores the third element)."""
 
     def __init__(self, config={}):
@@ -264,35 +266,235 @@ class dataset:
 
     def next_batch(self, category=None, batch_size=None, epoches=-1, start_epoch=None):
         """dataset.next_batch.  start_epoch = None continues behind the epochs this object has already handed out for the
-        category (0 for a fresh object); an integer starts there (resuming a run: ADAPT.train passes config "start_epoch")."""
-        import concurrent.futures
+        category (0 for a fresh object); an integer starts there (resuming a run: ADAPT.train passes config "start_epoch").
+
+        Per batch the consumer's thread does a handful of things -- collect the decoders' replies, draw the augmentation, queue ONE
+        host-to-device copy and ONE kernel (ops.voc_preprocess) on a side stream -- while decode runs `prefetch_batches` batches
+        ahead in worker processes (``_Pipeline``)."""
         category = category or self.default_category
         if start_epoch is None:
             start_epoch = self.info["next_epoch"].get(category, 0)
         batch_size = batch_size or self.config.get("batch_size", 1)
         files = self.data_f[category]
         train = category == "train"
-
-        with concurrent.futures.ThreadPoolExecutor(max(self.workers, 1)) as pool:
-            def submit(idx):
-                return [pool.submit(self._decode, files["img"][i], files["label"][i]) for i in idx]
-
+        depth = max(int(self.config.get("prefetch_batches", 2)), 1)
+        pipe = self._make_pipeline(batch_size, depth + 2)
+        try:
             it = self.sample_order(category, batch_size, epoches, start_epoch)
-            nxt = next(it, None)
-            pending = submit(nxt[2]) if nxt else None
-            while nxt is not None:
-                ep, s, idx = nxt
-                futs = pending
-                nxt = next(it, None)
-                pending = submit(nxt[2]) if nxt else None   # decode the next batch while this one is consumed
-                imgs, labs = [], []
-                for f in futs:
-                    img, lab = f.result()
-                    x, y = self.image_preprocess(img, lab, random_scale=train, flip=train)
-                    imgs.append(x)
-                    labs.append(y)
+            queue = []   # (epoch, position, indices, ticket) of the batches whose decode is under way, oldest first
+            k = 0
+            while True:
+                while len(queue) <= depth:
+                    nxt = next(it, None)
+                    if nxt is None:
+                        break
+                    queue.append(nxt + (pipe.submit(k, [(files["img"][i], files["label"][i]) for i in nxt[2]]),))
+                    k += 1
+                if not queue:
+                    break
+                ep, s, idx, ticket = queue.pop(0)
+                sizes = pipe.collect(ticket)
+                samples = []
+                for (h0, w0) in sizes:
+                    # the draws of image_preprocess(), in its order: the scale, then the coin
+                    scale = float(self.rng.uniform(0.75, 1.25)) if train else None
+                    flip = bool(train) and bool(self.rng.uniform() < 0.5)
+                    # tf.to_int32(tf.to_float(h) * scale): fp32 product, truncation (dataset.py:154-155)
+                    h1 = int(np.float32(h0) * np.float32(scale)) if scale is not None else 0
+                    w1 = int(np.float32(w0) * np.float32(scale)) if scale is not None else 0
+                    samples.append((h0, w0, h1, w1, flip))
+                x, y = pipe.preprocess(ticket, samples)
                 self.info["epoch"][category] = ep
                 self.info["index"][category] = s + len(idx) * self.world
                 # a later iterator over this category starts behind the last epoch this one has drawn from
                 self.info["next_epoch"][category] = ep + 1
-                yield torch.stack(imgs), torch.stack(labs), [files["id"][i] for i in idx]
+                yield x, y, [files["id"][i] for i in idx]
+        finally:
+            pipe.close()
+
+
+    def _make_pipeline(self, batch_size, slots):
+        """The staging ring, decode workers and device preprocessing of one iterator (a seam for the host-logic tests)."""
+        return _Pipeline(self.device, batch_size, (self.h, self.w), slots, max(self.workers, 1),
+                         str(self.config.get("decode_mode", "process")), int(self.config.get("max_sample_pixels", 640 * 640)))
+
+
+class _Pipeline:
+    """Staging ring + decode workers + device preprocessing behind ``dataset.next_batch``.
+
+    * a ring of `slots` batch slots in ONE host block; sample j of a slot owns 4 * max_pixels bytes (uint8 RGB, then the uint8 class
+      map).  decode_mode "process" (default): the block is POSIX shared memory, pinned with emadapt_host_register, and the decoders are
+      `workers` processes running ``_decode`` (each with its own interpreter lock: PIL's per-sample Python work neither serialises
+      them nor delays the training step's launch code); "thread": a pinned torch tensor and a thread pool (no child processes).
+    * per batch, on a side stream: one copy of the slot to its device twin, one ``ops.voc_preprocess`` launch into the slot's output
+      buffers; the consumer's stream waits for that, takes a copy (the tensors it is handed are its own) and marks the slot free.
+    Nothing on the consumer's stream waits for a decode or a copy that is not its own batch's."""
+
+    def __init__(self, device, batch, out_hw, slots, workers, mode, max_pixels):
+        import os
+        import torch
+        from . import _lib
+        self.device = torch.device(device)
+        self.batch, self.out_hw, self.slots, self.mode = int(batch), out_hw, int(slots), mode
+        self.max_pixels = int(max_pixels)
+        self.cap = 4 * self.max_pixels
+        self.slot_bytes = self.batch * self.cap
+        total = self.slots * self.slot_bytes
+        self._lib = _lib
+        self._registered = None
+        self._shm = None
+        self._procs = []
+        self._pool = None
+        self._closed = False
+        if mode == "process":
+            import subprocess
+            import sys
+            from multiprocessing import shared_memory
+            self._shm = shared_memory.SharedMemory(create=True, size=total)
+            self._host = np.ndarray((total,), dtype=np.uint8, buffer=self._shm.buf)
+            self._host_ptr = self._host.ctypes.data
+            try:   # pinned: the batch's copy is then one asynchronous DMA (unpinned it is staged by the runtime: slower, still right)
+                _lib.call("emadapt_host_register", ctypes_void_p(self._host_ptr), total)
+                self._registered = self._host_ptr
+            except _lib.EmadaptError:
+                self._registered = None
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+            for _ in range(workers):
+                self._procs.append(subprocess.Popen([sys.executable, "-m", "em_adapt_tensorflow_amd._decode", self._shm.name], env=env,
+                                                    stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1))
+        elif mode == "thread":
+            import concurrent.futures
+            self._pinned = torch.empty(total, dtype=torch.uint8).pin_memory()
+            self._host = self._pinned.numpy()
+            self._host_ptr = self._pinned.data_ptr()
+            self._pool = concurrent.futures.ThreadPoolExecutor(workers)
+        else:
+            raise ValueError("decode_mode must be 'process' or 'thread', got %r" % (mode,))
+        self._dev = torch.empty((self.slots, self.slot_bytes), dtype=torch.uint8, device=self.device)
+        H, W = out_hw
+        self._img = torch.empty((self.slots, self.batch, H, W, 3), dtype=torch.float32, device=self.device)
+        self._lab = torch.empty((self.slots, self.batch, H, W, 1), dtype=torch.float32, device=self.device)
+        self._side = torch.cuda.Stream(device=self.device)
+        self._copied = [None] * self.slots     # event on the side stream: the slot's host bytes have left for the device
+        self._consumed = [None] * self.slots   # event on the consumer's stream: its copy of the slot's outputs has been taken
+
+    def submit(self, k, paths):
+        """Start decoding batch k (a list of (image path, label path)) into slot k % slots.  Returns the ticket collect() takes."""
+        slot = k % self.slots
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()   # (the copy of what the slot held `slots` batches ago: long done)
+        base = slot * self.slot_bytes
+        jobs = []
+        for j, (img_f, lab_f) in enumerate(paths):
+            off = base + j * self.cap
+            if self._pool is not None:
+                from . import _decode
+                jobs.append(self._pool.submit(_decode.decode_into, self._host, off, off + 3 * self.max_pixels, self.cap, img_f, lab_f))
+            else:
+                p = self._procs[j % len(self._procs)]
+                if "\t" in img_f or "\n" in img_f or "\t" in lab_f or "\n" in lab_f:
+                    raise ValueError("file names with tabs or newlines are not supported: %r" % (img_f,))
+                p.stdin.write("%d\t%d\t%d\t%s\t%s\n" % (off, off + 3 * self.max_pixels, self.cap, img_f, lab_f))
+                jobs.append((p, img_f))
+        if self._pool is None:
+            for p in self._procs:
+                p.stdin.flush()
+        return (slot, jobs)
+
+    def collect(self, ticket):
+        """Wait for the batch's decoders; returns [(h0, w0)] in sample order."""
+        _, jobs = ticket
+        sizes = []
+        for job in jobs:
+            if self._pool is not None:
+                sizes.append(job.result())
+                continue
+            p, name = job
+            line = p.stdout.readline()
+            if not line:
+                raise RuntimeError("a decode worker ended (exit code %s) while decoding %s" % (p.poll(), name))
+            if not line.startswith("OK "):
+                raise RuntimeError("decoding %s failed: %s" % (name, line.strip()[4:]))
+            _, h, w = line.split()
+            sizes.append((int(h), int(w)))
+        return sizes
+
+    def preprocess(self, ticket, samples):
+        """samples: [(h0, w0, h1, w1, flip)] of the batch in the ticket's slot.  Returns (images, labels), the consumer's own tensors."""
+        import torch
+        from . import ops
+        slot, jobs = ticket
+        n = len(samples)
+        base = slot * self.slot_bytes
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._side):
+            if self._consumed[slot] is not None:
+                self._side.wait_event(self._consumed[slot])   # the outputs this launch overwrites have been copied out
+            self._lib.call("emadapt_memcpy_h2d_async", ctypes_void_p(self._dev[slot].data_ptr()), ctypes_void_p(self._host_ptr + base),
+                           n * self.cap, ctypes_void_p(self._side.cuda_stream))
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            self._copied[slot] = ev
+            descs = [(j * self.cap, j * self.cap + 3 * self.max_pixels, h0, w0, h1, w1, 1 if flip else 0)
+                     for j, (h0, w0, h1, w1, flip) in enumerate(samples)]
+            ops.voc_preprocess(self._dev[slot], descs, self.out_hw[0], self.out_hw[1], img_out=self._img[slot][:n], label_out=self._lab[slot][:n])
+            done = torch.cuda.Event()
+            done.record(self._side)
+        main.wait_event(done)
+        x, y = self._img[slot][:n].clone(), self._lab[slot][:n].clone()
+        took = torch.cuda.Event()
+        took.record(main)
+        self._consumed[slot] = took
+        return x, y
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        import torch
+        try:
+            self._side.synchronize()
+        except Exception:
+            pass
+        for p in self._procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self._procs:
+            try:
+                p.wait(timeout=5)
+            except Exception:
+                p.kill()
+                p.wait()
+            try:
+                p.stdout.close()
+            except Exception:
+                pass
+        if self._pool is not None:
+            self._pool.shutdown(wait=True, cancel_futures=True)
+        if self._registered is not None:
+            try:
+                self._lib.call("emadapt_host_unregister", ctypes_void_p(self._registered))
+            except Exception:
+                pass
+        if self._shm is not None:
+            self._host = None
+            try:
+                self._shm.close()
+                self._shm.unlink()
+            except Exception:
+                pass
+        del torch
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ctypes_void_p(v):
+    import ctypes
+    return ctypes.c_void_p(int(v))

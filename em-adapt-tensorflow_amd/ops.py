@@ -614,6 +614,27 @@ def bgr_mean_flip(img_rgb, label=None, flip=None, mean_bgr=IMG_MEAN_BGR):
     return out, lab_out
 
 
+def voc_preprocess(staging, samples, out_h, out_w, img_out=None, label_out=None, mean_bgr=IMG_MEAN_BGR):
+    """dataset.image_preprocess (dataset.py:147-185) of a whole batch in one launch (include/emadapt.h, emadapt_voc_preprocess).
+    staging: uint8 device tensor holding the decoded samples; samples: list of (img_off, lab_off, h0, w0, h1, w1, flip) -- h1 = w1 = 0
+    without the random-scale stage.  Returns (images f32 [B,H,W,3] BGR - mean, labels f32 [B,H,W,1])."""
+    _check(staging, torch.uint8, "staging")
+    B = len(samples)
+    arr = (_lib.VocSample * max(B, 1))()
+    for i, t in enumerate(samples):
+        arr[i].img_off, arr[i].lab_off, arr[i].h0, arr[i].w0, arr[i].h1, arr[i].w1, arr[i].flip = [int(v) for v in t]
+    if img_out is None:
+        img_out = torch.empty((B, out_h, out_w, 3), dtype=torch.float32, device=staging.device)
+    if label_out is None:
+        label_out = torch.empty((B, out_h, out_w, 1), dtype=torch.float32, device=staging.device)
+    _check(img_out, name="img_out"); _check(label_out, name="label_out")
+    if img_out.numel() != B * out_h * out_w * 3 or label_out.numel() != B * out_h * out_w:
+        raise ValueError("img_out / label_out must hold B x H x W (x 3) elements")
+    mean = (ctypes.c_float * 3)(*[float(m) for m in mean_bgr])
+    _lib.call("emadapt_voc_preprocess", _p(staging), staging.numel(), arr, B, int(out_h), int(out_w), mean, _p(img_out), _p(label_out), _stream())
+    return img_out, label_out
+
+
 def estep_device(logits, label, perms, num_classes, suppress_others=True, num_iter=5, margin_others=1e-5,
                  bg_p=0.5, fg_p=0.25, label_kind=LABEL_F32, want_map=False, labels_out=None, map_out=None):
     """Device E-step (deeplab.py:109-124 without the host round trip).

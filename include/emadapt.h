@@ -67,7 +67,7 @@ extern "C" {
  *        gradient runs by 2 x 2 pixel quads (same results).  emadapt_sgd_accumulate_momentum_tiles (+ _supported) and
  *        emadapt_sgd_momentum_payload_tiles: the optimizer pass of a layer that also writes the layer's two tiled bf16 filter images; emadapt_sgd_accumulate_momentum_multi: the pass
  *        over several layers' segments in one launch; emadapt_weights_to_bf16_multi: several filters' bf16 images in one launch.
- *   206  round 6, added: emadapt_status_raise; emadapt_status_collective (data-parallel jobs: the failure travels with the exchanged gradient instead of
+ *   206  round 6, added: emadapt_voc_preprocess (the input pipeline of a batch in one launch); emadapt_status_raise; emadapt_status_collective (data-parallel jobs: the failure travels with the exchanged gradient instead of
  *        being decided from each rank's own word), EMADAPT_STATUS_NAN_GRADIENT. */
 #define EMADAPT_ABI_VERSION 206
 int emadapt_version(void);
@@ -187,6 +187,29 @@ int emadapt_pred_bilinear_argmax(const float *logits, int64_t ldl, int B, int IH
  * C-channel image) and emadapt_resize_nearest.  img_rgb f32 [B,H,W,3]; label f32 [B,H,W] (may be NULL). */
 int emadapt_bgr_mean_flip(const float *img_rgb, const float *label, int B, int H, int W, const float mean_bgr[3],
                           const uint8_t *flip, float *img_out, float *label_out, void *stream);
+
+/* The whole of dataset.image_preprocess (dataset.py:147-185) behind the host's JPEG / PNG decode, for a BATCH, in one launch
+ * (ABI 206): uint8 -> f32, the "train" branch's random scale (bilinear image / nearest label to h1 x w1; h1 = w1 = 0 skips it: the
+ * "val" branch), the resize to OH x OW, RGB -> BGR, minus mean, left-right flip.  staging (device) holds the decoded samples as the
+ * decoder leaves them: sample b's image as uint8 [h0][w0][3] RGB at img_off, its class-index map as uint8 [h0][w0] at lab_off.
+ * samples is a HOST array (validated here, passed to the kernel by value).  img_out f32 [B,OH,OW,3], label_out f32 [B,OH,OW] (may
+ * be NULL).  Results are bit for bit those of the op-by-op path above (emadapt_pred_bilinear_argmax twice, emadapt_resize_nearest
+ * twice, emadapt_bgr_mean_flip): one thread per output pixel evaluates the same fp32 operations in the same order. */
+typedef struct emadapt_voc_sample {
+    int64_t img_off, lab_off;   /* byte offsets into staging */
+    int32_t h0, w0;             /* decoded size */
+    int32_t h1, w1;             /* size after the random scale: int(float(h0) * scale), int(float(w0) * scale) -- dataset.py:154-155; 0, 0 = none */
+    int32_t flip;               /* != 0: left-right flip of image and label */
+    int32_t reserved;
+} emadapt_voc_sample;
+int emadapt_voc_preprocess(const uint8_t *staging, int64_t staging_bytes, const emadapt_voc_sample *samples, int B, int OH, int OW,
+                           const float mean_bgr[3], float *img_out, float *label_out, void *stream);
+/* Staging of that batch (ABI 206): emadapt_host_register pins a host block the caller owns (the shared-memory ring the decode
+ * processes write into; hipHostRegister), emadapt_memcpy_h2d_async queues one host-to-device copy on `stream` (asynchronous when
+ * the source is pinned, staged by the runtime otherwise -- correct either way), emadapt_host_unregister undoes the pinning. */
+int emadapt_host_register(void *ptr, size_t bytes);
+int emadapt_host_unregister(void *ptr);
+int emadapt_memcpy_h2d_async(void *dst_device, const void *src_host, size_t bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution stack (DeepLab VGG-16 with dilation): implicit-GEMM on MFMA

@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--workers", type=int, default=0, help="decode threads (0 = the host cores this process may use)")
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--step-workers", type=int, default=0, help="decode processes beside the training step (0 = min(12, cores))")
     ap.add_argument("--out", default="")
     ap.add_argument("--no-steps", action="store_true", help="loader alone (no training step)")
     args = ap.parse_args()
@@ -107,8 +108,8 @@ def main():
                 dt = time.perf_counter() - t0
             say("decode alone      workers %2d: %8.1f images/s (%.2f ms per image per thread)" % (w, args.n / dt, dt / args.n * w * 1e3))
         # 2. next_batch alone
-        for w in sorted({4, workers}):
-            ds = D.dataset(dict(cfg, decode_workers=w))
+        for mode, w in [("thread", 4), ("thread", workers), ("process", 4), ("process", min(8, workers)), ("process", workers)]:
+            ds = D.dataset(dict(cfg, decode_workers=w, decode_mode=mode))
             it = ds.next_batch("train", args.batch)
             for _ in range(3):
                 next(it)
@@ -119,7 +120,7 @@ def main():
                 x, y, _ids = next(it)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            say("next_batch alone  workers %2d: %8.1f images/s (%.2f ms per batch of %d)" % (w, nb * args.batch / dt, dt / nb * 1e3, args.batch))
+            say("next_batch alone  %-7s x %2d: %8.1f images/s (%.2f ms per batch of %d)" % (mode, w, nb * args.batch / dt, dt / nb * 1e3, args.batch))
             it.close()
         if args.no_steps:
             return
@@ -148,12 +149,12 @@ def main():
                 return (time.perf_counter() - t0) / n
 
             t_syn = run(sit, args.steps)
-            ds = D.dataset(dict(cfg, decode_workers=workers))
+            ds = D.dataset(dict(cfg, decode_workers=args.step_workers or min(12, workers), decode_mode="process"))
             lit = ds.next_batch("train", args.batch)
             t_load = run(lit, args.steps)
             lit.close()
-            say("step %-5s resident synthetic batches: %7.2f ms = %7.1f images/s | fed by next_batch (workers %d): %7.2f ms = %7.1f images/s (%.0f %%)" % (
-                dtype, t_syn * 1e3, args.batch / t_syn, workers, t_load * 1e3, args.batch / t_load, 100.0 * t_syn / t_load))
+            say("step %-5s resident synthetic batches: %7.2f ms = %7.1f images/s | fed by next_batch (%d decode processes): %7.2f ms = %7.1f images/s (%.0f %%)" % (
+                dtype, t_syn * 1e3, args.batch / t_syn, args.step_workers or min(12, workers), t_load * 1e3, args.batch / t_load, 100.0 * t_syn / t_load))
             del a
             torch.cuda.empty_cache()
     finally:

@@ -87,6 +87,43 @@ def test_input_pipeline_matches_restatement(env, case):
     assert np.array_equal(got_img.cpu().numpy(), want_img), np.abs(got_img.cpu().numpy() - want_img).max()
 
 
+def test_batched_input_pipeline_is_the_op_by_op_one_bit_for_bit(env):
+    """emadapt_voc_preprocess: a whole batch -- mixed sizes, with and without the random-scale stage, flipped and not -- from the decoded
+    bytes in ONE launch equals dataset.image_preprocess sample by sample (the op list of dataset.py:147-185 as five kernels) bit for
+    bit, and the NumPy restatement of the TF-1 semantics."""
+    ops, ADAPT, do, torch = env
+    from em_adapt_tensorflow_amd.data import image_preprocess
+    rng = np.random.default_rng(11)
+    cases = [(375, 500, 1.1337, True), (333, 500, 0.75, False), (281, 413, None, True), (500, 375, 1.2499, False), (17, 23, 0.9, True),
+             (64, 64, None, False), (321, 321, 1.0, False)]
+    for out_hw in ((321, 321), (65, 33)):
+        chunks, descs, want = [], [], []
+        off = 0
+        for h0, w0, scale, flip in cases:
+            img = rng.integers(0, 256, (h0, w0, 3), dtype=np.uint8)
+            lab = rng.integers(0, 21, (h0, w0), dtype=np.uint8)
+            lab[:3] = 255
+            pad = int(rng.integers(0, 7))   # (samples need not be packed tightly)
+            h1 = int(np.float32(h0) * np.float32(scale)) if scale is not None else 0
+            w1 = int(np.float32(w0) * np.float32(scale)) if scale is not None else 0
+            descs.append((off, off + h0 * w0 * 3 + pad, h0, w0, h1, w1, 1 if flip else 0))
+            chunks += [img.reshape(-1), np.zeros(pad, np.uint8), lab.reshape(-1)]
+            off += h0 * w0 * 4 + pad
+            want.append((image_preprocess(img, lab, out_hw, scale, flip, device="cuda:0"), do.image_preprocess_oracle(img, lab, out_hw, scale, flip)))
+        staging = torch.as_tensor(np.concatenate(chunks)).cuda()
+        x, y = ops.voc_preprocess(staging, descs, out_hw[0], out_hw[1])
+        assert tuple(x.shape) == (len(cases),) + out_hw + (3,) and tuple(y.shape) == (len(cases),) + out_hw + (1,)
+        for b, ((gx, gy), (wx, wy)) in enumerate(want):
+            assert torch.equal(x[b], gx) and torch.equal(y[b], gy), (out_hw, cases[b])
+            assert np.array_equal(x[b].cpu().numpy(), wx) and np.array_equal(y[b].cpu().numpy(), wy), (out_hw, cases[b])
+    # offsets are checked on the host before anything is launched
+    from em_adapt_tensorflow_amd import _lib
+    with pytest.raises(_lib.EmadaptError):
+        ops.voc_preprocess(staging, [(staging.numel() - 10, 0, 8, 8, 0, 0, 0)], 33, 33)
+    with pytest.raises(_lib.EmadaptError):
+        ops.voc_preprocess(staging, [(0, 0, 8, 8, 9, 0, 0)], 33, 33)
+
+
 def _make_voc(tmp_path, sizes, n_classes=5, seed=0):
     """A tiny VOC-style tree: JPEGImages/<id>.jpg, SegmentationClassAug/<id>.png (palette PNG), txt/{train,val}.txt."""
     from PIL import Image
@@ -110,15 +147,17 @@ def _make_voc(tmp_path, sizes, n_classes=5, seed=0):
     return main, tmp_path / "txt", ids
 
 
-def test_dataset_class_feeds_the_device_pipeline(tmp_path):
-    """f1: the reference's ``dataset`` surface (dataset.py:6-145) over real files: lists, decode, device preprocessing."""
+@pytest.mark.parametrize("mode", ["process", "thread"])
+def test_dataset_class_feeds_the_device_pipeline(tmp_path, mode):
+    """f1: the reference's ``dataset`` surface (dataset.py:6-145) over real files: lists, decode (worker processes writing into a
+    pinned shared-memory ring, or a thread pool), one preprocessing launch per batch."""
     import torch
     from PIL import Image
     from em_adapt_tensorflow_amd.data import dataset
     from oracle import deeplab_oracle as do
     main, lists, ids = _make_voc(tmp_path, [(37, 53), (64, 48), (50, 50), (41, 77), (33, 35)])
     ds = dataset({"input_size": (33, 33), "categorys": ["train", "val"], "main_path": str(main), "list_path": str(lists),
-                  "seed": 4, "decode_workers": 2})
+                  "seed": 4, "decode_workers": 2, "decode_mode": mode})
     assert ds.get_data_len("train") == 5 and ds.get_data_len() == 5 and ds.get_cur_epoch() == 0
     assert ds.data_f["val"]["img"][0].endswith("JPEGImages/%s.jpg" % ids[0])
     # "val": no random scale, no flip -> equals the oracle's preprocessing of the decoded files, sample by sample
@@ -144,6 +183,29 @@ def test_dataset_class_feeds_the_device_pipeline(tmp_path):
         assert x.min().item() >= -123.0 and x.max().item() <= 255.0 - 104.0
     assert sizes == [3, 2, 3, 2]                # 5 samples per epoch: a full and a short batch, epoch after epoch
     it.close()
+    # the batches a consumer is handed are its own tensors (the staging ring behind them is reused), and the augmentation is a
+    # function of the seed alone: a second object draws the same scales and flips whatever decodes the files
+    a = dataset({"input_size": (33, 33), "categorys": ["train"], "main_path": str(main), "list_path": str(lists), "seed": 9,
+                 "decode_workers": 3, "decode_mode": mode, "prefetch_batches": 1})
+    b = dataset({"input_size": (33, 33), "categorys": ["train"], "main_path": str(main), "list_path": str(lists), "seed": 9,
+                 "decode_workers": 1, "decode_mode": "thread", "prefetch_batches": 3})
+    ia, ib = a.next_batch("train", batch_size=2, epoches=-1), b.next_batch("train", batch_size=2, epoches=-1)
+    kept = []
+    for _ in range(9):                          # more batches than the ring has slots
+        xa, ya, na = next(ia)
+        xb, yb, nb_ = next(ib)
+        assert na == nb_ and torch.equal(xa, xb) and torch.equal(ya, yb)
+        kept.append((xa, xa.clone()))
+    assert all(torch.equal(x, c) for x, c in kept), "a batch handed out earlier was overwritten by a later one"
+    ia.close(); ib.close()
+    # a file that cannot be decoded surfaces as an error naming it, not as a hang
+    (main / "JPEGImages" / (ids[0] + ".jpg")).write_bytes(b"not a jpeg")
+    bad = dataset({"input_size": (33, 33), "categorys": ["val"], "main_path": str(main), "list_path": str(lists), "seed": 4,
+                   "decode_workers": 2, "decode_mode": mode})
+    with pytest.raises(Exception) as ei:
+        for _ in bad.next_batch("val", batch_size=2, epoches=1):
+            pass
+    assert ids[0] in str(ei.value)
     # palette helpers
     lab = np.array([[0, 1], [20, 255]], np.uint8)
     rgb = dataset.label2rgb(lab)

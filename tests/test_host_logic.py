@@ -199,8 +199,12 @@ def test_resumed_runs_continue_in_their_epoch(tmp_path):
         assert (e0, s0) == (e1, s1) and np.array_equal(i0, i1)
     assert not np.array_equal(full[0][2], tail[0][2])                 # (epoch 2 is not epoch 0)
     # next_batch without start_epoch continues behind what this object has handed out (decode / preprocess stubbed out)
-    ds._decode = lambda img_f, label_f: (None, None)
-    ds.image_preprocess = lambda img, lab, random_scale=False, flip=False: (__import__("torch").zeros(1), __import__("torch").zeros(1))
+    class FakePipe:
+        def submit(self, k, paths): return (k, len(paths))
+        def collect(self, ticket): return [(8, 8)] * ticket[1]
+        def preprocess(self, ticket, samples): return torch.zeros(len(samples)), torch.zeros(len(samples))
+        def close(self): pass
+    ds._make_pipeline = lambda batch_size, slots: FakePipe()
     first = ds.next_batch("train", 4, epoches=1)
     ids_a = [ids for _, _, ids in first]
     assert ds.info["next_epoch"]["train"] == 1
