@@ -143,7 +143,6 @@ enum TuneKey {
     TUNE_BF16T_SK,     // 1: the LDS-DMA bf16 kernel's launches run stream-K over ALL rows whatever N (default: N > 1024 runs the rows of whole
                        //    rounds as plain tiles + a stream-K tail); A/B
     TUNE_POOL_ROWS,    // 1: the stride-2 max-pool gradient runs the row form (elementwise.hip maxpool_bwd_rows_kernel) instead of quads (A/B, tests)
-    TUNE_WGRAD_COMBINE,  // 1: the bf16 LDS-DMA filter-gradient kernel never combines its split-M partials inside the launch (slab_sum afterwards: A/B, parity)
     TUNE_COUNT
 };
 int tune(TuneKey key);

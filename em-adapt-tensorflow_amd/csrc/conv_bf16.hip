@@ -119,7 +119,7 @@ __device__ __forceinline__ float epilogue_t(const IgemmArgs &a, float v, int col
     if (a.epi == EMADAPT_EPI_BIAS_RELU) {
         v = relu_keep_nan(v);
         if (a.keep < 1.0f) {
-            const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
+            const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep, a.keep8);
             v = kp ? drop_scale(a, v) : 0.f;
         }
     }
@@ -543,12 +543,6 @@ struct WgradBf16Args {
     int rows_per_split;  // multiple of kRowsUnit
     unsigned x_bytes, y_bytes;
     unsigned magic_w, magic_h;
-    // in-launch combine of the split-M partials (wgrad_b16t.h, round 6; null arrive = the partials are summed by slab_sum afterwards)
-    unsigned *arrive;   // [tiles_k * tiles_n] arrivals per filter tile, then [tiles_n] arrivals per column tile (bias rows); zeroed ahead of the launch
-    float *dw;          // the filter gradient itself, [K][N]
-    float *db;          // the bias gradient itself, [N] (null: none asked for)
-    unsigned *status;   // device status word (a wait that ran out)
-    int drop_flag;      // tests (tune "sk_drop_flag"): nobody publishes, the waits give up early
 };
 
 constexpr int kRowsUnit = 64;  // rows_per_split is a multiple of this (covers both reduction step sizes)
@@ -847,19 +841,10 @@ int launch_wgrad_bf16(const WgradBf16Args &a, hipStream_t stream) {
 namespace {
 
 // tune "wgrad_gen" = 1 keeps the round-1 kernel everywhere (A/B, parity of both)
-inline bool wgrad_b16t_takes(int bko, int Cin, int N) { return bko == 256 && Cin % 256 == 0 && N % 8 == 0 && tune(TUNE_WGRAD_GEN) != 1; }
-// The split-M partials of a launch on the LDS-DMA kernel are combined INSIDE the launch (wgrad_b16t.h) when every workgroup is
-// resident at once -- a workgroup waits for the others of its tile -- i.e. at most one workgroup per CU; tune "wgrad_combine" = 1: never
-// (slab_sum afterwards, as before: the A/B and the parity reference).
-inline bool wgrad_combines(const PlanW &p, int Cin, int N, int x_dtype, int dy_dtype) {
-    return x_dtype && dy_dtype && p.splits > 1 && wgrad_b16t_takes(p.bko, Cin, N) && tune(TUNE_WGRAD_COMBINE) != 1 &&
-           (long long)p.tiles_k * p.tiles_n * p.splits <= plan_cus() && N % 4 == 0;
-}
-inline size_t wgrad_arrive_floats(const PlanW &p) { return (size_t)((p.tiles_k * p.tiles_n + p.tiles_n + 63) / 64 * 64); }
 template <bool XBF, bool DBF>
 int launch_wgrad_bf16_plan(const PlanW &p, const WgradBf16Args &a, hipStream_t stream) {
     if constexpr (XBF && DBF) {
-        if (wgrad_b16t_takes(p.bko, a.Cin, a.N)) return launch_wgrad_b16t(a, stream);
+        if (p.bko == 256 && a.Cin % 256 == 0 && a.N % 8 == 0 && tune(TUNE_WGRAD_GEN) != 1) return launch_wgrad_b16t(a, stream);
     }
     return p.bko == 256 ? launch_wgrad_bf16<256, 256, 32, XBF, DBF>(a, stream)
          : p.bn == 64   ? launch_wgrad_bf16<128, 64, 64, XBF, DBF>(a, stream)
@@ -1136,8 +1121,7 @@ static size_t wgrad_bf16_ws_floats(const emadapt_conv_desc *d, bool bias) {
         const PlanW p = direct ? plan_wgrad_bf16(d, 1, 1) : make_plan_bf16(d);
         const size_t w_floats = p.splits > 1 ? (size_t)p.splits * d->KH * d->KW * d->Cin * d->Cout : 0;
         const size_t b_rows = bias ? (size_t)p.splits * p.tiles_k : 0;
-        size_t n = w_floats + (b_rows > 1 ? b_rows * d->Cout : 0);
-        if (p.splits > 1 && p.bko == 256) n += wgrad_arrive_floats(p);   // arrival words of the in-launch combine (where it applies)
+        const size_t n = w_floats + (b_rows > 1 ? b_rows * d->Cout : 0);
         if (n > need) need = n;
     }
     return need;
@@ -1180,21 +1164,18 @@ static int wgrad_bf16_impl(const emadapt_conv_desc *d, const void *x, int x_dtyp
     a.x_bytes = (unsigned)((long long)a.M * d->Cin * (x_dtype ? 2 : 4));
     a.y_bytes = (unsigned)((long long)a.M * d->Cout * (dy_dtype ? 2 : 4));
     a.magic_w = magic_u32(d->W); a.magic_h = magic_u32(d->H);
-    a.arrive = nullptr; a.dw = dw; a.db = db; a.status = status_word(); a.drop_flag = tune(TUNE_SK_DROP_FLAG) == 1;
-    const bool combine = wgrad_combines(p, d->Cin, d->Cout, x_dtype, dy_dtype) &&
-                         KN * 4 < (1LL << 31) && (long long)p.splits * p.tiles_k * d->Cout * 4 < (1LL << 31) &&
-                         workspace_bytes >= (size_t)(w_floats + b_floats + (long long)wgrad_arrive_floats(p)) * sizeof(float);
     ProfScope prof(EMADAPT_K_IGEMM_WGRAD, 2.0 * a.M * (double)a.K * a.N, (double)a.x_bytes + (double)a.y_bytes + 4.0 * a.K * a.N, stream);
-    if (combine) {   // arrival words behind the partials: zeroed ahead of every launch
-        a.arrive = reinterpret_cast<unsigned *>(static_cast<float *>(workspace) + w_floats + b_floats);
-        EMADAPT_HIP_TRY(hipMemsetAsync(a.arrive, 0, wgrad_arrive_floats(p) * sizeof(float), stream));
-    }
     if (p.bko == 0) rc = launch_wgrad_d64(a, stream);
     else
     rc = x_dtype ? (dy_dtype ? launch_wgrad_bf16_plan<true, true>(p, a, stream) : launch_wgrad_bf16_plan<true, false>(p, a, stream))
                  : (dy_dtype ? launch_wgrad_bf16_plan<false, true>(p, a, stream) : launch_wgrad_bf16_plan<false, false>(p, a, stream));
-    if (rc || combine) return rc;   // (combined in the launch: the sums come out in slab_sum's order, bit for bit)
-    // one second-stage launch finishes both gradients (each in a fixed order)
+    if (rc) return rc;
+    // one second-stage launch finishes both gradients (each in a fixed order).  (Round 6 measured the alternative the round-5 verdict
+    // asked for -- the workgroups of a tile add up their partials INSIDE the launch, arrival word per tile, each workgroup 1 / S of the
+    // tile, slab_sum's order, bit-identical -- and refused it: this launch moves a conv4 / conv5 layer's 75 MB in 12 us (6.3 TB/s, the
+    // slabs still in the Infinity Cache); inside the launch the same bytes cost 24 us (every 16-byte load of another XCD's slab is
+    // a trip to memory with a handful in flight per lane, and more in flight cost the MFMA loop accumulator spills) plus 5.4 us for
+    // the fill node that zeroes the arrival words: 10.03 -> 10.20 ms per step.  DESIGN "round 6", profiles/r06_wgrad_combine.txt.)
     return launch_slab_sum2(static_cast<const float *>(workspace), p.splits, p.splits > 1 ? KN : 0, dw,
                             static_cast<const float *>(workspace) + w_floats, b_rows, b_floats ? d->Cout : 0, db, stream);
 }

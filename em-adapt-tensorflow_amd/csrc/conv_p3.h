@@ -330,13 +330,14 @@ __global__ void __launch_bounds__(P3_THREADS, 2) igemm_p3_kernel(IgemmArgs a, in
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = relu_keep_nan(v[e]);
                     if (a.keep < 1.0f) {
+                        {   // (o is a multiple of 4: o .. o + 3 is a quad of the generator)
+                            bool k[4];
+                            if (a.mask) {
 #pragma unroll
-                        for (int e = 0; e < 4; e += 2) {   // (o is a multiple of 4: (o + e, o + e + 1) is a pair of the generator)
-                            bool k0, k1;
-                            if (a.mask) { k0 = a.mask[o + e] != 0; k1 = a.mask[o + e + 1] != 0; }
-                            else dropout_keep2(a.seed, (unsigned long long)(o + e), a.keep, k0, k1);
-                            v[e] = k0 ? drop_scale(a, v[e]) : 0.f;
-                            v[e + 1] = k1 ? drop_scale(a, v[e + 1]) : 0.f;
+                                for (int q = 0; q < 4; q++) k[q] = a.mask[o + q] != 0;
+                            } else dropout_keep4(a, (unsigned long long)o, k);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) v[q] = k[q] ? drop_scale(a, v[q]) : 0.f;
                         }
                     }
                 }

@@ -346,13 +346,15 @@ __device__ __forceinline__ void store_acc_tile16(const IgemmArgs &a, const bt_f3
                 for (int e = 0; e < 8; e++) v[e] = relu_keep_nan(v[e]);
                 if (a.keep < 1.0f) {
 #pragma unroll
-                    for (int e = 0; e < 8; e += 2) {   // (o is a multiple of 4: (o + e, o + e + 1) is a pair of the generator)
+                    for (int e = 0; e < 8; e += 4) {   // (o is a multiple of 4: o + e .. o + e + 3 is a quad of the generator)
                         if (e >= 4 && !hi) break;
-                        bool k0, k1;
-                        if (a.mask) { k0 = a.mask[o + e] != 0; k1 = a.mask[o + e + 1] != 0; }
-                        else dropout_keep2(a.seed, (unsigned long long)(o + e), a.keep, k0, k1);
-                        v[e] = k0 ? drop_scale(a, v[e]) : 0.f;
-                        v[e + 1] = k1 ? drop_scale(a, v[e + 1]) : 0.f;
+                        bool k[4];
+                        if (a.mask) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) k[q] = a.mask[o + e + q] != 0;
+                        } else dropout_keep4(a, (unsigned long long)(o + e), k);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) v[e + q] = k[q] ? drop_scale(a, v[e + q]) : 0.f;
                     }
                 }
             }

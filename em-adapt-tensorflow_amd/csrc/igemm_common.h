@@ -65,6 +65,7 @@ struct IgemmArgs {
     float scale;        // gate scale
     float keep;         // dropout keep probability (1 = off)
     float inv_keep;     // 1.0f / keep (set_keep): what the kept elements are multiplied by
+    int keep8;          // keep * 256 when that is an integer in 1 .. 255 (set_keep), else 0: the built-in generator then draws four elements per hash
     unsigned long long seed;
     int tiles_m, tiles_n;
     unsigned x_bytes, w_bytes;  // extents for the bounds-checked buffer loads (< 2 GiB each)
@@ -92,15 +93,21 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// keep decision of the built-in dropout generator: a uniform 16-bit draw per (seed, element), two elements to one 32-bit hash
-// (element idx takes half idx & 1 of the hash of idx >> 1: the decision is a function of (seed, idx) alone, whatever kernel or
-// vector width evaluates it, and adjacent elements -- every epilogue handles 4 or 8 of them per lane -- share the work; keep
-// probabilities resolve to 2^-16).  The seed is hashed on its own into two words (it is a kernel argument, so this is
-// scalar-ALU work once per wave): one is XORed into the pair index's linear mix before a 32-bit multiply-xorshift finaliser,
-// the other added between the finaliser's two rounds.  A 32-bit state means every seed draws from the same 2^32 values, but
-// two seeds visit them in unrelated orders (XOR and add do not commute with the multiplies, so no seed's stream is a shifted
-// copy of another's -- scripts/dropout_quality.py checks the cross-seed correlation).  ~6 vector instructions per element:
-// the fc6 / fc7 forward epilogues draw 110 M + 110 M of these per step inside waves that share their SIMD with the MFMAs.
+// keep decision of the built-in dropout generator: a function of (seed, element index, keep_prob) alone, whatever kernel or vector
+// width evaluates it.  Two forms, chosen by the keep probability:
+//   * keep_prob = t / 256 (IgemmArgs::keep8 = t; the reference only ever feeds 0.5, deeplab.py:266): FOUR elements to one 32-bit hash --
+//     element idx takes byte idx & 3 of the hash of idx >> 2 and is kept when that byte is below t.  Round 6: the fc6 / fc7 forward
+//     epilogues draw 110 M + 110 M decisions per step inside waves that share their SIMD with the MFMAs, and the 32-bit multiplies
+//     of the hash run at a quarter of the vector rate -- three per four elements now instead of four per two, and the 16-bit form's
+//     int -> float conversion, multiply and float compare per element are a bit-field extract and an integer compare.
+//   * any other keep_prob: a uniform 16-bit draw per element, two elements to one hash (idx takes half idx & 1 of the hash of
+//     idx >> 1; keep probabilities resolve to 2^-16) -- rounds 2-5's generator, unchanged.
+// The hash (both forms): the seed is hashed on its own into two words (a kernel argument: scalar-ALU work once per wave); one is XORed
+// into the unit index's linear mix before a 32-bit multiply-xorshift finaliser, the other added between the finaliser's two rounds.
+// A 32-bit state means every seed draws from the same 2^32 values, but two seeds visit them in unrelated orders (XOR and add do not
+// commute with the multiplies, so no seed's stream is a shifted copy of another's -- scripts/dropout_quality.py checks the cross-seed
+// correlation, the keep rate, lag correlations along channels and pixels and the joint distribution of a quad's / an octet's
+// decisions).
 __device__ __forceinline__ unsigned fmix32(unsigned h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
@@ -109,17 +116,24 @@ __device__ __forceinline__ unsigned fmix32(unsigned h) {
     h ^= h >> 16;
     return h;
 }
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float keep) {
+__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned long long unit) {
     const unsigned s1 = fmix32((unsigned)seed ^ fmix32((unsigned)(seed >> 32) + 0x9E3779B9u));
     const unsigned s2 = fmix32(s1 + 0x7F4A7C15u);
-    const unsigned long long pair = idx >> 1;
-    unsigned h = ((unsigned)pair * 0x9E3779B1u + (unsigned)(pair >> 32) * 0x27D4EB2Fu) ^ s1;
+    unsigned h = (unsigned)unit * 0x9E3779B1u;
+    const unsigned hi = (unsigned)(unit >> 32);
+    if (__builtin_expect(hi != 0u, 0)) h += hi * 0x27D4EB2Fu;   // (tensors of 2^32 units and more: a branch the waves of a launch all skip)
+    h ^= s1;
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
     h += s2;
     h ^= h >> 12;
     h *= 0x297A2D39u;
     h ^= h >> 15;
+    return h;
+}
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float keep, int keep8) {
+    if (keep8) return (int)((drop_hash(seed, idx >> 2) >> (8u * ((unsigned)idx & 3u))) & 0xFFu) < keep8;
+    const unsigned h = drop_hash(seed, idx >> 1);
     const unsigned r = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
     return (float)r * (1.0f / 65536.0f) < keep;
 }
@@ -132,24 +146,26 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
 inline void set_keep(IgemmArgs &a, float keep_prob) {
     a.keep = keep_prob;
     a.inv_keep = 1.0f / keep_prob;
+    const float t = keep_prob * 256.0f;
+    a.keep8 = (t >= 1.0f && t <= 255.0f && t == (float)(int)t) ? (int)t : 0;
 }
 __device__ __forceinline__ float drop_scale(const IgemmArgs &a, float v) { return v * a.inv_keep; }
 
-// Two adjacent elements (idx0 even, idx0 + 1) from one hash -- what dropout_keep() returns for each, without relying on the
-// compiler to see that the two share their pair index.
-__device__ __forceinline__ void dropout_keep2(unsigned long long seed, unsigned long long idx0, float keep, bool &k0, bool &k1) {
-    const unsigned s1 = fmix32((unsigned)seed ^ fmix32((unsigned)(seed >> 32) + 0x9E3779B9u));
-    const unsigned s2 = fmix32(s1 + 0x7F4A7C15u);
-    const unsigned long long pair = idx0 >> 1;
-    unsigned h = ((unsigned)pair * 0x9E3779B1u + (unsigned)(pair >> 32) * 0x27D4EB2Fu) ^ s1;
-    h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
-    h += s2;
-    h ^= h >> 12;
-    h *= 0x297A2D39u;
-    h ^= h >> 15;
-    k0 = (float)(h & 0xFFFFu) * (1.0f / 65536.0f) < keep;
-    k1 = (float)(h >> 16) * (1.0f / 65536.0f) < keep;
+// The four elements idx0 .. idx0 + 3 (idx0 % 4 == 0: every fused epilogue handles whole quads) -- what dropout_keep() returns for
+// each: one hash in the 8-bit form, two in the 16-bit form.
+__device__ __forceinline__ void dropout_keep4(const IgemmArgs &a, unsigned long long idx0, bool (&k)[4]) {
+    if (a.keep8) {
+        const unsigned h = drop_hash(a.seed, idx0 >> 2);
+#pragma unroll
+        for (int e = 0; e < 4; e++) k[e] = (int)((h >> (8 * e)) & 0xFFu) < a.keep8;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            const unsigned h = drop_hash(a.seed, (idx0 + e) >> 1);
+            k[e] = (float)(h & 0xFFFFu) * (1.0f / 65536.0f) < a.keep;
+            k[e + 1] = (float)(h >> 16) * (1.0f / 65536.0f) < a.keep;
+        }
+    }
 }
 
 // bias / ReLU / dropout (tf.nn.dropout: x / keep_prob * mask) or the ReLU-gradient gate, on one output element.
@@ -158,7 +174,7 @@ __device__ __forceinline__ float epilogue(const IgemmArgs &a, float v, int col, 
     if (a.epi == EMADAPT_EPI_BIAS_RELU) {
         v = relu_keep_nan(v);
         if (a.keep < 1.0f) {
-            const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep);
+            const bool kp = a.mask ? (a.mask[o] != 0) : dropout_keep(a.seed, (unsigned long long)o, a.keep, a.keep8);
             v = kp ? drop_scale(a, v) : 0.f;  // tf.nn.dropout divides by keep_prob
         }
     }
@@ -188,7 +204,9 @@ struct MapRows {
 
 //   ADJ  = the lane's TN accumulator tiles are TN ADJACENT columns (column l31*TN + j) instead of l31 + 32*j
 //   RM   = GEMM row -> pixel (row0 is then a GEMM row)
-template <int TM, int TN, int ROWS, bool YBF, bool ADJ = false, typename RM = PixelRows>
+//   DROP = false: the dropout section is compiled out (data-gradient instantiations, which never drop: the fp32 stream-K data gradient's
+//          MFMA loop picked up scratch reloads when the round-6 generator made that dead section larger)
+template <int TM, int TN, int ROWS, bool YBF, bool ADJ = false, typename RM = PixelRows, bool DROP = true>
 __device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 (&acc)[TM][TN], float *stage, int lane,
                                                int row0, int col0, float *slab, RM rm = RM()) {
     constexpr int WN = TN * 32;
@@ -236,15 +254,17 @@ __device__ __forceinline__ void store_acc_tile(const IgemmArgs &a, const f32x16 
                 if (a.epi == EMADAPT_EPI_BIAS_RELU) {
 #pragma unroll
                     for (int e = 0; e < 8; e++) v[e] = relu_keep_nan(v[e]);
-                    if (a.keep < 1.0f) {
+                    if (DROP && a.keep < 1.0f) {
 #pragma unroll
-                        for (int e = 0; e < 8; e += 2) {   // (o is a multiple of 4: (o + e, o + e + 1) is a pair of the generator)
+                        for (int e = 0; e < 8; e += 4) {   // (o is a multiple of 4: o + e .. o + e + 3 is a quad of the generator)
                             if (e >= 4 && !hi) break;
-                            bool k0, k1;
-                            if (a.mask) { k0 = a.mask[o + e] != 0; k1 = a.mask[o + e + 1] != 0; }
-                            else dropout_keep2(a.seed, (unsigned long long)(o + e), a.keep, k0, k1);
-                            v[e] = k0 ? drop_scale(a, v[e]) : 0.f;
-                            v[e + 1] = k1 ? drop_scale(a, v[e + 1]) : 0.f;
+                            bool k[4];
+                            if (a.mask) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) k[q] = a.mask[o + e + q] != 0;
+                            } else dropout_keep4(a, (unsigned long long)(o + e), k);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) v[e + q] = k[q] ? drop_scale(a, v[e + q]) : 0.f;
                         }
                     }
                 }

@@ -520,10 +520,10 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
         // ring is dead after the last barrier
         static_assert(CONS * 16 * (128 + 4) <= NBUF * (A_BUF + B_BUF), "epilogue slabs must fit in the ring");
         if (packed)
-            store_acc_tile<TM, TN, 16, false, false, MapRows>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128,
-                                                              slab_, MapRows{a.pk.rowmap});
+            store_acc_tile<TM, TN, 16, false, false, MapRows, false>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128,
+                                                                     slab_, MapRows{a.pk.rowmap});
         else
-            store_acc_tile<TM, TN, 16, false>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+            store_acc_tile<TM, TN, 16, false, false, PixelRows, false>(a, acc, lds + wave * (16 * (128 + 4)), lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
     } else if constexpr (SK) {
         // (forward, stream-K: the same staged epilogue with the adjacent-column mapping -- inside the piece loop the direct
         // form below made the compiler spill operand fragments in the MFMA loop)
@@ -559,13 +559,14 @@ __global__ void __launch_bounds__((WMW * WNW + PW) * 64, 3) igemm2_kernel(IgemmA
                         if (a.keep < 1.0f) {
                             unsigned mk = 0;
                             if (a.mask) mk = *reinterpret_cast<const unsigned *>(a.mask + o);   // four keep bytes (o % 4 == 0)
+                            {   // (o % 4 == 0: o .. o + 3 is a quad of the generator)
+                                bool k[4];
+                                if (a.mask) {
 #pragma unroll
-                            for (int e = 0; e < 4; e += 2) {   // (o % 4 == 0: (o + e, o + e + 1) is a pair of the generator)
-                                bool k0, k1;
-                                if (a.mask) { k0 = ((mk >> (8 * e)) & 0xFFu) != 0; k1 = ((mk >> (8 * e + 8)) & 0xFFu) != 0; }
-                                else dropout_keep2(a.seed, (unsigned long long)(o + e), a.keep, k0, k1);
-                                v[e] = k0 ? drop_scale(a, v[e]) : 0.f;
-                                v[e + 1] = k1 ? drop_scale(a, v[e + 1]) : 0.f;
+                                    for (int e = 0; e < 4; e++) k[e] = ((mk >> (8 * e)) & 0xFFu) != 0;
+                                } else dropout_keep4(a, (unsigned long long)o, k);
+#pragma unroll
+                                for (int e = 0; e < 4; e++) v[e] = k[e] ? drop_scale(a, v[e]) : 0.f;
                             }
                         }
                     }

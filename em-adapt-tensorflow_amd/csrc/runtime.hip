@@ -26,7 +26,7 @@ std::vector<ProfRec *> g_prof_free;
 namespace {
 std::atomic<int> g_tune[TUNE_COUNT];
 const char *const kTuneNames[TUNE_COUNT] = {"fp32_tile", "wgrad_gen", "splitk", "bf16_tile", "x6_tile", "plan_cus", "fp32_loader",
-                                            "pack_pct", "estep_stop", "ablate", "dma_stagger", "raster_gm", "wgrad_bias", "sk_drop_flag", "bf16t_sk", "pool_rows", "wgrad_combine"};
+                                            "pack_pct", "estep_stop", "ablate", "dma_stagger", "raster_gm", "wgrad_bias", "sk_drop_flag", "bf16t_sk", "pool_rows"};
 std::mutex g_attr_mu;
 }  // namespace
 

@@ -23,15 +23,6 @@
 //   * DMA waves: per step 4 + 4 instructions each; the pixel -> (row, column) arithmetic of the gather (two multiply-high divisions
 //     per instruction) is theirs.  Pixels past the split's end and taps outside the image carry the out-of-range bit: zeros.
 //   * split-M exactly as the round-1 kernel (fp32 partial filter tiles, summed in a fixed order by slab_sum): bit-reproducible.
-//   * round 6: the partials are combined INSIDE the launch when the launch's workgroups are all resident at once (a.arrive; host:
-//     wgrad_combines) -- the slab_sum launch behind every split-M filter gradient read 7 x 9.4 MB and wrote 9.4 MB per conv4 / conv5
-//     layer on a cold start, 0.2 ms per step.  Every workgroup publishes its partial tile (and bias row) to its slab with
-//     write-through (sc1) stores, drains them, and after a workgroup barrier one lane counts it in at the tile's arrival word
-//     (relaxed, agent scope) -- the hand-off igemm_v2.h's stream-K combine uses.  Then the S workgroups of a tile, which all wait for
-//     the S-th arrival, each add up 1 / S of the tile's rows over the S slabs (sc1 loads) in slab_sum's order -- four chains over
-//     slabs g, g + 4, ..., then (c0 + c1) + (c2 + c3) -- so the gradient is bit for bit what the second launch produced.  The bias rows
-//     are summed likewise by the LAST workgroup to arrive at the column tile's word.  The wait is bounded (kSkSpinMax): a workgroup
-//     that never arrives leaves NaNs in the waiter's share and EMADAPT_STATUS_STREAMK_TIMEOUT in the status word.
 // Requirements: x and dy stored bf16, Cin % 256 == 0 (conv3_2 .. fc7), Cout % 8 == 0.
 #pragma once
 
@@ -81,7 +72,6 @@ __global__ void __launch_bounds__(WT_THREADS, 3) wgrad_b16t_kernel(WgradBf16Args
     if (m_end > a.M) m_end = a.M;
     const int nsteps = (m_end > m_begin) ? (m_end - m_begin + WT_PX - 1) / WT_PX : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool combine = a.arrive != nullptr;   // (host: splits > 1 and every workgroup resident at once)
 
     if (wave >= 8) {
         // ======================================= DMA waves =======================================
@@ -179,22 +169,9 @@ __global__ void __launch_bounds__(WT_THREADS, 3) wgrad_b16t_kernel(WgradBf16Args
             const int col = n0 + bchunk * 8;
             if (lane < 8 && col < a.N) {
                 float *bo = a.bias_out + ((long long)split * a.tiles_k + tile_k) * a.N + col;
-                if (combine) {   // (published to the other workgroups: write-through)
-                    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(bo, 0, 32, 0x00020000);
-                    u32x4 v0, v1;
-                    v0.x = __float_as_uint(bs[0]); v0.y = __float_as_uint(bs[1]); v0.z = __float_as_uint(bs[2]); v0.w = __float_as_uint(bs[3]);
-                    v1.x = __float_as_uint(bs[4]); v1.y = __float_as_uint(bs[5]); v1.z = __float_as_uint(bs[6]); v1.w = __float_as_uint(bs[7]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v0, br, 0, 0, 16);
-                    __builtin_amdgcn_raw_buffer_store_b128(v1, br, 16, 0, 16);
-                } else {
-                    *reinterpret_cast<float4 *>(bo) = make_float4(bs[0], bs[1], bs[2], bs[3]);
-                    *reinterpret_cast<float4 *>(bo + 4) = make_float4(bs[4], bs[5], bs[6], bs[7]);
-                }
+                *reinterpret_cast<float4 *>(bo) = make_float4(bs[0], bs[1], bs[2], bs[3]);
+                *reinterpret_cast<float4 *>(bo + 4) = make_float4(bs[4], bs[5], bs[6], bs[7]);
             }
-        }
-        if (combine) {
-            wait_vmcnt<0>();                  // the bias row has left
-            __builtin_amdgcn_s_barrier();     // pairs with the MFMA waves' barrier in front of the arrival count
         }
         return;
     }
@@ -257,139 +234,18 @@ __global__ void __launch_bounds__(WT_THREADS, 3) wgrad_b16t_kernel(WgradBf16Args
 #undef WT_SB
     // ---- the fp32 tile (or this split's partial tile): C/D layout of the 16 x 16 MFMA -- column = lane & 15, row = 4 (lane >> 4) + r
     float *out = a.out + (long long)split * a.K * a.N;
-    // (everything the epilogue derives from the thread index is derived HERE, from a copy the compiler cannot trace back across the
-    // MFMA loop: values kept alive over the loop for the longer round-6 epilogue cost it five registers it does not have -- an
-    // accumulator tile was spilled and reloaded inside the loop)
-    int tid_e = threadIdx.x;
-    asm volatile("" : "+v"(tid_e));
-    const int lane_e = tid_e & 63, wave_e = __builtin_amdgcn_readfirstlane(tid_e >> 6);
-    const int wm_e = wave_e & 3, wn_e = wave_e >> 2;
-    const int l15 = lane_e & 15, lq = lane_e >> 4;
-    if (!combine) {
+    const int l15 = lane & 15, lq = lane >> 4;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int col = n0 + wn_e * 128 + j * 16 + l15;
+        for (int j = 0; j < 8; j++) {
+            const int col = n0 + wn * 128 + j * 16 + l15;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = k0 + wm_e * 64 + i * 16 + 4 * lq + r;
-                    if (col < a.N && row < a.K) out[(long long)row * a.N + col] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-    // ---- in-launch combine (see the header): publish, count in, wait for the tile's S arrivals, add up this workgroup's rows
-    const unsigned slab_bytes = (unsigned)((long long)a.K * a.N * 4);   // (host: K * N * 4 < 2^31)
-    {
-        const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)slab_bytes, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int col = n0 + wn_e * 128 + j * 16 + l15;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = k0 + wm_e * 64 + i * 16 + 4 * lq + r;
-                    const unsigned off = (col < a.N && row < a.K) ? (unsigned)(((long long)row * a.N + col) * 4) : 0x80000000u;   // (out of range: dropped)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), sr, (int)off, 0, 16);   // aux 16 = sc1
-                }
-            }
-        wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();   // all twelve waves: every store of the workgroup (partial tile, bias row) has been drained
-    unsigned *lds_u = reinterpret_cast<unsigned *>(ldsb);   // (the ring is dead: every wave is past its last stage)
-    const int S = a.splits;
-    const int tile = tile_k * a.tiles_n + tile_n;
-    if (tid_e == 0) {
-        unsigned last_b = 0u;
-        if (!a.drop_flag) {
-            __hip_atomic_fetch_add(((sk_flag_t *)a.arrive) + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.db) {
-                const unsigned old = __hip_atomic_fetch_add(((sk_flag_t *)a.arrive) + a.tiles_k * a.tiles_n + tile_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last_b = old == (unsigned)(a.tiles_k * S - 1) ? 1u : 0u;
+            for (int r = 0; r < 4; r++) {
+                const int row = k0 + wm * 64 + i * 16 + 4 * lq + r;
+                if (col < a.N && row < a.K) out[(long long)row * a.N + col] = acc[i][j][r];
             }
         }
-        bool ok = false;
-        const sk_flag_t *f = ((const sk_flag_t *)a.arrive) + tile;
-        for (unsigned spins = 0; spins < (a.drop_flag ? (1u << 12) : kSkSpinMax); spins++) {
-            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)S) { ok = true; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        lds_u[0] = ok ? 1u : 0u;
-        lds_u[1] = last_b;
-    }
-    // (MFMA waves only from here on: the DMA waves end behind the barrier above, and ended waves do not count at a barrier)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    const bool ok = lds_u[0] != 0u, last_b = lds_u[1] != 0u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the sc1 loads below the poll)
-    {
-        // rows [r_lo, r_hi) of the tile are this workgroup's: 64 float4 per row, slab_sum's order per element
-        const int r_lo = split * 256 / S, r_hi = (split + 1) * 256 / S;
-        const int nf4 = (r_hi - r_lo) * 64;
-        for (int f4 = tid_e; f4 < nf4; f4 += 512) {
-            const int row = k0 + r_lo + (f4 >> 6), col = n0 + (f4 & 63) * 4;
-            if (row >= a.K || col >= a.N) continue;
-            const unsigned off = (unsigned)(((long long)row * a.N + col) * 4);
-            float4 c[4];
-#pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) c[g4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < S; k += 4) {
-                u32x4 v[4];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    // (slabs past the last: a zero-length resource returns zeros, and the add below is skipped anyway)
-                    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(a.out + (long long)(k + g4 < S ? k + g4 : 0) * a.K * a.N, 0,
-                                                                                         k + g4 < S ? (int)slab_bytes : 0, 0x00020000);
-                    v[g4] = __builtin_amdgcn_raw_buffer_load_b128(sr, (int)off, 0, 16);   // sc1
-                }
-#pragma unroll
-                for (int g4 = 0; g4 < 4; g4++)
-                    if (k + g4 < S) {
-                        c[g4].x += __uint_as_float(v[g4].x); c[g4].y += __uint_as_float(v[g4].y);
-                        c[g4].z += __uint_as_float(v[g4].z); c[g4].w += __uint_as_float(v[g4].w);
-                    }
-            }
-            float4 r4;
-            r4.x = (c[0].x + c[1].x) + (c[2].x + c[3].x);
-            r4.y = (c[0].y + c[1].y) + (c[2].y + c[3].y);
-            r4.z = (c[0].z + c[1].z) + (c[2].z + c[3].z);
-            r4.w = (c[0].w + c[1].w) + (c[2].w + c[3].w);
-            if (!ok) r4 = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-            *reinterpret_cast<float4 *>(a.dw + (long long)row * a.N + col) = r4;
-        }
-    }
-    if (last_b) {
-        // the last workgroup at the column tile's word: every bias row of these columns is out -- [splits * tiles_k] rows of N, summed
-        // in slab_sum's order (four chains of rows g, g + 4, ...; then (c0 + c1) + (c2 + c3)) by 4 x 64 threads
-        float4 *sh = reinterpret_cast<float4 *>(ldsb + 64);
-        const int g4 = tid_e >> 6, tx = tid_e & 63;
-        const int rows = S * a.tiles_k, col = n0 + tx * 4;
-        if (tid_e < 256) {
-            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col < a.N) {
-                const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(a.bias_out, 0, rows * a.N * 4, 0x00020000);
-                for (int k = g4; k < rows; k += 4) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(br, (k * a.N + col) * 4, 0, 16);   // sc1
-                    c.x += __uint_as_float(v.x); c.y += __uint_as_float(v.y); c.z += __uint_as_float(v.z); c.w += __uint_as_float(v.w);
-                }
-            }
-            sh[g4 * 64 + tx] = c;
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (tid_e < 64 && col < a.N) {
-            const float4 c0 = sh[tx], c1 = sh[64 + tx], c2 = sh[128 + tx], c3 = sh[192 + tx];
-            float4 r4;
-            r4.x = (c0.x + c1.x) + (c2.x + c3.x);
-            r4.y = (c0.y + c1.y) + (c2.y + c3.y);
-            r4.z = (c0.z + c1.z) + (c2.z + c3.z);
-            r4.w = (c0.w + c1.w) + (c2.w + c3.w);
-            *reinterpret_cast<float4 *>(a.db + col) = r4;
-        }
-    }
-    if (!ok && a.status && lane_e == 0) __hip_atomic_fetch_or(a.status, EMADAPT_STATUS_STREAMK_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 inline bool wgrad_b16t_ok(const emadapt_conv_desc *d, int x_bf16, int dy_bf16) {

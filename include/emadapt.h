@@ -67,7 +67,7 @@ extern "C" {
  *        gradient runs by 2 x 2 pixel quads (same results).  emadapt_sgd_accumulate_momentum_tiles (+ _supported) and
  *        emadapt_sgd_momentum_payload_tiles: the optimizer pass of a layer that also writes the layer's two tiled bf16 filter images; emadapt_sgd_accumulate_momentum_multi: the pass
  *        over several layers' segments in one launch; emadapt_weights_to_bf16_multi: several filters' bf16 images in one launch.
- *   206  round 6, added: emadapt_voc_preprocess (the input pipeline of a batch in one launch), emadapt_host_register / _unregister / emadapt_memcpy_h2d_async; tune "wgrad_combine" (the bf16 split-M filter gradients combine their partials inside the launch: no signature changed, emadapt_conv_wgrad[_bias]_bf16_workspace_bytes grew by the arrival words); emadapt_status_raise; emadapt_status_collective (data-parallel jobs: the failure travels with the exchanged gradient instead of
+ *   206  round 6, added: emadapt_voc_preprocess (the input pipeline of a batch in one launch), emadapt_host_register / _unregister / emadapt_memcpy_h2d_async; emadapt_status_raise; emadapt_status_collective (data-parallel jobs: the failure travels with the exchanged gradient instead of
  *        being decided from each rank's own word), EMADAPT_STATUS_NAN_GRADIENT. */
 #define EMADAPT_ABI_VERSION 206
 int emadapt_version(void);
@@ -563,9 +563,6 @@ int emadapt_sgd_accumulate_pack(const float *g, const float *w, int64_t n, int64
  *   "x6_tile"    128 | 256
  *   "pool_rows"  1: emadapt_maxpool_bwd[_dt] at stride 2 runs its row form (one thread per pixel) instead of 2 x 2 pixel quads
  *                (ABI 205; same results bit for bit)
- *   "wgrad_combine" 1: emadapt_conv_wgrad[_bias]_bf16 never combine their split-M partials inside the launch (the second-stage sum
- *                runs as a launch of its own, as up to ABI 205); default: combined in the launch where the launch's workgroups are
- *                all resident at once and the LDS-DMA kernel takes the shape (ABI 206; same results bit for bit)
  *   "plan_cus"  number of CUs the launch plans are laid out for (default 256: MI355X)
  *   "fp32_loader" 1: the 256x256 fp32 kernels' loader waves compute their offsets per K step (works for any tap count);
  *                0: loaders specialised for 1x1 / 3x3 / 4x4 filters where the filter has that many taps, and the

@@ -10,7 +10,8 @@ cp em-adapt-tensorflow_amd/libemadapt_hip.so /tmp/lib_keep.so
 for i in 1 2; do
   for L in "$A" "$B"; do
     cp "$L" em-adapt-tensorflow_amd/libemadapt_hip.so
-    timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-alt --steps 12 --warmup 4 "$@" 2>/dev/null | grep '"metric"' > gpurun_out/ab_line.json
+    extra=""; [ "$L" = "$A" ] && extra="$AB_A_FLAGS"   # (flags only the first library understands, e.g. a tune key it alone has)
+    timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-alt --steps ${AB_STEPS:-12} --warmup 4 $extra "$@" 2>/dev/null | grep '"metric"' > gpurun_out/ab_line.json
     python3 - "$L" <<'PY' >> $O
 import json, sys
 d = json.loads(open("gpurun_out/ab_line.json").read())

@@ -470,66 +470,6 @@ def test_bf16_wgrad_on_lds_dma(env, shape, cus):
     assert _rel(new.cpu(), old.cpu()) < 2e-5
 
 
-# split-M partials combined INSIDE the launch (round 6, csrc/wgrad_b16t.h): every shape above whose plan has more than one split, the
-# batch-16 shapes of the model's nine split-M layers (conv3_2 .. conv5_3: 252 workgroups = 9 x 28, 18 x 14, 36 x 7 tiles x splits),
-# a Cout tail across two n tiles, more splits than rows of a chain
-WGRAD_COMBINE = [(s, c) for s, c in WGRAD_T] + [
-    ((16, 41, 41, 512, 512, 3, 1), 256),    # conv4_2 / conv4_3
-    ((16, 41, 41, 512, 512, 3, 2), 256),    # conv5_x
-    ((16, 41, 41, 256, 512, 3, 1), 256),    # conv4_1
-    ((16, 81, 81, 256, 256, 3, 1), 256),    # conv3_2 / conv3_3: 28 splits
-    ((4, 23, 29, 256, 264, 1, 1), 250),     # 2 n tiles (one 8 wide) x many splits
-]
-
-
-@pytest.mark.parametrize("shape,cus", WGRAD_COMBINE)
-def test_bf16_wgrad_combines_its_split_m_partials_inside_the_launch(env, shape, cus):
-    """The workgroups of a filter tile add up their partial tiles themselves (arrival word per tile, each workgroup 1 / S of the rows,
-    slab_sum's order) and the last workgroup at a column tile's word adds up the bias rows: filter gradient AND bias gradient equal
-    the slab_sum path's (tune wgrad_combine = 1: the second launch) bit for bit, repeatably, and the status word stays clean."""
-    ops, do, torch = env
-    B, H, W, Cin, Cout, k, dil = shape
-    g = torch.Generator(device="cuda").manual_seed(B * 1000 + H * 10 + Cout)
-    xg = torch.randn((B, H, W, Cin), device="cuda", generator=g).bfloat16()
-    dyg = (torch.randn((B, H, W, Cout), device="cuda", generator=g) + 0.25).bfloat16()
-    assert ops.status_poll(clear=True, raise_on_error=False) == 0
-    with ops.tuned(plan_cus=cus, bf16_tile=256):
-        splits = ops.conv_bf16_plan(B, H, W, Cin, Cout, k, dil, "wgrad")[2]
-        with ops.tuned(wgrad_combine=1):
-            db0 = torch.full((Cout,), float("nan"), device="cuda")
-            dw0 = ops.conv_wgrad_bf16(xg, dyg, k, k, dil, bias_out=db0)
-            plain0 = ops.conv_wgrad_bf16(xg, dyg, k, k, dil)
-        for _ in range(3):
-            db1 = torch.full((Cout,), float("nan"), device="cuda")
-            dw1 = torch.full((k, k, Cin, Cout), float("nan"), device="cuda")
-            ops.conv_wgrad_bf16(xg, dyg, k, k, dil, out=dw1, bias_out=db1)
-            assert torch.equal(dw1, dw0) and torch.equal(db1, db0), (shape, splits)
-        assert torch.equal(ops.conv_wgrad_bf16(xg, dyg, k, k, dil), plain0)          # (without the bias gradient)
-    assert ops.status_poll(clear=True, raise_on_error=False) == 0
-    assert bool(torch.isfinite(dw0).all()) and _rel(db0.cpu().double(), dyg.double().sum(dim=(0, 1, 2)).cpu()) < 1e-5
-
-
-@pytest.mark.timeout(120)
-def test_bf16_wgrad_combine_wait_is_bounded_and_visible(env):
-    """A workgroup that never arrives at its tile's word (tune sk_drop_flag: nobody counts in, the waits give up early) must not hang
-    the queue: the launch ends, the gradient holds NaNs, the status word carries STATUS_STREAMK_TIMEOUT; the next launch is clean."""
-    ops, do, torch = env
-    B, H, W, Cin, Cout, k, dil = 3, 41, 41, 512, 512, 3, 1
-    g = torch.Generator(device="cuda").manual_seed(3)
-    xg = torch.randn((B, H, W, Cin), device="cuda", generator=g).bfloat16()
-    dyg = torch.randn((B, H, W, Cout), device="cuda", generator=g).bfloat16()
-    assert ops.conv_bf16_plan(B, H, W, Cin, Cout, k, dil, "wgrad")[2] > 1
-    assert ops.status_poll(clear=True, raise_on_error=False) == 0
-    good = ops.conv_wgrad_bf16(xg, dyg, k, k, dil)
-    with ops.tuned(sk_drop_flag=1):
-        bad = ops.conv_wgrad_bf16(xg, dyg, k, k, dil)
-        torch.cuda.synchronize()
-    assert bool(torch.isnan(bad).all())
-    assert ops.status_poll(clear=True, raise_on_error=False) == ops.STATUS_STREAMK_TIMEOUT
-    assert torch.equal(ops.conv_wgrad_bf16(xg, dyg, k, k, dil), good)
-    assert ops.status_poll(clear=True, raise_on_error=False) == 0
-
-
 # the bias gradient inside the filter-gradient launch (emadapt_conv_wgrad_bias_bf16): both kernel families, one split and many, column
 # tails, the narrow tiles whose loader lanes share columns (64 / 128 wide), fc8's 24 columns
 WGRAD_BIAS = WGRAD_T + [
