@@ -162,7 +162,6 @@ __global__ void __launch_bounds__(256) splitk_epilogue_t_kernel(IgemmArgs a) {
 }  // namespace
 
 #include "igemm_b16t.h"   // the LDS-DMA kernel for bf16-stored activations (uses epilogue_t / cvt4 / splitk_epilogue_t_kernel above)
-#include "conv_p3.h"      // the patch kernel for the 3 x 3 layers with 128 and fewer output columns
 #include "conv_d64.h"     // direct 3 x 3 convolution, 64 -> 64 channels, the filter in registers (conv1_2)
 #include "conv_d4.h"      // direct 3 x 3 convolution of the 4-channel f32 image into 64 bf16 channels (conv1_1 forward)
 #include "conv_k32.h"     // 1 x 1 convolution with at most 32 gathered channels, operands straight from memory (fc8's data gradient)
@@ -420,7 +419,7 @@ struct PlanG {
 
 PlanG plan_bf16(const IgemmArgs &a) {
     int force = tune(TUNE_BF16_TILE);  // 128|256 forces a configuration (the parity tests run both on small shapes)
-    if (force == 1 || force == 3) force = 0;   // (1: automatic without the patch kernel; 3: the patch kernel where eligible -- both: this plan elsewhere)
+    if (force == 1 || force == 3) force = 0;   // (1: the automatic plan with the direct kernels off; 3: round 5's patch kernel, deleted in round 6 -- the automatic plan)
     PlanG p;
     const long long t256 = ceil_div(a.M, 256) * ceil_div(a.N, 256);
     p.big = (a.N >= 256 && t256 >= 192) ? 1 : 0;
@@ -460,10 +459,9 @@ int launch_igemm_bf16(IgemmArgs &a, int Cxp, hipStream_t stream) {
 
 template <bool XBF, bool YBF>
 int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace_bytes, hipStream_t stream) {
-    // 3 x 3 layers with N <= 128 on bf16-stored activations: the patch kernel (conv_p3.h), OPT-IN (tune "bf16_tile" = 3): measured in the
-    // step it is 0.5 % behind the implicit-GEMM kernels it would replace (profiles/r05_p3_patch_kernel.txt: per layer 9 - 11 % ahead in
-    // isolation, but a K step of these layers is 16 - 32 MFMAs and the step-wise barrier of eight waves, the DMA issue rate and the
-    // per-tile epilogue each cost as much as the MFMAs)
+    // (round 5 carried an opt-in patch kernel for the 3 x 3 layers with N <= 128, conv_p3.h: 3 - 10 % ahead per layer in an isolated loop,
+    // a tie in the step.  Round 6's in-step trace has it 3.6 % BEHIND on the four conv2 launches it would take -- the isolated loop ran on
+    // operands resident in the Infinity Cache -- profiles/r06_p3_in_step.txt; deleted.)
     if constexpr (XBF && YBF) {   // fc8's data gradient (1 x 1, 24 gathered channels): one MFMA step, nothing staged
         if (tune(TUNE_BF16_TILE) == 0 && k32_shape_ok(a) && !a.bias && a.epi == EMADAPT_EPI_NONE) return launch_k32(a, stream);
     }
@@ -476,14 +474,6 @@ int dispatch_igemm_bf16(IgemmArgs &a, int Cxp, void *workspace, size_t workspace
     }
     if constexpr (!XBF && YBF) {   // conv1_1 (the 4-channel f32 image -> 64 bf16 channels, 3 x 3): the direct kernel, unless a tile is forced
         if (tune(TUNE_BF16_TILE) == 0 && d4_shape_ok(a) && !a.gate && !(a.epi == EMADAPT_EPI_BIAS_RELU && (a.keep < 1.0f || a.mask))) return launch_d4(a, stream);
-    }
-    if constexpr (XBF) {
-        const int force = tune(TUNE_BF16_TILE);
-        if (force == 3 && p3_ok(a, true)) {
-            a.m_begin = 0;
-            a.m_end = a.M;
-            return launch_p3<YBF>(a, Cxp, stream);
-        }
     }
     PlanG p = plan_bf16(a);
     if (p.splits > 1 && (!workspace || workspace_bytes < igemm_bf16_workspace_bytes(a))) p.splits = 1;
@@ -1026,12 +1016,6 @@ int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]) {
     }
     if (tune(TUNE_BF16_TILE) == 0 && d->B > 0 && kind == 0 && d4_shape_ok(a)) {   // (the f32 image in, bf16 out: conv1_1 as the model runs it)
         plan[0] = 5; plan[1] = 16; plan[2] = 16;
-        return EMADAPT_OK;
-    }
-    if (tune(TUNE_BF16_TILE) == 3 && d->B > 0 && p3_ok(a, true)) {   // (opt-in; bf16-stored activations assumed: what the model keeps)
-        P3Geo g;
-        p3_geometry(d->B, d->H, d->W, d->dil, g);
-        plan[0] = 3; plan[1] = g.TH; plan[2] = g.TW;
         return EMADAPT_OK;
     }
     const PlanG p = plan_bf16(a);

@@ -325,11 +325,7 @@ int emadapt_conv_wgrad_bias_bf16(const emadapt_conv_desc *d, const void *x, int 
 /* The plan a bf16 launch will take for this shape (kind 0 forward, 1 data gradient, 2 filter gradient): plan[0] x plan[1] = the
  * output tile (forward / data gradient: pixels x channels, 256 x 256 or 128 x 128; filter gradient: filter rows x columns),
  * plan[2] = split-K / split-M factor.  The parity tests assert through it that the benchmark shapes run the big tiles.  (ABI 200)
- * ABI 203: with tune "bf16_tile" = 3 (opt-in) plan[0] == 3 for forward / data gradient = the PATCH kernel (csrc/conv_p3.h: 3 x 3
- * filters, rate 1 or 2, at most 128 output columns, gathered channels a multiple of 32, bf16-stored activations -- conv1_2, conv2_x
- * and the data gradients into 64 / 128 channels): the input patch of a plan[1] x plan[2]-pixel output tile is staged in LDS once per
- * 32 channels and read by all nine taps (the implicit-GEMM kernels fetch every activation nine times); same arithmetic model, same
- * epilogues, bitwise reproducible.  Not the default: it ties the implicit-GEMM kernels in the step.
+ * (ABI 203-205 carried an opt-in patch kernel, tune "bf16_tile" = 3 -> plan[0] == 3; deleted in ABI 206: the key value is accepted and ignored.)
  * ABI 204: plan[0] == 4 (forward / data gradient, automatic -- any forced "bf16_tile" switches it off) = the DIRECT kernel
  * (csrc/conv_d64.h) for 3 x 3, rate 1, 64 -> 64 channels on bf16-stored tensors without dropout (conv1_2): plan[1] x plan[2] = its
  * output tile in pixels; the filter stays in registers / LDS for the whole launch, the input patch of a tile is fetched once.
@@ -555,8 +551,8 @@ int emadapt_sgd_accumulate_pack(const float *g, const float *w, int64_t n, int64
  *                A forced variant the shape is not eligible for is ignored.
  *   "wgrad_gen"  1: 128x128 wave-specialised filter-gradient kernel | 2: 256x256 second generation (LDS-DMA loaders)
  *   "splitk"     split-K factor of the forward / data-gradient launches (ignored when K is too short)
- *   "bf16_tile"  128 | 256 (emadapt_conv_*_bf16: 128 also keeps the 128-wide tile where 128 x 64 would be chosen); 3: the patch kernel
- *                (csrc/conv_p3.h) for the 3 x 3 layers with at most 128 output columns on bf16-stored activations, automatic elsewhere
+ *   "bf16_tile"  128 | 256 (emadapt_conv_*_bf16: 128 also keeps the 128-wide tile where 128 x 64 would be chosen); 1: the automatic plan
+ *                of the implicit-GEMM kernels with the direct kernels (plan[0] 4 / 5 / 6) switched off: the A/B of those kernels
  *   "bf16t_sk"   1: the tiled-filter bf16 launches (emadapt_conv_*_bf16t) run ALL their tiles as one stream-K launch (A/B aid: measured
  *                slower on fc6 / fc7, profiles/r05_bf16t_bench.txt) | 2: four and more rounds of tiles as whole rounds of plain tiles +
  *                a stream-K launch over the last partial round (rounds 4-5; the default is plain tiles all the way there: fc7 -4 %)

@@ -196,65 +196,6 @@ def test_bf16_wgrad_split_m_is_deterministic_and_right(env):
     assert _rel(a, wt.grad) < 2e-5
 
 
-# (B, H, W, Cin, Cout, dil), plan_cus: the OPT-IN patch kernel (csrc/conv_p3.h, tune bf16_tile = 3) takes 3 x 3 layers with <= 128 output
-# columns on bf16-stored activations.  Maps smaller and larger than a tile, ragged tile rows / columns, 1 .. 4 channel groups, N = 8 .. 128 (4 and 8 B
-# fragments per step, filter rows past N), rate 2, several tiles per workgroup (plan_cus small: the persistent loop, the patch and
-# filter streams running across tile boundaries) and one tile only
-PATCH = [
-    ((1, 5, 5, 32, 8, 1), 256),
-    ((2, 23, 29, 32, 64, 1), 256),
-    ((1, 40, 33, 64, 128, 2), 3),
-    ((3, 17, 50, 96, 40, 1), 2),
-    ((1, 70, 9, 128, 96, 1), 5),
-    ((2, 16, 16, 64, 64, 2), 1),
-    ((1, 64, 64, 64, 64, 1), 4),
-    ((2, 33, 47, 128, 128, 1), 7),
-]
-
-
-@pytest.mark.parametrize("shape,cus", PATCH)
-def test_bf16_patch_kernel(env, shape, cus):
-    ops, do, torch = env
-    B, H, W, Cin, Cout, dil = shape
-    k = 3
-    rng = np.random.default_rng(hash(shape) % (1 << 31))
-    x = torch.tensor(rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)).bfloat16()
-    w = torch.tensor(rng.normal(0, 0.2, (k, k, Cin, Cout)).astype(np.float32))
-    b = torch.tensor(rng.normal(0, 0.5, (Cout,)).astype(np.float32))
-    mask = torch.tensor((rng.random((B, H, W, Cout)) < 0.5).astype(np.uint8))
-    xr = x.double().requires_grad_(True)
-    y = do.conv_same(xr, w.bfloat16().double(), b.double(), dil)
-    xg, wg, bg, mg = x.cuda(), w.cuda(), b.cuda(), mask.cuda()
-    wf, wd = ops.weights_to_bf16(wg)
-    with ops.tuned(plan_cus=cus, bf16_tile=3):
-        assert ops.conv_bf16_plan(B, H, W, Cin, Cout, k, dil)[0] == 3
-        got = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=False, out_dtype=torch.float32)
-        assert _rel(got.cpu(), y.detach()) < 2e-5
-        assert torch.equal(got, ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=False, out_dtype=torch.float32))
-        assert _rel(ops.conv_fwd_bf16(xg, wf, (k, k), None, dil, out_dtype=torch.float32).cpu(), (y - b.double()).detach()) < 2e-5
-        want = torch.relu(y.detach()) * 2.0 * mask.double()
-        got = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=True, keep_prob=0.5, drop_mask=mg, out_dtype=torch.float32)
-        assert _rel(got.cpu(), want) < 2e-5
-        assert torch.equal(ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=True, keep_prob=0.5, drop_mask=mg, out_dtype=torch.bfloat16), got.bfloat16())
-        with ops.tuned(bf16_tile=128):   # the implicit-GEMM kernel: the same function, another order of the fp32 sums
-            old = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, relu=True, keep_prob=0.5, drop_mask=mg, out_dtype=torch.float32)
-        assert _rel(got.cpu(), old.cpu()) < 2e-5
-    if Cout % 32 == 0:   # the data gradient gathers dy's Cout channels and writes Cin <= 128 columns
-        dy = torch.tensor(rng.normal(0, 1, (B, H, W, Cout)).astype(np.float32)).bfloat16()
-        gate = torch.tensor(rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)).bfloat16()
-        y.backward(dy.double())
-        dyg, gg = dy.cuda(), gate.cuda()
-        with ops.tuned(plan_cus=cus, bf16_tile=3):
-            assert ops.conv_bf16_plan(B, H, W, Cin, Cout, k, dil, "dgrad")[0] == 3
-            got = ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, out_dtype=torch.float32)
-            assert _rel(got.cpu(), xr.grad) < 2e-5
-            want = torch.where(gate.double() > 0, xr.grad * 2.0, torch.zeros((), dtype=torch.float64))
-            g32 = ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=gg.float(), gate_scale=2.0)
-            assert g32.dtype == torch.float32 and _rel(g32.cpu(), want) < 2e-5
-            assert torch.equal(g32, ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=gg.float(), gate_scale=2.0))
-            assert torch.equal(ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=gg, gate_scale=2.0), g32.bfloat16())
-
-
 # (B, H, W), plan_cus: the direct kernel for 3 x 3, 64 -> 64 channels on bf16-stored tensors (csrc/conv_d64.h: conv1_2) -- maps smaller than
 # a 16 x 16 tile, ragged tile rows / columns, several tiles per workgroup (plan_cus small: both patch buffers, the persistent loop), one
 # workgroup with an odd number of tiles, more workgroups than tiles never happens (the grid is min(tiles, CUs))
