@@ -77,9 +77,10 @@ def parse():
                     help="rehearsal: initialise torch.distributed and the gradient exchange even with one rank")
     ap.add_argument("--overlap-trace", action="store_true",
                     help="N > 1: add per-bucket launch offsets / join stalls of the last update's gradient exchange")
-    ap.add_argument("--bucket-mb", type=int, default=32,
-                    help="gradient all-reduce bucket size; the LAST bucket (conv1..conv4 gradients) only leaves when backward ends, "
-                         "so it is what stays exposed: 32 MB buckets keep it small at 8 collectives per update")
+    ap.add_argument("--bucket-mb", type=int, default=0,
+                    help="gradient exchange bucket size in MB; 0 (default) = the library's plan: 32 MB buckets for the ring all-reduce (the LAST "
+                         "bucket only leaves when backward ends, so it is what stays exposed), two buckets for the direct exchange -- fc8 + fc7 + "
+                         "fc6 (77 %% of the bytes, final a third of the way into backward) and the convolutions")
     ap.add_argument("--release-at", default="none",
                     help="N > 1: layer of the backward pass at which the gradient all-reduces may start; \"none\" (default, as in "
                          "the library) = each bucket as soon as it is complete.  E.g. conv2_2 holds everything back until the "
@@ -556,7 +557,7 @@ def main():
 
     cfg = {"input_size": (args.size, args.size), "category_num": args.classes, "accum_num": 1,
            "batch_size": args.batch, "preset": args.preset, "width": args.width, "seed": 2, "device": device,
-           "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb,
+           "compute_dtype": args.dtype, "force_gradsync": bool(args.force_dist), "bucket_mb": args.bucket_mb or None,
            "allreduce_release_at": None if args.release_at == "none" else args.release_at, "grad_dtype": args.grad_dtype, "x6_planes": args.x6_planes,
            "fused_update": not args.no_fused_update, "bf16t": args.bf16t,
            "pool_gate_idx": not args.pool_gate_tensor, "fused_tiles": not args.no_fused_tiles,

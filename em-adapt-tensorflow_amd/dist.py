@@ -63,7 +63,8 @@ def _ops():
 
 
 class GradSync:
-    def __init__(self, flat, segments, bucket_bytes=64 << 20, group=None, algo="allreduce", payload="fp32", writeback=True, prepacked=False):
+    def __init__(self, flat, segments, bucket_bytes=64 << 20, group=None, algo="allreduce", payload="fp32", writeback=True, prepacked=False,
+                 boundaries=None):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("torch.distributed is not initialised")
         if algo not in ("allreduce", "direct") or payload not in ("fp32", "bf16"):
@@ -92,8 +93,17 @@ class GradSync:
         per = max(int(bucket_bytes) // flat.element_size(), 1)
         if algo == "direct":   # shards of equal size: bucket boundaries on multiples of the world size
             per = max(per // self.world_size, 1) * self.world_size
-        # bucket boundaries are multiples of `per`, clipped to the used extent of the flat buffer
-        self.buckets = [(s, min(s + per, self.total)) for s in range(0, self.total, per)]
+        # bucket boundaries are multiples of `per`, clipped to the used extent of the flat buffer -- or, with `boundaries`, the offsets
+        # given (round 6: ADAPT cuts the direct exchange into TWO buckets, fc8 + fc7 + fc6 = 77 % of the bytes, final when fc6's filter
+        # gradient ends, and conv5_3 .. conv1_1: two collectives per phase instead of eight, each large enough to run at the links'
+        # bandwidth; an offset is rounded down to a whole number of shards, so a bucket is complete no later than the segment it names)
+        if boundaries:
+            W = self.world_size if algo == "direct" else 1
+            cuts = sorted({(int(b) // W) * W for b in boundaries if 0 < (int(b) // W) * W < self.total})
+            edges = [0] + cuts + [self.total]
+            self.buckets = [(edges[i], edges[i + 1]) for i in range(len(edges) - 1)]
+        else:
+            self.buckets = [(s, min(s + per, self.total)) for s in range(0, self.total, per)]
         self._next_bucket = 0
         self._watermark = 0
         self._works = []

@@ -191,6 +191,19 @@ def _direct_worker(rank, world, port, out_dir):
         gs3.wait()
         assert np.array_equal(gs3.gathered[:total].float().numpy(), np.load(os.path.join(out_dir, "%s_%d.npy" % (payload, rank))))
         assert not GradSync(flat, segs, algo="allreduce", prepacked=True).prepacked      # (only the direct exchange without write-back)
+        # explicit bucket boundaries (round 6: ADAPT cuts the direct exchange behind the last fully connected layer): an offset is rounded
+        # down to whole shards, the first bucket leaves as soon as the segment it names is ready, the sums are the same bits
+        flat.copy_(mine)
+        gs4 = GradSync(flat, segs, algo="direct", payload=payload, writeback=False, boundaries=[segs[1][1]])
+        cut = segs[1][1] // world * world
+        assert gs4.buckets == [(0, cut), (cut, total)]
+        gs4.segment_ready(*segs[0])
+        assert gs4._next_bucket == 0
+        gs4.segment_ready(*segs[1])
+        assert gs4._next_bucket == 1                    # (77 % of the bytes are on their way before the last segment exists)
+        gs4.segment_ready(*segs[2])
+        gs4.wait()
+        assert np.array_equal(gs4.gathered[:total].float().numpy(), np.load(os.path.join(out_dir, "%s_%d.npy" % (payload, rank))))
     np.save(os.path.join(out_dir, "mine%d.npy" % rank), mine.numpy())
     dist.barrier()
     dist.destroy_process_group()

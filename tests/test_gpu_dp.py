@@ -68,6 +68,9 @@ def _worker(rank, world, port, out_dir, dtype, exchange=None):
     assert a._gradsync is not None and a._gradsync.world_size == world and len(a._gradsync.buckets) > 1
     if exchange:
         assert a._gradsync.algo == "direct" and a._gradsync.payload == exchange.get("grad_dtype", "fp32")
+        if "bucket_mb" in exchange and exchange["bucket_mb"] is None:
+            fc_end = max(op.seg["end"] for op in a._plan if op.kind == "conv" and op.name.startswith("fc"))
+            assert a._gradsync.buckets == [(0, fc_end // world * world), (fc_end // world * world, a._gradsync.total)]
     a._gradsync.timing = True   # off by default (a training run must not pile up events); stats() below reads them
     sl = slice(rank * B, (rank + 1) * B)
     for _ in range(2):  # two updates: the second exercises momentum and the re-armed GradSync
@@ -104,7 +107,9 @@ def test_two_ranks_match_single_process(tmp_path, dtype, bar):
 
 
 @pytest.mark.parametrize("dtype,exchange,bar", [("fp32", {"allreduce_algo": "direct"}, 1e-5),
-                                               ("bf16", {"grad_dtype": "bf16"}, 2e-3)])
+                                               ("bf16", {"grad_dtype": "bf16"}, 2e-3),
+                                               # (no bucket size given: the two-bucket plan, fc8 + fc7 + fc6 | the convolutions)
+                                               ("bf16", {"grad_dtype": "bf16", "bucket_mb": None}, 2e-3)])
 def test_direct_exchange_and_bf16_gradient_payload(tmp_path, dtype, exchange, bar):
     """The all-links exchange (reduce-scatter + all-gather as two all-to-all steps on a side stream, fp32 accumulation by the
     shard's owner) in fp32, and with the bf16 gradient payload beside bf16 compute (configs[2] / [3]): ranks bit-identical, and
