@@ -40,15 +40,6 @@ def implicit_gemm_kernel():
     ops.tune_set("bf16_tile", 0)
 
 
-@pytest.fixture
-def patch_kernel():
-    """tune bf16_tile = 3: the 3 x 3 layers with <= 128 output columns on the opt-in patch kernel (csrc/conv_p3.h)."""
-    import em_adapt_tensorflow_amd.ops as ops
-    ops.tune_set("bf16_tile", 3)
-    yield
-    ops.tune_set("bf16_tile", 0)
-
-
 # name, (B, H, W, Cin, Cout, k, dil), tile of forward / data gradient, tile of the filter gradient, dropout
 FULL = [
     ("fc6", (16, 41, 41, 512, 4096, 4, 4), 256, (256, 256), True),      # deeplab.py:92,145
@@ -57,8 +48,7 @@ FULL = [
     ("conv3_2", (16, 81, 81, 256, 256, 3, 1), 256, (256, 256), False),
     ("conv1_2", (16, 321, 321, 64, 64, 3, 1), 128, (128, 64), False),   # 12,881 workgroups; 1.65 M pixels (forced: tune bf16_tile = 128)
     ("conv1_2 direct", (16, 321, 321, 64, 64, 3, 1), 4, (4, 16), False),    # the automatic plan: the direct kernel (csrc/conv_d64.h), 7,056 tiles of 16 x 16
-    ("conv1_2 patch", (16, 321, 321, 64, 64, 3, 1), 3, (128, 64), False),     # the opt-in patch kernel (csrc/conv_p3.h): 18 x 14 tiles
-    ("conv2_2 patch", (16, 161, 161, 128, 128, 3, 1), 3, (128, 128), False),  # 128 columns: 8 B fragments per step, 4 channel groups
+    ("conv2_2", (16, 161, 161, 128, 128, 3, 1), 128, (128, 128), False),    # the automatic plan of the 128-column layers: 128 x 128 tiles, 3,241 workgroups
 ]
 
 
@@ -66,8 +56,6 @@ FULL = [
 def test_bf16_benchmark_shape_against_fp64_oracle_on_rounded_operands(env, request, name, shape, tile, wtile, drop):
     ops, do, torch = env
     B, H, W, Cin, Cout, k, dil = shape
-    if tile == 3:
-        request.getfixturevalue("patch_kernel")
     if name == "conv1_2":
         request.getfixturevalue("implicit_gemm_kernel")
     pf, pd, pw = (ops.conv_bf16_plan(B, H, W, Cin, Cout, k, dil, kind) for kind in ("fwd", "dgrad", "wgrad"))
@@ -134,10 +122,7 @@ def test_bf16_benchmark_shape_against_fp64_oracle_on_rounded_operands(env, reque
     y1 = ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, **kw)
     assert _rel(y1.cpu(), want_y) < 2e-5
     assert torch.equal(y1, ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, **kw)), "forward must repeat bitwise"
-    if tile == 3:   # (the patch kernel takes bf16-stored inputs only: an f32-stored one runs the implicit-GEMM kernel, other sums)
-        assert _rel(ops.conv_fwd_bf16(xg.float(), wf, (k, k), bg, dil, **kw).cpu(), y1.cpu()) < 2e-5
-    else:
-        assert torch.equal(y1, ops.conv_fwd_bf16(xg.float(), wf, (k, k), bg, dil, **kw)), "f32-stored input: the same sums"
+    assert torch.equal(y1, ops.conv_fwd_bf16(xg.float(), wf, (k, k), bg, dil, **kw)), "f32-stored input: the same sums"
     assert torch.equal(ops.conv_fwd_bf16(xg, wf, (k, k), bg, dil, out_dtype=torch.bfloat16, **kw), y1.bfloat16())
     del y1
 
@@ -145,10 +130,7 @@ def test_bf16_benchmark_shape_against_fp64_oracle_on_rounded_operands(env, reque
     dx1 = ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg.float(), gate_scale=scale)
     assert _rel(dx1.cpu(), want_dx) < 2e-5
     assert torch.equal(dx1, ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg.float(), gate_scale=scale))
-    if tile == 3:
-        assert _rel(ops.conv_dgrad_bf16(dyg.float(), wd, (k, k), dil, gate=xg.float(), gate_scale=scale).cpu(), dx1.cpu()) < 2e-5
-    else:
-        assert torch.equal(dx1, ops.conv_dgrad_bf16(dyg.float(), wd, (k, k), dil, gate=xg.float(), gate_scale=scale))
+    assert torch.equal(dx1, ops.conv_dgrad_bf16(dyg.float(), wd, (k, k), dil, gate=xg.float(), gate_scale=scale))
     assert torch.equal(ops.conv_dgrad_bf16(dyg, wd, (k, k), dil, gate=xg, gate_scale=scale), dx1.bfloat16())   # bf16 gate -> bf16 dx
     del dx1
 
