@@ -851,6 +851,7 @@ struct PlanBT {
     int main_sk;       // 1: stream-K
     int main_levels;   // its slab levels
     int tail_levels;   // rows [main_rows, M): a stream-K launch with this many slab levels (-1: a plain launch)
+    int m224;          // 1: the (single, plain) launch runs 224 x 256 tiles (igemm_b16t.h M224)
 };
 
 void fill_b16t(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
@@ -873,7 +874,7 @@ bool bt_ok(const emadapt_conv_desc *d, bool dgrad, int y_bf16) {
 
 PlanBT plan_b16t(const IgemmArgs &a) {
     const int cus = plan_cus();
-    PlanBT p = {a.M, 0, 0, 0};
+    PlanBT p = {a.M, 0, 0, 0, 0};
     constexpr int BM = 256, BN = 256;
     const long long tn = ceil_div(a.N, BN), tm = ceil_div(a.M, BM), t = tm * tn;
     const int bk = BT_BK;
@@ -881,7 +882,13 @@ PlanBT plan_b16t(const IgemmArgs &a) {
     if (t % cus == 0 || t * nk * bk / cus < 16 * BT_BK) return p;   // whole rounds, or too little work per CU to cut into pieces
     // one round that fills at least three quarters of the CUs (conv4_x / conv5_x: 212 tiles): plain tiles -- stream-K's second
     // prologue, published and combined accumulator image per CU cost more than the idle quarter (0.107 against 0.119 ms on conv4_2)
-    if (t <= cus && 4 * t >= 3LL * cus) return p;
+    // Round 6: when tiles of 224 rows still fit one round they do 7 / 8 of the work each on more of the CUs (M = 26,896 at N = 512: 242
+    // workgroups instead of 212) -- tune "bf16t_sk" = 3 keeps the 256-row tiles (A/B)
+    if (t <= cus && 4 * t >= 3LL * cus) {
+        const long long t224 = ceil_div(a.M, 224) * tn;
+        if (t224 <= cus && t224 > t && tune(TUNE_BF16T_SK) != 3) p.m224 = 1;
+        return p;
+    }
     // four and more rounds (fc6 / fc7: 6.6): plain tiles all the way -- the last round's idle CUs (a sixth of one round in seven) cost less than
     // the second launch, its prologue and the combined tiles of a stream-K tail: fc7 forward 0.697 -> 0.667 ms, data gradient 0.760 -> 0.727,
     // fc6 forward 1.201 -> 1.193 (same process, same tensors, A/B/A/B).  Fewer rounds keep whole rounds + stream-K tail below.
@@ -931,6 +938,7 @@ int dispatch_b16t(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStre
     }
     a.splits = 1;
     a.slab = nullptr;
+    if (p.m224) return launch_igemm_b16t<false, YBF, 0, true>(a, stream);
     int rc = launch_bt<false, YBF>(a, stream);
     if (rc || p.main_rows >= a.M) return rc;
     a.m_begin = p.main_rows;
@@ -1337,7 +1345,7 @@ int emadapt_conv_bf16t_plan(const emadapt_conv_desc *d, int kind, int plan[4]) {
     IgemmArgs a;
     fill_b16t(a, d, kind == 1);
     const PlanBT p = plan_b16t(a);
-    plan[0] = p.main_rows; plan[1] = p.main_sk; plan[2] = p.main_levels; plan[3] = p.tail_levels;
+    plan[0] = p.main_rows; plan[1] = p.main_sk; plan[2] = p.main_levels; plan[3] = p.m224 ? 224 : p.tail_levels;
     return EMADAPT_OK;
 }
 

@@ -304,15 +304,16 @@ __global__ void __launch_bounds__(256) sgd_payload_tiles_b16_both_kernel(float *
 // 4 (lane >> 4) + r): 16 rows at a time through the wave's private LDS slab ([16][128 + 4] floats), read back as 8 consecutive
 // columns per lane -- then exactly store_acc_tile's arithmetic (igemm_common.h: bias / ReLU / dropout / gate on 8 values, 16-byte
 // gate loads and output stores), element for element.
-template <bool YBF>
-__device__ __forceinline__ void store_acc_tile16(const IgemmArgs &a, const bt_f32x4 (&acc)[4][8], float *stage, int lane, int row0, int col0,
+//   NI x NJ = accumulator tiles of the wave's block: 4 x 8 (64 rows x 128 columns, the 256-row tile) or 7 x 4 (112 x 64, the 224-row tile)
+template <bool YBF, int NI = 4, int NJ = 8>
+__device__ __forceinline__ void store_acc_tile16(const IgemmArgs &a, const bt_f32x4 (&acc)[NI][NJ], float *stage, int lane, int row0, int col0,
                                                  float *slab) {
-    constexpr int WN = 128, SP = WN + 4, CPR = WN / 8;
+    constexpr int WN = NJ * 16, SP = WN + 4, CPR = WN / 8;
     const int l15 = lane & 15, lq = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {   // (fully unrolled: a dynamic index would move the accumulators to scratch)
+    for (int i = 0; i < NI; i++) {   // (fully unrolled: a dynamic index would move the accumulators to scratch)
 #pragma unroll
-        for (int j = 0; j < 8; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) stage[(4 * lq + r) * SP + j * 16 + l15] = acc[i][j][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -390,9 +391,16 @@ __device__ __forceinline__ void store_acc_tile16(const IgemmArgs &a, const bt_f3
 
 // ABLM (diagnostic library only, tune "ablate"): parts of the kernel COMPILED out -- 1 no DMAs (every stage filled once), 2 no
 // fragment reads, 4 no epilogue, 8 no MFMAs; results are garbage, scripts/bf16t_ablate.py reads the time.
-template <bool SK, bool YBF, int ABLM = 0>
+// M224 (round 6; plain launches only): 224 x 256 tiles -- the 8 MFMA waves as 2 (rows) x 4 (columns), a 112 x 64 block each = 7 x 4
+// accumulator tiles, 7 A + 4 B fragments per K step for 28 MFMAs (the 256-row tile: 12 for 32).  For the launches whose 256-row tiles
+// fill one partial round: M = 26,896 (batch 16 at 41 x 41) is 105.06 tile rows -- 212 tiles of 256 x 256 on 256 CUs at N = 512, but 121 x 2
+// = 242 tiles of 224 rows, each 7 / 8 of the work (conv4_x / conv5_x forward and data gradient, fc6's data gradient).  The operand stage
+// keeps its 256 A rows: rows 224 .. 255 are never requested (their DMA lanes carry the out-of-range bit) and never read.
+template <bool SK, bool YBF, int ABLM = 0, bool M224 = false>
 __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) {
-    constexpr int BM = 256, BN = 256, BK = BT_BK, NBUF = BT_NBUF, AHEAD = BT_AHEAD, STAGE = BT_STAGE, OPER = BT_OPER, IPW = BT_IPW;
+    constexpr int BM = M224 ? 224 : 256, BN = 256, BK = BT_BK, NBUF = BT_NBUF, AHEAD = BT_AHEAD, STAGE = BT_STAGE, OPER = BT_OPER, IPW = BT_IPW;
+    constexpr int NI = M224 ? 7 : 4, NJ = M224 ? 4 : 8;   // accumulator tiles (16 x 16) of a wave's block: rows x columns
+    static_assert(!(SK && M224), "the 224-row tile runs plain launches only");
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
     // ---- work of this workgroup: one (tile, K range) piece, or with SK a sequence of them (every wave computes the same list)
@@ -482,7 +490,7 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
 #pragma unroll
             for (int j = 0; j < IPW; j++) {
                 const int r = ld_row[j];
-                const int m = m0 + r < a.m_end ? m0 + r : -1;
+                const int m = (r < BM && m0 + r < a.m_end) ? m0 + r : -1;
                 if (m >= 0) {
                     const int t2 = m / a.W;
                     const int oh = t2 % a.H, ow = m - t2 * a.W;
@@ -553,17 +561,17 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
     }
 
     // ======================================= MFMA waves =======================================
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = M224 ? (wave & 1) : (wave & 3), wn = M224 ? (wave >> 1) : (wave >> 2);
     // fragment addresses (bytes inside a stage): lane (l15, lq) reads k 8 lq .. 8 lq + 7 of row l15 (+ 16 i): chunk lq, stored at
     // slot lq ^ bt_swz(row); 16 rows on are four row quads: the same swizzle
     const int l15 = lane & 15, lq = lane >> 4;
-    const int a_base = (wm * 64 + l15) * BT_ROWB + ((lq ^ bt_swz(l15)) << 4);
-    const int b_base = OPER + (wn * 128 + l15) * BT_ROWB + ((lq ^ bt_swz(l15)) << 4);
-    bt_f32x4 acc[4][8];
-    bt_bf16x8 av[4], bv[3];
+    const int a_base = (wm * (NI * 16) + l15) * BT_ROWB + ((lq ^ bt_swz(l15)) << 4);
+    const int b_base = OPER + (wn * (NJ * 16) + l15) * BT_ROWB + ((lq ^ bt_swz(l15)) << 4);
+    bt_f32x4 acc[NI][NJ];
+    bt_bf16x8 av[NI], bv[3];
     int sk_bad = 0;   // (scalar) a publisher of a tile this workgroup heads never arrived
 #pragma unroll
-    for (int n = 0; n < 4; n++)
+    for (int n = 0; n < NI; n++)
 #pragma unroll
         for (int e = 0; e < 8; e++) av[n][e] = (__bf16)0.f;
 #pragma unroll
@@ -574,9 +582,9 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
     do {   // one piece of work (SK: several)
     const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 8; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
     __syncthreads();                // (pairs with the DMA waves' barrier at the top of a piece)
@@ -586,6 +594,37 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
 #define BT_RDA(I, BASE) if constexpr (!(ABLM & 2)) { av[I] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BASE) + a_base + (I) * (16 * BT_ROWB)); BT_SB }
 #define BT_RDB(S, J, BASE) if constexpr (!(ABLM & 2)) { bv[S] = *reinterpret_cast<const bt_bf16x8 *>(ldsb + (BASE) + b_base + (J) * (16 * BT_ROWB)); BT_SB }
 #define BT_MF(I, J, S) if constexpr (!(ABLM & 8)) { acc[I][J] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[I], bv[S], acc[I][J], 0, 0, 0); BT_SB }
+    if constexpr (M224) {
+    // ---- 7 x 4 block: column J = 7 MFMAs on B fragment J; fragment J + 2 is requested in front of them (from the next stage once J + 2 >= 4:
+    // behind the step's barrier, which sits in front of column 2); the rotation slot of column J of step kt is (J + 4 kt) % 3 = (J + kt) % 3:
+    // three bodies, O = 0, 1, 2; the next step's A fragments replace the current ones behind their last MFMAs (column 3)
+    BT_RDA(0, 0) BT_RDA(1, 0) BT_RDA(2, 0) BT_RDA(3, 0) BT_RDA(4, 0) BT_RDA(5, 0) BT_RDA(6, 0) BT_RDB(0, 0, 0) BT_RDB(1, 1, 0)
+#define BT_COL7(J, O)                                                                                                                  \
+        if ((J) == 2) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); BT_SB }                                           \
+        if ((J) + 2 < 4) { BT_RDB(((J) + 2 + (O)) % 3, (J) + 2, cur) } else { BT_RDB(((J) + 2 + (O)) % 3, (J) + 2 - 4, nx) }           \
+        BT_MF(0, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(0, nx) }                                                                   \
+        BT_MF(1, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(1, nx) }                                                                   \
+        BT_MF(2, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(2, nx) }                                                                   \
+        BT_MF(3, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(3, nx) }                                                                   \
+        BT_MF(4, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(4, nx) }                                                                   \
+        BT_MF(5, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(5, nx) }                                                                   \
+        BT_MF(6, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(6, nx) }
+#define BT_STEP7(O)                                                                \
+        {                                                                          \
+            const int nx = cur == (NBUF - 1) * STAGE ? 0 : cur + STAGE;            \
+            BT_SB                                                                  \
+            BT_COL7(0, O) BT_COL7(1, O) BT_COL7(2, O) BT_COL7(3, O)                \
+            cur = nx;                                                              \
+        }
+        int cur = 0;
+        for (int kt = 0; kt < nk; kt += 3) {
+            BT_STEP7(0)
+            if (kt + 1 < nk) BT_STEP7(1)
+            if (kt + 2 < nk) BT_STEP7(2)
+        }
+#undef BT_STEP7
+#undef BT_COL7
+    } else {
     BT_RDA(0, 0) BT_RDA(1, 0) BT_RDA(2, 0) BT_RDA(3, 0) BT_RDB(0, 0, 0) BT_RDB(1, 1, 0)
     // column J of the wave's block: 4 MFMAs on B fragment J; fragment J + 2 is requested in front of them (from the next stage once
     // J + 2 >= 8: behind the step's barrier, which sits in front of column 4).  The rotation slot of column J of step kt is
@@ -613,6 +652,7 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
             if (kt + 2 < nk) BT_STEP(1)
         }
     }
+    }   // (!M224)
 #undef BT_STEP
 #undef BT_COL
 #undef BT_MF
@@ -677,10 +717,10 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
     }
     if (!(SK && lvl > 0)) {
         float *slab_ = !SK && lvl >= 0 ? a.slab + ((long long)lvl * (a.m_end - a.m_begin) - a.m_begin) * a.N : nullptr;   // (split-K levels of the plain launches)
-        float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (128 + 4));
+        float *stage = reinterpret_cast<float *>(ldsb) + wave * (16 * (NJ * 16 + 4));
         static_assert(BT_MWAVES * 16 * (128 + 4) * 4 <= BT_LDS, "epilogue slabs must fit in the ring");
         if (!(ABLM & 4) || a.m_end < -1)   // (ablation 4: a condition that is never true at run time keeps the accumulators alive)
-            store_acc_tile16<YBF>(a, acc, stage, lane_e, m0 + wm * 64, n0 + wn * 128, slab_);
+            store_acc_tile16<YBF, NI, NJ>(a, acc, stage, lane_e, m0 + wm * (NI * 16), n0 + wn * (NJ * 16), slab_);
     }
     if constexpr (SK) {
         __syncthreads();   // every wave's slab stores were drained ahead of this barrier
@@ -695,10 +735,10 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
 }
 
 // a.splits: SK = false -> split-K factor (>= 1; > 1 needs a.slab); SK = true -> number of workgroups (CUs), a.slab for the levels
-template <bool SK, bool YBF, int ABLM = 0>
+template <bool SK, bool YBF, int ABLM = 0, bool M224 = false>
 int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
 #ifdef EMADAPT_ABLATE_BUILD
-    if constexpr (ABLM == 0 && YBF) {
+    if constexpr (ABLM == 0 && YBF && !M224) {
         switch (tune(TUNE_ABLATE)) {
 #define EMADAPT_ABL_CASE(m) case m: return launch_igemm_b16t<SK, YBF, m>(a, stream);
             EMADAPT_ABL_CASE(1) EMADAPT_ABL_CASE(2) EMADAPT_ABL_CASE(3) EMADAPT_ABL_CASE(4) EMADAPT_ABL_CASE(8) EMADAPT_ABL_CASE(9) EMADAPT_ABL_CASE(10)
@@ -708,9 +748,9 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
     }
 #endif
     static DynLdsAttr attr;
-    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16t_kernel<SK, YBF, ABLM>), BT_LDS);
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16t_kernel<SK, YBF, ABLM, M224>), BT_LDS);
     if (rc) return rc;
-    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, 256);
+    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, M224 ? 224 : 256);
     a.tiles_n = (int)ceil_div(a.N, 256);
     const int nk_all = a.K / BT_BK;
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
@@ -728,7 +768,7 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
     } else {
         const long long nblk = tiles * a.splits;
         if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF, ABLM>), dim3((unsigned)nblk), dim3(BT_THREADS), BT_LDS, stream, a);
+        hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF, ABLM, M224>), dim3((unsigned)nblk), dim3(BT_THREADS), BT_LDS, stream, a);
         rc = launch_status();
         if (rc || a.splits <= 1) return rc;
         long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;

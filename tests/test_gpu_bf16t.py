@@ -120,6 +120,64 @@ def test_b16t_small_shapes_every_layout(env, shape, cus):
             assert torch.equal(ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=gg, gate_scale=2.0), g32.bfloat16())
 
 
+# (B, H, W, Cin, Cout, k, dil), plan_cus: launches of ONE partial round whose 224-row tiles still fit the round (round 6, igemm_b16t.h M224:
+# 8 MFMA waves as 2 x 4, 7 x 4 accumulator tiles each) -- M tails in the last tile (fewer than 112 rows: the second wave row idles; fewer than
+# 16), N tails, every tap geometry, K of 1 .. 3 steps and long, and the model's shapes at batch 16 (conv4_x / conv5_x: 242 workgroups)
+M224 = [
+    ((3, 41, 41, 64, 256, 3, 1), 24),        # 5043 rows: 20 -> 23 tiles on 24 "CUs"; last tile 115 rows
+    ((1, 30, 30, 32, 264, 1, 1), 10),        # two N tiles (one 8 wide), 4 -> 5 row tiles (the last: 4 rows); ONE K step
+    ((2, 28, 32, 96, 512, 3, 2), 18),        # 1792 rows = 8 x 224 exactly: 7 -> 8 row tiles x 2
+    ((1, 41, 41, 64, 128, 4, 4), 8),         # fc6's filter geometry; 128 columns in a 256-wide tile
+    ((1, 40, 42, 32, 256, 3, 12), 8),        # rate 12
+    ((16, 41, 41, 512, 512, 3, 1), 256),     # conv4_2 / conv4_3
+    ((16, 41, 41, 512, 512, 3, 2), 256),     # conv5_x
+]
+
+
+@pytest.mark.parametrize("shape,cus", M224)
+def test_b16t_224_row_tiles(env, shape, cus):
+    """The 224-row tile variant against the 256-row tiles of the same launch (tune bf16t_sk = 3): every output element is the same sum
+    in the same order (the K walk does not depend on the tile's shape), so forward and data gradient must agree BIT FOR BIT, with every
+    epilogue; and against the fp64 oracle on rounded operands at the small shapes."""
+    ops, do, torch = env
+    B, H, W, Cin, Cout, k, dil = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 131 + H + Cout)
+    xg = torch.randn((B, H, W, Cin), device="cuda", generator=g).relu_().bfloat16()
+    wg = torch.randn((k, k, Cin, Cout), device="cuda", generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+    bg = torch.randn((Cout,), device="cuda", generator=g) * 0.1
+    mg = (torch.rand((B, H, W, Cout), device="cuda", generator=g) < 0.5).to(torch.uint8)
+    wt = ops.filter_tiles_bf16(wg)
+    M = B * H * W
+    with ops.tuned(plan_cus=cus):
+        assert ops.conv_bf16t_plan(B, H, W, Cin, Cout, k, dil) == (M, 0, 0, 224)
+        new = [ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=False, out_dtype=torch.float32),
+               ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg),
+               ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_seed=11)]
+        assert torch.equal(new[0], ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=False, out_dtype=torch.float32))
+        with ops.tuned(bf16t_sk=3):
+            assert ops.conv_bf16t_plan(B, H, W, Cin, Cout, k, dil)[3] != 224
+            old = [ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=False, out_dtype=torch.float32),
+                   ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_mask=mg),
+                   ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_seed=11)]
+    for a_, b_ in zip(new, old):
+        assert torch.equal(a_, b_)
+    if B < 16:
+        y = do.conv_same(xg.cpu().double(), wg.cpu().bfloat16().double(), bg.cpu().double(), dil)
+        assert _rel(new[0].cpu(), y) < 2e-5
+    if Cout % 32 == 0:
+        dyg = torch.randn((B, H, W, Cout), device="cuda", generator=g).bfloat16()
+        wtd = ops.filter_tiles_bf16(wg, dgrad=True)
+        with ops.tuned(plan_cus=cus):
+            p = ops.conv_bf16t_plan(B, H, W, Cin, Cout, k, dil, "dgrad")
+            nd = [ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, out_dtype=torch.float32),
+                  ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=xg, gate_scale=2.0)]
+            with ops.tuned(bf16t_sk=3):
+                od = [ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, out_dtype=torch.float32),
+                      ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=xg, gate_scale=2.0)]
+        for a_, b_ in zip(nd, od):
+            assert torch.equal(a_, b_), p
+
+
 @pytest.mark.parametrize("shape", [(3, 256, 256), (1, 512, 4096), (4, 256, 512), (3, 512, 320), (1, 64, 96), (3, 288, 256)],
                          ids=lambda s: "k%d_%dto%d" % s)
 def test_both_tiled_images_in_one_pass(env, shape):
