@@ -879,20 +879,21 @@ PlanBT plan_b16t(const IgemmArgs &a) {
     const long long tn = ceil_div(a.N, BN), tm = ceil_div(a.M, BM), t = tm * tn;
     const int bk = BT_BK;
     const int nk = a.K / bk;
-    if (t % cus == 0 || t * nk * bk / cus < 16 * BT_BK) return p;   // whole rounds, or too little work per CU to cut into pieces
+    // Round 6: a plain launch of ONE round that leaves CUs idle runs 224-row tiles when those still fit the round: 7 / 8 of the work each on
+    // more of the CUs (M = 26,896 at N = 512: 242 workgroups instead of 212) -- tune "bf16t_sk" = 3 keeps the 256-row tiles (A/B)
+    auto one_round = [&](PlanBT q) {
+        const long long t224 = ceil_div(a.M, 224) * tn;
+        if (t < cus && t224 <= cus && t224 > t && tune(TUNE_BF16T_SK) != 3) q.m224 = 1;
+        return q;
+    };
+    if (t % cus == 0 || t * nk * bk / cus < 16 * BT_BK) return t <= cus ? one_round(p) : p;   // whole rounds, or too little work per CU to cut into pieces
     // one round that fills at least three quarters of the CUs (conv4_x / conv5_x: 212 tiles): plain tiles -- stream-K's second
     // prologue, published and combined accumulator image per CU cost more than the idle quarter (0.107 against 0.119 ms on conv4_2)
-    // Round 6: when tiles of 224 rows still fit one round they do 7 / 8 of the work each on more of the CUs (M = 26,896 at N = 512: 242
-    // workgroups instead of 212) -- tune "bf16t_sk" = 3 keeps the 256-row tiles (A/B)
-    if (t <= cus && 4 * t >= 3LL * cus) {
-        const long long t224 = ceil_div(a.M, 224) * tn;
-        if (t224 <= cus && t224 > t && tune(TUNE_BF16T_SK) != 3) p.m224 = 1;
-        return p;
-    }
+    if (t <= cus && 4 * t >= 3LL * cus) return one_round(p);
     // four and more rounds (fc6 / fc7: 6.6): plain tiles all the way -- the last round's idle CUs (a sixth of one round in seven) cost less than
     // the second launch, its prologue and the combined tiles of a stream-K tail: fc7 forward 0.697 -> 0.667 ms, data gradient 0.760 -> 0.727,
     // fc6 forward 1.201 -> 1.193 (same process, same tensors, A/B/A/B).  Fewer rounds keep whole rounds + stream-K tail below.
-    if (t >= 4LL * cus && tune(TUNE_BF16T_SK) == 0) return p;
+    if (t >= 4LL * cus && (tune(TUNE_BF16T_SK) == 0 || tune(TUNE_BF16T_SK) == 3)) return p;
     if (a.N <= 1024 || t < cus || tune(TUNE_BF16T_SK) == 1) {
         p.main_sk = 1;
         p.main_levels = streamk_levels(t, nk, cus);
