@@ -1225,6 +1225,8 @@ int emadapt_conv_bf16t_pays(const emadapt_conv_desc *d, int kind, int y_dtype) {
     // (third class: few tiles with a very long reduction -- fc6's data gradient: 212 tiles x 2048 K steps = 1696 steps per CU as one
     // stream-K launch, 55.3 % against 50.8 % for the older kernel's six-way split-K; fourth: a single round of at least three quarters
     // of the CUs with K >= 4608 -- conv4_2 .. conv5_3 as plain tiles: 47 - 50 % against 44 - 45 %)
+    // (round 6 tried a fifth class -- the same single round with 2304 <= K < 4608 on the new 224-row tiles: conv4_1's forward, 0.054 against
+    // 0.062 ms in an isolated loop -- and measured a tie in the step, 10.11 / 10.15 against 10.12 / 10.17 ms: profiles/r06_m224_tiles.txt)
     return N >= 256 && (tiles >= 4LL * cus || (2 * tiles >= 3LL * cus && K >= 2304) || tiles * (K / 32) >= 1024LL * cus ||
                         (tiles <= cus && 4 * tiles >= 3LL * cus && K >= 4608)) ? 1 : 0;
 }
