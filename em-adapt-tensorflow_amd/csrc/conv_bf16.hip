@@ -851,8 +851,7 @@ struct PlanBT {
     int main_sk;       // 1: stream-K
     int main_levels;   // its slab levels
     int tail_levels;   // rows [main_rows, M): a stream-K launch with this many slab levels (-1: a plain launch)
-    int m224;          // 1: the (single, plain) launch runs 224 x 256 tiles (igemm_b16t.h BMR = 224)
-    int tail_bm;       // plain tail launch (tail_levels == -1): its tile height, 256 | 224 | 160
+    int m224;          // 1: the (single, plain) launch runs 224 x 256 tiles (igemm_b16t.h M224)
 };
 
 void fill_b16t(IgemmArgs &a, const emadapt_conv_desc *d, bool dgrad) {
@@ -875,7 +874,7 @@ bool bt_ok(const emadapt_conv_desc *d, bool dgrad, int y_bf16) {
 
 PlanBT plan_b16t(const IgemmArgs &a) {
     const int cus = plan_cus();
-    PlanBT p = {a.M, 0, 0, 0, 0, 256};
+    PlanBT p = {a.M, 0, 0, 0, 0};
     constexpr int BM = 256, BN = 256;
     const long long tn = ceil_div(a.N, BN), tm = ceil_div(a.M, BM), t = tm * tn;
     const int bk = BT_BK;
@@ -894,24 +893,7 @@ PlanBT plan_b16t(const IgemmArgs &a) {
     // four and more rounds (fc6 / fc7: 6.6): plain tiles all the way -- the last round's idle CUs (a sixth of one round in seven) cost less than
     // the second launch, its prologue and the combined tiles of a stream-K tail: fc7 forward 0.697 -> 0.667 ms, data gradient 0.760 -> 0.727,
     // fc6 forward 1.201 -> 1.193 (same process, same tensors, A/B/A/B).  Fewer rounds keep whole rounds + stream-K tail below.
-    if (t >= 4LL * cus && (tune(TUNE_BF16T_SK) == 0 || tune(TUNE_BF16T_SK) >= 3)) {
-        // Round 6: ... and the last, partial round as a launch of its own on the SMALLEST tile height whose tiles fit one round: fc7 / fc6
-        // forward at batch 16 are 6.625 rounds that cost 7; the 2,320 rows behind six whole rounds are 240 tiles of 160 rows = 0.625 of
-        // a round's work (tune "bf16t_sk" = 4 keeps the one launch: the A/B)
-        const long long tm_whole = (t / cus) * cus / tn;
-        if (tune(TUNE_BF16T_SK) != 4 && tm_whole >= 1 && tm_whole < tm) {
-            const long long rest = a.M - tm_whole * BM;
-            for (int bm : {160, 224}) {
-                if (ceil_div(rest, bm) * tn <= cus) {
-                    p.main_rows = (int)(tm_whole * BM);
-                    p.tail_levels = -1;
-                    p.tail_bm = bm;
-                    break;
-                }
-            }
-        }
-        return p;
-    }
+    if (t >= 4LL * cus && (tune(TUNE_BF16T_SK) == 0 || tune(TUNE_BF16T_SK) == 3)) return p;
     if (a.N <= 1024 || t < cus || tune(TUNE_BF16T_SK) == 1) {
         p.main_sk = 1;
         p.main_levels = streamk_levels(t, nk, cus);
@@ -957,15 +939,12 @@ int dispatch_b16t(IgemmArgs &a, void *workspace, size_t workspace_bytes, hipStre
     }
     a.splits = 1;
     a.slab = nullptr;
-    if (p.m224) return launch_igemm_b16t<false, YBF, 0, 224>(a, stream);
+    if (p.m224) return launch_igemm_b16t<false, YBF, 0, true>(a, stream);
     int rc = launch_bt<false, YBF>(a, stream);
     if (rc || p.main_rows >= a.M) return rc;
     a.m_begin = p.main_rows;
     a.m_end = a.M;
-    if (p.tail_levels < 0) {
-        return p.tail_bm == 160 ? launch_igemm_b16t<false, YBF, 0, 160>(a, stream)
-             : p.tail_bm == 224 ? launch_igemm_b16t<false, YBF, 0, 224>(a, stream) : launch_bt<false, YBF>(a, stream);
-    }
+    if (p.tail_levels < 0) return launch_bt<false, YBF>(a, stream);
     a.splits = plan_cus();
     sk_ws(p.tail_levels);
     return launch_bt<true, YBF>(a, stream);
@@ -1369,8 +1348,7 @@ int emadapt_conv_bf16t_plan(const emadapt_conv_desc *d, int kind, int plan[4]) {
     IgemmArgs a;
     fill_b16t(a, d, kind == 1);
     const PlanBT p = plan_b16t(a);
-    plan[0] = p.main_rows; plan[1] = p.main_sk; plan[2] = p.main_levels;
-    plan[3] = p.m224 ? 224 : (p.main_rows < a.M && p.tail_levels < 0 && p.tail_bm != 256) ? -p.tail_bm : p.tail_levels;
+    plan[0] = p.main_rows; plan[1] = p.main_sk; plan[2] = p.main_levels; plan[3] = p.m224 ? 224 : p.tail_levels;
     return EMADAPT_OK;
 }
 

@@ -391,21 +391,16 @@ __device__ __forceinline__ void store_acc_tile16(const IgemmArgs &a, const bt_f3
 
 // ABLM (diagnostic library only, tune "ablate"): parts of the kernel COMPILED out -- 1 no DMAs (every stage filled once), 2 no
 // fragment reads, 4 no epilogue, 8 no MFMAs; results are garbage, scripts/bf16t_ablate.py reads the time.
-// BMR < 256 (round 6; plain launches only): BMR x 256 tiles, BMR = 224 | 160 -- the 8 MFMA waves as 2 (rows) x 4 (columns), a (BMR / 2) x 64
-// block each = NI x 4 accumulator tiles (NI = 7 | 5), NI A + 4 B fragments per K step for 4 NI MFMAs (the 256-row tile: 4 + 8 for 32).
-//   * 224: the launches whose 256-row tiles fill one partial round: M = 26,896 (batch 16 at 41 x 41) is 105.06 tile rows -- 212 tiles of
-//     256 x 256 on 256 CUs at N = 512, but 121 x 2 = 242 tiles of 224 rows, each 7 / 8 of the work (conv4_x / conv5_x forward and data
-//     gradient, fc6's data gradient);
-//   * 160 (or 224): the LAST round of a launch of four and more rounds, as a launch of its own: fc7 / fc6 forward at batch 16 are 6.625
-//     rounds of 256-row tiles that cost 7; the 2,320 rows behind six whole rounds are 15 x 16 = 240 tiles of 160 rows = 0.625 of a round.
-// The operand stage keeps its 256 A rows: rows BMR .. 255 are never requested (their DMA lanes carry the out-of-range bit) and never read.
-template <bool SK, bool YBF, int ABLM = 0, int BMR = 256>
+// M224 (round 6; plain launches only): 224 x 256 tiles -- the 8 MFMA waves as 2 (rows) x 4 (columns), a 112 x 64 block each = 7 x 4
+// accumulator tiles, 7 A + 4 B fragments per K step for 28 MFMAs (the 256-row tile: 12 for 32).  For the launches whose 256-row tiles
+// fill one partial round: M = 26,896 (batch 16 at 41 x 41) is 105.06 tile rows -- 212 tiles of 256 x 256 on 256 CUs at N = 512, but 121 x 2
+// = 242 tiles of 224 rows, each 7 / 8 of the work (conv4_x / conv5_x forward and data gradient, fc6's data gradient).  The operand stage
+// keeps its 256 A rows: rows 224 .. 255 are never requested (their DMA lanes carry the out-of-range bit) and never read.
+template <bool SK, bool YBF, int ABLM = 0, bool M224 = false>
 __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) {
-    constexpr bool M224 = BMR != 256;   // (the 2 x 4 wave layout)
-    constexpr int BM = BMR, BN = 256, BK = BT_BK, NBUF = BT_NBUF, AHEAD = BT_AHEAD, STAGE = BT_STAGE, OPER = BT_OPER, IPW = BT_IPW;
-    constexpr int NI = M224 ? BMR / 32 : 4, NJ = M224 ? 4 : 8;   // accumulator tiles (16 x 16) of a wave's block: rows x columns
-    static_assert(BMR == 256 || BMR == 224 || BMR == 160, "tile heights");
-    static_assert(!(SK && M224), "the narrower tiles run plain launches only");
+    constexpr int BM = M224 ? 224 : 256, BN = 256, BK = BT_BK, NBUF = BT_NBUF, AHEAD = BT_AHEAD, STAGE = BT_STAGE, OPER = BT_OPER, IPW = BT_IPW;
+    constexpr int NI = M224 ? 7 : 4, NJ = M224 ? 4 : 8;   // accumulator tiles (16 x 16) of a wave's block: rows x columns
+    static_assert(!(SK && M224), "the 224-row tile runs plain launches only");
     extern __shared__ __attribute__((aligned(16))) char ldsb[];
 
     // ---- work of this workgroup: one (tile, K range) piece, or with SK a sequence of them (every wave computes the same list)
@@ -603,14 +598,17 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
     // ---- 7 x 4 block: column J = 7 MFMAs on B fragment J; fragment J + 2 is requested in front of them (from the next stage once J + 2 >= 4:
     // behind the step's barrier, which sits in front of column 2); the rotation slot of column J of step kt is (J + 4 kt) % 3 = (J + kt) % 3:
     // three bodies, O = 0, 1, 2; the next step's A fragments replace the current ones behind their last MFMAs (column 3)
-    // (rows past NI -- 5 or 7 -- are discarded branches)
-#define BT_ROW7(I, J, O) if constexpr (NI > (I)) { BT_MF(I, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(I, nx) } }
-#define BT_PRE7(I) if constexpr (NI > (I)) { BT_RDA(I, 0) }
-    BT_PRE7(0) BT_PRE7(1) BT_PRE7(2) BT_PRE7(3) BT_PRE7(4) BT_PRE7(5) BT_PRE7(6) BT_RDB(0, 0, 0) BT_RDB(1, 1, 0)
+    BT_RDA(0, 0) BT_RDA(1, 0) BT_RDA(2, 0) BT_RDA(3, 0) BT_RDA(4, 0) BT_RDA(5, 0) BT_RDA(6, 0) BT_RDB(0, 0, 0) BT_RDB(1, 1, 0)
 #define BT_COL7(J, O)                                                                                                                  \
         if ((J) == 2) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); BT_SB }                                           \
         if ((J) + 2 < 4) { BT_RDB(((J) + 2 + (O)) % 3, (J) + 2, cur) } else { BT_RDB(((J) + 2 + (O)) % 3, (J) + 2 - 4, nx) }           \
-        BT_ROW7(0, J, O) BT_ROW7(1, J, O) BT_ROW7(2, J, O) BT_ROW7(3, J, O) BT_ROW7(4, J, O) BT_ROW7(5, J, O) BT_ROW7(6, J, O)
+        BT_MF(0, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(0, nx) }                                                                   \
+        BT_MF(1, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(1, nx) }                                                                   \
+        BT_MF(2, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(2, nx) }                                                                   \
+        BT_MF(3, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(3, nx) }                                                                   \
+        BT_MF(4, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(4, nx) }                                                                   \
+        BT_MF(5, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(5, nx) }                                                                   \
+        BT_MF(6, J, ((J) + (O)) % 3) if ((J) == 3) { BT_RDA(6, nx) }
 #define BT_STEP7(O)                                                                \
         {                                                                          \
             const int nx = cur == (NBUF - 1) * STAGE ? 0 : cur + STAGE;            \
@@ -626,8 +624,6 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
         }
 #undef BT_STEP7
 #undef BT_COL7
-#undef BT_PRE7
-#undef BT_ROW7
     } else {
     BT_RDA(0, 0) BT_RDA(1, 0) BT_RDA(2, 0) BT_RDA(3, 0) BT_RDB(0, 0, 0) BT_RDB(1, 1, 0)
     // column J of the wave's block: 4 MFMAs on B fragment J; fragment J + 2 is requested in front of them (from the next stage once
@@ -739,10 +735,10 @@ __global__ void __launch_bounds__(BT_THREADS, 3) igemm_b16t_kernel(IgemmArgs a) 
 }
 
 // a.splits: SK = false -> split-K factor (>= 1; > 1 needs a.slab); SK = true -> number of workgroups (CUs), a.slab for the levels
-template <bool SK, bool YBF, int ABLM = 0, int BMR = 256>
+template <bool SK, bool YBF, int ABLM = 0, bool M224 = false>
 int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
 #ifdef EMADAPT_ABLATE_BUILD
-    if constexpr (ABLM == 0 && YBF && BMR == 256) {
+    if constexpr (ABLM == 0 && YBF && !M224) {
         switch (tune(TUNE_ABLATE)) {
 #define EMADAPT_ABL_CASE(m) case m: return launch_igemm_b16t<SK, YBF, m>(a, stream);
             EMADAPT_ABL_CASE(1) EMADAPT_ABL_CASE(2) EMADAPT_ABL_CASE(3) EMADAPT_ABL_CASE(4) EMADAPT_ABL_CASE(8) EMADAPT_ABL_CASE(9) EMADAPT_ABL_CASE(10)
@@ -752,9 +748,9 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
     }
 #endif
     static DynLdsAttr attr;
-    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16t_kernel<SK, YBF, ABLM, BMR>), BT_LDS);
+    int rc = attr.ensure(reinterpret_cast<const void *>(&igemm_b16t_kernel<SK, YBF, ABLM, M224>), BT_LDS);
     if (rc) return rc;
-    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, BMR);
+    a.tiles_m = (int)ceil_div(a.m_end - a.m_begin, M224 ? 224 : 256);
     a.tiles_n = (int)ceil_div(a.N, 256);
     const int nk_all = a.K / BT_BK;
     const long long tiles = (long long)a.tiles_m * a.tiles_n;
@@ -772,7 +768,7 @@ int launch_igemm_b16t(IgemmArgs &a, hipStream_t stream) {
     } else {
         const long long nblk = tiles * a.splits;
         if (nblk > 0x7fffffffLL) return EMADAPT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF, ABLM, BMR>), dim3((unsigned)nblk), dim3(BT_THREADS), BT_LDS, stream, a);
+        hipLaunchKernelGGL((igemm_b16t_kernel<false, YBF, ABLM, M224>), dim3((unsigned)nblk), dim3(BT_THREADS), BT_LDS, stream, a);
         rc = launch_status();
         if (rc || a.splits <= 1) return rc;
         long long g = ((long long)(a.m_end - a.m_begin) * a.N / 4 + 255) / 256;

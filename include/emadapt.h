@@ -347,9 +347,7 @@ int emadapt_conv_bf16_plan(const emadapt_conv_desc *d, int kind, int plan[3]);
  * emadapt_conv_bf16t_supported: 1 when the shape qualifies.  emadapt_conv_bf16t_plan: plan[0] rows of the first launch (whole
  * rounds of 256 x 256 tiles on the CUs), [1] 1 = that launch is stream-K, [2] the most workgroups that share one of its tiles (0:
  * every tile whole), [3] the same for the stream-K launch over the remaining rows (-1: plain tiles; 0 with plan[0] == M: there is
- * none; -160 / -224 (ABI 206): the remaining rows run as a plain launch of 160- / 224-row tiles -- the last, partial round of a launch of
- * four and more rounds on the smallest tile height that still fits one round: fc7 / fc6 forward at batch 16 = 6 whole rounds + 240 tiles of
- * 160 rows instead of a seventh round, tune "bf16t_sk" = 4 keeps the one launch; 224 with plan[0] == M (ABI 206): the one plain launch runs 224 x 256 tiles -- a launch whose 256-row tiles fill one partial
+ * none; 224 with plan[0] == M (ABI 206): the one plain launch runs 224 x 256 tiles -- a launch whose 256-row tiles fill one partial
  * round and whose 224-row tiles still fit one round, e.g. M = 26,896, N = 512: 242 workgroups of 7 / 8 the work instead of 212; tune
  * "bf16t_sk" = 3 keeps the 256-row tiles; same results bit for bit).  Stream-K launches with shared tiles combine them INSIDE the launch (ABI 203; round 4 ran a second kernel over slab
  * levels): emadapt_conv_bf16t_workspace_bytes is then arrival words + one 256 KB accumulator image per workgroup (64 MB + 1 KB on 256
@@ -561,8 +559,6 @@ int emadapt_sgd_accumulate_pack(const float *g, const float *w, int64_t n, int64
  *                slower on fc6 / fc7, profiles/r05_bf16t_bench.txt) | 2: four and more rounds of tiles as whole rounds of plain tiles +
  *                a stream-K launch over the last partial round (rounds 4-5; the default is plain tiles all the way there: fc7 -4 %)
  *                | 3: a launch of one partial round keeps 256 x 256 tiles (default since ABI 206: 224 x 256 where they fill more CUs)
- *                | 4: a launch of four and more rounds stays ONE launch of 256-row tiles (default since ABI 206: whole rounds + the last
- *                round as a launch of 160- / 224-row tiles)
  *   "x6_tile"    128 | 256
  *   "pool_rows"  1: emadapt_maxpool_bwd[_dt] at stride 2 runs its row form (one thread per pixel) instead of 2 x 2 pixel quads
  *                (ABI 205; same results bit for bit)

@@ -134,52 +134,6 @@ M224 = [
 ]
 
 
-# (B, H, W, Cin, Cout, k, dil), plan_cus, tail tile: launches of four and more rounds whose last, partial round runs as a launch of its own on
-# 160- / 224-row tiles (round 6) -- small shapes under a shrunken plan_cus and fc7 at batch 16 (six whole rounds + 240 tiles of 160 rows)
-TAILS = [
-    ((1, 66, 67, 64, 512, 1, 1), 8, 160),        # 4422 rows: 16 whole row tiles + 326 rows = 3 x 2 tiles of 160 rows on 8 "CUs"
-    ((1, 66, 67, 32, 520, 3, 2), 12, 160),       # 3 N tiles (one 8 wide), rate 2
-    ((1, 61, 60, 96, 512, 3, 1), 4, 224),        # 3660 rows: 14 whole row tiles + 76 rows (one 224-row tile per column; 160 fits too -> 160 is chosen)
-    ((16, 41, 41, 4096, 4096, 1, 1), 256, 160),  # fc7
-]
-
-
-@pytest.mark.parametrize("shape,cus,bm", TAILS)
-def test_b16t_last_round_on_shorter_tiles(env, shape, cus, bm):
-    """Whole rounds of 256-row tiles + the last round as a launch of shorter tiles against the one launch of 256-row tiles (tune
-    bf16t_sk = 4): the same sums in the same order per output element -- forward (every epilogue) and data gradient bit for bit."""
-    ops, do, torch = env
-    B, H, W, Cin, Cout, k, dil = shape
-    g = torch.Generator(device="cuda").manual_seed(B * 17 + H + Cout)
-    xg = torch.randn((B, H, W, Cin), device="cuda", generator=g).relu_().bfloat16()
-    wg = torch.randn((k, k, Cin, Cout), device="cuda", generator=g) * (2.0 / (k * k * Cin)) ** 0.5
-    bg = torch.randn((Cout,), device="cuda", generator=g) * 0.1
-    wt = ops.filter_tiles_bf16(wg)
-    M = B * H * W
-    with ops.tuned(plan_cus=cus):
-        rows, sk, lv, tail = ops.conv_bf16t_plan(B, H, W, Cin, Cout, k, dil)
-        assert 0 < rows < M and rows % 256 == 0 and sk == 0 and tail in (-160, -224), (rows, sk, lv, tail)
-        new = [ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=False, out_dtype=torch.float32),
-               ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_seed=5)]
-        with ops.tuned(bf16t_sk=4):
-            assert ops.conv_bf16t_plan(B, H, W, Cin, Cout, k, dil) == (M, 0, 0, 0)
-            old = [ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=False, out_dtype=torch.float32),
-                   ops.conv_fwd_bf16t(xg, wt, (k, k), Cout, bg, dil, relu=True, keep_prob=0.5, drop_seed=5)]
-    for a_, b_ in zip(new, old):
-        assert torch.equal(a_, b_)
-    if B < 16:
-        y = do.conv_same(xg.cpu().double(), wg.cpu().bfloat16().double(), bg.cpu().double(), dil)
-        assert _rel(new[0].cpu(), y) < 2e-5
-    if Cout % 32 == 0:
-        dyg = torch.randn((B, H, W, Cout), device="cuda", generator=g).bfloat16()
-        wtd = ops.filter_tiles_bf16(wg, dgrad=True)
-        with ops.tuned(plan_cus=cus):
-            nd = ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=xg, gate_scale=2.0)
-            with ops.tuned(bf16t_sk=4):
-                od = ops.conv_dgrad_bf16t(dyg, wtd, (k, k), Cin, dil, gate=xg, gate_scale=2.0)
-        assert torch.equal(nd, od)
-
-
 @pytest.mark.parametrize("shape,cus", M224)
 def test_b16t_224_row_tiles(env, shape, cus):
     """The 224-row tile variant against the 256-row tiles of the same launch (tune bf16t_sk = 3): every output element is the same sum

@@ -387,7 +387,7 @@ def test_executed_fraction_and_new_plan_queries_without_a_device():
     assert ops.conv_bf16t_supported(d, "fwd") and ops.conv_bf16t_supported(d, "dgrad")
     assert not ops.conv_bf16t_supported(ops.conv_desc(16, 321, 321, 4, 64, 3, 3, 1), "fwd")            # conv1_1: 4 input channels
     rows, sk, levels, tail = ops.conv_bf16t_plan(16, 41, 41, 512, 512, 3, 1)
-    assert rows == 16 * 41 * 41 and sk == 0 and levels == 0 and tail == 224             # 212 tiles on 256 CUs: one round of plain tiles (round 5), 242 of 224 rows (round 6)
+    assert rows == 16 * 41 * 41 and sk == 0 and levels == 0                             # 212 tiles on 256 CUs: one round of plain tiles (round 5)
     rows, sk, levels, tail = ops.conv_bf16t_plan(16, 81, 81, 256, 256, 3, 1)
     assert rows == 16 * 81 * 81 and sk == 1 and levels >= 2                             # 411 tiles: stream-K, shared tiles combined in-launch
     d3, d41 = ops.conv_desc(16, 81, 81, 256, 256, 3, 3, 1), ops.conv_desc(16, 41, 41, 256, 512, 3, 3, 1)
@@ -395,9 +395,7 @@ def test_executed_fraction_and_new_plan_queries_without_a_device():
     assert ops.conv_bf16t_pays(ops.conv_desc(16, 41, 41, 512, 4096, 4, 4, 4), "dgrad")   # fc6's data gradient: 1696 K steps per CU
     assert not ops.conv_bf16t_pays(ops.conv_desc(16, 161, 161, 128, 128, 3, 3, 1), "fwd")   # narrower than a tile
     rows, sk, levels, tail = ops.conv_bf16t_plan(16, 41, 41, 4096, 4096, 1, 1)
-    assert rows == 96 * 256 and sk == 0 and levels == 0 and tail == -160                # 6.6 rounds: six whole rounds of plain tiles + 240 tiles of 160 rows (round 6; round 5: one launch, 7 rounds)
-    with ops.tuned(bf16t_sk=4):
-        assert ops.conv_bf16t_plan(16, 41, 41, 4096, 4096, 1, 1) == (16 * 41 * 41, 0, 0, 0)
+    assert rows == 16 * 41 * 41 and sk == 0 and levels == 0                             # 6.6 rounds: plain tiles all the way (round 5; rounds 4-5: + a stream-K tail)
     rows, sk, levels, tail = ops.conv_bf16t_plan(6, 41, 41, 4096, 4096, 1, 1)
     assert rows == 8192 and sk == 0 and tail >= 1                                      # 2.5 rounds: 2 whole rounds + a stream-K tail
     # tensors of 2 GiB and more: one launch is refused by the 32-bit offsets, the entries slice the batch; workspace = the largest slice's
