@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/soak_r05.txt
+O=gpurun_out/soak_r06.txt
 : > $O
 run() { timeout -k 10 400 python3 bench.py --no-alt --no-cpu-baseline --warmup 5 "$@" 2>/dev/null | grep '"metric"' | python3 -c "
 import json,sys
