@@ -1,10 +1,13 @@
 """CPU tests of the host-side mirror of the reference interface: plan construction, parameter shapes
 (deeplab.py:131-149), flat-buffer layout, FLOP/parameter counts of SURVEY section 8, perms drawing."""
+import os
 import random
 
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _adapt(**kw):
@@ -214,6 +217,67 @@ def test_resumed_runs_continue_in_their_epoch(tmp_path):
     assert sorted(sum(ids_a, [])) == sorted(sum(ids_b, [])) and ids_a != ids_b     # same samples, epoch 1's order
     again = [ids for _, _, ids in ds.next_batch("train", 4, epoches=1, start_epoch=0)]
     assert again == ids_a
+
+
+def test_decode_worker_process_fills_the_shared_staging_block(tmp_path):
+    """f1, host side (data._Pipeline, decode_mode "process"): a decode worker is a separate PROCESS (python -m ..._decode <shm>, stdlib +
+    NumPy + PIL only) that answers one line per request and writes the decoded bytes into the shared-memory block at the offsets it
+    is told: uint8 RGB rows at img_off, the palette indices at lab_off.  Several workers, requests in flight, a file that cannot be
+    decoded, a sample larger than its slot; the worker ends when its stdin closes."""
+    import subprocess
+    import sys
+    from multiprocessing import shared_memory
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    files = []
+    for i, (h, w) in enumerate([(37, 53), (64, 48), (50, 50), (41, 77)]):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        lab = rng.integers(0, 21, (h, w), dtype=np.uint8)
+        lab[:2] = 255
+        Image.fromarray(img).save(tmp_path / ("%d.jpg" % i), quality=95)
+        pl = Image.fromarray(lab, mode="P")
+        pl.putpalette([c for k in range(256) for c in ((k * 37) % 256, (k * 91) % 256, (k * 53) % 256)])
+        pl.save(tmp_path / ("%d.png" % i))
+        files.append((str(tmp_path / ("%d.jpg" % i)), str(tmp_path / ("%d.png" % i)), lab))
+    mp_, n = 80 * 80, len(files)
+    cap = 4 * mp_
+    shm = shared_memory.SharedMemory(create=True, size=cap * n)
+    procs = []
+    try:
+        host = np.ndarray((cap * n,), dtype=np.uint8, buffer=shm.buf)
+        host[:] = 7
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        procs = [subprocess.Popen([sys.executable, "-m", "em_adapt_tensorflow_amd._decode", shm.name], env=env, stdin=subprocess.PIPE,
+                                  stdout=subprocess.PIPE, text=True, bufsize=1) for _ in range(2)]
+        for j, (jf, pf, _) in enumerate(files):               # all requests first: two per worker in flight
+            procs[j % 2].stdin.write("%d\t%d\t%d\t%s\t%s\n" % (j * cap, j * cap + 3 * mp_, cap, jf, pf))
+        for p in procs:
+            p.stdin.flush()
+        for j, (jf, pf, lab) in enumerate(files):
+            reply = procs[j % 2].stdout.readline().split()
+            assert reply[0] == "OK", reply
+            h, w = int(reply[1]), int(reply[2])
+            assert (h, w) == lab.shape
+            want = np.asarray(Image.open(jf).convert("RGB"))
+            assert np.array_equal(host[j * cap:j * cap + h * w * 3].reshape(h, w, 3), want)
+            assert np.array_equal(host[j * cap + 3 * mp_:j * cap + 3 * mp_ + h * w].reshape(h, w), lab)
+            assert host[j * cap + h * w * 3] == 7               # nothing behind the sample was touched
+        (tmp_path / "bad.jpg").write_bytes(b"not a jpeg")
+        procs[0].stdin.write("0\t%d\t%d\t%s\t%s\n" % (3 * mp_, cap, tmp_path / "bad.jpg", files[0][1]))
+        procs[0].stdin.write("0\t%d\t%d\t%s\t%s\n" % (3 * 100, 4 * 100, files[0][0], files[0][1]))     # a slot of 100 pixels
+        procs[0].stdin.flush()
+        r1, r2 = procs[0].stdout.readline(), procs[0].stdout.readline()
+        assert r1.startswith("ERR ") and r2.startswith("ERR ") and "larger than the staging slot" in r2
+        for p in procs:
+            p.stdin.close()
+        assert [p.wait(timeout=20) for p in procs] == [0, 0]
+        del host
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shm.close()
+        shm.unlink()
 
 
 def test_synthetic_data_differs_per_rank():
